@@ -1,0 +1,185 @@
+/*
+ * rfw_hip.h — C ABI of the MI355X-native wavefront path-tracing backend.
+ *
+ * One entry point per method of the reference plugin trait
+ * `rfw_backend::Backend` (crates/rfw-backend/src/lib.rs:35-82) plus
+ * `FromWindowHandle::init` (:26-33), in the shape the reference already uses
+ * for its one native backend (backends/metal/cpp/src/library.h:119-135: opaque
+ * `void* instance`, POD payloads, pointer + count for slices).  The Rust shim
+ * that binds these symbols is shown in INTEGRATION.md.
+ *
+ * Contract:
+ *  - every pointer argument is BORROWED for the duration of the call only; the
+ *    library copies what it needs before returning and never retains it;
+ *  - no call throws; every call except create/destroy/last_error returns 0 on
+ *    success or a negative RFW_HIP_E_* code, with a human-readable message kept
+ *    per instance (rfw_hip_last_error);
+ *  - calls on one instance are serialised internally (one mutex) and may come
+ *    from any thread (bevy runs synchronize_system / render_system on arbitrary
+ *    workers: rfw/src/system/mod.rs:16-17, rfw/src/lib.rs:411-430);
+ *  - `changed` bit slices (bitvec BitSlice<Lsb0, usize> in the trait) arrive as
+ *    packed little-endian u32 words, bit i = element i; NULL means "all".
+ *  - there is no CPU fallback: without a HIP device rfw_hip_create fails.
+ */
+#ifndef RFW_HIP_H
+#define RFW_HIP_H
+
+#include "rfw_pod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFW_HIP_API __attribute__((visibility("default")))
+#define RFW_HIP_ABI_VERSION 1
+
+enum {
+    RFW_HIP_OK = 0,
+    RFW_HIP_E_INVALID = -1,   /* bad argument */
+    RFW_HIP_E_DEVICE = -2,    /* HIP runtime error */
+    RFW_HIP_E_STATE = -3,     /* call not valid in the current state */
+    RFW_HIP_E_NOMEM = -4
+};
+
+/* BLAS/TLAS builder selection (rfw_hip_options.builder) */
+enum { RFW_HIP_BUILDER_DEVICE_LBVH = 0, RFW_HIP_BUILDER_HOST_SAH = 1 };
+
+/*
+ * Creation options.  Zero-initialise, then set what you need; a NULL pointer
+ * means all defaults.  Defaults reproduce gpu-rt: max path length 3
+ * (backends/gpu-rt/src/lib.rs:1708), clamp 10 (:205), NEE on.
+ */
+typedef struct {
+    uint32_t struct_size;      /* = sizeof(rfw_hip_options) */
+    int32_t device;            /* HIP device ordinal; -1 = current */
+    uint32_t max_path_length;  /* 0 = default 3; 1 = primary (+shadow) only */
+    float clamp_value;         /* 0 = default 10.0 */
+    uint32_t rank;             /* tile shard of this instance (multi-GPU): rank in [0, world) */
+    uint32_t world;            /* 0/1 = render the whole frame */
+    uint32_t tile_size;        /* shard tile edge in pixels; 0 = default 64 */
+    uint32_t builder;          /* RFW_HIP_BUILDER_*; acceleration-structure builder for meshes */
+    uint32_t flags;            /* RFW_HIP_FLAG_* */
+} rfw_hip_options;
+
+enum {
+    RFW_HIP_FLAG_NO_NEE = 1u << 0,        /* skip light sampling / shadow rays */
+    RFW_HIP_FLAG_COUNT_TRAVERSAL = 1u << 1 /* accumulate node/triangle visit counters (slow; for roofline bytes) */
+};
+
+/* Per-frame counters and timings of the last rfw_hip_render (extension; no trait equivalent). */
+typedef struct {
+    uint64_t primary_rays;
+    uint64_t extension_rays;
+    uint64_t shadow_rays;
+    uint64_t nodes_visited;     /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
+    uint64_t tris_tested;       /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
+    uint64_t instances_entered; /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
+    float ms_total;             /* hipEvent span of the whole frame on the instance's stream */
+    float ms_trace_primary;
+    float ms_trace_extend;
+    float ms_trace_shadow;
+    float ms_shade;
+    float ms_other;
+    uint32_t sample_count;      /* samples accumulated so far */
+    uint32_t bounces;
+} rfw_hip_frame_stats;
+
+/* Sizes of the device-resident acceleration structures (for DESIGN.md byte accounting). */
+typedef struct {
+    uint64_t triangles;
+    uint64_t instances;
+    uint64_t blas_nodes;
+    uint64_t tlas_nodes;
+    uint32_t node_bytes;
+    uint32_t tri_bytes;
+    float ms_blas_build;  /* last synchronize */
+    float ms_tlas_build;
+} rfw_hip_scene_stats;
+
+/* Hit record of the ray-query extension: what ray_gen/ray_extend store per path
+ * (backends/gpu-rt/shaders/ray_gen.comp:66-69) before bary quantisation. */
+typedef struct {
+    int32_t inst;   /* global instance id, -1 = miss */
+    int32_t tri;    /* global triangle id (mesh triangle offset + id), -1 = miss */
+    float t;
+    float u, v;
+} rfw_hip_hit;
+
+/* ---- FromWindowHandle::init / Drop  (crates/rfw-backend/src/lib.rs:26-33; metal: library.h:119-120) ---- */
+RFW_HIP_API void* rfw_hip_create(uint32_t width, uint32_t height, double scale, const rfw_hip_options* options);
+RFW_HIP_API void rfw_hip_destroy(void* instance);
+/* instance may be NULL: returns the message of the last failed rfw_hip_create on this thread. */
+RFW_HIP_API const char* rfw_hip_last_error(void* instance);
+RFW_HIP_API uint32_t rfw_hip_abi_version(void);
+
+/* ---- Backend trait, in declaration order (crates/rfw-backend/src/lib.rs:36-81) ---- */
+/* :36 set_2d_mesh / :39 set_2d_instances — accepted and ignored; gpu-rt `unimplemented!()`s them
+ * (backends/gpu-rt/src/lib.rs:1131-1137). */
+RFW_HIP_API int rfw_hip_set_2d_mesh(void* instance, uint32_t id, const void* vertices, uint32_t num_vertices, int32_t tex_id);
+RFW_HIP_API int rfw_hip_set_2d_instances(void* instance, uint32_t mesh, const rfw_mat4* matrices, uint32_t num_matrices);
+/* :41 set_3d_mesh */
+RFW_HIP_API int rfw_hip_set_3d_mesh(void* instance, uint32_t id, const rfw_mesh_data_3d* data);
+/* :43 unload_3d_meshes */
+RFW_HIP_API int rfw_hip_unload_3d_meshes(void* instance, const uint32_t* ids, uint32_t num_ids);
+/* :46 set_3d_instances — a zero matrix marks a removed slot (crates/rfw-scene/src/instances_3d.rs:79-86). */
+RFW_HIP_API int rfw_hip_set_3d_instances(void* instance, uint32_t mesh, const rfw_instances_data_3d* data);
+/* :49 set_materials */
+RFW_HIP_API int rfw_hip_set_materials(void* instance, const rfw_device_material* materials, uint32_t num, const uint32_t* changed);
+/* :53 set_textures */
+RFW_HIP_API int rfw_hip_set_textures(void* instance, const rfw_texture_data* textures, uint32_t num, const uint32_t* changed);
+/* :57 synchronize — builds/refits acceleration structures for what changed. */
+RFW_HIP_API int rfw_hip_synchronize(void* instance);
+/* :60 render — one sample per pixel per call, accumulating (gpu-rt/src/lib.rs:1685-1731). */
+RFW_HIP_API int rfw_hip_render(void* instance, const rfw_mat4* view_2d, const rfw_camera_view_3d* view_3d, uint32_t mode);
+/* :63 resize */
+RFW_HIP_API int rfw_hip_resize(void* instance, uint32_t width, uint32_t height, double scale);
+/* :66-75 lights */
+RFW_HIP_API int rfw_hip_set_point_lights(void* instance, const rfw_point_light* lights, uint32_t num, const uint32_t* changed);
+RFW_HIP_API int rfw_hip_set_spot_lights(void* instance, const rfw_spot_light* lights, uint32_t num, const uint32_t* changed);
+RFW_HIP_API int rfw_hip_set_area_lights(void* instance, const rfw_area_light* lights, uint32_t num, const uint32_t* changed);
+RFW_HIP_API int rfw_hip_set_directional_lights(void* instance, const rfw_directional_light* lights, uint32_t num, const uint32_t* changed);
+/* :78 set_skybox */
+RFW_HIP_API int rfw_hip_set_skybox(void* instance, const rfw_texture_data* skybox);
+/* :81 set_skins */
+RFW_HIP_API int rfw_hip_set_skins(void* instance, const rfw_skin_data* skins, uint32_t num, const uint32_t* changed);
+
+/* ---- extensions: the trait presents to a swap chain and has no read-back, options or queries ---- */
+/* gpu-rt's RenderMode::Reset (gpu-rt/src/lib.rs:1690-1692): restart accumulation. */
+RFW_HIP_API int rfw_hip_reset_accumulation(void* instance);
+/* keys: "max_path_length", "clamp_value", "nee", "count_traversal", "sample_count" */
+RFW_HIP_API int rfw_hip_set_option(void* instance, const char* key, double value);
+/* tonemapped frame, RGBA32F, sqrt(acc/samples) (backends/gpu-rt/shaders/blit.comp:15-23); n_floats = w*h*4 */
+RFW_HIP_API int rfw_hip_read_framebuffer(void* instance, float* rgba, uint64_t n_floats);
+/* raw accumulator (acPixels), RGBA32F sums */
+RFW_HIP_API int rfw_hip_read_accumulator(void* instance, float* rgba, uint64_t n_floats);
+RFW_HIP_API int rfw_hip_get_frame_stats(void* instance, rfw_hip_frame_stats* out);
+RFW_HIP_API int rfw_hip_get_scene_stats(void* instance, rfw_hip_scene_stats* out);
+/* launch all work on this hipStream_t (NULL = the instance's own stream) */
+RFW_HIP_API int rfw_hip_set_stream(void* instance, void* hip_stream);
+RFW_HIP_API int rfw_hip_device_synchronize(void* instance);
+
+/* Multi-GPU tile sharding.  With world > 1 an instance renders only the
+ * tiles dealt to `rank` into a compact slab of `slab_floats` floats (RGBA32F accumulator
+ * values).  The caller all-gathers the slabs (RCCL) into a buffer of world*slab_floats and
+ * hands it back to rfw_hip_assemble_frame, which de-tiles into the full accumulator/frame. */
+RFW_HIP_API int rfw_hip_shard_info(void* instance, uint64_t* slab_floats, uint32_t* num_tiles_local, uint32_t* num_tiles_total);
+/* device pointer the slab is written to by render(); NULL restores the internal slab */
+RFW_HIP_API int rfw_hip_set_slab_output(void* instance, void* device_ptr);
+RFW_HIP_API int rfw_hip_assemble_frame(void* instance, const void* gathered_device_ptr);
+
+/* Ray queries against the synchronized scene — the C form of the reference's CPU query
+ * interface TIntersector::{intersect, occludes} (crates/rfw-scene/src/intersector.rs:45-75,
+ * 21-43).  Host pointers; origins/directions are n x 3 floats. */
+RFW_HIP_API int rfw_hip_intersect(void* instance, const float* origins, const float* directions,
+                                  float t_min, float t_max, uint64_t n, rfw_hip_hit* hits);
+RFW_HIP_API int rfw_hip_occludes(void* instance, const float* origins, const float* directions,
+                                 float t_min, const float* t_max, uint64_t n, uint8_t* occluded);
+
+/* Debug read-back of the wavefront queues after the last render() bounce `bounce`
+ * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
+RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFW_HIP_H */

@@ -1,0 +1,1449 @@
+/*
+ * oracle/oracle.cpp — TEST INFRASTRUCTURE.  CPU restatement of the reference's
+ * wavefront path-tracing hot path (backends/gpu-rt).  NOT part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; nothing under rfw-rs_amd/ links, includes or calls it.
+ *
+ * PARITY UNPINNED.  The reference's implementation of this path cannot be built
+ * or run here (no Rust toolchain; `rtbvh` not vendored; backends/gpu-rt targets
+ * APIs that no longer exist — SURVEY.md §0, §8c) and the reference holds no test,
+ * golden vector or fixture for it.  What pins this oracle instead
+ * are its own analytic known-answer tests and the brute-force == BVH equivalence
+ * checks in tests/ (tests/test_oracle_*.py), plus the committed golden images it
+ * generated (tests/golden/).
+ *
+ * What is restated, function by function (paths relative to /root/reference):
+ *   wang_hash / randi / randf         backends/gpu-rt/shaders/random.glsl:5-23
+ *   intersect / intersect_occludes    backends/gpu-rt/shaders/intersection.glsl:1-38, 40-70
+ *   intersect_mnode                   backends/gpu-rt/shaders/intersection.glsl:106-168
+ *   intersect_mbvh / intersect_top_mbvh (closest) backends/gpu-rt/shaders/ray_gen.comp:202-250, 310-362
+ *   intersect_mbvh / intersect_top_mbvh (any-hit) backends/gpu-rt/shaders/ray_shadow.comp:83-132, 191-243
+ *   generate_eye_ray                  backends/gpu-rt/shaders/ray_gen.comp:103-146
+ *   ray_gen main / ray_extend main    ray_gen.comp:39-70, ray_extend.comp:245-268
+ *   ray_shadow main                   ray_shadow.comp:245-268
+ *   shade main + light sampling       backends/gpu-rt/shaders/shade.comp:70-266, 283-528
+ *   Disney BSDF                       backends/gpu-rt/shaders/disney.glsl:11-285
+ *   utils                             backends/gpu-rt/shaders/utils.glsl:9-92
+ *   material unpack                   backends/gpu-rt/shaders/structs.glsl:217-270
+ *   blit                              backends/gpu-rt/shaders/blit.comp:15-23
+ *   host loop (render)                backends/gpu-rt/src/lib.rs:1685-1731
+ *   host synchronize (TLAS, instance descriptors) backends/gpu-rt/src/lib.rs:1576-1615
+ *   CPU query shape                   crates/rfw-scene/src/intersector.rs:21-75
+ *
+ * Documented deviations from a literal transcription (DESIGN.md §"oracle deviations"):
+ *   D1  sampling uses the xorshift branch for every sample (ray_gen.comp:116-122,
+ *       shade.comp:196-200, 222-226); the blue-noise branch needs the 41k-line Heitz tables
+ *       of backends/gpu-rt/src/blue_noise.rs which are not restated ("next").
+ *   D2  equal-t ties between triangles are resolved to the lowest (instance, triangle) id
+ *       instead of "first encountered in traversal order" so that the answer is a function
+ *       of the scene, not of the tree (option "tie_break"=0 restores the literal rule).
+ *   D3  textures (diffuse/normal/... maps) and the skybox image are not sampled: materials
+ *       are flat, a miss adds the constant sky colour (default black = gpu-rt's
+ *       zero-initialised 64x64 skybox, backends/gpu-rt/src/lib.rs:424-436).
+ *   D4  instance ids follow the live API numbering mesh_base[mesh] + slot.
+ */
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/rfw_pod.h"
+#include "bvh.h"
+#include "glsl.h"
+
+namespace orc {
+
+// ---------------------------------------------------------------- random.glsl:5-23
+static inline uint32_t wang_hash(uint32_t s)
+{
+    s = (s ^ 61u) ^ (s >> 16u);
+    s *= 9u;
+    s = s ^ (s >> 4u);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15u);
+    return s;
+}
+static inline uint32_t randi(uint32_t& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+static inline float randf(uint32_t& s) { return (float)randi(s) * 2.3283064365387e-10f; }
+
+// ---------------------------------------------------------------- utils.glsl
+static const float PI = 3.14159265359f;
+static const float TWOPI = 2.0f * 3.14159265359f;
+static const float INVPI = 1.0f / 3.14159265359f;
+static const float INV2PI = 1.0f / (2.0f * 3.14159265359f);
+
+// utils.glsl:22-26
+static inline uint32_t PackNormal(vec3 N)
+{
+    const float f = 65535.0f / std::sqrt(8.0f * N.z + 8.0f);
+    return f2u(N.x * f + 32767.0f) + (f2u(N.y * f + 32767.0f) << 16);
+}
+// utils.glsl:28-35
+static inline vec3 UnpackNormal(uint32_t p)
+{
+    float nx = (float)(p & 65535u) * (2.0f / 65535.0f);
+    float ny = (float)(p >> 16) * (2.0f / 65535.0f);
+    float nz = 0.0f;
+    nx += -1.0f; ny += -1.0f; nz += 1.0f;
+    // l = dot(nn.xyz, -nn.xyz)
+    float l = nx * -nx + ny * -ny + nz * -nz;
+    nz = l;
+    l = std::sqrt(l);
+    nx *= l;
+    ny *= l;
+    return V3(nx, ny, nz) * 2.0f + V3(0.0f, 0.0f, -1.0f);
+}
+// utils.glsl:55-70
+static inline vec3 DiffuseReflectionUniform(float r0, float r1)
+{
+    const float term1 = TWOPI * r0, term2 = std::sqrt(1.0f - r1 * r1);
+    float s, c;
+    rfw_sincosf(term1, &s, &c);
+    return V3(c * term2, s * term2, r1);
+}
+static inline vec3 DiffuseReflectionCosWeighted(float r0, float r1)
+{
+    const float term1 = TWOPI * r0;
+    const float term2 = std::sqrt(1.0f - r1);
+    float s, c;
+    rfw_sincosf(term1, &s, &c);
+    return V3(c * term2, s * term2, std::sqrt(r1));
+}
+// utils.glsl:72-80
+static inline void CLAMPINTENSITY(vec3& contribution, float clampValue)
+{
+    const float v = gl_max(contribution.x, gl_max(contribution.y, contribution.z));
+    if (v > clampValue) {
+        const float m = clampValue / v;
+        contribution = contribution * m;
+    }
+}
+// utils.glsl:83-92 (Ray Tracing Gems ch. 6)
+static inline float safe_origin_1(float o, float n)
+{
+    const int32_t of_i = f2i(256.0f * n);
+    const float p_i = bitsf((uint32_t)((int32_t)fbits(o) + ((o < 0.0f) ? -of_i : of_i)));
+    return gl_abs(o) < (1.0f / 32.0f) ? o + (1.0f / 65536.0f) * n : p_i;
+}
+static inline vec3 safe_origin(vec3 O, vec3 R, vec3 N, float /*epsilon*/)
+{
+    const vec3 _N = dot(N, R) > 0.0f ? N : -N;
+    return V3(safe_origin_1(O.x, _N.x), safe_origin_1(O.y, _N.y), safe_origin_1(O.z, _N.z));
+}
+
+// ---------------------------------------------------------------- structs.glsl:177-270
+struct ShadingData {
+    vec3 color, absorption, specular;
+    float metallic, subsurface, specular_f, roughness, specular_tint, anisotropic, sheen, sheen_tint;
+    float clearcoat, clearcoat_gloss, transmission, eta, custom0, custom1, custom2, custom3;
+};
+static inline float CHAR2FLT(uint32_t x, int s) { return (float)((x >> s) & 255u) * (1.0f / 255.0f); }
+static inline ShadingData extractParameters(const rfw_device_material& m)
+{
+    ShadingData d;
+    d.color = V3(m.color[0], m.color[1], m.color[2]);
+    d.absorption = V3(m.absorption[0], m.absorption[1], m.absorption[2]);
+    d.specular = V3(m.specular[0], m.specular[1], m.specular[2]);
+    const uint32_t* p = m.parameters;
+    d.metallic = CHAR2FLT(p[0], 0);
+    d.subsurface = CHAR2FLT(p[0], 8);
+    d.specular_f = CHAR2FLT(p[0], 16);
+    d.roughness = gl_max(0.01f, CHAR2FLT(p[0], 24));
+    d.specular_tint = CHAR2FLT(p[1], 0);
+    d.anisotropic = CHAR2FLT(p[1], 8);
+    d.sheen = CHAR2FLT(p[1], 16);
+    d.sheen_tint = CHAR2FLT(p[1], 24);
+    d.clearcoat = CHAR2FLT(p[2], 0);
+    d.clearcoat_gloss = CHAR2FLT(p[2], 8);
+    d.transmission = CHAR2FLT(p[2], 16);
+    d.eta = CHAR2FLT(p[2], 24);
+    d.custom0 = CHAR2FLT(p[3], 0);
+    d.custom1 = CHAR2FLT(p[3], 8);
+    d.custom2 = CHAR2FLT(p[3], 16);
+    d.custom3 = CHAR2FLT(p[3], 24);
+    return d;
+}
+
+// ---------------------------------------------------------------- disney.glsl
+enum { BSDF_TYPE_REFLECTED = 0, BSDF_TYPE_TRANSMITTED = 1, BSDF_TYPE_SPECULAR = 2 };
+static inline float sqr(float x) { return x * x; }
+
+// disney.glsl:13-25
+static inline bool Refract(vec3 wi, vec3 n, float eta, vec3& wt)
+{
+    const float cosThetaI = dot(n, wi);
+    const float sin2ThetaI = gl_max(0.0f, 1.0f - cosThetaI * cosThetaI);
+    const float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1.0f) return false;
+    const float cosThetaT = std::sqrt(1.0f - sin2ThetaT);
+    wt = eta * (wi * -1.0f) + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+// disney.glsl:27-31
+static inline float SchlickFresnel(float u)
+{
+    const float m = gl_clamp(1.0f - u, 0.0f, 1.0f);
+    return (m * m) * (m * m) * m;
+}
+// disney.glsl:45-52
+static inline float GTR1(float NDotH, float a)
+{
+    if (a >= 1.0f) return INVPI;
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return (a2 - 1.0f) / (PI * rfw_logf(a2) * t);
+}
+// disney.glsl:54-59
+static inline float GTR2(float NDotH, float a)
+{
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return a2 / (PI * t * t);
+}
+// disney.glsl:61-66
+static inline float SmithGGX(float NDotv, float alphaG)
+{
+    const float a = alphaG * alphaG;
+    const float b = NDotv * NDotv;
+    return 1.0f / (NDotv + std::sqrt(a + b - a * b));
+}
+// disney.glsl:68-78
+static inline float Fr(float VDotN, float eio)
+{
+    const float SinThetaT2 = sqr(eio) * (1.0f - VDotN * VDotN);
+    if (SinThetaT2 > 1.0f) return 1.0f;
+    const float LDotN = std::sqrt(1.0f - SinThetaT2);
+    const float eta = 1.0f / eio;
+    const float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
+    const float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+    return 0.5f * (sqr(r1) + sqr(r2));
+}
+// disney.glsl:80-87
+static inline vec3 SafeNormalize(vec3 a)
+{
+    const float ls = dot(a, a);
+    if (ls > 0.0f) return a * (1.0f / std::sqrt(ls));
+    return V3(0.0f);
+}
+// disney.glsl:89-108
+static inline float BSDFPdf(const ShadingData& sd, vec3 N, vec3 wo, vec3 wi)
+{
+    float bsdfPdf = 0.0f, brdfPdf;
+    if (dot(wi, N) <= 0.0f) {
+        brdfPdf = INV2PI * sd.subsurface * 0.5f;
+    } else {
+        const float F = Fr(dot(N, wo), sd.eta);
+        const vec3 halfway = SafeNormalize(wi + wo);
+        const float cosThetaHalf = gl_abs(dot(halfway, N));
+        const float pdfHalf = GTR2(cosThetaHalf, sd.roughness) * cosThetaHalf;
+        const float pdfSpec = 0.25f * pdfHalf / gl_max(1.e-6f, dot(wi, halfway));
+        const float pdfDiff = gl_abs(dot(wi, N)) * INVPI * (1.0f - sd.subsurface);
+        bsdfPdf = pdfSpec * F;
+        brdfPdf = gl_mix(pdfDiff, pdfSpec, 0.5f);
+    }
+    return gl_mix(brdfPdf, bsdfPdf, sd.transmission);
+}
+// disney.glsl:110-195
+static inline vec3 BSDFEval(const ShadingData& sd, vec3 N, vec3 wo, vec3 wi, float t, bool backfacing)
+{
+    const float NDotL = dot(N, wi);
+    const float NDotV = dot(N, wo);
+    const vec3 H = normalize(wi + wo);
+    const float NDotH = dot(N, H);
+    const float LDotH = dot(wi, H);
+    const vec3 Cdlin = sd.color;
+    const float Cdlum = .3f * Cdlin.x + .6f * Cdlin.y + .1f * Cdlin.z;
+    const vec3 Ctint = Cdlum > 0.0f ? Cdlin / Cdlum : V3(1.0f);
+    const vec3 Cspec0 = gl_mix(sd.specular * .08f * gl_mix(V3(1.0f), Ctint, sd.specular_tint), Cdlin, sd.metallic);
+    vec3 bsdf = V3(0.0f);
+    vec3 brdf = V3(0.0f);
+    if (sd.transmission > 0.0f) {
+        if (NDotL <= 0.0f) {
+            const float F = Fr(NDotV, sd.eta);
+            bsdf = V3((1.0f - F) / gl_abs(NDotL) * (1.0f - sd.metallic) * sd.transmission);
+        } else {
+            const float a = sd.roughness;
+            const float Ds = GTR2(NDotH, a);
+            const float FH = Fr(LDotH, sd.eta);
+            const vec3 Fs = gl_mix(Cspec0, V3(1.0f), FH);
+            const float Gs = SmithGGX(NDotV, a) * SmithGGX(NDotL, a);
+            bsdf = (Gs * Ds) * Fs;
+        }
+    }
+    if (sd.transmission < 1.0f) {
+        if (NDotL <= 0.0f) {
+            if (sd.subsurface > 0.0f) {
+                const vec3 s = V3(std::sqrt(sd.color.x), std::sqrt(sd.color.y), std::sqrt(sd.color.z));
+                const float FL = SchlickFresnel(gl_abs(NDotL)), FV = SchlickFresnel(NDotV);
+                const float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+                brdf = INVPI * s * sd.subsurface * Fd * (1.0f - sd.metallic);
+            }
+        } else {
+            const float a = sd.roughness;
+            const float Ds = GTR2(NDotH, a);
+            const float FH = SchlickFresnel(LDotH);
+            const vec3 Fs = gl_mix(Cspec0, V3(1.0f), FH);
+            const float Gs = SmithGGX(NDotV, a) * SmithGGX(NDotL, a);
+            const float FL = SchlickFresnel(NDotL), FV = SchlickFresnel(NDotV);
+            const float Fd90 = 0.5f + 2.0f * LDotH * LDotH * a;
+            const float Fd = gl_mix(1.0f, Fd90, FL) * gl_mix(1.0f, Fd90, FV);
+            const float Dr = GTR1(NDotH, gl_mix(.1f, .001f, sd.clearcoat_gloss));
+            const float Fc = gl_mix(.04f, 1.0f, FH);
+            const float Gr = SmithGGX(NDotL, .25f) * SmithGGX(NDotV, .25f);
+            brdf = INVPI * Fd * Cdlin * (1.0f - sd.metallic) * (1.0f - sd.subsurface) + Gs * Fs * Ds + V3(sd.clearcoat * Gr * Fc * Dr);
+        }
+    }
+    const vec3 fin = gl_mix(brdf, bsdf, sd.transmission);
+    if (backfacing) {
+        const vec3 a = -sd.absorption * t;
+        return fin * V3(rfw_expf(a.x), rfw_expf(a.y), rfw_expf(a.z));
+    }
+    return fin;
+}
+// disney.glsl:197-263
+static inline void BSDFSample(const ShadingData& sd, vec3 T, vec3 B, vec3 N, vec3 wo, vec3& wi, float& pdf, int& type,
+                              float /*t*/, bool /*backfacing*/, float r3, float r4)
+{
+    if (r3 < sd.transmission) {
+        const float F = Fr(dot(N, wo), sd.eta);
+        if (r4 < F) {
+            const float r1 = r3 / sd.transmission;
+            const float r2 = r4 / F;
+            const float cosThetaHalf = std::sqrt((1.0f - r2) / (1.0f + (sqr(sd.roughness) - 1.0f) * r2));
+            const float sinThetaHalf = std::sqrt(gl_max(0.0f, 1.0f - sqr(cosThetaHalf)));
+            float sinPhiHalf, cosPhiHalf;
+            rfw_sincosf(r1 * TWOPI, &sinPhiHalf, &cosPhiHalf);
+            vec3 halfway = T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
+            if (dot(halfway, wo) <= 0.0f) halfway = halfway * -1.0f;
+            type = BSDF_TYPE_REFLECTED;
+            wi = gl_reflect(wo * -1.0f, halfway);
+        } else {
+            pdf = 0.0f;
+            if (Refract(wo, N, sd.eta, wi)) {
+                type = BSDF_TYPE_SPECULAR;
+                pdf = (1.0f - F) * sd.transmission;
+            }
+            return;
+        }
+    } else {
+        const float r1 = (r3 - sd.transmission) / (1.0f - sd.transmission);
+        if (r4 < 0.5f) {
+            const float r2 = r4 * 2.0f;
+            vec3 d;
+            if (r2 < sd.subsurface) {
+                const float r5 = r2 / sd.subsurface;
+                d = DiffuseReflectionUniform(r1, r5);
+                type = BSDF_TYPE_TRANSMITTED;
+                d.z *= -1.0f;
+            } else {
+                const float r5 = (r2 - sd.subsurface) / (1.0f - sd.subsurface);
+                d = DiffuseReflectionCosWeighted(r1, r5);
+                type = BSDF_TYPE_REFLECTED;
+            }
+            wi = T * d.x + B * d.y + N * d.z;
+        } else {
+            const float r2 = (r4 - 0.5f) * 2.0f;
+            const float cosThetaHalf = std::sqrt((1.0f - r2) / (1.0f + (sqr(sd.roughness) - 1.0f) * r2));
+            const float sinThetaHalf = std::sqrt(gl_max(0.0f, 1.0f - sqr(cosThetaHalf)));
+            float sinPhiHalf, cosPhiHalf;
+            rfw_sincosf(r1 * TWOPI, &sinPhiHalf, &cosPhiHalf);
+            vec3 halfway = T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
+            if (dot(halfway, wo) <= 0.0f) halfway = halfway * -1.0f;
+            wi = gl_reflect(wo * -1.0f, halfway);
+            type = BSDF_TYPE_REFLECTED;
+        }
+    }
+    pdf = BSDFPdf(sd, N, wo, wi);
+}
+// disney.glsl:265-270
+static inline vec3 EvaluateBSDF(const ShadingData& sd, vec3 iN, vec3 /*T*/, vec3 /*B*/, vec3 wo, vec3 wi, float& pdf)
+{
+    const vec3 bsdf = BSDFEval(sd, iN, wo, wi, 0.0f, false);
+    pdf = BSDFPdf(sd, iN, wo, wi);
+    return bsdf;
+}
+// disney.glsl:272-283
+static inline vec3 SampleBSDF(const ShadingData& sd, vec3 iN, vec3 N, vec3 T, vec3 B, vec3 wo, float t, bool backfacing,
+                              float r3, float r4, vec3& wi, float& pdf, bool& specular)
+{
+    int type = BSDF_TYPE_REFLECTED; // GLSL leaves `type` undefined when Refract fails; pdf is 0 there and the path ends
+    BSDFSample(sd, T, B, N, wo, wi, pdf, type, t, backfacing, r3, r4);
+    specular = type != BSDF_TYPE_REFLECTED;
+    return BSDFEval(sd, iN, wo, wi, t, backfacing);
+}
+
+// ---------------------------------------------------------------- scene state
+struct Mesh {
+    bool present = false;
+    std::vector<rfw_rt_triangle> tris;
+    BVH bvh;
+    MBVH mbvh;
+    uint32_t tri_offset = 0; // into the concatenated triangle array (gpu-rt/src/lib.rs:1387-1461)
+};
+struct InstanceList {
+    rfw_aabb local_aabb{};
+    std::vector<rfw_mat4> matrices;
+};
+// structs.glsl:110-122 (offsets replaced by a mesh index; the arithmetic is the same)
+struct InstanceDescriptor {
+    uint32_t mesh;
+    const struct Mesh* meshp;
+    mat4 matrix, inverse, normal;
+};
+
+struct Counters {
+    uint64_t primary = 0, extension = 0, shadow = 0;
+    uint64_t top_nodes = 0, mesh_nodes = 0, tris = 0, instances = 0;
+    void add(const Counters& o)
+    {
+        primary += o.primary; extension += o.extension; shadow += o.shadow;
+        top_nodes += o.top_nodes; mesh_nodes += o.mesh_nodes; tris += o.tris; instances += o.instances;
+    }
+};
+
+struct Hit {
+    int32_t inst = -1, tri = -1;
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+};
+
+struct Oracle {
+    uint32_t width = 0, height = 0;
+    std::map<uint32_t, Mesh> meshes;
+    std::map<uint32_t, InstanceList> instance_lists;
+    std::vector<rfw_device_material> materials;
+    std::vector<rfw_area_light> area_lights;
+    std::vector<rfw_point_light> point_lights;
+    std::vector<rfw_spot_light> spot_lights;
+    std::vector<rfw_directional_light> directional_lights;
+    // synchronized state
+    std::vector<rfw_rt_triangle> all_tris; // concatenated; global triangle id indexes this
+    std::vector<InstanceDescriptor> instances;
+    std::vector<int32_t> instance_global_id; // TLAS prim -> global instance id (D4)
+    std::vector<int32_t> global_to_desc;     // global instance id -> descriptor index or -1
+    BVH top_bvh;
+    MBVH top_mbvh;
+    // render state
+    std::vector<vec4> acc;
+    uint32_t sample_count = 0;
+    uint32_t max_path_length = 3;
+    float clamp_value = 10.0f;
+    bool nee = true;
+    bool tie_break = true;
+    vec3 sky{0.0f, 0.0f, 0.0f};
+    int threads = 1;
+    Counters counters;
+    std::string error;
+};
+
+// MESA-style explicit 4x4 inverse, column-major, every term left to right.
+static mat4 inverse(const mat4& mm)
+{
+    float m[16], inv[16];
+    std::memcpy(m, &mm, 64);
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    det = 1.0f / det;
+    for (int i = 0; i < 16; i++) inv[i] = inv[i] * det;
+    mat4 r;
+    std::memcpy(&r, inv, 64);
+    return r;
+}
+static mat4 transpose(const mat4& a)
+{
+    float m[16], t[16];
+    std::memcpy(m, &a, 64);
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) t[c * 4 + r] = m[r * 4 + c];
+    mat4 o;
+    std::memcpy(&o, t, 64);
+    return o;
+}
+
+// ---------------------------------------------------------------- intersection.glsl:1-38
+static inline bool intersect_tri(const rfw_rt_triangle& tr, vec3 origin, vec3 direction, float t_min, float& t, float& uvx, float& uvy,
+                                 bool tie, bool tie_wins)
+{
+    const vec3 v0 = V3(tr.vertex0.x, tr.vertex0.y, tr.vertex0.z);
+    const vec3 v1 = V3(tr.vertex1.x, tr.vertex1.y, tr.vertex1.z);
+    const vec3 v2 = V3(tr.vertex2.x, tr.vertex2.y, tr.vertex2.z);
+    const vec3 edge1 = v1 - v0;
+    const vec3 edge2 = v2 - v0;
+    const vec3 h = cross(direction, edge2);
+    const float a = dot(edge1, h);
+    if (a > -0.0001f && a < 0.0001f) return false;
+    const float f = 1.0f / a;
+    const vec3 s = origin - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const vec3 q = cross(s, edge1);
+    const float v = f * dot(direction, q);
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    const float _t = f * dot(edge2, q);
+    // literal rule: _t > t_min && _t < t.  D2: an exact tie is accepted iff the candidate has the lower id.
+    if (_t > t_min && (_t < t || (tie && _t == t && tie_wins))) {
+        t = _t;
+        const vec3 gn = V3(tr.normal.x, tr.normal.y, tr.normal.z);
+        const float denom = 1.0f / dot(gn, gn);
+        uvx = u * denom;
+        uvy = v * denom;
+        return true;
+    }
+    return false;
+}
+// intersection.glsl:40-70
+static inline bool intersect_occludes(const rfw_rt_triangle& tr, vec3 origin, vec3 direction, float t_min, float t)
+{
+    const vec3 v0 = V3(tr.vertex0.x, tr.vertex0.y, tr.vertex0.z);
+    const vec3 v1 = V3(tr.vertex1.x, tr.vertex1.y, tr.vertex1.z);
+    const vec3 v2 = V3(tr.vertex2.x, tr.vertex2.y, tr.vertex2.z);
+    const vec3 edge1 = v1 - v0;
+    const vec3 edge2 = v2 - v0;
+    const vec3 h = cross(direction, edge2);
+    const float a = dot(edge1, h);
+    if (a > -0.0001f && a < 0.0001f) return false;
+    const float f = 1.0f / a;
+    const vec3 s = origin - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const vec3 q = cross(s, edge1);
+    const float v = f * dot(direction, q);
+    if (v < 0.0f || (u + v) > 1.0f) return false;
+    const float _t = f * dot(edge2, q);
+    return _t > t_min && _t < t;
+}
+
+// intersection.glsl:106-168
+static inline bool intersect_mnode(const MBVHNode& node, vec3 origin, vec3 dir_inverse, float t, float tmin[4], bool result[4], bool tie = false)
+{
+    float tmax[4];
+    for (int i = 0; i < 4; i++) {
+        float t1 = (node.min_x[i] - origin.x) * dir_inverse.x;
+        float t2 = (node.max_x[i] - origin.x) * dir_inverse.x;
+        tmin[i] = gl_min(t1, t2);
+        tmax[i] = gl_max(t1, t2);
+        t1 = (node.min_y[i] - origin.y) * dir_inverse.y;
+        t2 = (node.max_y[i] - origin.y) * dir_inverse.y;
+        tmin[i] = gl_max(tmin[i], gl_min(t1, t2));
+        tmax[i] = gl_min(tmax[i], gl_max(t1, t2));
+        t1 = (node.min_z[i] - origin.z) * dir_inverse.z;
+        t2 = (node.max_z[i] - origin.z) * dir_inverse.z;
+        tmin[i] = gl_max(tmin[i], gl_min(t1, t2));
+        tmax[i] = gl_min(tmax[i], gl_max(t1, t2));
+    }
+    bool any = false;
+    for (int i = 0; i < 4; i++) {
+        // literal: tmin < t.  With the tie rule (D2) a child entered at exactly t may still hold the lower-id twin.
+        result[i] = (tmax[i] >= tmin[i]) && (tie ? (tmin[i] <= t) : (tmin[i] < t));
+        any = any || result[i];
+    }
+    if (!any) return false;
+    tmin[0] = bitsf(fbits(tmin[0]) & 0xFFFFFFFCu);
+    tmin[1] = bitsf((fbits(tmin[1]) & 0xFFFFFFFCu) | 1u);
+    tmin[2] = bitsf((fbits(tmin[2]) & 0xFFFFFFFCu) | 2u);
+    tmin[3] = bitsf((fbits(tmin[3]) & 0xFFFFFFFCu) | 3u);
+    float tmp;
+    if (tmin[0] > tmin[1]) { tmp = tmin[0]; tmin[0] = tmin[1]; tmin[1] = tmp; }
+    if (tmin[2] > tmin[3]) { tmp = tmin[2]; tmin[2] = tmin[3]; tmin[3] = tmp; }
+    if (tmin[0] > tmin[2]) { tmp = tmin[0]; tmin[0] = tmin[2]; tmin[2] = tmp; }
+    if (tmin[1] > tmin[3]) { tmp = tmin[1]; tmin[1] = tmin[3]; tmin[3] = tmp; }
+    if (tmin[2] > tmin[3]) { tmp = tmin[2]; tmin[2] = tmin[3]; tmin[3] = tmp; }
+    return true;
+}
+
+struct Trav { int32_t left_first, count; };
+
+// ray_gen.comp:202-250.  cur_inst/best_inst carry what the tie rule (D2) needs.
+static int intersect_mbvh(const Oracle& o, const Mesh& mesh, vec3 origin, vec3 direction, float t_min, float& t, float& uvx, float& uvy,
+                          int32_t cur_inst, int32_t best_inst, int32_t best_tri, Counters& c)
+{
+    Trav hit_stack[64]; // reference: 32 (ray_gen.comp:204); deeper here so that no tree can overflow it
+    int stack_ptr = -1;
+    int hit = -1;
+    const vec3 dir_inverse = V3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+    bool result[4];
+    float index[4];
+    const std::vector<MBVHNode>& nodes = mesh.mbvh.nodes;
+    const std::vector<uint32_t>& prim_indices = mesh.bvh.prim_indices;
+    c.mesh_nodes++;
+    if (!intersect_mnode(nodes[0], origin, dir_inverse, t, index, result, o.tie_break)) return hit;
+    for (int i = 3; i >= 0; i--) {
+        const int idx = (int)(fbits(index[i]) & 3u);
+        if (result[idx] && nodes[0].children[idx] >= 0) {
+            stack_ptr++;
+            hit_stack[stack_ptr].left_first = nodes[0].children[idx];
+            hit_stack[stack_ptr].count = nodes[0].counts[idx];
+        }
+    }
+    while (stack_ptr >= 0) {
+        const int left_first = hit_stack[stack_ptr].left_first;
+        const int count = hit_stack[stack_ptr].count;
+        stack_ptr--;
+        if (count >= 0) {
+            for (int i = 0; i < count; i++) {
+                const int32_t prim = (int32_t)(mesh.tri_offset + prim_indices[left_first + i]);
+                c.tris++;
+                const int32_t bi = hit >= 0 ? cur_inst : best_inst;
+                const int32_t bt = hit >= 0 ? hit : best_tri;
+                const bool wins = (cur_inst < bi) || (cur_inst == bi && prim < bt);
+                if (intersect_tri(o.all_tris[prim], origin, direction, t_min, t, uvx, uvy, o.tie_break && bi >= 0, wins)) hit = prim;
+            }
+        } else {
+            c.mesh_nodes++;
+            if (!intersect_mnode(nodes[left_first], origin, dir_inverse, t, index, result, o.tie_break)) continue;
+            for (int i = 3; i >= 0; i--) {
+                const int idx = (int)(fbits(index[i]) & 3u);
+                if (result[idx] && nodes[left_first].children[idx] >= 0) {
+                    stack_ptr++;
+                    hit_stack[stack_ptr].left_first = nodes[left_first].children[idx];
+                    hit_stack[stack_ptr].count = nodes[left_first].counts[idx];
+                }
+            }
+        }
+    }
+    return hit;
+}
+
+// ray_gen.comp:310-362
+static void intersect_top_mbvh(const Oracle& o, vec3 origin, vec3 direction, float t_min, float& t, float& uvx, float& uvy, int32_t& hit_inst,
+                               int32_t& hit_tri, Counters& c)
+{
+    hit_inst = -1;
+    hit_tri = -1;
+    if (o.top_mbvh.nodes.empty()) return;
+    Trav hit_stack[64];
+    int stack_ptr = -1;
+    const vec3 dir_inverse = V3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+    bool result[4];
+    float index[4];
+    const std::vector<MBVHNode>& nodes = o.top_mbvh.nodes;
+    c.top_nodes++;
+    if (!intersect_mnode(nodes[0], origin, dir_inverse, t, index, result, o.tie_break)) return;
+    for (int i = 3; i >= 0; i--) {
+        const int idx = (int)(fbits(index[i]) & 3u);
+        if (result[idx] && nodes[0].children[idx] >= 0) {
+            stack_ptr++;
+            hit_stack[stack_ptr].left_first = nodes[0].children[idx];
+            hit_stack[stack_ptr].count = nodes[0].counts[idx];
+        }
+    }
+    while (stack_ptr >= 0) {
+        const int left_first = hit_stack[stack_ptr].left_first;
+        const int count = hit_stack[stack_ptr].count;
+        stack_ptr--;
+        if (count >= 0) {
+            for (int i = 0; i < count; i++) {
+                const uint32_t prim = o.top_bvh.prim_indices[left_first + i];
+                const InstanceDescriptor& inst = o.instances[prim];
+                const int32_t gid = o.instance_global_id[prim];
+                const vec3 inst_org = xyz(mul(inst.inverse, V4(origin, 1.0f)));
+                const vec3 inst_dir = xyz(mul(inst.inverse, V4(direction, 0.0f)));
+                c.instances++;
+                const int potential_hit =
+                    intersect_mbvh(o, *inst.meshp, inst_org, inst_dir, t_min, t, uvx, uvy, gid, hit_inst, hit_tri, c);
+                if (potential_hit >= 0) {
+                    hit_inst = gid;
+                    hit_tri = potential_hit;
+                }
+            }
+        } else {
+            c.top_nodes++;
+            if (!intersect_mnode(nodes[left_first], origin, dir_inverse, t, index, result, o.tie_break)) continue;
+            for (int i = 3; i >= 0; i--) {
+                const int idx = (int)(fbits(index[i]) & 3u);
+                if (result[idx] && nodes[left_first].children[idx] >= 0) {
+                    stack_ptr++;
+                    hit_stack[stack_ptr].left_first = nodes[left_first].children[idx];
+                    hit_stack[stack_ptr].count = nodes[left_first].counts[idx];
+                }
+            }
+        }
+    }
+}
+
+// ray_shadow.comp:83-132 — returns true when NOT occluded (as the GLSL does)
+static bool unoccluded_mbvh(const Oracle& o, const Mesh& mesh, vec3 origin, vec3 direction, float t_min, float t, Counters& c)
+{
+    Trav hit_stack[64];
+    int stack_ptr = -1;
+    const vec3 dir_inverse = V3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+    bool result[4];
+    float index[4];
+    const std::vector<MBVHNode>& nodes = mesh.mbvh.nodes;
+    const std::vector<uint32_t>& prim_indices = mesh.bvh.prim_indices;
+    c.mesh_nodes++;
+    if (!intersect_mnode(nodes[0], origin, dir_inverse, t, index, result)) return true;
+    for (int i = 3; i >= 0; i--) {
+        const int idx = (int)(fbits(index[i]) & 3u);
+        if (result[idx] && nodes[0].children[idx] >= 0) {
+            stack_ptr++;
+            hit_stack[stack_ptr].left_first = nodes[0].children[idx];
+            hit_stack[stack_ptr].count = nodes[0].counts[idx];
+        }
+    }
+    while (stack_ptr >= 0) {
+        const int left_first = hit_stack[stack_ptr].left_first;
+        const int count = hit_stack[stack_ptr].count;
+        stack_ptr--;
+        if (count >= 0) {
+            for (int i = 0; i < count; i++) {
+                c.tris++;
+                if (intersect_occludes(o.all_tris[mesh.tri_offset + prim_indices[left_first + i]], origin, direction, t_min, t)) return false;
+            }
+        } else {
+            c.mesh_nodes++;
+            if (!intersect_mnode(nodes[left_first], origin, dir_inverse, t, index, result)) continue;
+            for (int i = 3; i >= 0; i--) {
+                const int idx = (int)(fbits(index[i]) & 3u);
+                if (result[idx] && nodes[left_first].children[idx] >= 0) {
+                    stack_ptr++;
+                    hit_stack[stack_ptr].left_first = nodes[left_first].children[idx];
+                    hit_stack[stack_ptr].count = nodes[left_first].counts[idx];
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// ray_shadow.comp:191-243 — true when NOT occluded
+static bool unoccluded_top_mbvh(const Oracle& o, vec3 origin, vec3 direction, float t_min, float t, Counters& c)
+{
+    if (o.top_mbvh.nodes.empty()) return true;
+    Trav hit_stack[64];
+    int stack_ptr = -1;
+    const vec3 dir_inverse = V3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+    bool result[4];
+    float index[4];
+    const std::vector<MBVHNode>& nodes = o.top_mbvh.nodes;
+    c.top_nodes++;
+    if (!intersect_mnode(nodes[0], origin, dir_inverse, t, index, result)) return true;
+    for (int i = 3; i >= 0; i--) {
+        const int idx = (int)(fbits(index[i]) & 3u);
+        if (result[idx] && nodes[0].children[idx] >= 0) {
+            stack_ptr++;
+            hit_stack[stack_ptr].left_first = nodes[0].children[idx];
+            hit_stack[stack_ptr].count = nodes[0].counts[idx];
+        }
+    }
+    while (stack_ptr >= 0) {
+        const int left_first = hit_stack[stack_ptr].left_first;
+        const int count = hit_stack[stack_ptr].count;
+        stack_ptr--;
+        if (count >= 0) {
+            for (int i = 0; i < count; i++) {
+                const uint32_t prim = o.top_bvh.prim_indices[left_first + i];
+                const InstanceDescriptor& inst = o.instances[prim];
+                const vec3 inst_org = xyz(mul(inst.inverse, V4(origin, 1.0f)));
+                const vec3 inst_dir = xyz(mul(inst.inverse, V4(direction, 0.0f)));
+                c.instances++;
+                if (!unoccluded_mbvh(o, *inst.meshp, inst_org, inst_dir, t_min, t, c)) return false;
+            }
+        } else {
+            c.top_nodes++;
+            if (!intersect_mnode(nodes[left_first], origin, dir_inverse, t, index, result)) continue;
+            for (int i = 3; i >= 0; i--) {
+                const int idx = (int)(fbits(index[i]) & 3u);
+                if (result[idx] && nodes[left_first].children[idx] >= 0) {
+                    stack_ptr++;
+                    hit_stack[stack_ptr].left_first = nodes[left_first].children[idx];
+                    hit_stack[stack_ptr].count = nodes[left_first].counts[idx];
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// Brute force over every instance x triangle with the same per-triangle arithmetic: the tree-free
+// definition of the answer (what crates/rfw-scene/src/intersector.rs:45-75 computes, without the BVH).
+static void intersect_brute(const Oracle& o, vec3 origin, vec3 direction, float t_min, float& t, float& uvx, float& uvy, int32_t& hit_inst,
+                            int32_t& hit_tri)
+{
+    hit_inst = -1;
+    hit_tri = -1;
+    for (size_t k = 0; k < o.instances.size(); k++) {
+        const InstanceDescriptor& inst = o.instances[k];
+        const int32_t gid = o.instance_global_id[k];
+        const Mesh& mesh = *inst.meshp;
+        const vec3 inst_org = xyz(mul(inst.inverse, V4(origin, 1.0f)));
+        const vec3 inst_dir = xyz(mul(inst.inverse, V4(direction, 0.0f)));
+        for (size_t i = 0; i < mesh.tris.size(); i++) {
+            const int32_t prim = (int32_t)(mesh.tri_offset + i);
+            const bool wins = (gid < hit_inst) || (gid == hit_inst && prim < hit_tri);
+            if (intersect_tri(o.all_tris[prim], inst_org, inst_dir, t_min, t, uvx, uvy, hit_inst >= 0, wins)) {
+                hit_inst = gid;
+                hit_tri = prim;
+            }
+        }
+    }
+}
+static bool unoccluded_brute(const Oracle& o, vec3 origin, vec3 direction, float t_min, float t)
+{
+    for (size_t k = 0; k < o.instances.size(); k++) {
+        const InstanceDescriptor& inst = o.instances[k];
+        const Mesh& mesh = *inst.meshp;
+        const vec3 inst_org = xyz(mul(inst.inverse, V4(origin, 1.0f)));
+        const vec3 inst_dir = xyz(mul(inst.inverse, V4(direction, 0.0f)));
+        for (size_t i = 0; i < mesh.tris.size(); i++)
+            if (intersect_occludes(o.all_tris[mesh.tri_offset + i], inst_org, inst_dir, t_min, t)) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- ray_gen.comp:103-146 (xorshift branch, D1)
+static void generate_eye_ray(const rfw_camera_view_3d& cam, uint32_t width, uint32_t height, vec3& O, vec3& D, uint32_t pixelIdx, uint32_t& seed)
+{
+    const int sx = (int)pixelIdx % (int)width;
+    const int sy = (int)pixelIdx / (int)width;
+    float r0 = randf(seed);
+    float r1 = randf(seed);
+    float r2 = randf(seed);
+    float r3 = randf(seed);
+    const float blade = (float)f2i(r0 * 9.0f);
+    r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+    float x1, y1, x2, y2;
+    const float piOver4point5 = 3.14159265359f / 4.5f;
+    rfw_sincosf(blade * piOver4point5, &y1, &x1);
+    rfw_sincosf((blade + 1.0f) * piOver4point5, &y2, &x2);
+    if ((r2 + r3) > 1.0f) {
+        r2 = 1.0f - r2;
+        r3 = 1.0f - r3;
+    }
+    const float xr = x1 * r2 + x2 * r3;
+    const float yr = y1 * r2 + y2 * r3;
+    const vec3 pos = V3(cam.pos.x, cam.pos.y, cam.pos.z);
+    const vec3 right = V3(cam.right.x, cam.right.y, cam.right.z);
+    const vec3 up = V3(cam.up.x, cam.up.y, cam.up.z);
+    const vec3 p1 = V3(cam.p1.x, cam.p1.y, cam.p1.z);
+    O = pos + cam.lens_size * (right * xr + up * yr);
+    const float u = ((float)sx + r0) * (1.0f / (float)width);
+    const float v = ((float)sy + r1) * (1.0f / (float)height);
+    const vec3 pointOnPixel = p1 + u * right + v * up;
+    D = normalize(pointOnPixel - O);
+}
+
+// ---------------------------------------------------------------- shade.comp:283-528 light sampling
+static inline uint32_t light_count(const Oracle& o)
+{
+    return (uint32_t)(o.area_lights.size() + o.point_lights.size() + o.spot_lights.size() + o.directional_lights.size());
+}
+// shade.comp:325-328
+static inline float CalculateLightPDF(vec3 D, float t, float lightArea, vec3 lightNormal) { return (t * t) / (-dot(D, lightNormal) * lightArea); }
+// shade.comp:330-369 (ISLIGHTS undefined -> uniform)
+static inline float LightPickProb(const Oracle& o) { return 1.0f / (float)(int)light_count(o); }
+// shade.comp:371-411
+static vec3 RandomBarycentrics(float r0)
+{
+    const uint32_t uf = f2u(r0 * 4294967296.0f /* float(4294967295u) */);
+    vec2 A{1.0f, 0.0f}, B{0.0f, 1.0f}, C{0.0f, 0.0f};
+    for (int i = 0; i < 16; ++i) {
+        const int d = (int)((uf >> (2u * (15u - (uint32_t)i))) & 0x3u);
+        vec2 An, Bn, Cn;
+        switch (d) {
+        case 0: An = (B + C) * 0.5f; Bn = (A + C) * 0.5f; Cn = (A + B) * 0.5f; break;
+        case 1: An = A; Bn = (A + B) * 0.5f; Cn = (A + C) * 0.5f; break;
+        case 2: An = (B + A) * 0.5f; Bn = B; Cn = (B + C) * 0.5f; break;
+        default: An = (C + A) * 0.5f; Bn = (C + B) * 0.5f; Cn = C; break;
+        }
+        A = An; B = Bn; C = Cn;
+    }
+    const vec2 r = (A + B + C) * 0.3333333f;
+    return V3(r.x, r.y, 1.0f - r.x - r.y);
+}
+static inline vec3 P3(const rfw_vec3& v) { return V3(v.x, v.y, v.z); }
+// shade.comp:413-528 (uniform pick branch)
+static vec3 RandomPointOnLight(const Oracle& o, float r0, float /*r1*/, vec3 I, vec3 N, float& pickProb, float& lightPdf, vec3& lightColor)
+{
+    const int AREA = (int)o.area_lights.size(), POINT = (int)o.point_lights.size(), SPOT = (int)o.spot_lights.size();
+    const uint32_t lightCount = light_count(o);
+    const vec3 bary = RandomBarycentrics(r0);
+    int lightIdx = 0;
+    pickProb = 1.0f / (float)lightCount;
+    lightIdx = f2i(r0 * (float)lightCount);
+    r0 = (r0 - (float)lightIdx * (1.0f / (float)lightCount)) * (float)lightCount;
+    (void)r0;
+    lightIdx = lightIdx < 0 ? 0 : (lightIdx > (int)lightCount - 1 ? (int)lightCount - 1 : lightIdx);
+    if (lightIdx < AREA) {
+        const rfw_area_light& al = o.area_lights[lightIdx];
+        lightColor = P3(al.radiance);
+        const vec3 LN = P3(al.normal);
+        const vec3 P = bary.x * P3(al.vertex0) + bary.y * P3(al.vertex1) + bary.z * P3(al.vertex2);
+        vec3 L = I - P;
+        const float sqDist = dot(L, L);
+        L = normalize(L);
+        const float LNdotL = dot(L, LN);
+        const float reciSolidAngle = sqDist / (al.energy * LNdotL);
+        lightPdf = (LNdotL > 0.0f && dot(L, N) < 0.0f) ? (reciSolidAngle * (1.0f / al.area)) : 0.0f;
+        return P;
+    }
+    if (lightIdx < (AREA + POINT)) {
+        const rfw_point_light& pl = o.point_lights[lightIdx - AREA];
+        lightColor = P3(pl.radiance);
+        const vec3 L = I - P3(pl.position);
+        const float sqDist = dot(L, L);
+        lightPdf = dot(L, N) < 0.0f ? (sqDist / pl.energy) : 0.0f;
+        return P3(pl.position);
+    }
+    if (lightIdx < (AREA + POINT + SPOT)) {
+        const rfw_spot_light& sl = o.spot_lights[lightIdx - (AREA + POINT)];
+        vec3 L = I - P3(sl.position);
+        const float sqDist = dot(L, L);
+        L = normalize(L);
+        const float d = gl_max(0.0f, dot(L, P3(sl.direction)) - sl.cos_outer) / (sl.cos_inner - sl.cos_outer);
+        const float LNdotL = gl_min(1.0f, d);
+        lightPdf = (LNdotL > 0.0f && dot(L, N) < 0.0f) ? (sqDist / (LNdotL * sl.energy)) : 0.0f;
+        lightColor = P3(sl.radiance);
+        return P3(sl.position);
+    }
+    const rfw_directional_light& dl = o.directional_lights[lightIdx - (AREA + POINT + SPOT)];
+    const vec3 L = P3(dl.direction);
+    lightColor = P3(dl.radiance);
+    const float NdotL = dot(L, N);
+    lightPdf = NdotL < 0.0f ? (1.0f * (1.0f / dl.energy)) : 0.0f;
+    return I - 1000.0f * L;
+}
+
+// ---------------------------------------------------------------- one path = ray_gen -> [shade -> shadow -> extend]*
+struct PathState { // structs.glsl:4-9
+    int32_t inst, tri;
+    float t;
+    uint32_t bary;
+    vec3 origin; uint32_t path_id;
+    vec3 direction; uint32_t packed_normal;
+    vec3 throughput; float pdf;
+};
+struct Shadow { // structs.glsl:172-176
+    vec3 O; vec3 D; float dist; vec3 E; uint32_t pixel;
+};
+
+// shade.comp:70-266.  Returns: bit0 = extension pushed (into `next`), bit1 = shadow ray pushed.
+static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec4& acc, PathState& next, Shadow& shadow)
+{
+    const vec3 O = st.origin, D = st.direction;
+    vec3 throughput = path_length == 0 ? V3(1.0f) : st.throughput;
+    const float bsdfPdf = path_length == 0 ? 1.0f : st.pdf;
+    const uint32_t PATH_ID = st.path_id;
+
+    if (st.inst < 0) { // shade.comp:90-96 (D3: constant sky)
+        vec3 contribution = throughput * o.sky * (1.0f / bsdfPdf);
+        CLAMPINTENSITY(contribution, o.clamp_value);
+        acc.x += contribution.x; acc.y += contribution.y; acc.z += contribution.z; acc.w += 0.0f;
+        return 0;
+    }
+    const rfw_rt_triangle& tri = o.all_tris[st.tri];
+    const rfw_device_material& mat = o.materials[tri.mat_id];
+    ShadingData sd = extractParameters(mat);
+
+    const uint32_t sampleId = PATH_ID / (o.width * o.height) + o.sample_count;
+    uint32_t seed = wang_hash(PATH_ID * 16789u + sampleId * 1791u + path_length * 720898027u);
+
+    const float u = (float)(st.bary & 65535u) * (1.0f / 65535.0f);
+    const float v = (float)(st.bary >> 16) * (1.0f / 65535.0f);
+    const float w = 1.0f - u - v;
+
+    vec3 gN = P3(tri.normal);
+    vec3 N = w * P3(tri.n0) + u * P3(tri.n1) + v * P3(tri.n2);
+    const vec4 T0{tri.tangent0.x, tri.tangent0.y, tri.tangent0.z, tri.tangent0.w};
+    const vec4 T1{tri.tangent1.x, tri.tangent1.y, tri.tangent1.z, tri.tangent1.w};
+    const vec4 T2{tri.tangent2.x, tri.tangent2.y, tri.tangent2.z, tri.tangent2.w};
+    vec4 T = w * T0 + u * T1 + v * T2;
+
+    const InstanceDescriptor& inst = o.instances[o.global_to_desc[st.inst]];
+    gN = normalize(xyz(mul(inst.normal, V4(gN, 0.0f))));
+    N = normalize(xyz(mul(inst.normal, V4(N, 0.0f))));
+    T = V4(normalize(xyz(mul(inst.normal, V4(xyz(T), 0.0f)))), T.w);
+    const vec3 B = cross(N, xyz(T)) * T.w;
+    const vec3 P = O + st.t * D;
+
+    // shade.comp:128-160 hit a light (D3: no emissive maps)
+    if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) {
+        vec3 contribution = V3(0.0f);
+        const float DdotNL = -dot(D, N);
+        if (DdotNL > 0.0f) {
+            if (path_length == 0) {
+                contribution = throughput * sd.color * (1.0f / bsdfPdf);
+            } else {
+                const float lightPdf = CalculateLightPDF(D, st.t, tri.area, N);
+                const float pickProb = LightPickProb(o);
+                if ((bsdfPdf + lightPdf * pickProb) <= 0.0f) return 0;
+                contribution = throughput * sd.color * (1.0f / (bsdfPdf + lightPdf * pickProb));
+            }
+            CLAMPINTENSITY(contribution, o.clamp_value);
+        }
+        acc.x += contribution.x; acc.y += contribution.y; acc.z += contribution.z; acc.w += 0.0f;
+        return 0;
+    }
+
+    const bool backFacing = dot(D, gN) >= 0.0f;
+    if (backFacing) {
+        N = N * -1.0f;
+        gN = gN * -1.0f;
+    }
+    throughput = throughput * (1.0f / bsdfPdf);
+
+    float newBsdfPdf = 0.0f;
+    bool specular = false;
+    vec3 R = V3(0.0f);
+    const float r1 = randf(seed);
+    const float r2 = randf(seed);
+    const vec3 bsdf = SampleBSDF(sd, N, gN, xyz(T), B, D * -1.0f, st.t, backFacing, r1, r2, R, newBsdfPdf, specular);
+    throughput = throughput * bsdf * gl_abs(dot(N, R));
+    throughput = gl_max(throughput, V3(0.0f));
+    if (newBsdfPdf <= 1e-4f || gl_isnan(newBsdfPdf)) return 0;
+
+    int pushed = 0;
+    if (o.nee && light_count(o) > 0) {
+        const float r3 = randf(seed);
+        const float r4 = randf(seed);
+        vec3 lightColor = V3(0.0f);
+        float pickProb = 0.0f, lightPdf = 0.0f;
+        vec3 L = RandomPointOnLight(o, r3, r4, P, N, pickProb, lightPdf, lightColor) - P;
+        const float dist = length(L);
+        L = L * (1.0f / dist);
+        const float NdotL = dot(L, N);
+        if (NdotL > 0.0f && lightPdf > 0.0f) {
+            float shadowPdf = 0.0f;
+            const vec3 sampledBSDF = EvaluateBSDF(sd, gN, xyz(T), B, D * -1.0f, L, shadowPdf);
+            if (shadowPdf > 0.0f) {
+                vec3 contribution = throughput * sampledBSDF * lightColor * (NdotL / (lightPdf * pickProb));
+                if (!(gl_isnan(contribution.x) || gl_isnan(contribution.y) || gl_isnan(contribution.z))) {
+                    CLAMPINTENSITY(contribution, o.clamp_value);
+                    shadow.O = safe_origin(P, L, gN, 1e-4f);
+                    shadow.D = L;
+                    shadow.dist = dist - 1e-4f;
+                    shadow.E = contribution;
+                    shadow.pixel = PATH_ID;
+                    pushed |= 2;
+                }
+            }
+        }
+    }
+    next.origin = safe_origin(P, R, gN, 1e-4f);
+    next.path_id = PATH_ID;
+    next.direction = R;
+    next.packed_normal = PackNormal(N);
+    next.throughput = throughput;
+    next.pdf = newBsdfPdf;
+    pushed |= 1;
+    return pushed;
+}
+
+// ray_gen.comp:39-70 / ray_extend.comp:245-268: trace + pack
+static inline void trace_and_pack(const Oracle& o, PathState& st, Counters& c)
+{
+    float t = 1e26f, uvx = 0.0f, uvy = 0.0f;
+    int32_t hi, ht;
+    intersect_top_mbvh(o, st.origin, st.direction, 1e-4f, t, uvx, uvy, hi, ht, c);
+    st.inst = hi;
+    st.tri = ht;
+    st.t = t;
+    st.bary = f2u(65535.0f * uvx) + (f2u(65535.0f * uvy) << 16);
+}
+
+static void render_rows(Oracle& o, const rfw_camera_view_3d& cam, uint32_t y0, uint32_t y1, Counters& c)
+{
+    for (uint32_t y = y0; y < y1; y++) {
+        for (uint32_t x = 0; x < o.width; x++) {
+            const uint32_t path_id = x + y * o.width;
+            vec4& acc = o.acc[path_id];
+            if (o.sample_count == 0) acc = vec4{0.0f, 0.0f, 0.0f, 0.0f}; // ray_gen.comp:46-48
+            PathState st{};
+            uint32_t seed = wang_hash(path_id * 16789u + o.sample_count * 1791u + 0u * 720898027u); // ray_gen.comp:54
+            generate_eye_ray(cam, o.width, o.height, st.origin, st.direction, path_id, seed);
+            st.path_id = path_id;
+            st.packed_normal = 0;
+            bool alive = true;
+            for (uint32_t path_length = 0; alive && path_length < o.max_path_length; path_length++) { // gpu-rt/src/lib.rs:1708
+                if (path_length == 0) c.primary++; else c.extension++;
+                trace_and_pack(o, st, c);
+                PathState next{};
+                Shadow sh{};
+                const int pushed = shade(o, st, path_length, acc, next, sh);
+                if (pushed & 2) { // ray_shadow.comp:245-268
+                    c.shadow++;
+                    if (unoccluded_top_mbvh(o, sh.O, sh.D, 0.001f, sh.dist - 0.0001f, c)) {
+                        vec4& a = o.acc[sh.pixel];
+                        a.x += sh.E.x; a.y += sh.E.y; a.z += sh.E.z; a.w += 0.0f;
+                    }
+                }
+                alive = (pushed & 1) != 0;
+                st = next;
+            }
+        }
+    }
+}
+
+} // namespace orc
+
+// ==================================================================== C exports
+using namespace orc;
+#define ORC_API extern "C" __attribute__((visibility("default")))
+
+ORC_API void* orc_create(uint32_t width, uint32_t height)
+{
+    Oracle* o = new Oracle();
+    o->width = width;
+    o->height = height;
+    o->acc.assign((size_t)width * height, vec4{0, 0, 0, 0});
+    return o;
+}
+ORC_API void orc_destroy(void* p) { delete (Oracle*)p; }
+
+ORC_API int orc_set_3d_mesh(void* p, uint32_t id, const rfw_mesh_data_3d* data)
+{
+    Oracle& o = *(Oracle*)p;
+    Mesh& m = o.meshes[id];
+    m.present = true;
+    m.tris.assign(data->triangles, data->triangles + data->num_triangles);
+    m.bvh = BVH();
+    m.mbvh = MBVH();
+    return 0;
+}
+ORC_API int orc_unload_3d_meshes(void* p, const uint32_t* ids, uint32_t n)
+{
+    Oracle& o = *(Oracle*)p;
+    for (uint32_t i = 0; i < n; i++) { o.meshes.erase(ids[i]); o.instance_lists.erase(ids[i]); }
+    return 0;
+}
+ORC_API int orc_set_3d_instances(void* p, uint32_t mesh, const rfw_instances_data_3d* data)
+{
+    Oracle& o = *(Oracle*)p;
+    InstanceList& l = o.instance_lists[mesh];
+    l.local_aabb = data->local_aabb;
+    l.matrices.assign(data->matrices, data->matrices + data->num_matrices);
+    return 0;
+}
+ORC_API int orc_set_materials(void* p, const rfw_device_material* m, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->materials.assign(m, m + n); return 0; }
+ORC_API int orc_set_area_lights(void* p, const rfw_area_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->area_lights.assign(l, l + n); return 0; }
+ORC_API int orc_set_point_lights(void* p, const rfw_point_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->point_lights.assign(l, l + n); return 0; }
+ORC_API int orc_set_spot_lights(void* p, const rfw_spot_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->spot_lights.assign(l, l + n); return 0; }
+ORC_API int orc_set_directional_lights(void* p, const rfw_directional_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->directional_lights.assign(l, l + n); return 0; }
+
+ORC_API int orc_set_option(void* p, const char* key, double value)
+{
+    Oracle& o = *(Oracle*)p;
+    const std::string k(key);
+    if (k == "max_path_length") o.max_path_length = (uint32_t)value;
+    else if (k == "clamp_value") o.clamp_value = (float)value;
+    else if (k == "nee") o.nee = value != 0.0;
+    else if (k == "tie_break") o.tie_break = value != 0.0;
+    else if (k == "threads") o.threads = value < 1 ? 1 : (int)value;
+    else if (k == "sample_count") o.sample_count = (uint32_t)value;
+    else if (k == "sky_r") o.sky.x = (float)value;
+    else if (k == "sky_g") o.sky.y = (float)value;
+    else if (k == "sky_b") o.sky.z = (float)value;
+    else return -1;
+    return 0;
+}
+
+static bool is_zero_matrix(const rfw_mat4& m)
+{
+    for (int i = 0; i < 16; i++) if (m.m[i] != 0.0f) return false;
+    return true;
+}
+
+// gpu-rt/src/lib.rs:1345-1383 (BLAS per mesh), :1387-1461 (flatten), :1576-1615 (TLAS + instance descriptors)
+ORC_API int orc_synchronize(void* p)
+{
+    Oracle& o = *(Oracle*)p;
+    o.all_tris.clear();
+    for (auto& kv : o.meshes) {
+        Mesh& m = kv.second;
+        m.tri_offset = (uint32_t)o.all_tris.size();
+        o.all_tris.insert(o.all_tris.end(), m.tris.begin(), m.tris.end());
+        if (m.bvh.nodes.empty()) {
+            std::vector<Box> boxes(m.tris.size());
+            std::vector<float> centers(3 * m.tris.size());
+            for (size_t i = 0; i < m.tris.size(); i++) {
+                const rfw_rt_triangle& t = m.tris[i];
+                boxes[i].reset();
+                boxes[i].grow(&t.vertex0.x);
+                boxes[i].grow(&t.vertex1.x);
+                boxes[i].grow(&t.vertex2.x);
+                // RTTriangle::center (crates/rfw-backend/src/structs.rs:985-988)
+                centers[3 * i + 0] = (t.vertex0.x + t.vertex1.x + t.vertex2.x) * (1.0f / 3.0f);
+                centers[3 * i + 1] = (t.vertex0.y + t.vertex1.y + t.vertex2.y) * (1.0f / 3.0f);
+                centers[3 * i + 2] = (t.vertex0.z + t.vertex1.z + t.vertex2.z) * (1.0f / 3.0f);
+            }
+            build_binned_sah(boxes, centers, m.bvh);
+            collapse_mbvh(m.bvh, m.mbvh);
+        }
+    }
+    // instances: global id = mesh_base[mesh] + slot over mesh ids in ascending order (D4)
+    o.instances.clear();
+    o.instance_global_id.clear();
+    o.global_to_desc.clear();
+    std::vector<Box> boxes;
+    std::vector<float> centers;
+    int32_t base = 0;
+    for (auto& kv : o.instance_lists) {
+        const uint32_t mesh_id = kv.first;
+        const InstanceList& l = kv.second;
+        const bool mesh_ok = o.meshes.count(mesh_id) && !o.meshes[mesh_id].tris.empty();
+        o.global_to_desc.resize(base + l.matrices.size(), -1);
+        for (size_t s = 0; s < l.matrices.size(); s++) {
+            if (!mesh_ok || is_zero_matrix(l.matrices[s])) continue; // removed slot (instances_3d.rs:79-86)
+            InstanceDescriptor d;
+            d.mesh = mesh_id;
+            d.meshp = &o.meshes[mesh_id];
+            std::memcpy(&d.matrix, &l.matrices[s], 64);
+            d.inverse = inverse(d.matrix);
+            d.normal = transpose(d.inverse);
+            // world bounds: the 8 corners of the mesh-local AABB through the matrix
+            Box b; b.reset();
+            for (int c = 0; c < 8; c++) {
+                const vec4 corner{(c & 1) ? l.local_aabb.max[0] : l.local_aabb.min[0], (c & 2) ? l.local_aabb.max[1] : l.local_aabb.min[1],
+                                  (c & 4) ? l.local_aabb.max[2] : l.local_aabb.min[2], 1.0f};
+                const vec4 w = mul(d.matrix, corner);
+                const float pt[3] = {w.x, w.y, w.z};
+                b.grow(pt);
+            }
+            o.global_to_desc[base + s] = (int32_t)o.instances.size();
+            o.instances.push_back(d);
+            o.instance_global_id.push_back(base + (int32_t)s);
+            boxes.push_back(b);
+            centers.push_back((b.mn[0] + b.mx[0]) * 0.5f);
+            centers.push_back((b.mn[1] + b.mx[1]) * 0.5f);
+            centers.push_back((b.mn[2] + b.mx[2]) * 0.5f);
+        }
+        base += (int32_t)l.matrices.size();
+    }
+    build_binned_sah(boxes, centers, o.top_bvh);
+    collapse_mbvh(o.top_bvh, o.top_mbvh);
+    return 0;
+}
+
+// gpu-rt/src/lib.rs:1685-1731 — one sample per pixel per call
+ORC_API int orc_render(void* p, const rfw_camera_view_3d* view)
+{
+    Oracle& o = *(Oracle*)p;
+    const rfw_camera_view_3d cam = *view;
+    const int nt = o.threads;
+    std::vector<Counters> cs(nt);
+    if (nt <= 1) {
+        render_rows(o, cam, 0, o.height, cs[0]);
+    } else {
+        std::atomic<uint32_t> next_row{0};
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; i++) {
+            th.emplace_back([&, i]() {
+                for (;;) {
+                    const uint32_t y0 = next_row.fetch_add(8);
+                    if (y0 >= o.height) break;
+                    const uint32_t y1 = y0 + 8 < o.height ? y0 + 8 : o.height;
+                    render_rows(o, cam, y0, y1, cs[i]);
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    for (auto& c : cs) o.counters.add(c);
+    o.sample_count += 1;
+    return 0;
+}
+ORC_API int orc_reset(void* p)
+{
+    Oracle& o = *(Oracle*)p;
+    o.sample_count = 0;
+    o.counters = Counters();
+    return 0;
+}
+ORC_API int orc_read_accumulator(void* p, float* rgba, uint64_t n_floats)
+{
+    Oracle& o = *(Oracle*)p;
+    if (n_floats != (uint64_t)o.acc.size() * 4) return -1;
+    std::memcpy(rgba, o.acc.data(), n_floats * 4);
+    return 0;
+}
+// blit.comp:15-23
+ORC_API int orc_read_framebuffer(void* p, float* rgba, uint64_t n_floats)
+{
+    Oracle& o = *(Oracle*)p;
+    if (n_floats != (uint64_t)o.acc.size() * 4) return -1;
+    // blit runs after sample_count += 1 with camera.sample_count = the pre-increment value (lib.rs:1695-1731)
+    const float n = (float)(int)(o.sample_count == 0 ? 1 : o.sample_count);
+    for (size_t i = 0; i < o.acc.size(); i++) {
+        rgba[4 * i + 0] = std::sqrt(o.acc[i].x * 1.0f / n);
+        rgba[4 * i + 1] = std::sqrt(o.acc[i].y * 1.0f / n);
+        rgba[4 * i + 2] = std::sqrt(o.acc[i].z * 1.0f / n);
+        rgba[4 * i + 3] = std::sqrt(o.acc[i].w * 1.0f / n);
+    }
+    return 0;
+}
+
+struct orc_hit { int32_t inst, tri; float t, u, v; };
+// TIntersector::intersect (crates/rfw-scene/src/intersector.rs:45-75); mode 0 = MBVH, 1 = brute force
+ORC_API int orc_intersect(void* p, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, orc_hit* hits, int mode)
+{
+    Oracle& o = *(Oracle*)p;
+    Counters c;
+    for (uint64_t i = 0; i < n; i++) {
+        const vec3 O = V3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        const vec3 D = V3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
+        float t = t_max, u = 0.0f, v = 0.0f;
+        int32_t hi, ht;
+        if (mode == 0) intersect_top_mbvh(o, O, D, t_min, t, u, v, hi, ht, c);
+        else intersect_brute(o, O, D, t_min, t, u, v, hi, ht);
+        hits[i].inst = hi; hits[i].tri = ht; hits[i].t = t; hits[i].u = u; hits[i].v = v;
+    }
+    o.counters.add(c);
+    return 0;
+}
+// TIntersector::occludes (crates/rfw-scene/src/intersector.rs:21-43)
+ORC_API int orc_occludes(void* p, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded, int mode)
+{
+    Oracle& o = *(Oracle*)p;
+    Counters c;
+    for (uint64_t i = 0; i < n; i++) {
+        const vec3 O = V3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        const vec3 D = V3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
+        const bool un = mode == 0 ? unoccluded_top_mbvh(o, O, D, t_min, t_max[i], c) : unoccluded_brute(o, O, D, t_min, t_max[i]);
+        occluded[i] = un ? 0 : 1;
+    }
+    o.counters.add(c);
+    return 0;
+}
+
+struct orc_stats {
+    uint64_t primary, extension, shadow, top_nodes, mesh_nodes, tris, instances;
+    uint64_t n_tris, n_instances, n_mesh_mbvh_nodes, n_top_mbvh_nodes;
+    uint32_t sample_count, pad;
+};
+ORC_API int orc_get_stats(void* p, orc_stats* s)
+{
+    Oracle& o = *(Oracle*)p;
+    s->primary = o.counters.primary; s->extension = o.counters.extension; s->shadow = o.counters.shadow;
+    s->top_nodes = o.counters.top_nodes; s->mesh_nodes = o.counters.mesh_nodes; s->tris = o.counters.tris; s->instances = o.counters.instances;
+    s->n_tris = o.all_tris.size(); s->n_instances = o.instances.size();
+    uint64_t mn = 0;
+    for (auto& kv : o.meshes) mn += kv.second.mbvh.nodes.size();
+    s->n_mesh_mbvh_nodes = mn; s->n_top_mbvh_nodes = o.top_mbvh.nodes.size();
+    s->sample_count = o.sample_count; s->pad = 0;
+    return 0;
+}
+
+// Primary rays only, as generated by ray_gen (for the ray-query parity tests): origins/directions n x 3
+ORC_API int orc_generate_primary_rays(void* p, const rfw_camera_view_3d* view, uint32_t sample, float* origins, float* directions)
+{
+    Oracle& o = *(Oracle*)p;
+    for (uint32_t id = 0; id < o.width * o.height; id++) {
+        uint32_t seed = wang_hash(id * 16789u + sample * 1791u);
+        vec3 O, D;
+        generate_eye_ray(*view, o.width, o.height, O, D, id, seed);
+        origins[3 * id] = O.x; origins[3 * id + 1] = O.y; origins[3 * id + 2] = O.z;
+        directions[3 * id] = D.x; directions[3 * id + 1] = D.y; directions[3 * id + 2] = D.z;
+    }
+    return 0;
+}
+
+// Export of the MBVH for structural tests: validates leaf coverage and containment.
+ORC_API int orc_validate_bvh(void* p, uint64_t* out_errors)
+{
+    Oracle& o = *(Oracle*)p;
+    uint64_t errors = 0;
+    for (auto& kv : o.meshes) {
+        const Mesh& m = kv.second;
+        std::vector<uint32_t> seen(m.tris.size(), 0);
+        if (m.mbvh.nodes.empty()) { if (!m.tris.empty()) errors++; continue; }
+        struct W { uint32_t node; Box box; };
+        std::vector<W> st;
+        Box inf; for (int i = 0; i < 3; i++) { inf.mn[i] = -1e34f; inf.mx[i] = 1e34f; }
+        st.push_back({0u, inf});
+        while (!st.empty()) {
+            W w = st.back(); st.pop_back();
+            const MBVHNode& n = m.mbvh.nodes[w.node];
+            for (int i = 0; i < 4; i++) {
+                if (n.children[i] < 0) continue;
+                Box cb;
+                cb.mn[0] = n.min_x[i]; cb.mn[1] = n.min_y[i]; cb.mn[2] = n.min_z[i];
+                cb.mx[0] = n.max_x[i]; cb.mx[1] = n.max_y[i]; cb.mx[2] = n.max_z[i];
+                for (int a = 0; a < 3; a++) if (cb.mn[a] < w.box.mn[a] || cb.mx[a] > w.box.mx[a]) errors++;
+                if (n.counts[i] >= 0) {
+                    for (int k = 0; k < n.counts[i]; k++) {
+                        const uint32_t prim = m.bvh.prim_indices[n.children[i] + k];
+                        seen[prim]++;
+                        const rfw_rt_triangle& t = m.tris[prim];
+                        const float* vs[3] = {&t.vertex0.x, &t.vertex1.x, &t.vertex2.x};
+                        for (int vv = 0; vv < 3; vv++)
+                            for (int a = 0; a < 3; a++) if (vs[vv][a] < cb.mn[a] || vs[vv][a] > cb.mx[a]) errors++;
+                    }
+                } else {
+                    st.push_back({(uint32_t)n.children[i], cb});
+                }
+            }
+        }
+        for (uint32_t s : seen) if (s != 1) errors++;
+    }
+    *out_errors = errors;
+    return 0;
+}
+
+// detmath evaluation for tests/test_detmath.py: fn 0 sin, 1 cos, 2 log, 3 exp, 4 acos, 5 atan2(y=in, x=in2), 6 log2, 7 asin
+ORC_API int orc_detmath_eval(int fn, const float* in, const float* in2, float* out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = rfw_sinf(in[i]); break;
+        case 1: out[i] = rfw_cosf(in[i]); break;
+        case 2: out[i] = rfw_logf(in[i]); break;
+        case 3: out[i] = rfw_expf(in[i]); break;
+        case 4: out[i] = rfw_acosf(in[i]); break;
+        case 5: out[i] = rfw_atan2f(in[i], in2[i]); break;
+        case 6: out[i] = rfw_log2f(in[i]); break;
+        case 7: out[i] = rfw_asinf(in[i]); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+// Known-answer helpers for tests/test_oracle_kat.py
+ORC_API uint32_t orc_wang_hash(uint32_t s) { return wang_hash(s); }
+ORC_API uint32_t orc_randi(uint32_t* s) { return randi(*s); }
+ORC_API float orc_randf(uint32_t* s) { return randf(*s); }
+ORC_API uint32_t orc_pack_normal(float x, float y, float z) { return PackNormal(V3(x, y, z)); }
+ORC_API void orc_unpack_normal(uint32_t p, float* out) { vec3 n = UnpackNormal(p); out[0] = n.x; out[1] = n.y; out[2] = n.z; }
+ORC_API void orc_safe_origin(const float* O, const float* R, const float* N, float* out)
+{
+    vec3 r = safe_origin(V3(O[0], O[1], O[2]), V3(R[0], R[1], R[2]), V3(N[0], N[1], N[2]), 1e-4f);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+ORC_API int orc_intersect_triangle(const rfw_rt_triangle* tri, const float* O, const float* D, float t_min, float t_max, float* tuv)
+{
+    float t = t_max, u = 0.0f, v = 0.0f;
+    const bool h = intersect_tri(*tri, V3(O[0], O[1], O[2]), V3(D[0], D[1], D[2]), t_min, t, u, v, false, false);
+    tuv[0] = t; tuv[1] = u; tuv[2] = v;
+    return h ? 1 : 0;
+}
+ORC_API void orc_mat4_inverse(const float* m, float* out)
+{
+    mat4 a; std::memcpy(&a, m, 64);
+    mat4 r = inverse(a);
+    std::memcpy(out, &r, 64);
+}

@@ -1,0 +1,253 @@
+"""Python mirror of the reference's plugin interface for the path — `rfw_backend::Backend`
+(crates/rfw-backend/src/lib.rs:35-82) — over the C ABI of include/rfw_hip.h.  Method names,
+argument meaning and order follow the trait; every method is one call into librfw_hip.so
+(hand-written HIP for gfx950).  There is no Python or CPU fallback: if the library is missing
+or no HIP device is present, construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import pod
+from .scene import BackendTable
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "librfw_hip.so")
+
+EXPORTS = [
+    "rfw_hip_create", "rfw_hip_destroy", "rfw_hip_last_error", "rfw_hip_abi_version",
+    "rfw_hip_set_2d_mesh", "rfw_hip_set_2d_instances", "rfw_hip_set_3d_mesh", "rfw_hip_unload_3d_meshes",
+    "rfw_hip_set_3d_instances", "rfw_hip_set_materials", "rfw_hip_set_textures", "rfw_hip_synchronize",
+    "rfw_hip_render", "rfw_hip_resize", "rfw_hip_set_point_lights", "rfw_hip_set_spot_lights",
+    "rfw_hip_set_area_lights", "rfw_hip_set_directional_lights", "rfw_hip_set_skybox", "rfw_hip_set_skins",
+    "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
+    "rfw_hip_get_frame_stats", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_device_synchronize",
+    "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
+    "rfw_hip_debug_read",
+]
+
+_lib = None
+
+
+def hip_lib():
+    """Load librfw_hip.so (loudly: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"HIP extension {HIP_LIB} is missing — build it with __graft_entry__.build(); there is no CPU fallback")
+        l = C.CDLL(HIP_LIB)
+        vp, u32, u64, f32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_char_p
+        l.rfw_hip_create.restype = vp
+        l.rfw_hip_create.argtypes = [u32, u32, C.c_double, C.POINTER(pod.HipOptions)]
+        l.rfw_hip_destroy.argtypes = [vp]
+        l.rfw_hip_destroy.restype = None
+        l.rfw_hip_last_error.argtypes = [vp]
+        l.rfw_hip_last_error.restype = cp
+        l.rfw_hip_abi_version.restype = u32
+        l.rfw_hip_set_2d_mesh.argtypes = [vp, u32, vp, u32, C.c_int32]
+        l.rfw_hip_set_2d_instances.argtypes = [vp, u32, vp, u32]
+        l.rfw_hip_set_3d_mesh.argtypes = [vp, u32, C.POINTER(pod.MeshData3D)]
+        l.rfw_hip_unload_3d_meshes.argtypes = [vp, C.POINTER(u32), u32]
+        l.rfw_hip_set_3d_instances.argtypes = [vp, u32, C.POINTER(pod.InstancesData3D)]
+        l.rfw_hip_set_materials.argtypes = [vp, vp, u32, vp]
+        l.rfw_hip_set_textures.argtypes = [vp, vp, u32, vp]
+        l.rfw_hip_synchronize.argtypes = [vp]
+        l.rfw_hip_render.argtypes = [vp, C.POINTER(pod.Mat4), C.POINTER(pod.CameraView3D), u32]
+        l.rfw_hip_resize.argtypes = [vp, u32, u32, C.c_double]
+        for n in ("point", "spot", "area", "directional"):
+            getattr(l, f"rfw_hip_set_{n}_lights").argtypes = [vp, vp, u32, vp]
+        l.rfw_hip_set_skybox.argtypes = [vp, C.POINTER(pod.TextureData)]
+        l.rfw_hip_set_skins.argtypes = [vp, vp, u32, vp]
+        l.rfw_hip_reset_accumulation.argtypes = [vp]
+        l.rfw_hip_set_option.argtypes = [vp, cp, C.c_double]
+        l.rfw_hip_read_framebuffer.argtypes = [vp, vp, u64]
+        l.rfw_hip_read_accumulator.argtypes = [vp, vp, u64]
+        l.rfw_hip_get_frame_stats.argtypes = [vp, C.POINTER(pod.FrameStats)]
+        l.rfw_hip_get_scene_stats.argtypes = [vp, C.POINTER(pod.SceneStats)]
+        l.rfw_hip_set_stream.argtypes = [vp, vp]
+        l.rfw_hip_device_synchronize.argtypes = [vp]
+        l.rfw_hip_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+        l.rfw_hip_set_slab_output.argtypes = [vp, vp]
+        l.rfw_hip_assemble_frame.argtypes = [vp, vp]
+        l.rfw_hip_intersect.argtypes = [vp, vp, vp, f32, f32, u64, vp]
+        l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
+        l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
+        _lib = l
+    return _lib
+
+
+HIT_DTYPE = np.dtype([("inst", "<i4"), ("tri", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class HipBackend:
+    """`impl Backend for HipBackend` — see crates/rfw-backend/src/lib.rs:35-82 for each method."""
+
+    @classmethod
+    def init(cls, width, height, scale=1.0, **options):
+        """FromWindowHandle::init(window, width, height, scale) — headless, the window handle is dropped."""
+        return cls(width, height, scale, **options)
+
+    def __init__(self, width, height, scale=1.0, device=-1, max_path_length=0, clamp_value=0.0, rank=0, world=1,
+                 tile_size=0, builder=pod.RFW_HIP_BUILDER_DEVICE_LBVH, flags=0):
+        self._l = hip_lib()
+        o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags)
+        h = self._l.rfw_hip_create(width, height, scale, C.byref(o))
+        if not h:
+            raise BackendError("rfw_hip_create failed: " + self._l.rfw_hip_last_error(None).decode())
+        self._h = C.c_void_p(h)
+        self.width, self.height = width, height
+        self.rank, self.world = rank, max(world, 1)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rfw_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return self._l.rfw_hip_last_error(self._h).decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(f"rfw_hip error {rc}: {self.last_error()}")
+
+    def table(self):
+        t = BackendTable()
+        t.instance = self._h
+        for name in ("set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
+                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights"):
+            setattr(t, name, C.cast(getattr(self._l, "rfw_hip_" + name), C.c_void_p))
+        return t
+
+    # ---- trait methods (same order as the trait) ----
+    def set_2d_mesh(self, id, data=None):
+        self._check(self._l.rfw_hip_set_2d_mesh(self._h, id, None, 0, -1))
+
+    def set_2d_instances(self, mesh, instances=None):
+        self._check(self._l.rfw_hip_set_2d_instances(self._h, mesh, None, 0))
+
+    def set_3d_mesh(self, id, data):
+        self._check(self._l.rfw_hip_set_3d_mesh(self._h, id, C.byref(data)))
+
+    def unload_3d_meshes(self, ids):
+        arr = (C.c_uint32 * len(ids))(*ids)
+        self._check(self._l.rfw_hip_unload_3d_meshes(self._h, arr, len(ids)))
+
+    def set_3d_instances(self, mesh, instances):
+        self._check(self._l.rfw_hip_set_3d_instances(self._h, mesh, C.byref(instances)))
+
+    def set_materials(self, materials, changed=None):
+        arr = (pod.DeviceMaterial * len(materials))(*materials)
+        self._check(self._l.rfw_hip_set_materials(self._h, arr, len(materials), None))
+
+    def set_textures(self, textures, changed=None):
+        arr = (pod.TextureData * len(textures))(*textures)
+        self._check(self._l.rfw_hip_set_textures(self._h, arr, len(textures), None))
+
+    def synchronize(self):
+        self._check(self._l.rfw_hip_synchronize(self._h))
+
+    def render(self, view_3d, view_2d=None, mode=0):
+        self._check(self._l.rfw_hip_render(self._h, None, C.byref(view_3d), mode))
+
+    def resize(self, window_size, scale_factor=1.0):
+        self._check(self._l.rfw_hip_resize(self._h, window_size[0], window_size[1], scale_factor))
+        self.width, self.height = window_size
+
+    def _set_lights(self, kind, ctype, lights):
+        arr = (ctype * len(lights))(*lights)
+        self._check(getattr(self._l, f"rfw_hip_set_{kind}_lights")(self._h, arr, len(lights), None))
+
+    def set_point_lights(self, lights, changed=None):
+        self._set_lights("point", pod.PointLight, lights)
+
+    def set_spot_lights(self, lights, changed=None):
+        self._set_lights("spot", pod.SpotLight, lights)
+
+    def set_area_lights(self, lights, changed=None):
+        self._set_lights("area", pod.AreaLight, lights)
+
+    def set_directional_lights(self, lights, changed=None):
+        self._set_lights("directional", pod.DirectionalLight, lights)
+
+    def set_skybox(self, skybox):
+        self._check(self._l.rfw_hip_set_skybox(self._h, C.byref(skybox)))
+
+    def set_skins(self, skins, changed=None):
+        self._check(self._l.rfw_hip_set_skins(self._h, None, 0, None))
+
+    # ---- extensions ----
+    def reset_accumulation(self):
+        self._check(self._l.rfw_hip_reset_accumulation(self._h))
+
+    def set_option(self, key, value):
+        self._check(self._l.rfw_hip_set_option(self._h, key.encode(), float(value)))
+
+    def framebuffer(self):
+        a = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._l.rfw_hip_read_framebuffer(self._h, a.ctypes.data, a.size))
+        return a
+
+    def accumulator(self):
+        a = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._l.rfw_hip_read_accumulator(self._h, a.ctypes.data, a.size))
+        return a
+
+    def frame_stats(self):
+        s = pod.FrameStats()
+        self._check(self._l.rfw_hip_get_frame_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in pod.FrameStats._fields_}
+
+    def scene_stats(self):
+        s = pod.SceneStats()
+        self._check(self._l.rfw_hip_get_scene_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in pod.SceneStats._fields_}
+
+    def set_stream(self, stream_handle):
+        self._check(self._l.rfw_hip_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def device_synchronize(self):
+        self._check(self._l.rfw_hip_device_synchronize(self._h))
+
+    def shard_info(self):
+        f, a, b = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self._l.rfw_hip_shard_info(self._h, C.byref(f), C.byref(a), C.byref(b)))
+        return {"slab_floats": int(f.value), "tiles_local": int(a.value), "tiles_total": int(b.value)}
+
+    def set_slab_output(self, device_ptr):
+        self._check(self._l.rfw_hip_set_slab_output(self._h, C.c_void_p(device_ptr)))
+
+    def assemble_frame(self, gathered_device_ptr):
+        self._check(self._l.rfw_hip_assemble_frame(self._h, C.c_void_p(gathered_device_ptr)))
+
+    def intersect(self, origins, directions, t_min=1e-4, t_max=1e26):
+        """TIntersector::intersect (crates/rfw-scene/src/intersector.rs:45-75) for a batch of rays."""
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32)
+        hits = np.empty(len(o), dtype=HIT_DTYPE)
+        self._check(self._l.rfw_hip_intersect(self._h, o.ctypes.data, d.ctypes.data, t_min, t_max, len(o), hits.ctypes.data))
+        return hits
+
+    def occludes(self, origins, directions, t_max, t_min=1e-3):
+        """TIntersector::occludes (crates/rfw-scene/src/intersector.rs:21-43) for a batch of rays."""
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32)
+        tm = np.ascontiguousarray(t_max, dtype=np.float32)
+        out = np.empty(len(o), dtype=np.uint8)
+        self._check(self._l.rfw_hip_occludes(self._h, o.ctypes.data, d.ctypes.data, t_min, tm.ctypes.data, len(o), out.ctypes.data))
+        return out
+
+    def debug_read(self, what, nbytes):
+        buf = np.empty(nbytes, dtype=np.uint8)
+        w = C.c_uint64(0)
+        self._check(self._l.rfw_hip_debug_read(self._h, what.encode(), buf.ctypes.data, nbytes, C.byref(w)))
+        return buf[: int(w.value)]

@@ -1,0 +1,1053 @@
+// rfw_host.cpp — scene-side inputs of the Backend boundary + synthetic scenes (see rfw_host.hpp).
+#include "rfw_host.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace rfw {
+
+namespace {
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a * (1.0f / length(a)); }
+inline rfw_vec3 pod(V3 a) { return rfw_vec3{a.x, a.y, a.z}; }
+inline V3 unpod(rfw_vec3 a) { return V3{a.x, a.y, a.z}; }
+
+inline void aabb_reset(rfw_aabb& b)
+{
+    for (int i = 0; i < 3; i++) { b.min[i] = 1e34f; b.max[i] = -1e34f; }
+    b.extra1 = 0; b.extra2 = 0;
+}
+inline void aabb_grow(rfw_aabb& b, V3 p)
+{
+    const float v[3] = {p.x, p.y, p.z};
+    for (int i = 0; i < 3; i++) { b.min[i] = std::min(b.min[i], v[i]); b.max[i] = std::max(b.max[i], v[i]); }
+}
+// crates/rfw-backend/src/structs.rs:970-984
+inline V3 tri_normal(V3 v0, V3 v1, V3 v2) { return normalize(cross(v1 - v0, v2 - v0)); }
+inline float tri_area(V3 v0, V3 v1, V3 v2)
+{
+    const float a = length(v1 - v0), b = length(v2 - v1), c = length(v0 - v2);
+    const float s = (a + b + c) * 0.5f;
+    return std::sqrt(s * (s - a) * (s - b) * (s - c));
+}
+inline V3 mul_point(const rfw_mat4& m, V3 p)
+{
+    return V3{m.m[0] * p.x + m.m[4] * p.y + m.m[8] * p.z + m.m[12], m.m[1] * p.x + m.m[5] * p.y + m.m[9] * p.z + m.m[13],
+              m.m[2] * p.x + m.m[6] * p.y + m.m[10] * p.z + m.m[14]};
+}
+struct Rng {
+    uint32_t s;
+    explicit Rng(uint32_t seed) : s(seed * 747796405u + 2891336453u) { next(); }
+    uint32_t next() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+    float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+    float range(float a, float b) { return a + (b - a) * uniform(); }
+};
+} // namespace
+
+// ------------------------------------------------------------------ materials
+rfw_device_material into_device_material(const Material& mat)
+{
+    auto to_char = [](float f) -> uint32_t { return (uint32_t)(uint8_t)std::min(f * 255.0f, 255.0f); };
+    auto to_u32 = [&](float a, float b, float c, float d) -> uint32_t { return to_char(a) | (to_char(b) << 8) | (to_char(c) << 16) | (to_char(d) << 24); };
+    rfw_device_material d;
+    std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.color, mat.color, 16);
+    std::memcpy(d.absorption, mat.absorption, 16);
+    std::memcpy(d.specular, mat.specular, 16);
+    d.parameters[0] = to_u32(mat.metallic, mat.subsurface, mat.specular_f, mat.roughness);
+    d.parameters[1] = to_u32(mat.specular_tint, mat.anisotropic, mat.sheen, mat.sheen_tint);
+    d.parameters[2] = to_u32(mat.clearcoat, mat.clearcoat_gloss, mat.transmission, mat.eta);
+    d.parameters[3] = to_u32(mat.custom0, mat.custom1, mat.custom2, mat.custom3);
+    uint32_t flags = 0;
+    if (mat.diffuse_tex >= 0) flags |= RFW_MAT_HAS_DIFFUSE_MAP;
+    if (mat.normal_tex >= 0) flags |= RFW_MAT_HAS_NORMAL_MAP;
+    if (mat.metallic_roughness_tex >= 0) flags |= RFW_MAT_HAS_ROUGHNESS_MAP | RFW_MAT_HAS_METALLIC_MAP;
+    if (mat.emissive_tex >= 0) flags |= RFW_MAT_HAS_EMISSIVE_MAP;
+    if (mat.sheen_tex >= 0) flags |= RFW_MAT_HAS_SHEEN_MAP;
+    d.flags = flags;
+    d.diffuse_map = mat.diffuse_tex;
+    d.normal_map = mat.normal_tex;
+    d.metallic_roughness_map = mat.metallic_roughness_tex;
+    d.emissive_map = mat.emissive_tex;
+    d.sheen_map = mat.sheen_tex;
+    return d;
+}
+bool is_emissive(const Material& m) { return m.color[0] > 1.0f || m.color[1] > 1.0f || m.color[2] > 1.0f; }
+
+// ------------------------------------------------------------------ Mesh3D::from(MeshDescriptor)
+Mesh3D Mesh3D::from(const MeshDescriptor& desc)
+{
+    Mesh3D out;
+    out.name = desc.name;
+    const size_t nv = desc.vertices.size();
+    const size_t nt = nv / 3;
+    aabb_reset(out.bounds);
+    auto P = [&](size_t i) { return v3(desc.vertices[i].x, desc.vertices[i].y, desc.vertices[i].z); };
+
+    std::vector<uint32_t> material_ids(nt);
+    for (size_t i = 0; i < nt; i++) material_ids[i] = (uint32_t)desc.material_ids[3 * i];
+
+    // objects_3d/mod.rs:680-711: generate area-weighted normals when the descriptor has none
+    std::vector<V3> normals(nv);
+    const bool gen = desc.normals.empty() || (desc.normals[0].x == 0.0f && desc.normals[0].y == 0.0f && desc.normals[0].z == 0.0f);
+    if (gen) {
+        for (size_t i = 0; i < nv; i += 3) {
+            const V3 v0 = P(i), v1 = P(i + 1), v2 = P(i + 2);
+            const V3 n = normalize(cross(v1 - v0, v2 - v0)) * tri_area(v0, v1, v2);
+            normals[i] = normalize(n);
+            normals[i + 1] = normalize(n);
+            normals[i + 2] = normalize(n);
+        }
+    } else {
+        for (size_t i = 0; i < nv; i++) normals[i] = unpod(desc.normals[i]);
+    }
+    for (size_t i = 0; i < nv; i++) aabb_grow(out.bounds, P(i));
+
+    out.vertices.resize(nv);
+    for (size_t i = 0; i < nv; i++) {
+        rfw_vertex_3d v;
+        std::memset(&v, 0, sizeof(v));
+        v.vertex = desc.vertices[i];
+        v.normal = pod(normals[i]);
+        v.mat_id = material_ids[i / 3];
+        v.uv = desc.uvs.empty() ? rfw_vec2{0, 0} : desc.uvs[i];
+        v.tangent = desc.tangents.empty() ? rfw_vec4{0, 0, 0, 0} : desc.tangents[i];
+        out.vertices[i] = v;
+    }
+
+    // objects_3d/mod.rs:733-785: one VertexMesh per run of equal material ids (first/last are vertex indices)
+    {
+        uint32_t start = 0;
+        rfw_aabb vb;
+        aabb_reset(vb);
+        for (size_t i = 0; i < nt; i++) {
+            if (i > 0 && material_ids[i] != material_ids[i - 1]) {
+                out.ranges.push_back(rfw_vertex_mesh{vb, start * 3, (uint32_t)i * 3, material_ids[i - 1], 0});
+                start = (uint32_t)i;
+                aabb_reset(vb);
+            }
+            for (int j = 0; j < 3; j++) aabb_grow(vb, P(3 * i + j));
+        }
+        if (nt > 0) out.ranges.push_back(rfw_vertex_mesh{vb, start * 3, (uint32_t)nt * 3, material_ids[nt - 1], 0});
+    }
+
+    // objects_3d/mod.rs:787-850
+    out.triangles.resize(nt);
+    for (size_t i = 0; i < nt; i++) {
+        const size_t i0 = 3 * i, i1 = i0 + 1, i2 = i0 + 2;
+        const V3 v0 = P(i0), v1 = P(i1), v2 = P(i2);
+        const rfw_vec2 uv0 = desc.uvs.empty() ? rfw_vec2{0, 0} : desc.uvs[i0];
+        const rfw_vec2 uv1 = desc.uvs.empty() ? rfw_vec2{0, 0} : desc.uvs[i1];
+        const rfw_vec2 uv2 = desc.uvs.empty() ? rfw_vec2{0, 0} : desc.uvs[i2];
+        const float ta = (float)(1024 * 1024) * std::fabs((uv1.x - uv0.x) * (uv2.y - uv0.y) - (uv2.x - uv0.x) * (uv1.y - uv0.y));
+        const float pa = length(cross(v1 - v0, v2 - v0));
+        float lod = std::sqrt(0.5f * std::log2(ta / pa));
+        if (!(lod > 0.0f)) lod = 0.0f; // 0.0_f32.max(NaN) == 0
+        rfw_rt_triangle t;
+        std::memset(&t, 0, sizeof(t));
+        t.vertex0 = pod(v0); t.u0 = uv0.x;
+        t.vertex1 = pod(v1); t.u1 = uv1.x;
+        t.vertex2 = pod(v2); t.u2 = uv2.x;
+        t.normal = pod(tri_normal(v0, v1, v2)); t.v0 = uv0.y;
+        t.n0 = pod(normals[i0]); t.v1 = uv1.y;
+        t.n1 = pod(normals[i1]); t.v2 = uv2.y;
+        t.n2 = pod(normals[i2]); t.id = (int32_t)i;
+        if (!desc.tangents.empty()) {
+            t.tangent0 = desc.tangents[i0];
+            t.tangent1 = desc.tangents[i1];
+            t.tangent2 = desc.tangents[i2]; // the reference reads tangents[i1] here (objects_3d/mod.rs:818) — not inherited
+        }
+        t.light_id = -1;
+        t.mat_id = (int32_t)material_ids[i];
+        t.lod = lod;
+        t.area = tri_area(v0, v1, v2);
+        out.triangles[i] = t;
+    }
+    out.materials = material_ids;
+    return out;
+}
+
+rfw_mesh_data_3d Mesh3D::as_data() const
+{
+    rfw_mesh_data_3d d;
+    std::memset(&d, 0, sizeof(d));
+    d.vertices = vertices.data(); d.num_vertices = (uint32_t)vertices.size();
+    d.triangles = triangles.data(); d.num_triangles = (uint32_t)triangles.size();
+    d.ranges = ranges.data(); d.num_ranges = (uint32_t)ranges.size();
+    d.skin_data = nullptr; d.num_skin_data = 0;
+    d.flags = flags;
+    d.bounds = bounds;
+    return d;
+}
+
+size_t InstanceList3D::allocate(const rfw_mat4& m)
+{
+    matrices.push_back(m);
+    skin_ids.push_back(-1);
+    flags.push_back(RFW_INSTANCE_TRANSFORMED);
+    return matrices.size() - 1;
+}
+void InstanceList3D::make_invalid(size_t slot)
+{
+    std::memset(&matrices[slot], 0, sizeof(rfw_mat4));
+    flags[slot] = RFW_INSTANCE_TRANSFORMED;
+}
+
+// ------------------------------------------------------------------ Camera3D::get_view (camera/mod.rs:77-115, 246-252)
+rfw_camera_view_3d Camera3D::get_view(uint32_t width, uint32_t height) const
+{
+    const float PI = 3.14159265358979323846f;
+    const V3 yup = v3(0, 1, 0);
+    const V3 z = normalize(v3(direction[0], direction[1], direction[2]));
+    const V3 x = normalize(cross(z, yup));
+    const V3 y = normalize(cross(x, z));
+    const V3 right = x, up = y, forward = z;
+    const V3 p = v3(pos[0], pos[1], pos[2]);
+    const float spread_angle = (fov * PI / 180.0f) * (1.0f / (float)height);
+    const float screen_size = std::tan(fov * 0.5f / (180.0f / PI));
+    const V3 center = p + focal_distance * forward;
+    const V3 p1 = center - screen_size * right * focal_distance * aspect_ratio + screen_size * focal_distance * up;
+    const V3 p2 = center + screen_size * right * focal_distance * aspect_ratio + screen_size * focal_distance * up;
+    const V3 p3 = center - screen_size * right * focal_distance * aspect_ratio - screen_size * focal_distance * up;
+    rfw_camera_view_3d v;
+    std::memset(&v, 0, sizeof(v));
+    v.pos = pod(p);
+    v.lens_size = aperture;
+    v.right = pod(p2 - p1);
+    v.p1 = pod(p1);
+    v.direction = pod(forward);
+    v.spread_angle = spread_angle;
+    v.up = pod(p3 - p1);
+    v.epsilon = 1e-4f; // crates/rfw-scene/src/constants.rs:1
+    v.inv_width = 1.0f / (float)width;
+    v.inv_height = 1.0f / (float)height;
+    v.aspect_ratio = aspect_ratio;
+    v.fov = fov * PI / 180.0f;
+    v.near_plane = near_plane;
+    v.far_plane = far_plane;
+    return v;
+}
+
+// ------------------------------------------------------------------ Scene
+uint32_t Scene::add_material(const Material& m)
+{
+    materials.push_back(m);
+    materials_changed = true;
+    return (uint32_t)materials.size() - 1;
+}
+uint32_t Scene::add_mesh(const Mesh3D& m)
+{
+    const uint32_t id = meshes_3d.empty() ? 0u : meshes_3d.rbegin()->first + 1;
+    meshes_3d[id] = m;
+    instances_3d[id];
+    mesh_changed[id] = true;
+    return id;
+}
+size_t Scene::add_instance(uint32_t mesh, const rfw_mat4& m)
+{
+    instances_changed[mesh] = true;
+    return instances_3d[mesh].allocate(m);
+}
+void Scene::set_matrix(uint32_t mesh, size_t slot, const rfw_mat4& m)
+{
+    instances_3d[mesh].matrices[slot] = m;
+    instances_3d[mesh].flags[slot] |= RFW_INSTANCE_TRANSFORMED;
+    instances_changed[mesh] = true;
+}
+std::vector<rfw_device_material> Scene::device_materials() const
+{
+    std::vector<rfw_device_material> d(materials.size());
+    for (size_t i = 0; i < materials.size(); i++) d[i] = into_device_material(materials[i]);
+    return d;
+}
+uint64_t Scene::triangle_count() const
+{
+    uint64_t n = 0;
+    for (auto& kv : meshes_3d) {
+        auto it = instances_3d.find(kv.first);
+        const uint64_t k = it == instances_3d.end() ? 0 : it->second.matrices.size();
+        n += (uint64_t)kv.second.triangles.size() * k;
+    }
+    return n;
+}
+
+// crates/rfw-scene/src/lib.rs:575-648: one AreaLight per emissive triangle per instance; light ids written back to the
+// mesh triangles.  Global instance numbering: mesh_base[mesh] + slot.
+void Scene::update_lights()
+{
+    area_lights.clear();
+    int32_t base = 0;
+    for (auto& kv : meshes_3d) {
+        Mesh3D& m = kv.second;
+        InstanceList3D& insts = instances_3d[kv.first];
+        for (size_t s = 0; s < insts.matrices.size(); s++) {
+            const rfw_mat4& transform = insts.matrices[s];
+            bool zero = true;
+            for (int i = 0; i < 16; i++) zero = zero && transform.m[i] == 0.0f;
+            if (zero) continue;
+            for (const rfw_vertex_mesh& r : m.ranges) {
+                if (r.mat_id >= materials.size() || !is_emissive(materials[r.mat_id])) continue;
+                // NOTE: the reference iterates triangle i but reads vertices[i], [i+1], [i+2] (lib.rs:601-607) — an
+                // indexing bug (vertex index, not 3*i); not inherited: triangle i is vertices 3i..3i+2.
+                for (uint32_t i = r.first / 3; i < r.last / 3; i++) {
+                    const V3 v0 = mul_point(transform, v3(m.vertices[3 * i].vertex.x, m.vertices[3 * i].vertex.y, m.vertices[3 * i].vertex.z));
+                    const V3 v1 = mul_point(transform, v3(m.vertices[3 * i + 1].vertex.x, m.vertices[3 * i + 1].vertex.y, m.vertices[3 * i + 1].vertex.z));
+                    const V3 v2 = mul_point(transform, v3(m.vertices[3 * i + 2].vertex.x, m.vertices[3 * i + 2].vertex.y, m.vertices[3 * i + 2].vertex.z));
+                    const Material& mat = materials[r.mat_id];
+                    // AreaLight::new (crates/rfw-backend/src/lights.rs:70-97)
+                    rfw_area_light al;
+                    std::memset(&al, 0, sizeof(al));
+                    const V3 radiance = v3(std::fabs(mat.color[0]), std::fabs(mat.color[1]), std::fabs(mat.color[2]));
+                    al.position = pod((v0 + v1 + v2) * (1.0f / 3.0f));
+                    al.energy = length(radiance);
+                    al.normal = pod(tri_normal(v0, v1, v2));
+                    al.area = tri_area(v0, v1, v2);
+                    al.vertex0 = pod(v0); al.inst_idx = base + (int32_t)s;
+                    al.vertex1 = pod(v1); al.mesh_id = (int32_t)kv.first;
+                    al.radiance = pod(radiance); al._dummy1 = 1;
+                    al.vertex2 = pod(v2); al._dummy2 = 2;
+                    m.triangles[i].light_id = (int32_t)area_lights.size();
+                    area_lights.push_back(al);
+                    mesh_changed[kv.first] = true;
+                }
+            }
+        }
+        base += (int32_t)insts.matrices.size();
+    }
+    lights_changed = true;
+}
+
+rfw_mat4 mat4_identity()
+{
+    rfw_mat4 m;
+    std::memset(&m, 0, sizeof(m));
+    m.m[0] = m.m[5] = m.m[10] = m.m[15] = 1.0f;
+    return m;
+}
+rfw_mat4 mat4_from_translation(float x, float y, float z)
+{
+    rfw_mat4 m = mat4_identity();
+    m.m[12] = x; m.m[13] = y; m.m[14] = z;
+    return m;
+}
+rfw_mat4 mat4_from_scale_translation(float s, float x, float y, float z)
+{
+    rfw_mat4 m = mat4_from_translation(x, y, z);
+    m.m[0] = m.m[5] = m.m[10] = s;
+    return m;
+}
+rfw_mat4 mat4_from_trs(const float t[3], const float axis_in[3], float angle, float scale)
+{
+    const V3 a = normalize(v3(axis_in[0], axis_in[1], axis_in[2]));
+    const float c = std::cos(angle), s = std::sin(angle), ic = 1.0f - c;
+    rfw_mat4 m = mat4_identity();
+    m.m[0] = (c + a.x * a.x * ic) * scale; m.m[1] = (a.y * a.x * ic + a.z * s) * scale; m.m[2] = (a.z * a.x * ic - a.y * s) * scale;
+    m.m[4] = (a.x * a.y * ic - a.z * s) * scale; m.m[5] = (c + a.y * a.y * ic) * scale; m.m[6] = (a.z * a.y * ic + a.x * s) * scale;
+    m.m[8] = (a.x * a.z * ic + a.y * s) * scale; m.m[9] = (a.y * a.z * ic - a.x * s) * scale; m.m[10] = (c + a.z * a.z * ic) * scale;
+    m.m[12] = t[0]; m.m[13] = t[1]; m.m[14] = t[2];
+    return m;
+}
+
+// ------------------------------------------------------------------ rfw/src/system/mod.rs:19-206
+void synchronize_system(Scene& scene, Backend& renderer)
+{
+    bool changed = false;
+    for (auto& kv : scene.meshes_3d) { // :63-76 changed meshes
+        if (!scene.mesh_changed[kv.first]) continue;
+        renderer.set_3d_mesh(kv.first, kv.second.as_data());
+        scene.mesh_changed[kv.first] = false;
+        changed = true;
+    }
+    for (auto& kv : scene.instances_3d) { // :82-112 instance lists with any flag set
+        if (!scene.instances_changed[kv.first]) continue;
+        auto mit = scene.meshes_3d.find(kv.first);
+        if (mit == scene.meshes_3d.end()) continue;
+        rfw_instances_data_3d d;
+        std::memset(&d, 0, sizeof(d));
+        d.local_aabb = mit->second.bounds;
+        d.matrices = kv.second.matrices.data(); d.num_matrices = (uint32_t)kv.second.matrices.size();
+        d.skin_ids = kv.second.skin_ids.data(); d.num_skin_ids = (uint32_t)kv.second.skin_ids.size();
+        d.flags = kv.second.flags.data(); d.num_flags = (uint32_t)kv.second.flags.size();
+        renderer.set_3d_instances(kv.first, d);
+        for (auto& f : kv.second.flags) f = 0;
+        scene.instances_changed[kv.first] = false;
+        changed = true;
+    }
+    if (scene.materials_changed) { // :138-147
+        renderer.set_materials(scene.device_materials(), nullptr);
+        scene.materials_changed = false;
+        changed = true;
+    }
+    if (scene.lights_changed) { // :159-190
+        renderer.set_point_lights(scene.point_lights, nullptr);
+        renderer.set_spot_lights(scene.spot_lights, nullptr);
+        renderer.set_area_lights(scene.area_lights, nullptr);
+        renderer.set_directional_lights(scene.directional_lights, nullptr);
+        scene.lights_changed = false;
+        changed = true;
+    }
+    if (changed) renderer.synchronize(); // :203-205
+}
+
+void render_system(const Camera3D& camera, uint32_t width, uint32_t height, Backend& renderer)
+{
+    const rfw_camera_view_3d view = camera.get_view(width, height);
+    renderer.render(mat4_identity(), view, RFW_RENDER_DEFAULT);
+}
+
+// ------------------------------------------------------------------ geometry helpers
+namespace {
+struct Builder {
+    MeshDescriptor d;
+    void tri(V3 a, V3 b, V3 c, int mat, rfw_vec2 ua = {0, 0}, rfw_vec2 ub = {1, 0}, rfw_vec2 uc = {0, 1})
+    {
+        const V3 e1 = b - a, e2 = c - a;
+        const V3 n = cross(e1, e2);
+        if (!(dot(n, n) > 1e-24f)) return; // skip degenerate
+        // tangent from uv derivatives (what l3d hands to MeshDescriptor.tangents), w = handedness
+        const float du1 = ub.x - ua.x, dv1 = ub.y - ua.y, du2 = uc.x - ua.x, dv2 = uc.y - ua.y;
+        float det = du1 * dv2 - du2 * dv1;
+        V3 t;
+        if (std::fabs(det) > 1e-12f) t = (e1 * dv2 - e2 * dv1) * (1.0f / det);
+        else t = e1;
+        if (!(dot(t, t) > 1e-24f)) t = e1;
+        t = normalize(t);
+        const rfw_vec4 tan4{t.x, t.y, t.z, 1.0f};
+        const V3 ps[3] = {a, b, c};
+        const rfw_vec2 us[3] = {ua, ub, uc};
+        for (int i = 0; i < 3; i++) {
+            d.vertices.push_back(rfw_vec4{ps[i].x, ps[i].y, ps[i].z, 1.0f});
+            d.normals.push_back(rfw_vec3{0, 0, 0});
+            d.uvs.push_back(us[i]);
+            d.tangents.push_back(tan4);
+            d.material_ids.push_back(mat);
+        }
+    }
+    void tri_n(V3 a, V3 b, V3 c, V3 na, V3 nb, V3 nc, int mat, rfw_vec2 ua, rfw_vec2 ub, rfw_vec2 uc)
+    {
+        const size_t before = d.vertices.size();
+        tri(a, b, c, mat, ua, ub, uc);
+        if (d.vertices.size() == before) return;
+        d.normals[before] = pod(na); d.normals[before + 1] = pod(nb); d.normals[before + 2] = pod(nc);
+    }
+    void quad(V3 a, V3 b, V3 c, V3 dd, int mat)
+    {
+        tri(a, b, c, mat, {0, 0}, {1, 0}, {1, 1});
+        tri(a, c, dd, mat, {0, 0}, {1, 1}, {0, 1});
+    }
+    // axis-aligned box with outward-facing normals
+    void box(V3 lo, V3 hi, int mat, const rfw_mat4* xf = nullptr)
+    {
+        V3 c[8];
+        for (int i = 0; i < 8; i++) {
+            c[i] = v3((i & 1) ? hi.x : lo.x, (i & 2) ? hi.y : lo.y, (i & 4) ? hi.z : lo.z);
+            if (xf) c[i] = mul_point(*xf, c[i]);
+        }
+        quad(c[0], c[2], c[3], c[1], mat); // -z
+        quad(c[4], c[5], c[7], c[6], mat); // +z
+        quad(c[0], c[4], c[6], c[2], mat); // -x
+        quad(c[1], c[3], c[7], c[5], mat); // +x
+        quad(c[0], c[1], c[5], c[4], mat); // -y
+        quad(c[2], c[6], c[7], c[3], mat); // +y
+    }
+    // parametric surface f(u,v) on [0,1]^2 tessellated nu x nv, smooth normals by finite differences when smooth=true
+    template <typename F> void surface(F f, int nu, int nv, int mat, bool flip = false)
+    {
+        nu = std::max(nu, 1); nv = std::max(nv, 1);
+        for (int j = 0; j < nv; j++) {
+            for (int i = 0; i < nu; i++) {
+                const float u0 = (float)i / nu, u1 = (float)(i + 1) / nu, v0 = (float)j / nv, v1 = (float)(j + 1) / nv;
+                const V3 a = f(u0, v0), b = f(u1, v0), c = f(u1, v1), dd = f(u0, v1);
+                if (!flip) {
+                    tri(a, b, c, mat, {u0, v0}, {u1, v0}, {u1, v1});
+                    tri(a, c, dd, mat, {u0, v0}, {u1, v1}, {u0, v1});
+                } else {
+                    tri(a, c, b, mat, {u0, v0}, {u1, v1}, {u1, v0});
+                    tri(a, dd, c, mat, {u0, v0}, {u0, v1}, {u1, v1});
+                }
+            }
+        }
+    }
+};
+
+float hash2(int x, int y, uint32_t seed)
+{
+    uint32_t h = (uint32_t)x * 374761393u + (uint32_t)y * 668265263u + seed * 2246822519u;
+    h = (h ^ (h >> 13)) * 1274126177u;
+    h ^= h >> 16;
+    return (float)(h & 0xffffff) * (1.0f / 16777216.0f);
+}
+float vnoise(float x, float y, uint32_t seed)
+{
+    const float fx = std::floor(x), fy = std::floor(y);
+    const int ix = (int)fx, iy = (int)fy;
+    float tx = x - fx, ty = y - fy;
+    tx = tx * tx * (3 - 2 * tx); ty = ty * ty * (3 - 2 * ty);
+    const float a = hash2(ix, iy, seed), b = hash2(ix + 1, iy, seed), c = hash2(ix, iy + 1, seed), d = hash2(ix + 1, iy + 1, seed);
+    return (a * (1 - tx) + b * tx) * (1 - ty) + (c * (1 - tx) + d * tx) * ty;
+}
+} // namespace
+
+MeshDescriptor make_icosphere(int quality, uint32_t mat_id)
+{
+    const float PI = 3.14159265358979323846f;
+    std::vector<V3> vertices;
+    std::vector<std::array<uint32_t, 3>> faces;
+    const float s = std::sqrt((5.0f - std::sqrt(5.0f)) / 10.0f), t = std::sqrt((5.0f + std::sqrt(5.0f)) / 10.0f);
+    auto add_vertex = [&](V3 v) { vertices.push_back(normalize(v)); return (uint32_t)vertices.size() - 1; };
+    add_vertex(v3(-s, t, 0)); add_vertex(v3(s, t, 0)); add_vertex(v3(-s, -t, 0)); add_vertex(v3(s, -t, 0));
+    add_vertex(v3(0, -s, t)); add_vertex(v3(0, s, t)); add_vertex(v3(0, -s, -t)); add_vertex(v3(0, s, -t));
+    add_vertex(v3(t, 0, -s)); add_vertex(v3(t, 0, s)); add_vertex(v3(-t, 0, -s)); add_vertex(v3(-t, 0, s));
+    const uint32_t f0[20][3] = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4}, {11, 10, 2}, {10, 7, 6}, {7, 1, 8},
+                                {3, 9, 4},  {3, 4, 2}, {3, 2, 6}, {3, 6, 8},  {3, 8, 9},   {4, 9, 5}, {2, 4, 11}, {6, 2, 10},  {8, 6, 7},  {9, 8, 1}};
+    for (auto& f : f0) faces.push_back({f[0], f[1], f[2]});
+    std::unordered_map<uint64_t, uint32_t> mid;
+    auto middle = [&](uint32_t a, uint32_t b) {
+        const uint64_t key = ((uint64_t)std::min(a, b) << 32) + std::max(a, b);
+        auto it = mid.find(key);
+        if (it != mid.end()) return it->second;
+        const uint32_t idx = add_vertex((vertices[a] + vertices[b]) * 0.5f);
+        mid[key] = idx;
+        return idx;
+    };
+    for (int q = 0; q < quality; q++) {
+        std::vector<std::array<uint32_t, 3>> nf;
+        nf.reserve(faces.size() * 4);
+        for (auto& f : faces) {
+            const uint32_t a = middle(f[0], f[1]), b = middle(f[1], f[2]), c = middle(f[2], f[0]);
+            nf.push_back({f[0], a, c}); nf.push_back({f[1], b, a}); nf.push_back({f[2], c, b}); nf.push_back({a, b, c});
+        }
+        faces.swap(nf);
+    }
+    MeshDescriptor d;
+    d.name = "sphere";
+    for (auto& f : faces) {
+        for (int k = 0; k < 3; k++) {
+            const V3 v = vertices[f[k]];
+            d.vertices.push_back(rfw_vec4{v.x, v.y, v.z, 1.0f});
+            d.normals.push_back(pod(v));
+            d.uvs.push_back(rfw_vec2{std::atan2(v.x, v.z) / (2.0f * PI) + 0.5f, v.y * 0.5f + 0.5f});
+            V3 tg = cross(v3(0, 1, 0), v);
+            if (!(dot(tg, tg) > 1e-12f)) tg = v3(1, 0, 0);
+            tg = normalize(tg);
+            d.tangents.push_back(rfw_vec4{tg.x, tg.y, tg.z, 1.0f});
+            d.material_ids.push_back((int32_t)mat_id);
+        }
+    }
+    return d;
+}
+
+// C1: Cornell box in [-1,1]^3, 36 triangles; materials from assets/models/cbox.mtl:4-40
+void build_cornell_box(Scene& scene, Camera3D& cam)
+{
+    Material khaki; khaki.color[0] = 0.8f; khaki.color[1] = 0.659f; khaki.color[2] = 0.44f; khaki.roughness = 1.0f; khaki.specular_f = 0.0f;
+    Material red = khaki; red.color[0] = 0.445f; red.color[1] = 0.0f; red.color[2] = 0.0f;
+    Material green = khaki; green.color[0] = 0.0f; green.color[1] = 0.32f; green.color[2] = 0.0f;
+    Material light = khaki; light.color[0] = 10.0f; light.color[1] = 10.0f; light.color[2] = 10.0f;
+    const int m_khaki = (int)scene.add_material(khaki), m_red = (int)scene.add_material(red), m_green = (int)scene.add_material(green),
+              m_light = (int)scene.add_material(light);
+    Builder b;
+    b.d.name = "cornell";
+    // inward-facing walls (camera at z = -3.4 looks along +z; the -z side is open)
+    b.quad(v3(-1, -1, -1), v3(-1, -1, 1), v3(1, -1, 1), v3(1, -1, -1), m_khaki); // floor, normal +y
+    b.quad(v3(-1, 1, -1), v3(1, 1, -1), v3(1, 1, 1), v3(-1, 1, 1), m_khaki);     // ceiling, normal -y
+    b.quad(v3(-1, -1, 1), v3(-1, 1, 1), v3(1, 1, 1), v3(1, -1, 1), m_khaki);     // back, normal -z
+    b.quad(v3(-1, -1, -1), v3(-1, 1, -1), v3(-1, 1, 1), v3(-1, -1, 1), m_red);   // left, normal +x
+    b.quad(v3(1, -1, -1), v3(1, -1, 1), v3(1, 1, 1), v3(1, 1, -1), m_green);     // right, normal -x
+    b.quad(v3(-0.25f, 0.995f, -0.25f), v3(0.25f, 0.995f, -0.25f), v3(0.25f, 0.995f, 0.25f), v3(-0.25f, 0.995f, 0.25f), m_light); // light, normal -y
+    const float t0[3] = {0.35f, -0.7f, -0.2f}, ax[3] = {0, 1, 0};
+    rfw_mat4 m_short = mat4_from_trs(t0, ax, -0.3f, 1.0f);
+    b.box(v3(-0.3f, -0.3f, -0.3f), v3(0.3f, 0.3f, 0.3f), m_khaki, &m_short);
+    const float t1[3] = {-0.35f, -0.4f, 0.35f};
+    rfw_mat4 m_tall = mat4_from_trs(t1, ax, 0.3f, 1.0f);
+    b.box(v3(-0.3f, -0.6f, -0.3f), v3(0.3f, 0.6f, 0.3f), m_khaki, &m_tall);
+    const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
+    scene.add_instance(mesh, mat4_identity());
+    scene.update_lights();
+    cam = Camera3D();
+    cam.pos[0] = 0; cam.pos[1] = 0; cam.pos[2] = -3.4f;
+    cam.direction[0] = 0; cam.direction[1] = 0; cam.direction[2] = 1;
+    cam.fov = 40.0f;
+    cam.aperture = 0.0f;
+}
+
+namespace {
+// atrium ("Sponza-class") pieces; `s` scales the tessellation of every part, triangle count ~ s^2
+void atrium_geometry(Builder& b, float s, uint32_t seed, const std::vector<int>& mats, int m_light)
+{
+    auto T = [&](float base) { return std::max(1, (int)std::lround(base * s)); };
+    const float X = 15.0f, Z = 6.0f, H = 12.0f;
+    const float PI = 3.14159265358979323846f;
+    int mi = 0;
+    auto next_mat = [&]() { return mats[(mi++) % mats.size()]; };
+    // floor with shallow relief (tiles)
+    b.surface([&](float u, float v) { const float x = -X + 2 * X * u, z = -Z + 2 * Z * v; return v3(x, 0.03f * vnoise(x * 2.0f, z * 2.0f, seed), z); },
+              T(60), T(24), next_mat(), true);
+    // long walls (z = +-Z) with brick relief, short walls (x = +-X)
+    for (int side = 0; side < 2; side++) {
+        const float zs = side ? Z : -Z;
+        const int m = next_mat();
+        b.surface([&](float u, float v) {
+            const float x = -X + 2 * X * u, y = H * v;
+            const float r = 0.05f * vnoise(x * 3.0f, y * 3.0f, seed + 7 + side);
+            return v3(x, y, zs + (side ? -r : r));
+        }, T(60), T(24), m, side == 0);
+        const float xs = side ? X : -X;
+        const int m2 = next_mat();
+        b.surface([&](float u, float v) {
+            const float z = -Z + 2 * Z * u, y = H * v;
+            const float r = 0.05f * vnoise(z * 3.0f, y * 3.0f, seed + 11 + side);
+            return v3(xs + (side ? -r : r), y, z);
+        }, T(24), T(24), m2, side == 1);
+    }
+    // ceiling ring around the open court (court: |x| < 10, |z| < 3)
+    {
+        const int m = next_mat();
+        b.surface([&](float u, float v) { return v3(-X + 2 * X * u, H, -Z + 3.0f * v); }, T(60), T(6), m, false);
+        b.surface([&](float u, float v) { return v3(-X + 2 * X * u, H, 3.0f + 3.0f * v); }, T(60), T(6), m, false);
+        b.surface([&](float u, float v) { return v3(-X + 5.0f * u, H, -3.0f + 6.0f * v); }, T(10), T(12), m, false);
+        b.surface([&](float u, float v) { return v3(10.0f + 5.0f * u, H, -3.0f + 6.0f * v); }, T(10), T(12), m, false);
+    }
+    // gallery slabs at y = 5 (top and underside)
+    {
+        const int m = next_mat();
+        for (int side = 0; side < 2; side++) {
+            const float z0 = side ? 3.0f : -Z, z1 = side ? Z : -3.0f;
+            b.surface([&](float u, float v) { return v3(-X + 2 * X * u, 5.0f, z0 + (z1 - z0) * v); }, T(60), T(6), m, true);
+            b.surface([&](float u, float v) { return v3(-X + 2 * X * u, 4.7f, z0 + (z1 - z0) * v); }, T(60), T(6), m, false);
+            const float zi = side ? 3.0f : -3.0f;
+            b.surface([&](float u, float v) { return v3(-X + 2 * X * u, 4.7f + 0.3f * v, zi); }, T(60), T(1), m, side == 1);
+        }
+    }
+    // columns: two rows x two storeys, fluted shafts
+    {
+        const int m_col = next_mat(), m_cap = next_mat();
+        for (int row = 0; row < 2; row++) {
+            const float zc = row ? 3.0f : -3.0f;
+            for (int k = 0; k < 9; k++) {
+                const float xc = -12.0f + 3.0f * k;
+                for (int storey = 0; storey < 2; storey++) {
+                    const float y0 = storey ? 5.0f : 0.0f, y1 = storey ? 9.5f : 4.7f;
+                    b.surface([&](float u, float v) {
+                        const float a = 2 * PI * u;
+                        const float flute = 1.0f + 0.04f * std::cos(a * 16.0f);
+                        const float taper = 1.0f - 0.12f * v;
+                        const float r = 0.33f * flute * taper;
+                        return v3(xc + r * std::cos(a), y0 + (y1 - y0) * v, zc + r * std::sin(a));
+                    }, T(40), T(12), m_col, true);
+                    // capital + base as boxes
+                    b.box(v3(xc - 0.45f, y1 - 0.25f, zc - 0.45f), v3(xc + 0.45f, y1, zc + 0.45f), m_cap);
+                    b.box(v3(xc - 0.45f, y0, zc - 0.45f), v3(xc + 0.45f, y0 + 0.2f, zc + 0.45f), m_cap);
+                }
+            }
+        }
+    }
+    // arches between ground-storey columns (half tori)
+    {
+        const int m = next_mat();
+        for (int row = 0; row < 2; row++) {
+            const float zc = row ? 3.0f : -3.0f;
+            for (int k = 0; k < 8; k++) {
+                const float xc = -10.5f + 3.0f * k;
+                b.surface([&](float u, float v) {
+                    const float a = PI * u, bb = 2 * PI * v;
+                    const float R = 1.17f, r = 0.18f;
+                    return v3(xc + (R + r * std::cos(bb)) * std::cos(a), 3.4f + (R + r * std::cos(bb)) * std::sin(a), zc + r * std::sin(bb));
+                }, T(24), T(10), m, false);
+            }
+        }
+    }
+    // drapes hanging from the upper gallery: sheets with folds (the dense, thin geometry Sponza is known for)
+    {
+        for (int k = 0; k < 8; k++) {
+            const int m = next_mat();
+            const float xc = -10.5f + 3.0f * k;
+            const float zc = (k & 1) ? 2.6f : -2.6f;
+            const float phase = hash2(k, 3, seed) * 6.28f;
+            b.surface([&](float u, float v) {
+                const float x = xc - 1.2f + 2.4f * u;
+                const float y = 9.3f - 3.8f * v;
+                const float fold = 0.12f * std::sin(u * 22.0f + phase) * (0.3f + v) + 0.05f * std::sin(v * 9.0f + u * 5.0f);
+                return v3(x, y, zc + fold);
+            }, T(56), T(64), m, (k & 1) != 0);
+        }
+    }
+    // balustrade: rows of small balusters along the gallery edge
+    {
+        const int m = next_mat();
+        for (int row = 0; row < 2; row++) {
+            const float zc = row ? 3.15f : -3.15f;
+            for (int k = 0; k < 96; k++) {
+                const float xc = -14.2f + 0.3f * k;
+                b.surface([&](float u, float v) {
+                    const float a = 2 * PI * u;
+                    const float r = 0.04f + 0.025f * std::sin(v * PI * 3.0f) * std::sin(v * PI);
+                    return v3(xc + r * std::cos(a), 5.0f + 0.9f * v, zc + r * std::sin(a));
+                }, T(8), T(6), m, true);
+            }
+            b.box(v3(-14.4f, 5.9f, zc - 0.08f), v3(14.4f, 6.0f, zc + 0.08f), m);
+        }
+    }
+    // clutter: vases (surfaces of revolution) and crates on the court floor
+    {
+        Rng rng(seed + 99);
+        for (int k = 0; k < 14; k++) {
+            const int m = next_mat();
+            const float xc = rng.range(-9.0f, 9.0f), zc = rng.range(-2.3f, 2.3f), sc = rng.range(0.5f, 1.1f);
+            if (k & 1) {
+                b.surface([&](float u, float v) {
+                    const float a = 2 * PI * u;
+                    const float r = sc * (0.18f + 0.22f * std::sin(v * PI) * (1.0f - 0.5f * v));
+                    return v3(xc + r * std::cos(a), 0.03f + sc * 1.1f * v, zc + r * std::sin(a));
+                }, T(24), T(16), m, true);
+            } else {
+                const float t[3] = {xc, 0.03f + 0.35f * sc, zc}, ax[3] = {0, 1, 0};
+                rfw_mat4 xf = mat4_from_trs(t, ax, rng.range(0, 3.0f), sc);
+                b.box(v3(-0.35f, -0.35f, -0.35f), v3(0.35f, 0.35f, 0.35f), m, &xf);
+            }
+        }
+    }
+    // two emissive panels under the ceiling ring (area lights)
+    b.quad(v3(-13.0f, H - 0.05f, -5.0f), v3(-11.0f, H - 0.05f, -5.0f), v3(-11.0f, H - 0.05f, -4.0f), v3(-13.0f, H - 0.05f, -4.0f), m_light);
+    b.quad(v3(11.0f, H - 0.05f, 4.0f), v3(13.0f, H - 0.05f, 4.0f), v3(13.0f, H - 0.05f, 5.0f), v3(11.0f, H - 0.05f, 5.0f), m_light);
+}
+} // namespace
+
+// C2 ("Sponza-class", target 262 267) and C4 (target ~1 048 576: atrium + 64 displaced icospheres)
+void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed)
+{
+    std::vector<int> mats;
+    Rng rng(seed);
+    for (int i = 0; i < 23; i++) {
+        Material m;
+        m.color[0] = rng.range(0.25f, 0.9f); m.color[1] = rng.range(0.25f, 0.9f); m.color[2] = rng.range(0.25f, 0.9f);
+        const float rough[] = {0.1f, 0.25f, 0.4f, 0.55f, 0.7f, 0.85f, 1.0f};
+        m.roughness = rough[i % 7];
+        m.metallic = (i % 5 == 4) ? 1.0f : 0.0f;
+        m.specular_f = 0.5f;
+        m.clearcoat = (i % 6 == 3) ? 0.5f : 0.0f;
+        mats.push_back((int)scene.add_material(m));
+    }
+    Material light; light.color[0] = 24.0f; light.color[1] = 22.0f; light.color[2] = 18.0f;
+    const int m_light = (int)scene.add_material(light);
+    Material sphere_mat; sphere_mat.color[0] = 0.8f; sphere_mat.color[1] = 0.75f; sphere_mat.color[2] = 0.6f; sphere_mat.roughness = 0.3f;
+    const int m_sphere = (int)scene.add_material(sphere_mat);
+
+    const bool with_spheres = target_triangles > 600000u;
+    const uint32_t sphere_tris = with_spheres ? 64u * 5120u : 0u;
+    const uint32_t atrium_target = target_triangles - sphere_tris;
+    // triangle count ~ s^2: secant iterations on s
+    float s = 1.0f;
+    size_t count = 0;
+    for (int it = 0; it < 6; it++) {
+        Builder probe;
+        atrium_geometry(probe, s, seed, mats, m_light);
+        count = probe.d.vertices.size() / 3;
+        const float ratio = (float)atrium_target / (float)count;
+        if (std::fabs(ratio - 1.0f) < 0.002f) break;
+        s *= std::sqrt(ratio);
+    }
+    Builder b;
+    b.d.name = "atrium";
+    atrium_geometry(b, s, seed, mats, m_light);
+    const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
+    scene.add_instance(mesh, mat4_identity());
+
+    if (with_spheres) {
+        // 64 displaced icospheres (Quality::VeryHigh = 5120 triangles each), baked into one static mesh
+        MeshDescriptor all;
+        all.name = "displaced-spheres";
+        const MeshDescriptor base = make_icosphere(4, (uint32_t)m_sphere);
+        Rng r2(seed + 5);
+        for (int k = 0; k < 64; k++) {
+            const float cx = -13.0f + 26.0f * ((k % 16) + 0.5f) / 16.0f, cz = ((k / 16) % 2 ? 4.6f : -4.6f), cy = (k / 32) ? 5.6f : 0.65f;
+            const float rad = 0.55f;
+            const uint32_t sd = seed + 1000 + k;
+            for (size_t i = 0; i < base.vertices.size(); i++) {
+                const V3 n = v3(base.vertices[i].x, base.vertices[i].y, base.vertices[i].z);
+                const float disp = 1.0f + 0.18f * vnoise(n.x * 4.0f + 10.0f, n.y * 4.0f + n.z * 3.0f + 10.0f, sd);
+                const V3 p = v3(cx, cy, cz) + n * (rad * disp);
+                all.vertices.push_back(rfw_vec4{p.x, p.y, p.z, 1.0f});
+                all.normals.push_back(rfw_vec3{0, 0, 0}); // regenerate: displacement changed the surface
+                all.uvs.push_back(base.uvs[i]);
+                all.tangents.push_back(base.tangents[i]);
+                all.material_ids.push_back(mats[(k * 7) % mats.size()]);
+            }
+        }
+        (void)r2;
+        const uint32_t m2 = scene.add_mesh(Mesh3D::from(all));
+        scene.add_instance(m2, mat4_identity());
+    }
+    // sun through the open court
+    rfw_directional_light sun;
+    std::memset(&sun, 0, sizeof(sun));
+    const V3 dir = normalize(v3(0.25f, -1.0f, 0.18f));
+    sun.direction = pod(dir);
+    sun.radiance = rfw_vec3{6.0f, 5.6f, 5.0f};
+    sun.energy = length(v3(6.0f, 5.6f, 5.0f));
+    scene.directional_lights.push_back(sun);
+    scene.update_lights();
+
+    cam = Camera3D();
+    cam.pos[0] = -13.0f; cam.pos[1] = 2.2f; cam.pos[2] = 0.4f;
+    const V3 d = normalize(v3(1.0f, 0.12f, -0.03f));
+    cam.direction[0] = d.x; cam.direction[1] = d.y; cam.direction[2] = d.z;
+    cam.fov = 60.0f;
+    cam.aperture = 0.0f;
+    cam.aspect_ratio = 1920.0f / 1080.0f;
+}
+
+// C3: nx*nz instances of the 320-triangle icosphere on a grid (examples/animated/src/main.rs:35-118)
+void add_sphere_grid(Scene& scene, uint32_t nx, uint32_t nz, float spacing)
+{
+    Material m; m.color[0] = 0.9f; m.color[1] = 0.3f; m.color[2] = 0.25f; m.roughness = 0.4f;
+    const uint32_t mat = scene.add_material(m);
+    const uint32_t mesh = scene.add_mesh(Mesh3D::from(make_icosphere(2, mat)));
+    for (uint32_t x = 0; x < nx; x++)
+        for (uint32_t z = 0; z < nz; z++) scene.add_instance(mesh, mat4_identity());
+    animate_sphere_grid(scene, mesh, nx, nz, spacing, 0.0f);
+}
+// examples/animated/src/main.rs:197-219: y = 0.3 + ((sin(x + t) + sin(z + t)) * 0.5 + 1)
+void animate_sphere_grid(Scene& scene, uint32_t mesh, uint32_t nx, uint32_t nz, float spacing, float time)
+{
+    const float r = 0.4f * spacing;
+    for (uint32_t x = 0; x < nx; x++) {
+        for (uint32_t z = 0; z < nz; z++) {
+            const float px = ((float)x - 0.5f * (float)(nx - 1)) * spacing;
+            const float pz = ((float)z - 0.5f * (float)(nz - 1)) * spacing;
+            const float height = (std::sin((float)x + time) + std::sin((float)z + time)) * 0.5f + 1.0f;
+            scene.set_matrix(mesh, (size_t)x * nz + z, mat4_from_scale_translation(r, px, 0.3f + height * spacing, pz));
+        }
+    }
+}
+
+// random triangle soups + transformed instances: the BVH-vs-brute-force and CPU-vs-GPU equivalence inputs
+void build_soup(Scene& scene, Camera3D& cam, uint32_t triangles, uint32_t instances, uint32_t seed)
+{
+    Rng rng(seed);
+    std::vector<int> mats;
+    for (int i = 0; i < 6; i++) {
+        Material m;
+        m.color[0] = rng.range(0.2f, 0.95f); m.color[1] = rng.range(0.2f, 0.95f); m.color[2] = rng.range(0.2f, 0.95f);
+        m.roughness = rng.range(0.05f, 1.0f);
+        m.metallic = (i == 2) ? 1.0f : 0.0f;
+        m.subsurface = (i == 3) ? 0.4f : 0.0f;
+        m.clearcoat = (i == 4) ? 1.0f : 0.0f;
+        m.transmission = (i == 5) ? 0.6f : 0.0f;
+        m.eta = (i == 5) ? 0.66f : 1.0f;
+        if (i == 5) { m.absorption[0] = 0.2f; m.absorption[1] = 0.05f; m.absorption[2] = 0.4f; }
+        mats.push_back((int)scene.add_material(m));
+    }
+    Material light; light.color[0] = 12.0f; light.color[1] = 11.0f; light.color[2] = 9.0f;
+    const int m_light = (int)scene.add_material(light);
+    Builder b;
+    b.d.name = "soup";
+    for (uint32_t i = 0; i < triangles; i++) {
+        const V3 c = v3(rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1));
+        const float sz = rng.range(0.02f, 0.35f);
+        const V3 p0 = c + v3(rng.range(-sz, sz), rng.range(-sz, sz), rng.range(-sz, sz));
+        const V3 p1 = c + v3(rng.range(-sz, sz), rng.range(-sz, sz), rng.range(-sz, sz));
+        const V3 p2 = c + v3(rng.range(-sz, sz), rng.range(-sz, sz), rng.range(-sz, sz));
+        b.tri(p0, p1, p2, (i % 37 == 0) ? m_light : mats[i % mats.size()]);
+    }
+    // a few exactly shared edges / coplanar duplicates to exercise the tie rule
+    b.quad(v3(-1.5f, -1.2f, -1.5f), v3(-1.5f, -1.2f, 1.5f), v3(1.5f, -1.2f, 1.5f), v3(1.5f, -1.2f, -1.5f), mats[0]);
+    b.quad(v3(-0.5f, -1.2f, -0.5f), v3(-0.5f, -1.2f, 0.5f), v3(0.5f, -1.2f, 0.5f), v3(0.5f, -1.2f, -0.5f), mats[1]);
+    const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
+    scene.add_instance(mesh, mat4_identity());
+    for (uint32_t k = 1; k < instances; k++) {
+        const float t[3] = {rng.range(-3, 3), rng.range(-1, 2), rng.range(-3, 3)};
+        const float ax[3] = {rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1) + 1.5f};
+        scene.add_instance(mesh, mat4_from_trs(t, ax, rng.range(0, 6.28f), rng.range(0.3f, 1.4f)));
+    }
+    rfw_point_light pl;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.position = rfw_vec3{0.5f, 3.5f, -2.0f};
+    pl.radiance = rfw_vec3{20, 20, 20};
+    pl.energy = length(v3(20, 20, 20));
+    scene.point_lights.push_back(pl);
+    rfw_spot_light sl;
+    std::memset(&sl, 0, sizeof(sl));
+    sl.position = rfw_vec3{-3.0f, 4.0f, -3.0f};
+    const V3 sd = normalize(v3(0.6f, -0.8f, 0.6f));
+    sl.direction = pod(sd);
+    sl.radiance = rfw_vec3{30, 28, 25};
+    sl.energy = length(v3(30, 28, 25));
+    sl.cos_inner = 0.92f; sl.cos_outer = 0.8f;
+    scene.spot_lights.push_back(sl);
+    scene.update_lights();
+    cam = Camera3D();
+    cam.pos[0] = 0.3f; cam.pos[1] = 0.8f; cam.pos[2] = -6.5f;
+    const V3 d = normalize(v3(-0.03f, -0.08f, 1.0f));
+    cam.direction[0] = d.x; cam.direction[1] = d.y; cam.direction[2] = d.z;
+    cam.fov = 55.0f;
+    cam.aperture = 0.02f; // thin lens: exercises the 9-blade aperture code
+    cam.focal_distance = 1.0f;
+}
+
+} // namespace rfw
+
+// ==================================================================== C exports (for the Python tests / bench)
+#define HOST_API extern "C" __attribute__((visibility("default")))
+namespace {
+struct HostScene {
+    rfw::Scene scene;
+    rfw::Camera3D cam;
+    std::vector<rfw_device_material> dev_mats;
+    uint32_t grid_mesh = 0, grid_nx = 0, grid_nz = 0;
+    float grid_spacing = 1.0f;
+};
+// Backend over a table of C function pointers with the rfw_hip_* signatures: lets the tests drive the product
+// library and the oracle through the SAME synchronize_system.
+struct rfwhost_backend_table {
+    void* instance;
+    int (*set_3d_mesh)(void*, uint32_t, const rfw_mesh_data_3d*);
+    int (*unload_3d_meshes)(void*, const uint32_t*, uint32_t);
+    int (*set_3d_instances)(void*, uint32_t, const rfw_instances_data_3d*);
+    int (*set_materials)(void*, const rfw_device_material*, uint32_t, const uint32_t*);
+    int (*synchronize)(void*);
+    int (*set_point_lights)(void*, const rfw_point_light*, uint32_t, const uint32_t*);
+    int (*set_spot_lights)(void*, const rfw_spot_light*, uint32_t, const uint32_t*);
+    int (*set_area_lights)(void*, const rfw_area_light*, uint32_t, const uint32_t*);
+    int (*set_directional_lights)(void*, const rfw_directional_light*, uint32_t, const uint32_t*);
+};
+struct TableBackend : rfw::Backend {
+    rfwhost_backend_table t;
+    int rc = 0;
+    void acc(int r) { if (r != 0 && rc == 0) rc = r; }
+    void set_2d_mesh(size_t, const void*, uint32_t, int32_t) override {}
+    void set_2d_instances(size_t, const rfw_mat4*, uint32_t) override {}
+    void set_3d_mesh(size_t id, const rfw_mesh_data_3d& d) override { acc(t.set_3d_mesh(t.instance, (uint32_t)id, &d)); }
+    void unload_3d_meshes(const std::vector<size_t>& ids) override
+    {
+        std::vector<uint32_t> v(ids.begin(), ids.end());
+        acc(t.unload_3d_meshes(t.instance, v.data(), (uint32_t)v.size()));
+    }
+    void set_3d_instances(size_t mesh, const rfw_instances_data_3d& d) override { acc(t.set_3d_instances(t.instance, (uint32_t)mesh, &d)); }
+    void set_materials(const std::vector<rfw_device_material>& m, const std::vector<uint32_t>*) override
+    {
+        acc(t.set_materials(t.instance, m.data(), (uint32_t)m.size(), nullptr));
+    }
+    void set_textures(const std::vector<rfw_texture_data>&, const std::vector<uint32_t>*) override {}
+    void synchronize() override { acc(t.synchronize(t.instance)); }
+    void render(const rfw_mat4&, const rfw_camera_view_3d&, uint32_t) override {}
+    void resize(uint32_t, uint32_t, double) override {}
+    void set_point_lights(const std::vector<rfw_point_light>& l, const std::vector<uint32_t>*) override
+    {
+        acc(t.set_point_lights(t.instance, l.data(), (uint32_t)l.size(), nullptr));
+    }
+    void set_spot_lights(const std::vector<rfw_spot_light>& l, const std::vector<uint32_t>*) override
+    {
+        acc(t.set_spot_lights(t.instance, l.data(), (uint32_t)l.size(), nullptr));
+    }
+    void set_area_lights(const std::vector<rfw_area_light>& l, const std::vector<uint32_t>*) override
+    {
+        acc(t.set_area_lights(t.instance, l.data(), (uint32_t)l.size(), nullptr));
+    }
+    void set_directional_lights(const std::vector<rfw_directional_light>& l, const std::vector<uint32_t>*) override
+    {
+        acc(t.set_directional_lights(t.instance, l.data(), (uint32_t)l.size(), nullptr));
+    }
+    void set_skybox(const rfw_texture_data&) override {}
+    void set_skins(const std::vector<rfw_skin_data>&, const std::vector<uint32_t>*) override {}
+};
+} // namespace
+
+HOST_API void* rfwhost_scene_create() { return new HostScene(); }
+HOST_API void rfwhost_scene_destroy(void* p) { delete (HostScene*)p; }
+// kind: "cornell" | "atrium" (a = target triangles) | "soup" (a = triangles, b = instances) | "spheres" (adds a x b animated grid, spacing c)
+HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, float c, uint32_t seed)
+{
+    HostScene& h = *(HostScene*)p;
+    const std::string k(kind);
+    if (k == "cornell") rfw::build_cornell_box(h.scene, h.cam);
+    else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed);
+    else if (k == "soup") rfw::build_soup(h.scene, h.cam, a, b, seed);
+    else if (k == "spheres") {
+        rfw::add_sphere_grid(h.scene, a, b, c);
+        h.grid_mesh = h.scene.meshes_3d.rbegin()->first;
+        h.grid_nx = a; h.grid_nz = b; h.grid_spacing = c;
+    } else return -1;
+    return 0;
+}
+HOST_API int rfwhost_animate(void* p, float time)
+{
+    HostScene& h = *(HostScene*)p;
+    if (h.grid_nx == 0) return -1;
+    rfw::animate_sphere_grid(h.scene, h.grid_mesh, h.grid_nx, h.grid_nz, h.grid_spacing, time);
+    return 0;
+}
+HOST_API int rfwhost_set_camera(void* p, const float* pos, const float* dir, float fov, float aperture, float aspect)
+{
+    HostScene& h = *(HostScene*)p;
+    for (int i = 0; i < 3; i++) { h.cam.pos[i] = pos[i]; h.cam.direction[i] = dir[i]; }
+    h.cam.fov = fov; h.cam.aperture = aperture; h.cam.aspect_ratio = aspect;
+    return 0;
+}
+HOST_API int rfwhost_set_aspect(void* p, float aspect) { ((HostScene*)p)->cam.aspect_ratio = aspect; return 0; }
+HOST_API int rfwhost_camera_view(void* p, uint32_t w, uint32_t h, rfw_camera_view_3d* out) { *out = ((HostScene*)p)->cam.get_view(w, h); return 0; }
+HOST_API int rfwhost_mark_all_changed(void* p)
+{
+    HostScene& h = *(HostScene*)p;
+    for (auto& kv : h.scene.meshes_3d) h.scene.mesh_changed[kv.first] = true;
+    for (auto& kv : h.scene.instances_3d) h.scene.instances_changed[kv.first] = true;
+    h.scene.materials_changed = true;
+    h.scene.lights_changed = true;
+    return 0;
+}
+// runs rfw::synchronize_system against a table of C entry points (rfw_hip_* or orc_*)
+HOST_API int rfwhost_synchronize(void* p, const rfwhost_backend_table* table)
+{
+    HostScene& h = *(HostScene*)p;
+    TableBackend b;
+    b.t = *table;
+    rfw::synchronize_system(h.scene, b);
+    return b.rc;
+}
+HOST_API uint64_t rfwhost_triangle_count(void* p) { return ((HostScene*)p)->scene.triangle_count(); }
+HOST_API uint32_t rfwhost_counts(void* p, uint32_t what)
+{
+    HostScene& h = *(HostScene*)p;
+    switch (what) {
+    case 0: return (uint32_t)h.scene.meshes_3d.size();
+    case 1: { uint32_t n = 0; for (auto& kv : h.scene.instances_3d) n += (uint32_t)kv.second.matrices.size(); return n; }
+    case 2: return (uint32_t)h.scene.materials.size();
+    case 3: return (uint32_t)h.scene.area_lights.size();
+    case 4: return (uint32_t)h.scene.point_lights.size();
+    case 5: return (uint32_t)h.scene.spot_lights.size();
+    case 6: return (uint32_t)h.scene.directional_lights.size();
+    default: return 0;
+    }
+}
+HOST_API int rfwhost_mesh_data(void* p, uint32_t id, rfw_mesh_data_3d* out)
+{
+    HostScene& h = *(HostScene*)p;
+    auto it = h.scene.meshes_3d.find(id);
+    if (it == h.scene.meshes_3d.end()) return -1;
+    *out = it->second.as_data();
+    return 0;
+}
+HOST_API int rfwhost_into_device_material(const float* color, const float* params16, rfw_device_material* out)
+{
+    rfw::Material m;
+    for (int i = 0; i < 4; i++) m.color[i] = color[i];
+    m.metallic = params16[0]; m.subsurface = params16[1]; m.specular_f = params16[2]; m.roughness = params16[3];
+    m.specular_tint = params16[4]; m.anisotropic = params16[5]; m.sheen = params16[6]; m.sheen_tint = params16[7];
+    m.clearcoat = params16[8]; m.clearcoat_gloss = params16[9]; m.transmission = params16[10]; m.eta = params16[11];
+    m.custom0 = params16[12]; m.custom1 = params16[13]; m.custom2 = params16[14]; m.custom3 = params16[15];
+    *out = rfw::into_device_material(m);
+    return 0;
+}

@@ -1,0 +1,112 @@
+"""Bindings of the C++ host library (rfw-rs_amd/host/librfw_host.so): scene-side inputs of the
+Backend boundary (Mesh3D::from, into_device_material, update_lights, Camera3D::get_view,
+synchronize_system) and the synthetic scenes standing in for the assets the reference lacks."""
+import ctypes as C
+import os
+
+from . import pod
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(_HERE, "host", "librfw_host.so")
+
+
+class BackendTable(C.Structure):
+    """Table of C entry points with the rfw_hip_* signatures (see rfw_host.cpp rfwhost_backend_table)."""
+    _fields_ = [("instance", C.c_void_p)] + [(n, C.c_void_p) for n in (
+        "set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
+        "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights")]
+
+
+_lib = None
+
+
+def host_lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+        l = C.CDLL(HOST_LIB)
+        l.rfwhost_scene_create.restype = C.c_void_p
+        l.rfwhost_scene_destroy.argtypes = [C.c_void_p]
+        l.rfwhost_build.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
+        l.rfwhost_animate.argtypes = [C.c_void_p, C.c_float]
+        l.rfwhost_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]
+        l.rfwhost_set_aspect.argtypes = [C.c_void_p, C.c_float]
+        l.rfwhost_camera_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(pod.CameraView3D)]
+        l.rfwhost_mark_all_changed.argtypes = [C.c_void_p]
+        l.rfwhost_synchronize.argtypes = [C.c_void_p, C.POINTER(BackendTable)]
+        l.rfwhost_triangle_count.argtypes = [C.c_void_p]
+        l.rfwhost_triangle_count.restype = C.c_uint64
+        l.rfwhost_counts.argtypes = [C.c_void_p, C.c_uint32]
+        l.rfwhost_counts.restype = C.c_uint32
+        l.rfwhost_mesh_data.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(pod.MeshData3D)]
+        l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
+        _lib = l
+    return _lib
+
+
+class Scene:
+    """A host-side scene (rfw::Scene + Camera3D).  `sync(backend)` runs rfw::synchronize_system against any
+    object exposing `.table()` (the product's HipBackend, or the oracle binding used by the tests)."""
+
+    def __init__(self):
+        self._l = host_lib()
+        self._h = C.c_void_p(self._l.rfwhost_scene_create())
+
+    def __del__(self):
+        try:
+            self._l.rfwhost_scene_destroy(self._h)
+        except Exception:
+            pass
+
+    def build(self, kind, a=0, b=0, c=0.0, seed=1):
+        rc = self._l.rfwhost_build(self._h, kind.encode(), a, b, c, seed)
+        if rc != 0:
+            raise ValueError(f"unknown scene kind {kind}")
+        return self
+
+    def animate(self, time):
+        if self._l.rfwhost_animate(self._h, time) != 0:
+            raise RuntimeError("scene has no animated instance grid")
+
+    def set_camera(self, pos, direction, fov=40.0, aperture=0.0, aspect=1.0):
+        p = (C.c_float * 3)(*pos)
+        d = (C.c_float * 3)(*direction)
+        self._l.rfwhost_set_camera(self._h, p, d, fov, aperture, aspect)
+
+    def set_aspect(self, aspect):
+        self._l.rfwhost_set_aspect(self._h, aspect)
+
+    def view(self, width, height):
+        v = pod.CameraView3D()
+        self._l.rfwhost_camera_view(self._h, width, height, C.byref(v))
+        return v
+
+    def mark_all_changed(self):
+        self._l.rfwhost_mark_all_changed(self._h)
+
+    def sync(self, backend):
+        t = backend.table()
+        rc = self._l.rfwhost_synchronize(self._h, C.byref(t))
+        if rc != 0:
+            raise RuntimeError(f"synchronize_system failed: {backend.last_error()}")
+
+    @property
+    def triangle_count(self):
+        return int(self._l.rfwhost_triangle_count(self._h))
+
+    def counts(self):
+        names = ["meshes", "instances", "materials", "area_lights", "point_lights", "spot_lights", "directional_lights"]
+        return {n: int(self._l.rfwhost_counts(self._h, i)) for i, n in enumerate(names)}
+
+    def mesh_data(self, mesh_id):
+        d = pod.MeshData3D()
+        if self._l.rfwhost_mesh_data(self._h, mesh_id, C.byref(d)) != 0:
+            raise KeyError(mesh_id)
+        return d
+
+
+def into_device_material(color, params16):
+    out = pod.DeviceMaterial()
+    host_lib().rfwhost_into_device_material((C.c_float * 4)(*color), (C.c_float * 16)(*params16), C.byref(out))
+    return out
