@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (primary + shadow, 1 spp) of the hot path on N MI355X (contract in the task statement).
+
+A step = one render() of one 1920x1080 frame of the ~1M-triangle synthetic atrium scene (the configuration the
+metric's target is quoted on, BASELINE.json north_star; SURVEY.md §8d C4 geometry, primary + shadow rays), all
+inputs resident in HBM.  For N > 1 the frame is sharded by 64x64 tiles across ranks and the accumulator slabs are
+all-gathered with RCCL once per frame (strong scaling: the frame is fixed)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    from rfw_rs_amd import HipBackend, Scene
+
+    w, h = args.width, args.height
+    tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0}[args.workload]
+    scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 0, 0.0, 0xC0FFEE)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=1, rank=rank, world=world)
+    stream = torch.cuda.current_stream()
+    be.set_stream(stream.cuda_stream)
+    t0 = time.time()
+    scene.sync(be)
+    sync_s = time.time() - t0
+    sstats = be.scene_stats()
+
+    gathered = None
+    if world > 1:
+        slab = be.shard_info()["slab_floats"]
+        gathered = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
+        be.set_slab_output(gathered[rank].data_ptr())
+
+    def step():
+        be.reset_accumulation()
+        be.render(view)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), gathered[rank])
+            be.assemble_frame(gathered.data_ptr())
+
+    # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
+    be.set_option("count_traversal", 1)
+    step()
+    cs = be.frame_stats()
+    be.set_option("count_traversal", 0)
+    rays_local = cs["primary_rays"] + cs["shadow_rays"] + cs["extension_rays"]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = {"ms_trace_primary": 0.0, "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-kernel HIP-event durations on the launch stream (events are recorded inside render(); reading them
+        # waits for this frame only)
+        fs = be.frame_stats()
+        for k in kernel_ms:
+            kernel_ms[k] += fs[k]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        elapsed, rays_total = float(tmax[0]), float(t[1])
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = rays_total / (elapsed / args.steps) / 1e6
+        # roofline of the dominant kernel: algorithmic bytes per launch / its mean HIP-event duration
+        node_b, tri_b = sstats["node_bytes"], sstats["tri_bytes"]
+        dom = "trace_primary" if kernel_ms["ms_trace_primary"] >= kernel_ms["ms_trace_shadow"] else "trace_shadow"
+        # B_stream: primary 16 B hit + 32 B ray write; shadow 32 B ray read + 16 B accumulator RMW
+        trav_bytes = cs["nodes_visited"] * node_b + cs["tris_tested"] * tri_b + cs["instances_entered"] * 64
+        stream_bytes = cs["primary_rays"] * 48 + cs["shadow_rays"] * (32 + 32)
+        both_ms = (kernel_ms["ms_trace_primary"] + kernel_ms["ms_trace_shadow"]) / args.steps
+        achieved = (trav_bytes + stream_bytes) / (both_ms * 1e-3) / 1e9 if both_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles, {w}x{h}, 1 spp primary+shadow (max path length 1), static BVH4",
+                       "rays_per_frame": int(rays_total), "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
+                       "synchronize_s": round(sync_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_primary+k_shadow (BVH4 traversal)", "dominant": dom,
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None,
+                         "bytes_per_ray": round((trav_bytes + stream_bytes) / max(rays_local, 1), 1),
+                         "nodes_per_ray": round(cs["nodes_visited"] / max(rays_local, 1), 2),
+                         "tris_per_ray": round(cs["tris_tested"] / max(rays_local, 1), 2),
+                         "kernel_ms": {k: round(v / args.steps, 4) for k, v in kernel_ms.items()}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, view, w, h, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    be.close()
+
+
+def cpu_baseline(scene, view, w, h, budget_s):
+    """The oracle (CPU restatement of the reference's rtbvh/MBVH path) timed on this host's cores on a bounded
+    sample of the same workload: the same scene and camera at reduced resolution, 1 spp primary + shadow."""
+    from oracle.bindings import Oracle
+    cores = os.cpu_count() or 1
+    sw, sh = 480, 270
+    orc = Oracle(sw, sh, threads=cores, max_path_length=1)
+    scene.mark_all_changed()
+    t0 = time.time()
+    scene.sync(orc)
+    build_s = time.time() - t0
+    v = scene.view(sw, sh)
+    orc.render(v)  # warm
+    s0 = orc.stats()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.reset()
+        orc.render(v)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    s = orc.stats()
+    rays = s["primary"] + s["shadow"]
+    return {"value": round(rays * n / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"same scene and camera at {sw}x{sh}, 1 spp primary+shadow, {n} frames, {cores} threads; BVH build {build_s:.1f}s excluded"}
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,7 @@ enum {
 };
 
 /* BLAS/TLAS builder selection (rfw_hip_options.builder) */
-enum { RFW_HIP_BUILDER_DEVICE_LBVH = 0, RFW_HIP_BUILDER_HOST_SAH = 1 };
+enum { RFW_HIP_BUILDER_AUTO = 0, RFW_HIP_BUILDER_HOST_SAH = 1, RFW_HIP_BUILDER_DEVICE_LBVH = 2 };
 
 /*
  * Creation options.  Zero-initialise, then set what you need; a NULL pointer

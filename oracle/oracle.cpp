@@ -1186,6 +1186,9 @@ ORC_API int orc_synchronize(void* p)
                 boxes[i].grow(&t.vertex0.x);
                 boxes[i].grow(&t.vertex1.x);
                 boxes[i].grow(&t.vertex2.x);
+                // AABB_EPSILON (crates/rfw-scene/src/constants.rs:2): boxes are padded so that a slab test can never cull a
+                // triangle whose Moeller-Trumbore t differs from the box's entry distance by rounding only
+                for (int a = 0; a < 3; a++) { boxes[i].mn[a] -= 1e-4f; boxes[i].mx[a] += 1e-4f; }
                 // RTTriangle::center (crates/rfw-backend/src/structs.rs:985-988)
                 centers[3 * i + 0] = (t.vertex0.x + t.vertex1.x + t.vertex2.x) * (1.0f / 3.0f);
                 centers[3 * i + 1] = (t.vertex0.y + t.vertex1.y + t.vertex2.y) * (1.0f / 3.0f);

@@ -35,6 +35,13 @@ def hip_lib():
     if _lib is None:
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"HIP extension {HIP_LIB} is missing — build it with __graft_entry__.build(); there is no CPU fallback")
+        try:
+            # torch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's): whichever is loaded first serves the
+            # whole process.  Load torch's first so that torch (device memory, streams, torch.distributed) and this
+            # library share ONE HIP runtime and stream handles can cross between them.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(HIP_LIB)
         vp, u32, u64, f32, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_char_p
         l.rfw_hip_create.restype = vp
@@ -92,7 +99,7 @@ class HipBackend:
         return cls(width, height, scale, **options)
 
     def __init__(self, width, height, scale=1.0, device=-1, max_path_length=0, clamp_value=0.0, rank=0, world=1,
-                 tile_size=0, builder=pod.RFW_HIP_BUILDER_DEVICE_LBVH, flags=0):
+                 tile_size=0, builder=pod.RFW_HIP_BUILDER_AUTO, flags=0):
         self._l = hip_lib()
         o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags)
         h = self._l.rfw_hip_create(width, height, scale, C.byref(o))

@@ -1,0 +1,83 @@
+// device_types.h — layout of everything that lives in HBM (shared by host code and kernels).
+//
+// All buffers are structure-of-arrays of 16-byte elements so that a wavefront reading element
+// `lane` of an array issues one coalesced dwordx4 load (1 KiB per wave-instruction).
+#pragma once
+#include <cstdint>
+
+#include "../../include/rfw_pod.h"
+
+namespace rfwhip {
+
+// 4-wide BVH node, 128 B = one cache line, 128-B aligned.  Child boxes SoA across the 4 children.
+// child[i]: kInvalidRef = empty slot; bit31 set = leaf: (count-1) << 27 | first  (first: index into the
+// leaf-ordered triangle packets of the mesh, or into the TLAS instance-index list); else interior node index
+// (relative to the owning BVH's node base).
+struct Node4 {
+    float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "Node4 must be one 128-B line");
+constexpr uint32_t kInvalidRef = 0xffffffffu;
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLeafFirstMask = 0x07ffffffu;
+constexpr int kMaxLeafTris = 8;
+inline __host__ __device__ uint32_t make_leaf(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 27) | first; }
+
+// Triangle packet for traversal, 48 B, stored in BLAS leaf order (no index indirection in the leaf loop):
+//   p0 = (v0.xyz, bits(global triangle id)), p1 = (edge1.xyz, 1/dot(gn,gn)), p2 = (edge2.xyz, 0)
+// edge1 = v1 - v0 and edge2 = v2 - v0 are the very subtractions intersection.glsl:7-8 performs per test, done once.
+// The reference's leaf loop gathers the whole 176-B RTTriangle (ray_gen.comp:230-233).
+struct TriPacket {
+    float v0x, v0y, v0z; uint32_t tri_id;
+    float e1x, e1y, e1z; float inv_gn2;
+    float e2x, e2y, e2z; float pad;
+};
+static_assert(sizeof(TriPacket) == 48, "TriPacket");
+
+// Per-instance record used by traversal (64 B): rows of the inverse matrix + where the mesh's BLAS lives.
+struct InstanceXform {
+    float inv_r0[4], inv_r1[4], inv_r2[4]; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major inverse
+    uint32_t node_base;                    // first node of the mesh's BLAS in blas_nodes
+    uint32_t tri_base;                     // first packet of the mesh in tri_packets
+    uint32_t flags;                        // bit0: valid
+    uint32_t mesh;
+};
+static_assert(sizeof(InstanceXform) == 64, "InstanceXform");
+
+// Per-instance record used by shade (48 B): rows of the normal matrix transpose(inverse(M)).
+struct InstanceNormal {
+    float n_r0[4], n_r1[4], n_r2[4];
+};
+
+struct MeshRecord {
+    uint32_t node_base, node_count;
+    uint32_t tri_base, tri_count; // tri_base doubles as the global triangle id offset (same concatenation order)
+};
+
+// Camera block handed to the kernels (CameraData of backends/gpu-rt/src/lib.rs:147-175 without the queue counters).
+struct CameraParams {
+    float pos[3]; float lens_size;
+    float right[3]; float spread_angle;
+    float up[3]; float clamp_value;
+    float p1[3]; float pad0;
+    uint32_t width, height, sample_count, path_length;
+    uint32_t point_light_count, area_light_count, spot_light_count, directional_light_count;
+    // shard description: tiles of tile_size^2 pixels dealt round-robin to `world` ranks
+    uint32_t tile_size, tiles_x, tiles_y, rank;
+    uint32_t world, local_tiles, flags, pad1;
+    float sky[3]; float pad2;
+};
+
+// Device-side queue counters; one slot per bounce so nothing has to be reset or read back between bounces
+// (the reference reads extensionId/shadowId back to the host every bounce: gpu-rt/src/lib.rs:2052-2069).
+struct QueueCounters {
+    uint32_t ext[8];
+    uint32_t shadow[8];
+    unsigned long long nodes_visited, tris_tested, instances_entered, pad;
+};
+
+enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };
+
+} // namespace rfwhip

@@ -1,0 +1,58 @@
+// kernels.h — launch wrappers of the HIP kernels (defined in kernels.hip), callable from the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rfw_hip.h"
+#include "device_types.h"
+
+namespace rfwhip {
+
+struct SceneDev {
+    const Node4* tlas_nodes;
+    const uint32_t* tlas_prims;
+    const InstanceXform* instances;
+    const InstanceNormal* instance_normals;
+    const Node4* blas_nodes;
+    const TriPacket* tri_packets;
+    const rfw_rt_triangle* triangles; // shading attributes, global triangle id order
+    const rfw_device_material* materials;
+    const rfw_area_light* area_lights;
+    const rfw_point_light* point_lights;
+    const rfw_spot_light* spot_lights;
+    const rfw_directional_light* directional_lights;
+    uint32_t* spill;
+    uint32_t spill_stride;
+    QueueCounters* counters;
+};
+
+// Wavefront state, structure-of-arrays of 16-B elements (the reference's 64-B AoS PathState, structs.glsl:4-9, split):
+//   ray_o  = (origin.xyz, bits(path id))        ray_d = (direction.xyz, bits(packed previous normal))
+//   thr    = (throughput.rgb, postponed bsdf pdf)  hit = (inst, tri, bits(t), bary 16:16)
+// two halves each (ping-pong on path_length % 2, shade.comp:77-81); shadow queue = PotentialContribution (structs.glsl:172-176)
+struct PathDev {
+    float4* ray_o[2];
+    float4* ray_d[2];
+    float4* thr[2];
+    uint4* hit[2];
+    float4* sh_o; // (origin.xyz, bits(pixel))
+    float4* sh_d; // (direction.xyz, distance)
+    float4* sh_e; // (contribution.rgb, 0)
+    float4* acc;  // accumulator in slab order (this rank's tiles)
+    uint32_t capacity; // local paths = local_tiles * tile_size^2
+};
+
+void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n,
+                              InstanceXform* xf, InstanceNormal* nm);
+void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count);
+void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
+void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
+void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
+void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples);
+void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+                     uint32_t samples);
+void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
+                          rfw_hip_hit* hits);
+void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
+                      uint8_t* occluded);
+
+} // namespace rfwhip

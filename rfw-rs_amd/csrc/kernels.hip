@@ -1,0 +1,553 @@
+// kernels.hip — the wavefront path-tracing kernels for gfx950 (wave64).
+//
+// One kernel per stage of the reference's per-bounce loop (backends/gpu-rt/src/lib.rs:1708-1728):
+//   k_primary  = ray_gen.comp   (generate + trace primary)      k_extend = ray_extend.comp
+//   k_shade    = shade.comp                                       k_shadow = ray_shadow.comp
+//   k_blit     = blit.comp
+// with the queues compacted by wavefront ballot + one atomic per wave (shade.comp:250,261 issue one
+// global atomic per thread) and all queue counters resident on the device, one slot per bounce, so a
+// frame is a fixed sequence of launches with no host read-back (gpu-rt/src/lib.rs:2052-2069 blocks
+// on a map_async per bounce).
+#include "kernels.h"
+#include "shade_device.h"
+#include "traverse.h"
+
+namespace rfwhip {
+
+// ---------------------------------------------------------------- shard / slab indexing
+// Local path index -> pixel.  Tiles of tile_size^2 pixels are dealt round-robin to ranks; inside a tile, pixels are
+// ordered in 8x8 blocks so that one wavefront = one 8x8 pixel block (coherent primary rays).
+RFW_DI bool slab_to_pixel(const CameraParams& c, uint32_t idx, uint32_t& px, uint32_t& py)
+{
+    const uint32_t ts = c.tile_size, per_tile = ts * ts;
+    const uint32_t lt = idx / per_tile, within = idx - lt * per_tile;
+    const uint32_t tile = lt * c.world + c.rank;
+    if (tile >= c.tiles_x * c.tiles_y) return false;
+    const uint32_t ty = tile / c.tiles_x, tx = tile - ty * c.tiles_x;
+    const uint32_t block = within >> 6, lane = within & 63u, bpr = ts >> 3;
+    const uint32_t by = block / bpr, bx = block - by * bpr;
+    px = tx * ts + bx * 8u + (lane & 7u);
+    py = ty * ts + by * 8u + (lane >> 3);
+    return px < c.width && py < c.height;
+}
+RFW_DI uint32_t pixel_to_slab(const CameraParams& c, uint32_t px, uint32_t py, uint32_t& owner)
+{
+    const uint32_t ts = c.tile_size;
+    const uint32_t tx = px / ts, ty = py / ts;
+    const uint32_t tile = ty * c.tiles_x + tx;
+    owner = tile % c.world;
+    const uint32_t lt = tile / c.world;
+    const uint32_t ix = px - tx * ts, iy = py - ty * ts;
+    const uint32_t block = (iy >> 3) * (ts >> 3) + (ix >> 3);
+    return lt * ts * ts + block * 64u + ((iy & 7u) << 3) + (ix & 7u);
+}
+
+RFW_DI SceneView scene_view(const SceneDev& sc)
+{
+    SceneView v;
+    v.tlas_nodes = sc.tlas_nodes;
+    v.tlas_prims = sc.tlas_prims;
+    v.instances = sc.instances;
+    v.blas_nodes = sc.blas_nodes;
+    v.tri_packets = sc.tri_packets;
+    v.spill = sc.spill;
+    v.spill_stride = sc.spill_stride;
+    v.counters = sc.counters;
+    return v;
+}
+
+template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCounters& tc)
+{
+    if (!COUNT) return;
+    // wave reduction, then one atomic per wave
+    unsigned long long n = tc.nodes, t = tc.tris, i = tc.insts;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off);
+        t += __shfl_down(t, off);
+        i += __shfl_down(i, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&qc->nodes_visited, n);
+        atomicAdd(&qc->tris_tested, t);
+        atomicAdd(&qc->instances_entered, i);
+    }
+}
+
+// ---------------------------------------------------------------- instance descriptors (gpu-rt/src/lib.rs:1589-1615)
+// matrix -> inverse (explicit cofactor expansion, every term left to right) and normal = transpose(inverse)
+__global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                                    const MeshRecord* __restrict__ meshes, uint32_t n, InstanceXform* __restrict__ xf,
+                                    InstanceNormal* __restrict__ nm)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float m[16], inv[16];
+    bool zero = true;
+    for (int k = 0; k < 16; k++) {
+        m[k] = matrices[i].m[k];
+        zero = zero && (m[k] == 0.0f);
+    }
+    const uint32_t mesh = mesh_of_instance[i];
+    InstanceXform x;
+    InstanceNormal nn;
+    const bool valid = !zero && mesh != 0xffffffffu && meshes[mesh].tri_count > 0;
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    det = 1.0f / det;
+    for (int k = 0; k < 16; k++) inv[k] = inv[k] * det;
+    // traversal rows: row i of the inverse = (inv[i], inv[4+i], inv[8+i], inv[12+i])
+    for (int c = 0; c < 4; c++) {
+        x.inv_r0[c] = inv[4 * c + 0];
+        x.inv_r1[c] = inv[4 * c + 1];
+        x.inv_r2[c] = inv[4 * c + 2];
+    }
+    // normal matrix N = transpose(inverse): N[col c][row r] = inv[col r][row c]; row i of N = (inv[4i], inv[4i+1], inv[4i+2], inv[4i+3])
+    for (int c = 0; c < 4; c++) {
+        nn.n_r0[c] = inv[0 + c];
+        nn.n_r1[c] = inv[4 + c];
+        nn.n_r2[c] = inv[8 + c];
+    }
+    x.node_base = valid ? meshes[mesh].node_base : 0u;
+    x.tri_base = valid ? meshes[mesh].tri_base : 0u;
+    x.flags = valid ? 1u : 0u;
+    x.mesh = mesh;
+    xf[i] = x;
+    nm[i] = nn;
+}
+
+// ---------------------------------------------------------------- ray_gen.comp:103-146 (xorshift branch)
+RFW_DI void generate_eye_ray(const CameraParams& cam, f3& O, f3& D, uint32_t sx, uint32_t sy, uint32_t& seed)
+{
+    float r0 = randf(seed);
+    float r1 = randf(seed);
+    float r2 = randf(seed);
+    float r3 = randf(seed);
+    const float blade = (float)f2i(r0 * 9.0f);
+    r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+    float x1, y1, x2, y2;
+    const float piOver4point5 = 3.14159265359f / 4.5f;
+    rfw_sincosf(blade * piOver4point5, &y1, &x1);
+    rfw_sincosf((blade + 1.0f) * piOver4point5, &y2, &x2);
+    if ((r2 + r3) > 1.0f) {
+        r2 = 1.0f - r2;
+        r3 = 1.0f - r3;
+    }
+    const float xr = x1 * r2 + x2 * r3;
+    const float yr = y1 * r2 + y2 * r3;
+    const f3 pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const f3 right = mk3(cam.right[0], cam.right[1], cam.right[2]);
+    const f3 up = mk3(cam.up[0], cam.up[1], cam.up[2]);
+    const f3 p1 = mk3(cam.p1[0], cam.p1[1], cam.p1[2]);
+    O = pos + cam.lens_size * (right * xr + up * yr);
+    const float u = ((float)(int)sx + r0) * (1.0f / (float)(int)cam.width);
+    const float v = ((float)(int)sy + r1) * (1.0f / (float)(int)cam.height);
+    const f3 pointOnPixel = p1 + u * right + v * up;
+    D = normalize(pointOnPixel - O);
+}
+
+// ---------------------------------------------------------------- ray_gen.comp:39-70
+template <bool COUNT> __global__ __launch_bounds__(kTraceBlock) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
+    TravCounters tc{0, 0, 0};
+    uint32_t px = 0, py = 0;
+    const bool valid = idx < p.capacity && slab_to_pixel(cam, idx, px, py);
+    if (valid) {
+        if (cam.sample_count == 0) p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t path_id = px + py * cam.width;
+        uint32_t seed = wang_hash(path_id * 16789u + cam.sample_count * 1791u + 0u * 720898027u);
+        f3 O, D;
+        generate_eye_ray(cam, O, D, px, py, seed);
+        float t = 1e26f, hu = 0.0f, hv = 0.0f;
+        int32_t hi = -1, ht = -1;
+        const SceneView sv = scene_view(sc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id));
+        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
+        p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    }
+    flush_counters<COUNT>(sc.counters, tc);
+}
+
+// ---------------------------------------------------------------- ray_extend.comp:245-268
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t count = sc.counters->ext[bounce - 1];
+    if (blockIdx.x * kTraceBlock >= count) return;
+    TravCounters tc{0, 0, 0};
+    const uint32_t half = bounce & 1u;
+    if (idx < count) {
+        const float4 o4 = p.ray_o[half][idx], d4 = p.ray_d[half][idx];
+        const f3 O = mk3(o4.x, o4.y, o4.z), D = mk3(d4.x, d4.y, d4.z);
+        float t = 1e26f, hu = 0.0f, hv = 0.0f;
+        int32_t hi = -1, ht = -1;
+        const SceneView sv = scene_view(sc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.hit[half][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    }
+    flush_counters<COUNT>(sc.counters, tc);
+}
+
+// ---------------------------------------------------------------- ray_shadow.comp:245-268
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t count = sc.counters->shadow[bounce];
+    if (blockIdx.x * kTraceBlock >= count) return;
+    TravCounters tc{0, 0, 0};
+    if (idx < count) {
+        const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
+        const f3 O = mk3(o4.x, o4.y, o4.z), D = mk3(d4.x, d4.y, d4.z);
+        float t = d4.w - 0.0001f, hu, hv;
+        int32_t hi = -1, ht = -1;
+        const SceneView sv = scene_view(sc);
+        const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        if (!occluded) {
+            const float4 e = p.sh_e[idx];
+            const uint32_t pixel = fbits(o4.w);
+            uint32_t owner;
+            const uint32_t slot = pixel_to_slab(cam, pixel % cam.width, pixel / cam.width, owner);
+            // single writer per pixel per pass (one shadow ray per path per bounce), as ray_shadow.comp:268
+            float4 a = p.acc[slot];
+            a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
+            p.acc[slot] = a;
+        }
+    }
+    flush_counters<COUNT>(sc.counters, tc);
+}
+
+// ---------------------------------------------------------------- shade.comp:70-266
+constexpr int kShadeBlock = 256;
+__global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+{
+    const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
+    const uint32_t count = bounce == 0 ? p.capacity : sc.counters->ext[bounce - 1];
+    if (blockIdx.x * kShadeBlock >= count) return;
+    const uint32_t half = bounce & 1u, next_half = half ^ 1u;
+    const uint32_t path_length = bounce;
+
+    bool live = idx < count;
+    uint32_t px = 0, py = 0;
+    if (live && bounce == 0) live = slab_to_pixel(cam, idx, px, py);
+
+    bool push_ext = false, push_shadow = false;
+    f3 ext_o = mk3(0.0f), ext_d = mk3(0.0f), ext_thr = mk3(0.0f);
+    float ext_pdf = 0.0f;
+    uint32_t ext_normal = 0;
+    f3 sh_o = mk3(0.0f), sh_d = mk3(0.0f), sh_e = mk3(0.0f);
+    float sh_dist = 0.0f;
+    uint32_t PATH_ID = 0;
+
+    if (live) {
+        const uint4 S = p.hit[half][idx];
+        const float4 O4 = p.ray_o[half][idx], D4 = p.ray_d[half][idx];
+        const f3 O = mk3(O4.x, O4.y, O4.z), D = mk3(D4.x, D4.y, D4.z);
+        f3 throughput = mk3(1.0f);
+        float bsdfPdf = 1.0f;
+        if (path_length != 0) {
+            const float4 T4 = p.thr[half][idx];
+            throughput = mk3(T4.x, T4.y, T4.z);
+            bsdfPdf = T4.w;
+        }
+        PATH_ID = fbits(O4.w);
+        uint32_t owner;
+        const uint32_t slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner);
+        const int32_t INST_ID = (int32_t)S.x;
+        const uint32_t TRI_ID = S.y;
+        const float T_VAL = bitsf(S.z);
+
+        if (INST_ID < 0) { // shade.comp:90-96, constant sky (textures/skybox image: SURVEY §8f rank 4)
+            f3 contribution = throughput * mk3(cam.sky[0], cam.sky[1], cam.sky[2]) * (1.0f / bsdfPdf);
+            CLAMPINTENSITY(contribution, cam.clamp_value);
+            float4 a = p.acc[slot];
+            a.x += contribution.x; a.y += contribution.y; a.z += contribution.z; a.w += 0.0f;
+            p.acc[slot] = a;
+        } else {
+            // 176-B RTTriangle as 11 dwordx4 loads (only here, once per shaded hit)
+            const float4* tp = reinterpret_cast<const float4*>(sc.triangles + TRI_ID);
+            const float4 q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6], T0 = tp[7], T1 = tp[8], T2 = tp[9];
+            const uint4 q10 = *reinterpret_cast<const uint4*>(tp + 10);
+            const int32_t mat_id = (int32_t)q10.y;
+            const float tri_area = bitsf(q10.w);
+            ShadingData sd = extractParameters(sc.materials + mat_id);
+
+            const uint32_t sampleId = PATH_ID / (cam.width * cam.height) + cam.sample_count;
+            uint32_t seed = wang_hash(PATH_ID * 16789u + sampleId * 1791u + path_length * 720898027u);
+
+            const float u = (float)(S.w & 65535u) * (1.0f / 65535.0f);
+            const float v = (float)(S.w >> 16) * (1.0f / 65535.0f);
+            const float w = 1.0f - u - v;
+
+            f3 gN = mk3(q3.x, q3.y, q3.z);
+            f3 N = w * mk3(q4.x, q4.y, q4.z) + u * mk3(q5.x, q5.y, q5.z) + v * mk3(q6.x, q6.y, q6.z);
+            f3 T = w * mk3(T0.x, T0.y, T0.z) + u * mk3(T1.x, T1.y, T1.z) + v * mk3(T2.x, T2.y, T2.z);
+            const float Tw = w * T0.w + u * T1.w + v * T2.w;
+
+            const float4* np = reinterpret_cast<const float4*>(sc.instance_normals + INST_ID);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+            gN = normalize(xform_rows(n0, n1, n2, gN, 0.0f));
+            N = normalize(xform_rows(n0, n1, n2, N, 0.0f));
+            T = normalize(xform_rows(n0, n1, n2, T, 0.0f));
+            const f3 B = cross(N, T) * Tw;
+            const f3 P = O + T_VAL * D;
+
+            if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) { // shade.comp:128-160 hit a light
+                f3 contribution = mk3(0.0f);
+                const float DdotNL = -dot(D, N);
+                bool add = true;
+                if (DdotNL > 0.0f) {
+                    if (path_length == 0) {
+                        contribution = throughput * sd.color * (1.0f / bsdfPdf);
+                    } else {
+                        const float lightPdf = CalculateLightPDF(D, T_VAL, tri_area, N);
+                        const int lc = (int)(cam.area_light_count + cam.point_light_count + cam.spot_light_count + cam.directional_light_count);
+                        const float pickProb = 1.0f / (float)lc;
+                        if ((bsdfPdf + lightPdf * pickProb) <= 0.0f) add = false;
+                        else contribution = throughput * sd.color * (1.0f / (bsdfPdf + lightPdf * pickProb));
+                    }
+                    CLAMPINTENSITY(contribution, cam.clamp_value);
+                }
+                if (add) {
+                    float4 a = p.acc[slot];
+                    a.x += contribution.x; a.y += contribution.y; a.z += contribution.z; a.w += 0.0f;
+                    p.acc[slot] = a;
+                }
+            } else {
+                const bool backFacing = dot(D, gN) >= 0.0f;
+                if (backFacing) {
+                    N = N * -1.0f;
+                    gN = gN * -1.0f;
+                }
+                throughput = throughput * (1.0f / bsdfPdf);
+                float newBsdfPdf = 0.0f;
+                f3 R = mk3(0.0f);
+                const float r1 = randf(seed);
+                const float r2 = randf(seed);
+                const f3 bsdf = SampleBSDF(sd, N, gN, T, B, D * -1.0f, T_VAL, backFacing, r1, r2, R, newBsdfPdf);
+                throughput = throughput * bsdf * gl_abs(dot(N, R));
+                throughput = gl_max(throughput, mk3(0.0f));
+                if (!(newBsdfPdf <= 1e-4f || gl_isnan(newBsdfPdf))) {
+                    const int lc = (int)(cam.area_light_count + cam.point_light_count + cam.spot_light_count + cam.directional_light_count);
+                    if (!(cam.flags & kFlagNoNee) && lc > 0) {
+                        const float r3 = randf(seed);
+                        const float r4 = randf(seed);
+                        (void)r4;
+                        LightView lv;
+                        lv.area = sc.area_lights; lv.point = sc.point_lights; lv.spot = sc.spot_lights; lv.directional = sc.directional_lights;
+                        lv.n_area = (int)cam.area_light_count; lv.n_point = (int)cam.point_light_count;
+                        lv.n_spot = (int)cam.spot_light_count; lv.n_directional = (int)cam.directional_light_count;
+                        f3 lightColor = mk3(0.0f);
+                        float pickProb = 0.0f, lightPdf = 0.0f;
+                        f3 L = RandomPointOnLight(lv, r3, P, N, pickProb, lightPdf, lightColor) - P;
+                        const float dist = length(L);
+                        L = L * (1.0f / dist);
+                        const float NdotL = dot(L, N);
+                        if (NdotL > 0.0f && lightPdf > 0.0f) {
+                            float shadowPdf = 0.0f;
+                            const f3 sampledBSDF = EvaluateBSDF(sd, gN, D * -1.0f, L, shadowPdf);
+                            if (shadowPdf > 0.0f) {
+                                f3 contribution = throughput * sampledBSDF * lightColor * (NdotL / (lightPdf * pickProb));
+                                if (!(gl_isnan(contribution.x) || gl_isnan(contribution.y) || gl_isnan(contribution.z))) {
+                                    CLAMPINTENSITY(contribution, cam.clamp_value);
+                                    sh_o = safe_origin(P, L, gN);
+                                    sh_d = L;
+                                    sh_dist = dist - 1e-4f;
+                                    sh_e = contribution;
+                                    push_shadow = true;
+                                }
+                            }
+                        }
+                    }
+                    ext_o = safe_origin(P, R, gN);
+                    ext_d = R;
+                    ext_normal = PackNormal(N);
+                    ext_thr = throughput;
+                    ext_pdf = newBsdfPdf;
+                    push_ext = true;
+                }
+            }
+        }
+    }
+
+    // ---- queue compaction: ballot + prefix inside the wavefront, one atomic per wave and queue
+    const uint32_t lane = threadIdx.x & 63u;
+    {
+        const unsigned long long m = __ballot(push_shadow);
+        if (m) {
+            const uint32_t n = (uint32_t)__popcll(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&sc.counters->shadow[bounce], n);
+            base = __shfl(base, leader);
+            if (push_shadow) {
+                const uint32_t j = base + rank;
+                p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_ID));
+                p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
+                p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
+            }
+        }
+    }
+    {
+        const unsigned long long m = __ballot(push_ext);
+        if (m) {
+            const uint32_t n = (uint32_t)__popcll(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&sc.counters->ext[bounce], n);
+            base = __shfl(base, leader);
+            if (push_ext) {
+                const uint32_t j = base + rank;
+                p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_ID));
+                p.ray_d[next_half][j] = make_float4(ext_d.x, ext_d.y, ext_d.z, bitsf(ext_normal));
+                p.thr[next_half][j] = make_float4(ext_thr.x, ext_thr.y, ext_thr.z, ext_pdf);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- blit.comp:15-23 (+ slab -> frame de-tiling)
+__global__ void k_blit(const CameraParams cam, const float4* __restrict__ acc_slab, float4* __restrict__ frame_acc, float4* __restrict__ frame_out,
+                       const uint32_t samples)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= cam.width || py >= cam.height) return;
+    uint32_t owner;
+    const uint32_t slot = pixel_to_slab(cam, px, py, owner);
+    if (owner != cam.rank) return;
+    const float4 a = acc_slab[slot];
+    const float n = (float)(int)samples;
+    frame_acc[px + py * cam.width] = a;
+    frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
+                                                 __builtin_sqrtf(a.w * 1.0f / n));
+}
+// all-gathered slabs [world][slab_elems] -> full frame
+__global__ void k_assemble(const CameraParams cam, const float4* __restrict__ gathered, const uint64_t slab_elems, float4* __restrict__ frame_acc,
+                           float4* __restrict__ frame_out, const uint32_t samples)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= cam.width || py >= cam.height) return;
+    uint32_t owner;
+    const uint32_t slot = pixel_to_slab(cam, px, py, owner);
+    const float4 a = gathered[(uint64_t)owner * slab_elems + slot];
+    const float n = (float)(int)samples;
+    frame_acc[px + py * cam.width] = a;
+    frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
+                                                 __builtin_sqrtf(a.w * 1.0f / n));
+}
+
+// ---------------------------------------------------------------- ray queries (TIntersector::intersect / occludes)
+__global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                                const float t_min, const float t_max, const uint64_t n, rfw_hip_hit* __restrict__ hits)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
+    if (idx >= n) return;
+    const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
+    const f3 D = mk3(directions[3 * idx], directions[3 * idx + 1], directions[3 * idx + 2]);
+    float t = t_max, hu = 0.0f, hv = 0.0f;
+    int32_t hi = -1, ht = -1;
+    TravCounters tc{0, 0, 0};
+    const SceneView sv = scene_view(sc);
+    traverse<false, false>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    rfw_hip_hit h;
+    h.inst = hi; h.tri = ht; h.t = t; h.u = hu; h.v = hv;
+    hits[idx] = h;
+}
+__global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                            const float t_min, const float* __restrict__ t_max, const uint64_t n,
+                                                            uint8_t* __restrict__ occluded)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
+    if (idx >= n) return;
+    const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
+    const f3 D = mk3(directions[3 * idx], directions[3 * idx + 1], directions[3 * idx + 2]);
+    float t = t_max[idx], hu, hv;
+    int32_t hi = -1, ht = -1;
+    TravCounters tc{0, 0, 0};
+    const SceneView sv = scene_view(sc);
+    const bool occ = traverse<true, false>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    occluded[idx] = occ ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- launch wrappers
+static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n,
+                              InstanceXform* xf, InstanceNormal* nm)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_prepare_instances, dim3(ceil_div(n, 64)), dim3(64), 0, s, matrices, mesh_of_instance, meshes, n, xf, nm);
+}
+void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count)
+{
+    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, s, cam, sc, p);
+    else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, s, cam, sc, p);
+}
+void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
+{
+    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    if (count) hipLaunchKernelGGL(k_extend<true>, grid, block, 0, s, cam, sc, p, bounce);
+    else hipLaunchKernelGGL(k_extend<false>, grid, block, 0, s, cam, sc, p, bounce);
+}
+void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce)
+{
+    hipLaunchKernelGGL(k_shade, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
+}
+void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
+{
+    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, s, cam, sc, p, bounce);
+    else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, s, cam, sc, p, bounce);
+}
+void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples)
+{
+    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4));
+    hipLaunchKernelGGL(k_blit, grid, block, 0, s, cam, acc_slab, frame_acc, frame_out, samples);
+}
+void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+                     uint32_t samples)
+{
+    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4));
+    hipLaunchKernelGGL(k_assemble, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+}
+void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
+                          rfw_hip_hit* hits)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_query_closest, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, hits);
+}
+void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
+                      uint8_t* occluded)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_query_any, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, occluded);
+}
+
+} // namespace rfwhip

@@ -1,0 +1,930 @@
+// rfw_hip_api.cpp — the C ABI of include/rfw_hip.h: instance state, scene upload, acceleration-structure
+// builds and the per-frame launch sequence.  Host-side counterpart of backends/gpu-rt/src/lib.rs
+// (synchronize :1309-1683, render :1685-1780) with every buffer resident in HBM and no per-bounce
+// host read-back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rfw_hip.h"
+#include "bvh_host.h"
+#include "kernels.h"
+#include "traverse.h"
+
+using namespace rfwhip;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T> struct DevBuf {
+    T* ptr = nullptr;
+    size_t cap = 0; // elements
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(n, 16);
+        hipError_t e = hipMalloc((void**)&ptr, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct MeshHost {
+    std::vector<rfw_rt_triangle> tris;
+    HostBvh4 bvh;
+    std::vector<TriPacket> packets; // leaf order
+    bool dirty = true;
+};
+struct InstList {
+    rfw_aabb local_aabb{};
+    std::vector<rfw_mat4> matrices;
+};
+
+enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
+constexpr int kMaxBounces = 8;
+constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
+constexpr int kNumEvents = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce + 1);
+
+struct Instance {
+    std::mutex mu;
+    std::string err;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t width = 0, height = 0;
+    uint32_t max_path_length = 3;
+    float clamp_value = 10.0f;
+    uint32_t rank = 0, world = 1, tile_size = 64;
+    uint32_t builder = RFW_HIP_BUILDER_HOST_SAH;
+    uint32_t flags = 0;
+    float sky[3] = {0, 0, 0};
+    bool timing = true;
+    int build_threads = 8;
+
+    // host-side scene copies (the trait's borrows end with each call)
+    std::map<uint32_t, MeshHost> meshes;
+    std::map<uint32_t, InstList> inst_lists;
+    std::vector<rfw_device_material> materials;
+    std::vector<rfw_area_light> area_lights;
+    std::vector<rfw_point_light> point_lights;
+    std::vector<rfw_spot_light> spot_lights;
+    std::vector<rfw_directional_light> directional_lights;
+    bool meshes_dirty = true, instances_dirty = true, materials_dirty = true, lights_dirty = true;
+    bool synchronized = false;
+
+    // device scene
+    DevBuf<Node4> d_blas_nodes, d_tlas_nodes;
+    DevBuf<TriPacket> d_packets;
+    DevBuf<rfw_rt_triangle> d_triangles;
+    DevBuf<MeshRecord> d_mesh_records;
+    DevBuf<rfw_mat4> d_matrices;
+    DevBuf<uint32_t> d_mesh_of_instance, d_tlas_prims;
+    DevBuf<InstanceXform> d_xforms;
+    DevBuf<InstanceNormal> d_normals;
+    DevBuf<rfw_device_material> d_materials;
+    DevBuf<rfw_area_light> d_area;
+    DevBuf<rfw_point_light> d_point;
+    DevBuf<rfw_spot_light> d_spot;
+    DevBuf<rfw_directional_light> d_dir;
+    DevBuf<uint32_t> d_spill;
+    DevBuf<QueueCounters> d_counters;
+    std::vector<MeshRecord> mesh_records;
+    std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
+    uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
+    float ms_blas_build = 0, ms_tlas_build = 0;
+
+    // device path state
+    DevBuf<float4> d_ray_o[2], d_ray_d[2], d_thr[2], d_sh_o, d_sh_d, d_sh_e, d_acc_slab, d_frame_acc, d_frame_out;
+    DevBuf<uint4> d_hit[2];
+    void* external_slab = nullptr;
+    uint32_t tiles_x = 0, tiles_y = 0, local_tiles = 0, capacity = 0;
+    uint64_t local_pixels = 0;
+    uint32_t sample_count = 0;
+    bool have_last_view = false;
+    rfw_camera_view_3d last_view{};
+    hipEvent_t events[kNumEvents] = {};
+    uint32_t last_bounces = 0;
+    bool frame_recorded = false;
+    bool last_count_flag = false;
+};
+
+#define HIP_TRY(inst, expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (inst)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return RFW_HIP_E_DEVICE;                                                            \
+        }                                                                                       \
+    } while (0)
+
+int fail(Instance* I, int code, const std::string& msg)
+{
+    I->err = msg;
+    return code;
+}
+
+bool is_zero_matrix(const rfw_mat4& m)
+{
+    for (int i = 0; i < 16; i++)
+        if (m.m[i] != 0.0f) return false;
+    return true;
+}
+
+template <typename T> int upload(Instance* I, DevBuf<T>& buf, const T* src, size_t n)
+{
+    HIP_TRY(I, buf.ensure(n));
+    if (n) HIP_TRY(I, hipMemcpyAsync(buf.ptr, src, n * sizeof(T), hipMemcpyHostToDevice, I->stream));
+    return RFW_HIP_OK;
+}
+
+void compute_shard(Instance* I)
+{
+    I->tiles_x = (I->width + I->tile_size - 1) / I->tile_size;
+    I->tiles_y = (I->height + I->tile_size - 1) / I->tile_size;
+    const uint32_t total = I->tiles_x * I->tiles_y;
+    I->local_tiles = (total + I->world - 1) / I->world; // slab is padded to the same size on every rank
+    I->capacity = I->local_tiles * I->tile_size * I->tile_size;
+    uint64_t px = 0;
+    for (uint32_t t = I->rank; t < total; t += I->world) {
+        const uint32_t tx = t % I->tiles_x, ty = t / I->tiles_x;
+        const uint32_t w = std::min(I->tile_size, I->width - tx * I->tile_size), h = std::min(I->tile_size, I->height - ty * I->tile_size);
+        px += (uint64_t)w * h;
+    }
+    I->local_pixels = px;
+}
+
+int alloc_paths(Instance* I)
+{
+    compute_shard(I);
+    const size_t n = I->capacity;
+    for (int h = 0; h < 2; h++) {
+        HIP_TRY(I, I->d_ray_o[h].ensure(n));
+        HIP_TRY(I, I->d_ray_d[h].ensure(n));
+        HIP_TRY(I, I->d_thr[h].ensure(n));
+        HIP_TRY(I, I->d_hit[h].ensure(n));
+    }
+    HIP_TRY(I, I->d_sh_o.ensure(n));
+    HIP_TRY(I, I->d_sh_d.ensure(n));
+    HIP_TRY(I, I->d_sh_e.ensure(n));
+    HIP_TRY(I, I->d_acc_slab.ensure(n));
+    HIP_TRY(I, hipMemsetAsync(I->d_acc_slab.ptr, 0, n * sizeof(float4), I->stream));
+    const size_t px = (size_t)I->width * I->height;
+    HIP_TRY(I, I->d_frame_acc.ensure(px));
+    HIP_TRY(I, I->d_frame_out.ensure(px));
+    HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
+    HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
+    HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * std::max<size_t>(n, 65536)));
+    HIP_TRY(I, I->d_counters.ensure(1));
+    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, sizeof(QueueCounters), I->stream));
+    I->sample_count = 0;
+    return RFW_HIP_OK;
+}
+
+uint32_t spill_stride(const Instance* I) { return (uint32_t)(I->d_spill.cap / kStackSpill); }
+
+SceneDev scene_dev(Instance* I)
+{
+    SceneDev s;
+    s.tlas_nodes = I->d_tlas_nodes.ptr;
+    s.tlas_prims = I->d_tlas_prims.ptr;
+    s.instances = I->d_xforms.ptr;
+    s.instance_normals = I->d_normals.ptr;
+    s.blas_nodes = I->d_blas_nodes.ptr;
+    s.tri_packets = I->d_packets.ptr;
+    s.triangles = I->d_triangles.ptr;
+    s.materials = I->d_materials.ptr;
+    s.area_lights = I->d_area.ptr;
+    s.point_lights = I->d_point.ptr;
+    s.spot_lights = I->d_spot.ptr;
+    s.directional_lights = I->d_dir.ptr;
+    s.spill = I->d_spill.ptr;
+    s.spill_stride = spill_stride(I);
+    s.counters = I->d_counters.ptr;
+    return s;
+}
+
+// pad so that the slab test is conservative w.r.t. the rounding of the Moeller-Trumbore arithmetic
+inline void pad_box(PrimBox& b)
+{
+    for (int a = 0; a < 3; a++) {
+        const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+        const float e = 1e-4f + 4e-6f * m;
+        b.lo[a] -= e;
+        b.hi[a] += e;
+    }
+}
+
+void build_mesh(Instance* I, MeshHost& m)
+{
+    const size_t n = m.tris.size();
+    std::vector<PrimBox> boxes(n);
+    for (size_t i = 0; i < n; i++) {
+        const rfw_rt_triangle& t = m.tris[i];
+        const float* v[3] = {&t.vertex0.x, &t.vertex1.x, &t.vertex2.x};
+        for (int a = 0; a < 3; a++) {
+            boxes[i].lo[a] = std::min(v[0][a], std::min(v[1][a], v[2][a]));
+            boxes[i].hi[a] = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+        }
+        pad_box(boxes[i]);
+    }
+    build_bvh4_host(boxes, 4, I->build_threads, m.bvh);
+    m.packets.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t id = m.bvh.prim_order[k];
+        const rfw_rt_triangle& t = m.tris[id];
+        TriPacket p;
+        p.v0x = t.vertex0.x; p.v0y = t.vertex0.y; p.v0z = t.vertex0.z;
+        p.tri_id = id; // mesh-local; the global offset is added when the mega-buffer is assembled
+        // edge1 = v1 - v0, edge2 = v2 - v0 (intersection.glsl:7-8), single IEEE subtractions
+        p.e1x = t.vertex1.x - t.vertex0.x; p.e1y = t.vertex1.y - t.vertex0.y; p.e1z = t.vertex1.z - t.vertex0.z;
+        p.e2x = t.vertex2.x - t.vertex0.x; p.e2y = t.vertex2.y - t.vertex0.y; p.e2z = t.vertex2.z - t.vertex0.z;
+        // denom = 1 / dot(gn, gn) (intersection.glsl:32)
+        p.inv_gn2 = 1.0f / (t.normal.x * t.normal.x + t.normal.y * t.normal.y + t.normal.z * t.normal.z);
+        p.pad = 0.0f;
+        m.packets[k] = p;
+    }
+    m.dirty = false;
+}
+
+int do_synchronize(Instance* I)
+{
+    HIP_TRY(I, hipSetDevice(I->device));
+    bool any_change = false;
+    // ---- BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383) and the flattened mega-buffers (:1387-1548)
+    if (I->meshes_dirty) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (auto& kv : I->meshes)
+            if (kv.second.dirty) build_mesh(I, kv.second);
+        I->mesh_records.clear();
+        I->mesh_index.clear();
+        std::vector<Node4> nodes;
+        std::vector<TriPacket> packets;
+        std::vector<rfw_rt_triangle> tris;
+        for (auto& kv : I->meshes) {
+            MeshHost& m = kv.second;
+            MeshRecord r;
+            r.node_base = (uint32_t)nodes.size();
+            r.node_count = (uint32_t)m.bvh.nodes.size();
+            r.tri_base = (uint32_t)tris.size();
+            r.tri_count = (uint32_t)m.tris.size();
+            I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
+            I->mesh_records.push_back(r);
+            nodes.insert(nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
+            const size_t p0 = packets.size();
+            packets.insert(packets.end(), m.packets.begin(), m.packets.end());
+            for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
+            tris.insert(tris.end(), m.tris.begin(), m.tris.end());
+        }
+        I->n_tris = tris.size();
+        I->n_blas_nodes = nodes.size();
+        int rc;
+        if ((rc = upload(I, I->d_blas_nodes, nodes.data(), nodes.size()))) return rc;
+        if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
+        if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
+        if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+        HIP_TRY(I, hipStreamSynchronize(I->stream)); // the host vectors above go out of scope
+        I->ms_blas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        I->meshes_dirty = false;
+        I->instances_dirty = true;
+        any_change = true;
+    }
+    // ---- instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
+    if (I->instances_dirty) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<rfw_mat4> mats;
+        std::vector<uint32_t> mesh_of;
+        std::vector<PrimBox> boxes;
+        std::vector<uint32_t> box_gid;
+        for (auto& kv : I->inst_lists) {
+            const auto mit = I->mesh_index.find(kv.first);
+            const bool mesh_ok = mit != I->mesh_index.end() && I->mesh_records[mit->second].tri_count > 0;
+            for (size_t s = 0; s < kv.second.matrices.size(); s++) {
+                const rfw_mat4& m = kv.second.matrices[s];
+                const uint32_t gid = (uint32_t)mats.size();
+                mats.push_back(m);
+                mesh_of.push_back(mesh_ok ? mit->second : 0xffffffffu);
+                if (!mesh_ok || is_zero_matrix(m)) continue; // removed slot (crates/rfw-scene/src/instances_3d.rs:79-86)
+                PrimBox b;
+                for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+                const rfw_aabb& lb = kv.second.local_aabb;
+                for (int c = 0; c < 8; c++) {
+                    const float x = (c & 1) ? lb.max[0] : lb.min[0], y = (c & 2) ? lb.max[1] : lb.min[1], z = (c & 4) ? lb.max[2] : lb.min[2];
+                    const float w[3] = {m.m[0] * x + m.m[4] * y + m.m[8] * z + m.m[12], m.m[1] * x + m.m[5] * y + m.m[9] * z + m.m[13],
+                                        m.m[2] * x + m.m[6] * y + m.m[10] * z + m.m[14]};
+                    for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], w[a]); b.hi[a] = std::max(b.hi[a], w[a]); }
+                }
+                // the mesh-local box holds unpadded vertices; pad for the transform's rounding and the BLAS padding
+                for (int a = 0; a < 3; a++) {
+                    const float ext = b.hi[a] - b.lo[a];
+                    const float e = 2e-4f + 1e-5f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + 1e-5f * ext;
+                    b.lo[a] -= e;
+                    b.hi[a] += e;
+                }
+                boxes.push_back(b);
+                box_gid.push_back(gid);
+            }
+        }
+        I->n_instances = mats.size();
+        I->n_valid_instances = boxes.size();
+        HostBvh4 tlas;
+        build_bvh4_host(boxes, 1, I->build_threads, tlas);
+        std::vector<uint32_t> prims(tlas.prim_order.size());
+        for (size_t k = 0; k < prims.size(); k++) prims[k] = box_gid[tlas.prim_order[k]];
+        I->n_tlas_nodes = tlas.nodes.size();
+        int rc;
+        if ((rc = upload(I, I->d_matrices, mats.data(), mats.size()))) return rc;
+        if ((rc = upload(I, I->d_mesh_of_instance, mesh_of.data(), mesh_of.size()))) return rc;
+        if ((rc = upload(I, I->d_tlas_nodes, tlas.nodes.data(), tlas.nodes.size()))) return rc;
+        if ((rc = upload(I, I->d_tlas_prims, prims.data(), prims.size()))) return rc;
+        HIP_TRY(I, I->d_xforms.ensure(mats.size()));
+        HIP_TRY(I, I->d_normals.ensure(mats.size()));
+        launch_prepare_instances(I->stream, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)mats.size(),
+                                 I->d_xforms.ptr, I->d_normals.ptr);
+        HIP_TRY(I, hipGetLastError());
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        I->instances_dirty = false;
+        any_change = true;
+    }
+    if (I->materials_dirty) {
+        int rc;
+        if ((rc = upload(I, I->d_materials, I->materials.data(), I->materials.size()))) return rc;
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->materials_dirty = false;
+        any_change = true;
+    }
+    if (I->lights_dirty) {
+        int rc;
+        if ((rc = upload(I, I->d_area, I->area_lights.data(), I->area_lights.size()))) return rc;
+        if ((rc = upload(I, I->d_point, I->point_lights.data(), I->point_lights.size()))) return rc;
+        if ((rc = upload(I, I->d_spot, I->spot_lights.data(), I->spot_lights.size()))) return rc;
+        if ((rc = upload(I, I->d_dir, I->directional_lights.data(), I->directional_lights.size()))) return rc;
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->lights_dirty = false;
+        any_change = true;
+    }
+    if (any_change) I->sample_count = 0; // the accumulated image no longer matches the scene
+    I->synchronized = true;
+    return RFW_HIP_OK;
+}
+
+CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v)
+{
+    CameraParams c;
+    std::memset(&c, 0, sizeof(c));
+    c.pos[0] = v.pos.x; c.pos[1] = v.pos.y; c.pos[2] = v.pos.z;
+    c.lens_size = v.lens_size;
+    c.right[0] = v.right.x; c.right[1] = v.right.y; c.right[2] = v.right.z;
+    c.spread_angle = v.spread_angle;
+    c.up[0] = v.up.x; c.up[1] = v.up.y; c.up[2] = v.up.z;
+    c.clamp_value = I->clamp_value;
+    c.p1[0] = v.p1.x; c.p1[1] = v.p1.y; c.p1[2] = v.p1.z;
+    c.width = I->width; c.height = I->height;
+    c.sample_count = I->sample_count;
+    c.point_light_count = (uint32_t)I->point_lights.size();
+    c.area_light_count = (uint32_t)I->area_lights.size();
+    c.spot_light_count = (uint32_t)I->spot_lights.size();
+    c.directional_light_count = (uint32_t)I->directional_lights.size();
+    c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
+    c.rank = I->rank; c.world = I->world; c.local_tiles = I->local_tiles;
+    c.flags = I->flags;
+    c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
+    return c;
+}
+
+PathDev path_dev(Instance* I)
+{
+    PathDev p;
+    for (int h = 0; h < 2; h++) {
+        p.ray_o[h] = I->d_ray_o[h].ptr;
+        p.ray_d[h] = I->d_ray_d[h].ptr;
+        p.thr[h] = I->d_thr[h].ptr;
+        p.hit[h] = I->d_hit[h].ptr;
+    }
+    p.sh_o = I->d_sh_o.ptr;
+    p.sh_d = I->d_sh_d.ptr;
+    p.sh_e = I->d_sh_e.ptr;
+    p.acc = I->external_slab ? (float4*)I->external_slab : I->d_acc_slab.ptr;
+    p.capacity = I->capacity;
+    return p;
+}
+
+inline int ev_index(uint32_t bounce, int kernel, int end) { return EV_KERNEL_BASE + 2 * ((int)bounce * kKernelsPerBounce + kernel) + end; }
+constexpr int kEvBlit = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce);
+
+int do_render(Instance* I, const rfw_camera_view_3d& view)
+{
+    HIP_TRY(I, hipSetDevice(I->device));
+    if (!I->synchronized || I->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
+    if (I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) I->sample_count = 0;
+    I->last_view = view;
+    I->have_last_view = true;
+
+    CameraParams cam = camera_params(I, view);
+    const SceneDev sc = scene_dev(I);
+    const PathDev p = path_dev(I);
+    const bool count = (I->flags & RFW_HIP_FLAG_COUNT_TRAVERSAL) != 0;
+    hipStream_t s = I->stream;
+    const bool tm = I->timing;
+    auto rec = [&](int ev) { if (tm) (void)hipEventRecord(I->events[ev], s); };
+
+    rec(EV_FRAME0);
+    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, sizeof(QueueCounters), s));
+    const uint32_t bounces = std::min<uint32_t>(I->max_path_length, kMaxBounces);
+    for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back
+        cam.path_length = b;
+        rec(ev_index(b, 0, 0));
+        if (b == 0) launch_primary(s, cam, sc, p, count);
+        else launch_extend(s, cam, sc, p, b, count);
+        rec(ev_index(b, 0, 1));
+        rec(ev_index(b, 1, 0));
+        launch_shade(s, cam, sc, p, b);
+        rec(ev_index(b, 1, 1));
+        if (!(I->flags & RFW_HIP_FLAG_NO_NEE)) {
+            rec(ev_index(b, 2, 0));
+            launch_shadow(s, cam, sc, p, b, count);
+            rec(ev_index(b, 2, 1));
+        }
+    }
+    I->sample_count += 1;
+    rec(kEvBlit);
+    if (I->world <= 1) launch_blit(s, cam, p.acc, I->d_frame_acc.ptr, I->d_frame_out.ptr, I->sample_count);
+    rec(kEvBlit + 1);
+    rec(EV_FRAME1);
+    HIP_TRY(I, hipGetLastError());
+    I->last_bounces = bounces;
+    I->frame_recorded = tm;
+    I->last_count_flag = count;
+    return RFW_HIP_OK;
+}
+
+} // namespace
+
+// ==================================================================== C ABI
+#define LOCK(inst)                                    \
+    if (!(inst)) return RFW_HIP_E_INVALID;            \
+    Instance* I = static_cast<Instance*>(inst);       \
+    std::lock_guard<std::mutex> guard_(I->mu)
+
+extern "C" {
+
+uint32_t rfw_hip_abi_version(void) { return RFW_HIP_ABI_VERSION; }
+
+void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rfw_hip_options* o)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available (") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+                         "); this backend has no CPU fallback";
+        return nullptr;
+    }
+    if (width == 0 || height == 0) {
+        g_create_error = "width and height must be non-zero";
+        return nullptr;
+    }
+    Instance* I = new Instance();
+    I->width = width;
+    I->height = height;
+    int dev = -1;
+    if (o) {
+        dev = o->device;
+        if (o->max_path_length) I->max_path_length = std::min<uint32_t>(o->max_path_length, kMaxBounces);
+        if (o->clamp_value > 0.0f) I->clamp_value = o->clamp_value;
+        I->world = std::max<uint32_t>(o->world, 1);
+        I->rank = o->rank;
+        if (o->tile_size) I->tile_size = o->tile_size;
+        if (o->builder) I->builder = o->builder;
+        I->flags = o->flags;
+    }
+    if (I->rank >= I->world || (I->tile_size % 8) != 0) {
+        g_create_error = "invalid shard options (rank >= world, or tile_size not a multiple of 8)";
+        delete I;
+        return nullptr;
+    }
+    if (I->builder == RFW_HIP_BUILDER_DEVICE_LBVH) {
+        g_create_error = "builder DEVICE_LBVH is not available in this build";
+        delete I;
+        return nullptr;
+    }
+    if (dev < 0) (void)hipGetDevice(&dev);
+    I->device = dev;
+    I->build_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto bail = [&](const char* what, hipError_t err) -> void* {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete I;
+        return nullptr;
+    };
+    if ((e = hipSetDevice(dev)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&I->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    I->stream = I->own_stream;
+    for (int i = 0; i < kNumEvents; i++)
+        if ((e = hipEventCreate(&I->events[i])) != hipSuccess) return bail("hipEventCreate", e);
+    if (alloc_paths(I) != RFW_HIP_OK) {
+        g_create_error = I->err;
+        delete I;
+        return nullptr;
+    }
+    (void)hipStreamSynchronize(I->stream);
+    return I;
+}
+
+void rfw_hip_destroy(void* inst)
+{
+    if (!inst) return;
+    Instance* I = static_cast<Instance*>(inst);
+    {
+        std::lock_guard<std::mutex> g(I->mu);
+        (void)hipSetDevice(I->device);
+        (void)hipDeviceSynchronize();
+        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_packets.release(); I->d_triangles.release();
+        I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
+        I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
+        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release();
+        for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
+        I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
+        for (int i = 0; i < kNumEvents; i++)
+            if (I->events[i]) (void)hipEventDestroy(I->events[i]);
+        if (I->own_stream) (void)hipStreamDestroy(I->own_stream);
+    }
+    delete I;
+}
+
+const char* rfw_hip_last_error(void* inst)
+{
+    if (!inst) return g_create_error.c_str();
+    return static_cast<Instance*>(inst)->err.c_str();
+}
+
+int rfw_hip_set_2d_mesh(void* inst, uint32_t, const void*, uint32_t, int32_t) { LOCK(inst); return RFW_HIP_OK; }
+int rfw_hip_set_2d_instances(void* inst, uint32_t, const rfw_mat4*, uint32_t) { LOCK(inst); return RFW_HIP_OK; }
+
+int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
+{
+    LOCK(inst);
+    if (!d || (d->num_triangles && !d->triangles)) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: null data");
+    if (d->num_triangles > kLeafFirstMask) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: more than 2^27 triangles in one mesh");
+    MeshHost& m = I->meshes[id];
+    m.tris.assign(d->triangles, d->triangles + d->num_triangles); // copy: the borrow ends with this call
+    m.dirty = true;
+    I->meshes_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_unload_3d_meshes(void* inst, const uint32_t* ids, uint32_t n)
+{
+    LOCK(inst);
+    if (n && !ids) return fail(I, RFW_HIP_E_INVALID, "unload_3d_meshes: null ids");
+    for (uint32_t i = 0; i < n; i++) {
+        I->meshes.erase(ids[i]);
+        I->inst_lists.erase(ids[i]);
+    }
+    I->meshes_dirty = true;
+    I->instances_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_3d_instances(void* inst, uint32_t mesh, const rfw_instances_data_3d* d)
+{
+    LOCK(inst);
+    if (!d || (d->num_matrices && !d->matrices)) return fail(I, RFW_HIP_E_INVALID, "set_3d_instances: null data");
+    InstList& l = I->inst_lists[mesh];
+    l.local_aabb = d->local_aabb;
+    l.matrices.assign(d->matrices, d->matrices + d->num_matrices);
+    I->instances_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, const uint32_t* /*changed*/)
+{
+    LOCK(inst);
+    if (n && !m) return fail(I, RFW_HIP_E_INVALID, "set_materials: null data");
+    I->materials.assign(m, m + n);
+    I->materials_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_textures(void* inst, const rfw_texture_data*, uint32_t, const uint32_t*)
+{
+    LOCK(inst); // accepted; texture sampling is a "next" row — materials shade with their flat colour
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_synchronize(void* inst)
+{
+    LOCK(inst);
+    return do_synchronize(I);
+}
+
+int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_view_3d* view, uint32_t /*mode*/)
+{
+    LOCK(inst);
+    if (!view) return fail(I, RFW_HIP_E_INVALID, "render: null view");
+    return do_render(I, *view);
+}
+
+int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
+{
+    LOCK(inst);
+    if (w == 0 || h == 0) return fail(I, RFW_HIP_E_INVALID, "resize: zero size");
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    I->width = w;
+    I->height = h;
+    return alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
+}
+
+int rfw_hip_set_point_lights(void* inst, const rfw_point_light* l, uint32_t n, const uint32_t*)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_point_lights: null data");
+    I->point_lights.assign(l, l + n);
+    I->lights_dirty = true;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_spot_lights(void* inst, const rfw_spot_light* l, uint32_t n, const uint32_t*)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_spot_lights: null data");
+    I->spot_lights.assign(l, l + n);
+    I->lights_dirty = true;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_area_lights(void* inst, const rfw_area_light* l, uint32_t n, const uint32_t*)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_area_lights: null data");
+    I->area_lights.assign(l, l + n);
+    I->lights_dirty = true;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_directional_lights(void* inst, const rfw_directional_light* l, uint32_t n, const uint32_t*)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_directional_lights: null data");
+    I->directional_lights.assign(l, l + n);
+    I->lights_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_skybox(void* inst, const rfw_texture_data*)
+{
+    LOCK(inst); // accepted; the skybox image is a "next" row — a miss adds the constant sky colour (option sky_r/g/b, default black)
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_skins(void* inst, const rfw_skin_data*, uint32_t, const uint32_t*)
+{
+    LOCK(inst); // accepted and stored nowhere yet: GPU skinning is a "next" row
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_reset_accumulation(void* inst)
+{
+    LOCK(inst);
+    I->sample_count = 0;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_option(void* inst, const char* key, double value)
+{
+    LOCK(inst);
+    if (!key) return fail(I, RFW_HIP_E_INVALID, "set_option: null key");
+    const std::string k(key);
+    if (k == "max_path_length") I->max_path_length = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)value, kMaxBounces));
+    else if (k == "clamp_value") I->clamp_value = (float)value;
+    else if (k == "nee") I->flags = value != 0.0 ? (I->flags & ~RFW_HIP_FLAG_NO_NEE) : (I->flags | RFW_HIP_FLAG_NO_NEE);
+    else if (k == "count_traversal") I->flags = value != 0.0 ? (I->flags | RFW_HIP_FLAG_COUNT_TRAVERSAL) : (I->flags & ~RFW_HIP_FLAG_COUNT_TRAVERSAL);
+    else if (k == "sample_count") I->sample_count = (uint32_t)value;
+    else if (k == "timing") I->timing = value != 0.0;
+    else if (k == "sky_r") I->sky[0] = (float)value;
+    else if (k == "sky_g") I->sky[1] = (float)value;
+    else if (k == "sky_b") I->sky[2] = (float)value;
+    else if (k == "build_threads") I->build_threads = std::max(1, (int)value);
+    else return fail(I, RFW_HIP_E_INVALID, "set_option: unknown key " + k);
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n)
+{
+    LOCK(inst);
+    if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_framebuffer: size mismatch");
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_out.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    return RFW_HIP_OK;
+}
+int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
+{
+    LOCK(inst);
+    if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_accumulator: size mismatch");
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_acc.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
+{
+    LOCK(inst);
+    if (!out) return fail(I, RFW_HIP_E_INVALID, "get_frame_stats: null out");
+    HIP_TRY(I, hipSetDevice(I->device));
+    std::memset(out, 0, sizeof(*out));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    QueueCounters qc;
+    HIP_TRY(I, hipMemcpy(&qc, I->d_counters.ptr, sizeof(qc), hipMemcpyDeviceToHost));
+    if (qc.pad) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
+    const uint32_t nb = I->last_bounces;
+    out->primary_rays = nb ? I->local_pixels : 0;
+    for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc.ext[b];
+    if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
+        for (uint32_t b = 0; b < nb; b++) out->shadow_rays += qc.shadow[b];
+    out->nodes_visited = qc.nodes_visited;
+    out->tris_tested = qc.tris_tested;
+    out->instances_entered = qc.instances_entered;
+    out->sample_count = I->sample_count;
+    out->bounces = nb;
+    if (I->frame_recorded) {
+        auto el = [&](int a, int b) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, I->events[a], I->events[b]); return ms; };
+        out->ms_total = el(EV_FRAME0, EV_FRAME1);
+        for (uint32_t b = 0; b < nb; b++) {
+            const float tr = el(ev_index(b, 0, 0), ev_index(b, 0, 1));
+            if (b == 0) out->ms_trace_primary += tr; else out->ms_trace_extend += tr;
+            out->ms_shade += el(ev_index(b, 1, 0), ev_index(b, 1, 1));
+            if (!(I->flags & RFW_HIP_FLAG_NO_NEE)) out->ms_trace_shadow += el(ev_index(b, 2, 0), ev_index(b, 2, 1));
+        }
+        out->ms_other = el(kEvBlit, kEvBlit + 1);
+    }
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
+{
+    LOCK(inst);
+    if (!out) return fail(I, RFW_HIP_E_INVALID, "get_scene_stats: null out");
+    out->triangles = I->n_tris;
+    out->instances = I->n_valid_instances;
+    out->blas_nodes = I->n_blas_nodes;
+    out->tlas_nodes = I->n_tlas_nodes;
+    out->node_bytes = sizeof(Node4);
+    out->tri_bytes = sizeof(TriPacket);
+    out->ms_blas_build = I->ms_blas_build;
+    out->ms_tlas_build = I->ms_tlas_build;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_stream(void* inst, void* stream)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    I->stream = stream ? (hipStream_t)stream : I->own_stream;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_device_synchronize(void* inst)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_shard_info(void* inst, uint64_t* slab_floats, uint32_t* local, uint32_t* total)
+{
+    LOCK(inst);
+    if (slab_floats) *slab_floats = (uint64_t)I->capacity * 4;
+    if (local) *local = I->local_tiles;
+    if (total) *total = I->tiles_x * I->tiles_y;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_slab_output(void* inst, void* ptr)
+{
+    LOCK(inst);
+    I->external_slab = ptr;
+    I->sample_count = 0;
+    return RFW_HIP_OK;
+}
+int rfw_hip_assemble_frame(void* inst, const void* gathered)
+{
+    LOCK(inst);
+    if (!gathered) return fail(I, RFW_HIP_E_INVALID, "assemble_frame: null buffer");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const CameraParams cam = camera_params(I, I->last_view);
+    launch_assemble(I->stream, cam, (const float4*)gathered, I->capacity, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
+    HIP_TRY(I, hipGetLastError());
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_intersect(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits)
+{
+    LOCK(inst);
+    if (n && (!origins || !directions || !hits)) return fail(I, RFW_HIP_E_INVALID, "intersect: null pointer");
+    if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "intersect: scene not synchronized");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const uint64_t chunk = spill_stride(I);
+    DevBuf<float> d_o, d_d;
+    DevBuf<rfw_hip_hit> d_h;
+    HIP_TRY(I, d_o.ensure(3 * std::min(n, chunk)));
+    HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
+    HIP_TRY(I, d_h.ensure(std::min(n, chunk)));
+    const SceneDev sc = scene_dev(I);
+    int rc = RFW_HIP_OK;
+    for (uint64_t off = 0; off < n && rc == RFW_HIP_OK; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        hipError_t e = hipMemcpyAsync(d_o.ptr, origins + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_d.ptr, directions + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
+        if (e == hipSuccess) {
+            launch_query_closest(I->stream, sc, d_o.ptr, d_d.ptr, t_min, t_max, m, d_h.ptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hits + off, d_h.ptr, m * sizeof(rfw_hip_hit), hipMemcpyDeviceToHost, I->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
+        if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("intersect: ") + hipGetErrorString(e));
+    }
+    d_o.release(); d_d.release(); d_h.release();
+    return rc;
+}
+
+int rfw_hip_occludes(void* inst, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded)
+{
+    LOCK(inst);
+    if (n && (!origins || !directions || !t_max || !occluded)) return fail(I, RFW_HIP_E_INVALID, "occludes: null pointer");
+    if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "occludes: scene not synchronized");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const uint64_t chunk = spill_stride(I);
+    DevBuf<float> d_o, d_d, d_t;
+    DevBuf<uint8_t> d_r;
+    HIP_TRY(I, d_o.ensure(3 * std::min(n, chunk)));
+    HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
+    HIP_TRY(I, d_t.ensure(std::min(n, chunk)));
+    HIP_TRY(I, d_r.ensure(std::min(n, chunk)));
+    const SceneDev sc = scene_dev(I);
+    int rc = RFW_HIP_OK;
+    for (uint64_t off = 0; off < n && rc == RFW_HIP_OK; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        hipError_t e = hipMemcpyAsync(d_o.ptr, origins + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_d.ptr, directions + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_t.ptr, t_max + off, m * sizeof(float), hipMemcpyHostToDevice, I->stream);
+        if (e == hipSuccess) {
+            launch_query_any(I->stream, sc, d_o.ptr, d_d.ptr, t_min, d_t.ptr, m, d_r.ptr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(occluded + off, d_r.ptr, m, hipMemcpyDeviceToHost, I->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
+        if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("occludes: ") + hipGetErrorString(e));
+    }
+    d_o.release(); d_d.release(); d_t.release(); d_r.release();
+    return rc;
+}
+
+// what: "hit0"/"hit1" (uint4), "ray_o0"/"ray_o1", "ray_d0"/"ray_d1", "thr0"/"thr1", "sh_o", "sh_d", "sh_e" (float4), "counters",
+//       "xforms" (InstanceXform), "normals" (InstanceNormal)
+int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, uint64_t* written)
+{
+    LOCK(inst);
+    if (!what || !dst) return fail(I, RFW_HIP_E_INVALID, "debug_read: null pointer");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const std::string w(what);
+    const void* src = nullptr;
+    uint64_t avail = 0;
+    const uint64_t q = (uint64_t)I->capacity * 16;
+    if (w == "hit0") { src = I->d_hit[0].ptr; avail = q; }
+    else if (w == "hit1") { src = I->d_hit[1].ptr; avail = q; }
+    else if (w == "ray_o0") { src = I->d_ray_o[0].ptr; avail = q; }
+    else if (w == "ray_o1") { src = I->d_ray_o[1].ptr; avail = q; }
+    else if (w == "ray_d0") { src = I->d_ray_d[0].ptr; avail = q; }
+    else if (w == "ray_d1") { src = I->d_ray_d[1].ptr; avail = q; }
+    else if (w == "thr0") { src = I->d_thr[0].ptr; avail = q; }
+    else if (w == "thr1") { src = I->d_thr[1].ptr; avail = q; }
+    else if (w == "sh_o") { src = I->d_sh_o.ptr; avail = q; }
+    else if (w == "sh_d") { src = I->d_sh_d.ptr; avail = q; }
+    else if (w == "sh_e") { src = I->d_sh_e.ptr; avail = q; }
+    else if (w == "counters") { src = I->d_counters.ptr; avail = sizeof(QueueCounters); }
+    else if (w == "xforms") { src = I->d_xforms.ptr; avail = I->n_instances * sizeof(InstanceXform); }
+    else if (w == "normals") { src = I->d_normals.ptr; avail = I->n_instances * sizeof(InstanceNormal); }
+    else return fail(I, RFW_HIP_E_INVALID, "debug_read: unknown buffer " + w);
+    const uint64_t n = std::min(bytes, avail);
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    if (n) HIP_TRY(I, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    if (written) *written = n;
+    return RFW_HIP_OK;
+}
+
+} // extern "C"

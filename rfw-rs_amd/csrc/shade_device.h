@@ -1,0 +1,389 @@
+// shade_device.h — material evaluation, BSDF sampling and light sampling for the shade kernel.
+// Device restatement of backends/gpu-rt/shaders/{disney.glsl, utils.glsl, structs.glsl:217-270} and
+// shade.comp:283-528 under the arithmetic contract of device_math.h.  Function names follow the GLSL.
+#pragma once
+#include "device_math.h"
+#include "device_types.h"
+
+namespace rfwhip {
+
+#define RFW_PI 3.14159265359f
+#define RFW_TWOPI (2.0f * 3.14159265359f)
+#define RFW_INVPI (1.0f / 3.14159265359f)
+#define RFW_INV2PI (1.0f / (2.0f * 3.14159265359f))
+
+// utils.glsl:22-26
+RFW_DI uint32_t PackNormal(f3 N)
+{
+    const float f = 65535.0f / __builtin_sqrtf(8.0f * N.z + 8.0f);
+    return f2u(N.x * f + 32767.0f) + (f2u(N.y * f + 32767.0f) << 16);
+}
+// utils.glsl:28-35
+RFW_DI f3 UnpackNormal(uint32_t p)
+{
+    float nx = (float)(p & 65535u) * (2.0f / 65535.0f);
+    float ny = (float)(p >> 16) * (2.0f / 65535.0f);
+    float nz = 0.0f;
+    nx += -1.0f; ny += -1.0f; nz += 1.0f;
+    float l = nx * -nx + ny * -ny + nz * -nz;
+    nz = l;
+    l = __builtin_sqrtf(l);
+    nx *= l;
+    ny *= l;
+    return mk3(nx, ny, nz) * 2.0f + mk3(0.0f, 0.0f, -1.0f);
+}
+// utils.glsl:55-70
+RFW_DI f3 DiffuseReflectionUniform(float r0, float r1)
+{
+    const float term1 = RFW_TWOPI * r0, term2 = __builtin_sqrtf(1.0f - r1 * r1);
+    float s, c;
+    rfw_sincosf(term1, &s, &c);
+    return mk3(c * term2, s * term2, r1);
+}
+RFW_DI f3 DiffuseReflectionCosWeighted(float r0, float r1)
+{
+    const float term1 = RFW_TWOPI * r0;
+    const float term2 = __builtin_sqrtf(1.0f - r1);
+    float s, c;
+    rfw_sincosf(term1, &s, &c);
+    return mk3(c * term2, s * term2, __builtin_sqrtf(r1));
+}
+// utils.glsl:72-80
+RFW_DI void CLAMPINTENSITY(f3& contribution, float clampValue)
+{
+    const float v = gl_max(contribution.x, gl_max(contribution.y, contribution.z));
+    if (v > clampValue) {
+        const float m = clampValue / v;
+        contribution = contribution * m;
+    }
+}
+// utils.glsl:83-92
+RFW_DI float safe_origin_1(float o, float n)
+{
+    const int32_t of_i = f2i(256.0f * n);
+    const float p_i = bitsf((uint32_t)((int32_t)fbits(o) + ((o < 0.0f) ? -of_i : of_i)));
+    return gl_abs(o) < (1.0f / 32.0f) ? o + (1.0f / 65536.0f) * n : p_i;
+}
+RFW_DI f3 safe_origin(f3 O, f3 R, f3 N)
+{
+    const f3 _N = dot(N, R) > 0.0f ? N : -N;
+    return mk3(safe_origin_1(O.x, _N.x), safe_origin_1(O.y, _N.y), safe_origin_1(O.z, _N.z));
+}
+
+// structs.glsl:177-270
+struct ShadingData {
+    f3 color, absorption, specular;
+    float metallic, subsurface, specular_f, roughness, specular_tint, anisotropic, sheen, sheen_tint;
+    float clearcoat, clearcoat_gloss, transmission, eta;
+};
+RFW_DI float CHAR2FLT(uint32_t x, int s) { return (float)((x >> s) & 255u) * (1.0f / 255.0f); }
+RFW_DI ShadingData extractParameters(const rfw_device_material* m)
+{
+    // 96-B material = 6 dwordx4 loads
+    const float4* mp = reinterpret_cast<const float4*>(m);
+    const float4 c = mp[0], a = mp[1], s = mp[2];
+    const uint4 p = *reinterpret_cast<const uint4*>(mp + 3);
+    ShadingData d;
+    d.color = mk3(c.x, c.y, c.z);
+    d.absorption = mk3(a.x, a.y, a.z);
+    d.specular = mk3(s.x, s.y, s.z);
+    d.metallic = CHAR2FLT(p.x, 0);
+    d.subsurface = CHAR2FLT(p.x, 8);
+    d.specular_f = CHAR2FLT(p.x, 16);
+    d.roughness = gl_max(0.01f, CHAR2FLT(p.x, 24));
+    d.specular_tint = CHAR2FLT(p.y, 0);
+    d.anisotropic = CHAR2FLT(p.y, 8);
+    d.sheen = CHAR2FLT(p.y, 16);
+    d.sheen_tint = CHAR2FLT(p.y, 24);
+    d.clearcoat = CHAR2FLT(p.z, 0);
+    d.clearcoat_gloss = CHAR2FLT(p.z, 8);
+    d.transmission = CHAR2FLT(p.z, 16);
+    d.eta = CHAR2FLT(p.z, 24);
+    return d;
+}
+
+enum { BSDF_TYPE_REFLECTED = 0, BSDF_TYPE_TRANSMITTED = 1, BSDF_TYPE_SPECULAR = 2 };
+RFW_DI float sqr(float x) { return x * x; }
+
+// disney.glsl:13-25
+RFW_DI bool Refract(f3 wi, f3 n, float eta, f3& wt)
+{
+    const float cosThetaI = dot(n, wi);
+    const float sin2ThetaI = gl_max(0.0f, 1.0f - cosThetaI * cosThetaI);
+    const float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1.0f) return false;
+    const float cosThetaT = __builtin_sqrtf(1.0f - sin2ThetaT);
+    wt = eta * (wi * -1.0f) + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+// disney.glsl:27-31
+RFW_DI float SchlickFresnel(float u)
+{
+    const float m = gl_clamp(1.0f - u, 0.0f, 1.0f);
+    return (m * m) * (m * m) * m;
+}
+// disney.glsl:45-52
+RFW_DI float GTR1(float NDotH, float a)
+{
+    if (a >= 1.0f) return RFW_INVPI;
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return (a2 - 1.0f) / (RFW_PI * rfw_logf(a2) * t);
+}
+// disney.glsl:54-59
+RFW_DI float GTR2(float NDotH, float a)
+{
+    const float a2 = a * a;
+    const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return a2 / (RFW_PI * t * t);
+}
+// disney.glsl:61-66
+RFW_DI float SmithGGX(float NDotv, float alphaG)
+{
+    const float a = alphaG * alphaG;
+    const float b = NDotv * NDotv;
+    return 1.0f / (NDotv + __builtin_sqrtf(a + b - a * b));
+}
+// disney.glsl:68-78
+RFW_DI float Fr(float VDotN, float eio)
+{
+    const float SinThetaT2 = sqr(eio) * (1.0f - VDotN * VDotN);
+    if (SinThetaT2 > 1.0f) return 1.0f;
+    const float LDotN = __builtin_sqrtf(1.0f - SinThetaT2);
+    const float eta = 1.0f / eio;
+    const float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
+    const float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+    return 0.5f * (sqr(r1) + sqr(r2));
+}
+// disney.glsl:80-87
+RFW_DI f3 SafeNormalize(f3 a)
+{
+    const float ls = dot(a, a);
+    if (ls > 0.0f) return a * (1.0f / __builtin_sqrtf(ls));
+    return mk3(0.0f);
+}
+// disney.glsl:89-108
+RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi)
+{
+    float bsdfPdf = 0.0f, brdfPdf;
+    if (dot(wi, N) <= 0.0f) {
+        brdfPdf = RFW_INV2PI * sd.subsurface * 0.5f;
+    } else {
+        const float F = Fr(dot(N, wo), sd.eta);
+        const f3 halfway = SafeNormalize(wi + wo);
+        const float cosThetaHalf = gl_abs(dot(halfway, N));
+        const float pdfHalf = GTR2(cosThetaHalf, sd.roughness) * cosThetaHalf;
+        const float pdfSpec = 0.25f * pdfHalf / gl_max(1.e-6f, dot(wi, halfway));
+        const float pdfDiff = gl_abs(dot(wi, N)) * RFW_INVPI * (1.0f - sd.subsurface);
+        bsdfPdf = pdfSpec * F;
+        brdfPdf = gl_mix(pdfDiff, pdfSpec, 0.5f);
+    }
+    return gl_mix(brdfPdf, bsdfPdf, sd.transmission);
+}
+// disney.glsl:110-195
+RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool backfacing)
+{
+    const float NDotL = dot(N, wi);
+    const float NDotV = dot(N, wo);
+    const f3 H = normalize(wi + wo);
+    const float NDotH = dot(N, H);
+    const float LDotH = dot(wi, H);
+    const f3 Cdlin = sd.color;
+    const float Cdlum = .3f * Cdlin.x + .6f * Cdlin.y + .1f * Cdlin.z;
+    const f3 Ctint = Cdlum > 0.0f ? Cdlin / Cdlum : mk3(1.0f);
+    const f3 Cspec0 = gl_mix(sd.specular * .08f * gl_mix(mk3(1.0f), Ctint, sd.specular_tint), Cdlin, sd.metallic);
+    f3 bsdf = mk3(0.0f);
+    f3 brdf = mk3(0.0f);
+    if (sd.transmission > 0.0f) {
+        if (NDotL <= 0.0f) {
+            const float F = Fr(NDotV, sd.eta);
+            bsdf = mk3((1.0f - F) / gl_abs(NDotL) * (1.0f - sd.metallic) * sd.transmission);
+        } else {
+            const float a = sd.roughness;
+            const float Ds = GTR2(NDotH, a);
+            const float FH = Fr(LDotH, sd.eta);
+            const f3 Fs = gl_mix(Cspec0, mk3(1.0f), FH);
+            const float Gs = SmithGGX(NDotV, a) * SmithGGX(NDotL, a);
+            bsdf = (Gs * Ds) * Fs;
+        }
+    }
+    if (sd.transmission < 1.0f) {
+        if (NDotL <= 0.0f) {
+            if (sd.subsurface > 0.0f) {
+                const f3 s = mk3(__builtin_sqrtf(sd.color.x), __builtin_sqrtf(sd.color.y), __builtin_sqrtf(sd.color.z));
+                const float FL = SchlickFresnel(gl_abs(NDotL)), FV = SchlickFresnel(NDotV);
+                const float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+                brdf = RFW_INVPI * s * sd.subsurface * Fd * (1.0f - sd.metallic);
+            }
+        } else {
+            const float a = sd.roughness;
+            const float Ds = GTR2(NDotH, a);
+            const float FH = SchlickFresnel(LDotH);
+            const f3 Fs = gl_mix(Cspec0, mk3(1.0f), FH);
+            const float Gs = SmithGGX(NDotV, a) * SmithGGX(NDotL, a);
+            const float FL = SchlickFresnel(NDotL), FV = SchlickFresnel(NDotV);
+            const float Fd90 = 0.5f + 2.0f * LDotH * LDotH * a;
+            const float Fd = gl_mix(1.0f, Fd90, FL) * gl_mix(1.0f, Fd90, FV);
+            const float Dr = GTR1(NDotH, gl_mix(.1f, .001f, sd.clearcoat_gloss));
+            const float Fc = gl_mix(.04f, 1.0f, FH);
+            const float Gr = SmithGGX(NDotL, .25f) * SmithGGX(NDotV, .25f);
+            brdf = RFW_INVPI * Fd * Cdlin * (1.0f - sd.metallic) * (1.0f - sd.subsurface) + Gs * Fs * Ds + mk3(sd.clearcoat * Gr * Fc * Dr);
+        }
+    }
+    const f3 fin = gl_mix(brdf, bsdf, sd.transmission);
+    if (backfacing) {
+        const f3 a = -sd.absorption * t;
+        return fin * mk3(rfw_expf(a.x), rfw_expf(a.y), rfw_expf(a.z));
+    }
+    return fin;
+}
+// disney.glsl:197-263
+RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, float& pdf, int& type, float r3, float r4)
+{
+    if (r3 < sd.transmission) {
+        const float F = Fr(dot(N, wo), sd.eta);
+        if (r4 < F) {
+            const float r1 = r3 / sd.transmission;
+            const float r2 = r4 / F;
+            const float cosThetaHalf = __builtin_sqrtf((1.0f - r2) / (1.0f + (sqr(sd.roughness) - 1.0f) * r2));
+            const float sinThetaHalf = __builtin_sqrtf(gl_max(0.0f, 1.0f - sqr(cosThetaHalf)));
+            float sinPhiHalf, cosPhiHalf;
+            rfw_sincosf(r1 * RFW_TWOPI, &sinPhiHalf, &cosPhiHalf);
+            f3 halfway = T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
+            if (dot(halfway, wo) <= 0.0f) halfway = halfway * -1.0f;
+            type = BSDF_TYPE_REFLECTED;
+            wi = gl_reflect(wo * -1.0f, halfway);
+        } else {
+            pdf = 0.0f;
+            if (Refract(wo, N, sd.eta, wi)) {
+                type = BSDF_TYPE_SPECULAR;
+                pdf = (1.0f - F) * sd.transmission;
+            }
+            return;
+        }
+    } else {
+        const float r1 = (r3 - sd.transmission) / (1.0f - sd.transmission);
+        if (r4 < 0.5f) {
+            const float r2 = r4 * 2.0f;
+            f3 d;
+            if (r2 < sd.subsurface) {
+                const float r5 = r2 / sd.subsurface;
+                d = DiffuseReflectionUniform(r1, r5);
+                type = BSDF_TYPE_TRANSMITTED;
+                d.z *= -1.0f;
+            } else {
+                const float r5 = (r2 - sd.subsurface) / (1.0f - sd.subsurface);
+                d = DiffuseReflectionCosWeighted(r1, r5);
+                type = BSDF_TYPE_REFLECTED;
+            }
+            wi = T * d.x + B * d.y + N * d.z;
+        } else {
+            const float r2 = (r4 - 0.5f) * 2.0f;
+            const float cosThetaHalf = __builtin_sqrtf((1.0f - r2) / (1.0f + (sqr(sd.roughness) - 1.0f) * r2));
+            const float sinThetaHalf = __builtin_sqrtf(gl_max(0.0f, 1.0f - sqr(cosThetaHalf)));
+            float sinPhiHalf, cosPhiHalf;
+            rfw_sincosf(r1 * RFW_TWOPI, &sinPhiHalf, &cosPhiHalf);
+            f3 halfway = T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
+            if (dot(halfway, wo) <= 0.0f) halfway = halfway * -1.0f;
+            wi = gl_reflect(wo * -1.0f, halfway);
+            type = BSDF_TYPE_REFLECTED;
+        }
+    }
+    pdf = BSDFPdf(sd, N, wo, wi);
+}
+// disney.glsl:265-270
+RFW_DI f3 EvaluateBSDF(const ShadingData& sd, f3 iN, f3 wo, f3 wi, float& pdf)
+{
+    const f3 bsdf = BSDFEval(sd, iN, wo, wi, 0.0f, false);
+    pdf = BSDFPdf(sd, iN, wo, wi);
+    return bsdf;
+}
+// disney.glsl:272-283
+RFW_DI f3 SampleBSDF(const ShadingData& sd, f3 iN, f3 N, f3 T, f3 B, f3 wo, float t, bool backfacing, float r3, float r4, f3& wi, float& pdf)
+{
+    int type = BSDF_TYPE_REFLECTED;
+    BSDFSample(sd, T, B, N, wo, wi, pdf, type, r3, r4);
+    return BSDFEval(sd, iN, wo, wi, t, backfacing);
+}
+
+// ---- shade.comp:283-528 (uniform light pick: ISLIGHTS undefined) ----
+struct LightView {
+    const rfw_area_light* area;
+    const rfw_point_light* point;
+    const rfw_spot_light* spot;
+    const rfw_directional_light* directional;
+    int n_area, n_point, n_spot, n_directional;
+};
+RFW_DI f3 ld3(const rfw_vec3& v) { return mk3(v.x, v.y, v.z); }
+
+// shade.comp:325-328
+RFW_DI float CalculateLightPDF(f3 D, float t, float lightArea, f3 lightNormal) { return (t * t) / (-dot(D, lightNormal) * lightArea); }
+
+// shade.comp:371-411
+RFW_DI f3 RandomBarycentrics(float r0)
+{
+    const uint32_t uf = f2u(r0 * 4294967296.0f);
+    f2 A{1.0f, 0.0f}, B{0.0f, 1.0f}, C{0.0f, 0.0f};
+    for (int i = 0; i < 16; ++i) {
+        const int d = (int)((uf >> (2u * (15u - (uint32_t)i))) & 0x3u);
+        f2 An, Bn, Cn;
+        if (d == 0) { An = (B + C) * 0.5f; Bn = (A + C) * 0.5f; Cn = (A + B) * 0.5f; }
+        else if (d == 1) { An = A; Bn = (A + B) * 0.5f; Cn = (A + C) * 0.5f; }
+        else if (d == 2) { An = (B + A) * 0.5f; Bn = B; Cn = (B + C) * 0.5f; }
+        else { An = (C + A) * 0.5f; Bn = (C + B) * 0.5f; Cn = C; }
+        A = An; B = Bn; C = Cn;
+    }
+    const f2 r = (A + B + C) * 0.3333333f;
+    return mk3(r.x, r.y, 1.0f - r.x - r.y);
+}
+
+// shade.comp:413-528
+RFW_DI f3 RandomPointOnLight(const LightView& lv, float r0, f3 I, f3 N, float& pickProb, float& lightPdf, f3& lightColor)
+{
+    const int AREA = lv.n_area, POINT = lv.n_point, SPOT = lv.n_spot;
+    const uint32_t lightCount = (uint32_t)(lv.n_area + lv.n_point + lv.n_spot + lv.n_directional);
+    const f3 bary = RandomBarycentrics(r0);
+    pickProb = 1.0f / (float)lightCount;
+    int lightIdx = f2i(r0 * (float)lightCount);
+    lightIdx = lightIdx < 0 ? 0 : (lightIdx > (int)lightCount - 1 ? (int)lightCount - 1 : lightIdx);
+    if (lightIdx < AREA) {
+        const rfw_area_light* al = lv.area + lightIdx;
+        lightColor = ld3(al->radiance);
+        const f3 LN = ld3(al->normal);
+        const f3 P = bary.x * ld3(al->vertex0) + bary.y * ld3(al->vertex1) + bary.z * ld3(al->vertex2);
+        f3 L = I - P;
+        const float sqDist = dot(L, L);
+        L = normalize(L);
+        const float LNdotL = dot(L, LN);
+        const float reciSolidAngle = sqDist / (al->energy * LNdotL);
+        lightPdf = (LNdotL > 0.0f && dot(L, N) < 0.0f) ? (reciSolidAngle * (1.0f / al->area)) : 0.0f;
+        return P;
+    }
+    if (lightIdx < (AREA + POINT)) {
+        const rfw_point_light* pl = lv.point + (lightIdx - AREA);
+        lightColor = ld3(pl->radiance);
+        const f3 L = I - ld3(pl->position);
+        const float sqDist = dot(L, L);
+        lightPdf = dot(L, N) < 0.0f ? (sqDist / pl->energy) : 0.0f;
+        return ld3(pl->position);
+    }
+    if (lightIdx < (AREA + POINT + SPOT)) {
+        const rfw_spot_light* sl = lv.spot + (lightIdx - (AREA + POINT));
+        f3 L = I - ld3(sl->position);
+        const float sqDist = dot(L, L);
+        L = normalize(L);
+        const float d = gl_max(0.0f, dot(L, ld3(sl->direction)) - sl->cos_outer) / (sl->cos_inner - sl->cos_outer);
+        const float LNdotL = gl_min(1.0f, d);
+        lightPdf = (LNdotL > 0.0f && dot(L, N) < 0.0f) ? (sqDist / (LNdotL * sl->energy)) : 0.0f;
+        lightColor = ld3(sl->radiance);
+        return ld3(sl->position);
+    }
+    const rfw_directional_light* dl = lv.directional + (lightIdx - (AREA + POINT + SPOT));
+    const f3 L = ld3(dl->direction);
+    lightColor = ld3(dl->radiance);
+    const float NdotL = dot(L, N);
+    lightPdf = NdotL < 0.0f ? (1.0f * (1.0f / dl->energy)) : 0.0f;
+    return I - 1000.0f * L;
+}
+
+} // namespace rfwhip

@@ -1,0 +1,186 @@
+// traverse.h — two-level (TLAS of instances -> per-mesh BLAS) BVH4 traversal, one ray per lane.
+//
+// Replaces intersect_top_mbvh/intersect_mbvh of backends/gpu-rt/shaders/ray_gen.comp:202-250,310-362
+// (closest hit) and ray_shadow.comp:83-132,191-243 (any hit).  Same results, different machine:
+//   * one loop, one stack: TLAS and BLAS entries share a short per-lane stack held in LDS
+//     (lane-interleaved, conflict-free), spilling to HBM only past kStackLds entries — the reference
+//     keeps two 32-entry private arrays per thread in scratch memory (ray_gen.comp:204,312);
+//   * leaves hold 48-B triangle packets in leaf order — no prim-index indirection and no 176-B
+//     RTTriangle gather in the leaf loop (ray_gen.comp:230-233);
+//   * node boxes are padded at build time, so the slab test is conservative with respect to the
+//     Moeller-Trumbore arithmetic and the answer is independent of the tree.
+// The per-triangle arithmetic is intersection.glsl:1-38 / 40-70 operation for operation.
+#pragma once
+#include "device_math.h"
+#include "device_types.h"
+
+namespace rfwhip {
+
+constexpr int kTraceBlock = 64;   // threads per workgroup of the trace kernels (one wavefront)
+constexpr int kStackLds = 16;     // stack entries per lane kept in LDS
+constexpr int kStackSpill = 48;   // further entries per lane in HBM (rarely touched)
+
+struct SceneView {
+    const Node4* tlas_nodes;
+    const uint32_t* tlas_prims; // instance ids in TLAS leaf order
+    const InstanceXform* instances;
+    const Node4* blas_nodes;
+    const TriPacket* tri_packets;
+    uint32_t* spill;            // kStackSpill x spill_stride
+    uint32_t spill_stride;
+    QueueCounters* counters;
+};
+
+struct TravCounters {
+    uint32_t nodes, tris, insts;
+};
+
+RFW_DI uint32_t sel4(const uint4 c, uint32_t i) { return i == 0 ? c.x : (i == 1 ? c.y : (i == 2 ? c.z : c.w)); }
+
+#define RFW_CSWAP(a, b)                       \
+    {                                         \
+        const float lo_ = __builtin_fminf(a, b); \
+        const float hi_ = __builtin_fmaxf(a, b); \
+        a = lo_;                              \
+        b = hi_;                              \
+    }
+
+// Closest hit (ANY_HIT = false): on return t/hu/hv/hit_inst/hit_tri describe the nearest accepted hit, ties resolved
+// to the lowest (instance, triangle) id.  Any hit (ANY_HIT = true): returns true as soon as one triangle has
+// t_min < t' < t.
+template <bool ANY_HIT, bool COUNT>
+RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_min, float& t, float& hu, float& hv, int32_t& hit_inst,
+                     int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
+{
+    f3 o = O, d = D;
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    int blas_sp = -1;          // stack height at BLAS entry; -1 = currently in the TLAS
+    int32_t cur_inst = -1;
+    uint32_t node_base = 0, tri_base = 0;
+    uint32_t cur = 0;          // TLAS root (interior ref 0)
+    const Node4* nodes = sc.tlas_nodes;
+
+    auto push = [&](uint32_t v) {
+        if (sp < kStackLds) lds_stack[sp * kTraceBlock + lane_slot] = v;
+        else if (sp < kStackLds + kStackSpill) sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot] = v;
+        else sc.counters->pad = 1ull; // overflow: reported by the host, never silently dropped
+        sp++;
+    };
+    auto pop = [&]() -> uint32_t {
+        sp--;
+        if (sp < kStackLds) return lds_stack[sp * kTraceBlock + lane_slot];
+        return sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot];
+    };
+
+    for (;;) {
+        if (!(cur & kLeafBit)) {
+            // ---- interior node: 4-wide slab test
+            const float4* np = reinterpret_cast<const float4*>(nodes + node_base + cur);
+            const float4 lox = np[0], hix = np[1], loy = np[2], hiy = np[3], loz = np[4], hiz = np[5];
+            const uint4 ch = *reinterpret_cast<const uint4*>(np + 6);
+            if (COUNT) tc.nodes++;
+            float key[4];
+            uint32_t nhit = 0;
+#define RFW_SLAB(i, LX, HX, LY, HY, LZ, HZ, CH)                                                        \
+    {                                                                                                  \
+        const float ax = (LX - o.x) * inv.x, bx = (HX - o.x) * inv.x;                                  \
+        const float ay = (LY - o.y) * inv.y, by = (HY - o.y) * inv.y;                                  \
+        const float az = (LZ - o.z) * inv.z, bz = (HZ - o.z) * inv.z;                                  \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)); \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)); \
+        const bool h = (tf >= tn) && (tn <= t) && (tf >= 0.0f) && (CH != kInvalidRef);                 \
+        nhit += h ? 1u : 0u;                                                                           \
+        key[i] = h ? bitsf((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : bitsf(0x7f7ffffcu | (uint32_t)i); \
+    }
+            RFW_SLAB(0, lox.x, hix.x, loy.x, hiy.x, loz.x, hiz.x, ch.x)
+            RFW_SLAB(1, lox.y, hix.y, loy.y, hiy.y, loz.y, hiz.y, ch.y)
+            RFW_SLAB(2, lox.z, hix.z, loy.z, hiy.z, loz.z, hiz.z, ch.z)
+            RFW_SLAB(3, lox.w, hix.w, loy.w, hiy.w, loz.w, hiz.w, ch.w)
+#undef RFW_SLAB
+            if (nhit == 0) {
+                cur = kInvalidRef;
+            } else {
+                // sort the 4 keys ascending (misses are FLT_MAX-class keys and sink to the end; +inf | idx would be a NaN); child index rides in the 2 LSBs
+                RFW_CSWAP(key[0], key[1])
+                RFW_CSWAP(key[2], key[3])
+                RFW_CSWAP(key[0], key[2])
+                RFW_CSWAP(key[1], key[3])
+                RFW_CSWAP(key[1], key[2])
+                if (nhit > 3) push(sel4(ch, fbits(key[3]) & 3u));
+                if (nhit > 2) push(sel4(ch, fbits(key[2]) & 3u));
+                if (nhit > 1) push(sel4(ch, fbits(key[1]) & 3u));
+                cur = sel4(ch, fbits(key[0]) & 3u);
+                continue;
+            }
+        } else if (blas_sp >= 0) {
+            // ---- BLAS leaf: Moeller-Trumbore over the packets (intersection.glsl:1-38 / 40-70)
+            const uint32_t first = cur & kLeafFirstMask, count = ((cur >> 27) & 15u) + 1u;
+            const float4* tp = reinterpret_cast<const float4*>(sc.tri_packets + tri_base + first);
+            for (uint32_t k = 0; k < count; k++) {
+                const float4 p0 = tp[3 * k], p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
+                if (COUNT) tc.tris++;
+                const f3 v0 = mk3(p0.x, p0.y, p0.z), edge1 = mk3(p1.x, p1.y, p1.z), edge2 = mk3(p2.x, p2.y, p2.z);
+                const f3 h = cross(d, edge2);
+                const float a = dot(edge1, h);
+                if (a > -0.0001f && a < 0.0001f) continue;
+                const float f = 1.0f / a;
+                const f3 s = o - v0;
+                const float u = f * dot(s, h);
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 q = cross(s, edge1);
+                const float v = f * dot(d, q);
+                if (v < 0.0f || (u + v) > 1.0f) continue;
+                const float tt = f * dot(edge2, q);
+                if (ANY_HIT) {
+                    if (tt > t_min && tt < t) return true;
+                } else {
+                    const int32_t prim = (int32_t)fbits(p0.w);
+                    const bool lower = (cur_inst < hit_inst) || (cur_inst == hit_inst && prim < hit_tri);
+                    if (tt > t_min && (tt < t || (tt == t && hit_inst >= 0 && lower))) {
+                        t = tt;
+                        hu = u * p1.w;
+                        hv = v * p1.w;
+                        hit_inst = cur_inst;
+                        hit_tri = prim;
+                    }
+                }
+            }
+            cur = kInvalidRef;
+        } else {
+            // ---- TLAS leaf: enter the first instance, keep the rest of the list on the stack
+            const uint32_t first = cur & kLeafFirstMask, count = ((cur >> 27) & 15u) + 1u;
+            if (count > 1) push(make_leaf(first + 1, count - 1));
+            const uint32_t gid = sc.tlas_prims[first];
+            const float4* ip = reinterpret_cast<const float4*>(sc.instances + gid);
+            const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+            const uint4 meta = *reinterpret_cast<const uint4*>(ip + 3);
+            if (COUNT) tc.insts++;
+            // ray into object space with the inverse instance matrix; direction NOT renormalised (ray_gen.comp:340-341)
+            o = xform_rows(r0, r1, r2, O, 1.0f);
+            d = xform_rows(r0, r1, r2, D, 0.0f);
+            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            node_base = meta.x;
+            tri_base = meta.y;
+            cur_inst = (int32_t)gid;
+            nodes = sc.blas_nodes;
+            blas_sp = sp;
+            cur = 0;
+            continue;
+        }
+        // ---- next entry
+        if (blas_sp >= 0 && sp == blas_sp) { // BLAS exhausted: back to world space
+            blas_sp = -1;
+            o = O;
+            d = D;
+            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            nodes = sc.tlas_nodes;
+            node_base = 0;
+        }
+        if (sp == 0) break;
+        cur = pop();
+    }
+    return false;
+}
+
+} // namespace rfwhip

@@ -142,5 +142,6 @@ for _t, _n in EXPECTED_SIZES.items():
 
 RFW_HIP_FLAG_NO_NEE = 1
 RFW_HIP_FLAG_COUNT_TRAVERSAL = 2
-RFW_HIP_BUILDER_DEVICE_LBVH = 0
+RFW_HIP_BUILDER_AUTO = 0
 RFW_HIP_BUILDER_HOST_SAH = 1
+RFW_HIP_BUILDER_DEVICE_LBVH = 2

@@ -1,0 +1,205 @@
+"""Parity proper: the HIP path through the C ABI against the oracle on the same seeded inputs.
+Ray queries (ids, t, u, v) must be bit-exact; accumulated radiance must match to <= 1e-4 relative L2
+(north_star tolerance) — the arithmetic contract actually yields identical bits, which is asserted too."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # relative L2 per image, BASELINE.json north_star
+
+
+def make(kind, w, h, a=0, b=0, c=0.0, seed=1, **opts):
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build(kind, a, b, c, seed)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, **{k: v for k, v in opts.items() if k in ("max_path_length", "flags")})
+    scene.sync(be)
+    orc = Oracle(w, h, threads=8)
+    if "max_path_length" in opts:
+        orc.set_option("max_path_length", opts["max_path_length"])
+    scene.mark_all_changed()
+    scene.sync(orc)
+    return scene, be, orc
+
+
+def random_rays(n, seed, extent=4.0):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-extent, extent, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def assert_hits_equal(g, r):
+    assert np.array_equal(g["inst"], r["inst"]), np.flatnonzero(g["inst"] != r["inst"])[:10]
+    assert np.array_equal(g["tri"], r["tri"]), np.flatnonzero(g["tri"] != r["tri"])[:10]
+    hit = r["inst"] >= 0
+    for f in ("t", "u", "v"):
+        assert np.array_equal(g[f][hit].view(np.uint32), r[f][hit].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("kind,a,b", [("cornell", 0, 0), ("soup", 3000, 1), ("soup", 800, 12)])
+def test_closest_hit_bit_exact(kind, a, b):
+    scene, be, orc = make(kind, 64, 64, a, b, seed=7)
+    o, d = random_rays(20000, 11)
+    # add the camera's own primary rays (coherent) and axis-parallel rays (inf / nan slab arithmetic)
+    po, pd = orc.primary_rays(scene.view(64, 64), 0)
+    ax = np.zeros((6, 3), np.float32)
+    for i in range(6):
+        ax[i, i % 3] = 1.0 if i < 3 else -1.0
+    o = np.concatenate([o, po, np.zeros((6, 3), np.float32)])
+    d = np.concatenate([d, pd, ax])
+    g = be.intersect(o, d)
+    assert_hits_equal(g, orc.intersect(o, d))                # oracle through its MBVH
+    assert_hits_equal(g, orc.intersect(o, d, brute=True))    # and the tree-free definition
+
+
+@pytest.mark.parametrize("kind,a,b", [("cornell", 0, 0), ("soup", 3000, 1), ("soup", 800, 12)])
+def test_any_hit_exact(kind, a, b):
+    scene, be, orc = make(kind, 32, 32, a, b, seed=5)
+    o, d = random_rays(20000, 13)
+    tmax = np.random.default_rng(2).uniform(0.05, 8.0, size=len(o)).astype(np.float32)
+    g = be.occludes(o, d, tmax)
+    assert np.array_equal(g, orc.occludes(o, d, tmax))
+    assert np.array_equal(g, orc.occludes(o, d, tmax, brute=True))
+    # metamorphic: occluded <=> the closest hit (same t_min) lies before t_max
+    h = be.intersect(o, d, t_min=1e-3)
+    assert np.array_equal(g.astype(bool), (h["inst"] >= 0) & (h["t"] < tmax))
+
+
+def test_edge_cases_empty_and_removed_instances():
+    from rfw_rs_amd import HipBackend, Scene, pod
+    import ctypes as C
+    be = HipBackend.init(16, 16)
+    be.synchronize()  # nothing uploaded at all
+    o, d = random_rays(100, 1)
+    assert (be.intersect(o, d)["inst"] == -1).all()
+    assert (be.occludes(o, d, np.full(100, 10.0, np.float32)) == 0).all()
+    be.render(Scene().build("cornell").view(16, 16))  # render before any mesh: a no-op, as gpu-rt (lib.rs:1686-1688)
+    # zero matrix = removed instance slot (crates/rfw-scene/src/instances_3d.rs:79-86)
+    scene, be2, orc = make("soup", 16, 16, 200, 3, seed=3)
+    md = scene.mesh_data(0)
+    mats = (pod.Mat4 * 3)()
+    for i in range(3):
+        for k in (0, 5, 10, 15):
+            mats[i].m[k] = 1.0
+        mats[i].m[12] = 2.5 * i
+    for k in range(16):
+        mats[1].m[k] = 0.0
+    inst = pod.InstancesData3D()
+    inst.local_aabb = md.bounds
+    inst.matrices = mats
+    inst.num_matrices = 3
+    for b in (be2, ):
+        b.set_3d_instances(0, inst)
+        b.synchronize()
+    orc._l.orc_set_3d_instances(orc._h, 0, C.byref(inst))
+    orc._l.orc_synchronize(orc._h)
+    o, d = random_rays(5000, 4, extent=6.0)
+    g, r = be2.intersect(o, d), orc.intersect(o, d, brute=True)
+    assert_hits_equal(g, r)
+    assert set(np.unique(g["inst"])) <= {-1, 0, 2}
+
+
+@pytest.mark.parametrize("kind,a,b,mpl,spp", [("cornell", 0, 0, 1, 1), ("cornell", 0, 0, 3, 4), ("soup", 1500, 6, 3, 2)])
+def test_radiance_matches_oracle(kind, a, b, mpl, spp):
+    w, h = 96, 64
+    scene, be, orc = make(kind, w, h, a, b, seed=9, max_path_length=mpl)
+    view = scene.view(w, h)
+    for _ in range(spp):
+        be.render(view)
+        orc.render(view)
+    ga, ra = be.accumulator(), orc.accumulator()
+    assert np.isfinite(ga).all()
+    assert rel_l2(ga, ra) <= TOL
+    assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32)), f"{(ga != ra).sum()} differing floats"
+    assert rel_l2(be.framebuffer(), orc.framebuffer()) <= TOL
+    s, os_ = be.frame_stats(), orc.stats()
+    assert s["sample_count"] == spp
+    # ray counts of the last frame: the oracle counts all frames
+    assert s["primary_rays"] == w * h
+
+
+def test_counts_and_queues_match_oracle_one_frame():
+    w, h = 64, 64
+    scene, be, orc = make("soup", w, h, 1200, 4, seed=2, max_path_length=3)
+    view = scene.view(w, h)
+    be.render(view)
+    orc.render(view)
+    s, o = be.frame_stats(), orc.stats()
+    assert (s["primary_rays"], s["extension_rays"], s["shadow_rays"]) == (o["primary"], o["extension"], o["shadow"])
+
+
+def test_accumulation_reset_on_camera_change():
+    w, h = 32, 32
+    scene, be, orc = make("cornell", w, h)
+    v1 = scene.view(w, h)
+    be.render(v1); be.render(v1)
+    assert be.frame_stats()["sample_count"] == 2
+    scene.set_camera([0.1, 0, -3.4], [0, 0, 1], 40.0, 0.0, 1.0)
+    be.render(scene.view(w, h))
+    assert be.frame_stats()["sample_count"] == 1
+    be.reset_accumulation()
+    be.render(scene.view(w, h))
+    assert be.frame_stats()["sample_count"] == 1
+
+
+def test_tile_sharding_is_bit_exact():
+    """1 GPU == N shards: each rank renders its tiles into a slab; gathered + assembled frame == the unsharded frame."""
+    import torch
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 200, 136  # not a multiple of the tile size: ragged edge tiles
+    scene = Scene().build("soup", 1500, 5, 0.0, 4)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    full = HipBackend.init(w, h, 1.0)
+    scene.sync(full)
+    for _ in range(2):
+        full.render(view)
+    ref = full.accumulator()
+    world = 3
+    ranks = []
+    for r in range(world):
+        be = HipBackend.init(w, h, 1.0, rank=r, world=world, tile_size=32)
+        scene.mark_all_changed()
+        scene.sync(be)
+        ranks.append(be)
+    slab = ranks[0].shard_info()["slab_floats"]
+    gathered = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
+    for r, be in enumerate(ranks):
+        be.set_slab_output(gathered[r].data_ptr())
+        for _ in range(2):
+            be.render(view)
+        be.device_synchronize()
+    ranks[0].assemble_frame(gathered.data_ptr())
+    got = ranks[0].accumulator()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_full_size_properties():
+    """BASELINE config C2 at full size (1920x1080, ~262k triangles): properties that need no oracle run."""
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 1920, 1080
+    scene = Scene().build("atrium", 262267, 0, 0.0, 0xC0FFEE)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=1)
+    scene.sync(be)
+    be.render(view)
+    a1 = be.accumulator().copy()
+    s = be.frame_stats()
+    assert s["primary_rays"] == w * h and 0 < s["shadow_rays"] <= w * h
+    be.reset_accumulation()
+    be.render(view)
+    assert np.array_equal(a1.view(np.uint32), be.accumulator().view(np.uint32))  # idempotent / deterministic
+    assert np.isfinite(a1).all() and a1[..., :3].max() <= 10.0 * 2 + 1e-3       # clamp 10 per contribution, <= 2 adds per pixel
+    # closest-hit vs any-hit consistency on the frame's own primary rays
+    from oracle.bindings import Oracle
+    po, pd = Oracle(w // 8, h // 8).primary_rays(scene.view(w // 8, h // 8), 0)
+    hit = be.intersect(po, pd, t_min=1e-3)
+    tm = np.where(hit["inst"] >= 0, hit["t"], np.float32(50.0)).astype(np.float32)
+    assert (be.occludes(po, pd, tm * np.float32(1.01) + np.float32(1e-3)) == (hit["inst"] >= 0)).all()
+    assert (be.occludes(po, pd, tm * np.float32(0.99)) == 0).sum() >= 0.999 * len(po)
