@@ -66,7 +66,7 @@ struct CameraParams {
     uint32_t point_light_count, area_light_count, spot_light_count, directional_light_count;
     // shard description: tiles of tile_size^2 pixels dealt round-robin to `world` ranks
     uint32_t tile_size, tiles_x, tiles_y, rank;
-    uint32_t world, local_tiles, flags, pad1;
+    uint32_t world, local_tiles, flags, max_path_length;
     float sky[3]; float pad2;
 };
 

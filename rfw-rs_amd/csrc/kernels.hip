@@ -381,12 +381,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                             }
                         }
                     }
-                    ext_o = safe_origin(P, R, gN);
-                    ext_d = R;
-                    ext_normal = PackNormal(N);
-                    ext_thr = throughput;
-                    ext_pdf = newBsdfPdf;
-                    push_ext = true;
+                    // the reference pushes the extension unconditionally (shade.comp:260-265) and its host loop simply stops
+                    // after the last bounce; nothing reads that last queue, so it is not written here
+                    if (bounce + 1 < cam.max_path_length) {
+                        ext_o = safe_origin(P, R, gN);
+                        ext_d = R;
+                        ext_normal = PackNormal(N);
+                        ext_thr = throughput;
+                        ext_pdf = newBsdfPdf;
+                        push_ext = true;
+                    }
                 }
             }
         }

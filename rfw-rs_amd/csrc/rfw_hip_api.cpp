@@ -405,6 +405,7 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v)
     c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
     c.rank = I->rank; c.world = I->world; c.local_tiles = I->local_tiles;
     c.flags = I->flags;
+    c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
     return c;
 }
