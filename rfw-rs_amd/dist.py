@@ -1,0 +1,58 @@
+"""Multi-GPU plumbing: primary rays shard by image tile, one process per GPU, and ONE all-gather
+of the per-rank accumulator slabs per frame (RCCL over xGMI through torch.distributed; gloo in the CPU tests).
+No other exchange: the scene is replicated, the BVH build is deterministic, pixels are independent.
+
+The tile -> rank dealing and the slab layout are defined by the kernels (kernels.hip slab_to_pixel /
+pixel_to_slab); `slab_index_map` restates them in numpy so that host code and tests can assemble gathered slabs."""
+import numpy as np
+
+
+def shard_geometry(width, height, world, tile_size=64):
+    tiles_x = (width + tile_size - 1) // tile_size
+    tiles_y = (height + tile_size - 1) // tile_size
+    total = tiles_x * tiles_y
+    local_tiles = (total + world - 1) // world
+    return {"tiles_x": tiles_x, "tiles_y": tiles_y, "tiles_total": total, "tiles_local": local_tiles,
+            "slab_elems": local_tiles * tile_size * tile_size}
+
+
+def slab_index_map(width, height, world, tile_size=64):
+    """owner[y, x] = rank that renders pixel (x, y); slot[y, x] = its index in that rank's slab."""
+    ys, xs = np.mgrid[0:height, 0:width]
+    g = shard_geometry(width, height, world, tile_size)
+    tx, ty = xs // tile_size, ys // tile_size
+    tile = ty * g["tiles_x"] + tx
+    owner = tile % world
+    lt = tile // world
+    ix, iy = xs - tx * tile_size, ys - ty * tile_size
+    block = (iy >> 3) * (tile_size >> 3) + (ix >> 3)
+    slot = lt * tile_size * tile_size + block * 64 + ((iy & 7) << 3) + (ix & 7)
+    return owner.astype(np.int64), slot.astype(np.int64)
+
+
+def extract_slab(frame, rank, world, tile_size=64):
+    """The slab rank `rank` would produce for a full frame (H, W, C): used by the CPU tests as a stand-in renderer."""
+    h, w, c = frame.shape
+    owner, slot = slab_index_map(w, h, world, tile_size)
+    slab = np.zeros((shard_geometry(w, h, world, tile_size)["slab_elems"], c), dtype=frame.dtype)
+    m = owner == rank
+    slab[slot[m]] = frame[m]
+    return slab
+
+
+def assemble(gathered, width, height, tile_size=64):
+    """gathered: (world, slab_elems, C) -> frame (H, W, C); the numpy twin of the k_assemble kernel."""
+    world = gathered.shape[0]
+    owner, slot = slab_index_map(width, height, world, tile_size)
+    return gathered[owner, slot]
+
+
+def all_gather_slabs(local_slab, group=None):
+    """One collective per frame: every rank contributes its slab, receives all.  `local_slab` is a torch tensor (any device);
+    returns (world, *local_slab.shape).  With backend "nccl" on ROCm this is RCCL over xGMI."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
+    dist.all_gather_into_tensor(out.view(-1), local_slab.contiguous().view(-1), group=group)
+    return out

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors with the CPU oracle (run from the repo root: python tests/golden/make_golden.py).
+Each case = a synthetic scene of the host library + camera + options -> accumulator (RGBA32F sums) and primary hit records.
+The reference has no fixtures for this path; these pin the oracle against regressions and give the GPU
+tests an oracle-free target."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+CASES = {
+    # name: (kind, a, b, seed, width, height, max_path_length, spp)
+    "cornell_primary_shadow": ("cornell", 0, 0, 1, 64, 64, 1, 1),
+    "cornell_path3_4spp": ("cornell", 0, 0, 1, 64, 64, 3, 4),
+    "soup_instanced_path3_2spp": ("soup", 900, 5, 11, 64, 48, 3, 2),
+}
+
+
+def run_case(case):
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import Scene
+    kind, a, b, seed, w, h, mpl, spp = case
+    scene = Scene().build(kind, a, b, 0.0, seed)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    orc = Oracle(w, h, threads=4, max_path_length=mpl)
+    scene.sync(orc)
+    for _ in range(spp):
+        orc.render(view)
+    o, d = orc.primary_rays(view, 0)
+    hits = orc.intersect(o, d)
+    return orc.accumulator(), hits, orc.stats()
+
+
+def main():
+    out = os.path.dirname(os.path.abspath(__file__))
+    for name, case in CASES.items():
+        acc, hits, st = run_case(case)
+        np.savez_compressed(os.path.join(out, name + ".npz"), acc=acc, hit_inst=hits["inst"], hit_tri=hits["tri"], hit_t=hits["t"],
+                            hit_u=hits["u"], hit_v=hits["v"], rays=np.array([st["primary"], st["extension"], st["shadow"]], dtype=np.int64))
+        print(name, acc.shape, "mean", acc[..., :3].mean(), st["primary"], st["extension"], st["shadow"])
+
+
+if __name__ == "__main__":
+    main()
