@@ -52,7 +52,10 @@ def main():
     scene.set_aspect(w / h)
     view = scene.view(w, h)
     be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=1, rank=rank, world=world)
-    stream = torch.cuda.current_stream()
+    # a real (non-null) torch stream: the library launches on it, so does RCCL's all-gather ordering, and the HIP events
+    # that time the kernels are recorded on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     be.set_stream(stream.cuda_stream)
     t0 = time.time()
     scene.sync(be)
@@ -86,14 +89,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = {"ms_trace_primary": 0.0, "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
+    be.drain_timing()
+    timed_frames = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
-        # per-kernel HIP-event durations on the launch stream (events are recorded inside render(); reading them
-        # waits for this frame only)
-        fs = be.frame_stats()
-        for k in kernel_ms:
-            kernel_ms[k] += fs[k]
+        if (i + 1) % 48 == 0 or i + 1 == args.steps:
+            # per-kernel HIP-event durations, recorded inside render() on the launch stream for EVERY timed frame and
+            # read back in batches (one stream sync per 48 frames instead of one per frame)
+            ms, n = be.drain_timing()
+            timed_frames += n
+            for k in kernel_ms:
+                kernel_ms[k] += ms[k]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -111,14 +118,24 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = rays_total / (elapsed / args.steps) / 1e6
-        # roofline of the dominant kernel: algorithmic bytes per launch / its mean HIP-event duration
+        # roofline: ALGORITHMIC bytes each kernel moves per launch (DESIGN.md §"algorithmic bytes") / its mean HIP-event duration
         node_b, tri_b = sstats["node_bytes"], sstats["tri_bytes"]
-        dom = "trace_primary" if kernel_ms["ms_trace_primary"] >= kernel_ms["ms_trace_shadow"] else "trace_shadow"
-        # B_stream: primary 16 B hit + 32 B ray write; shadow 32 B ray read + 16 B accumulator RMW
-        trav_bytes = cs["nodes_visited"] * node_b + cs["tris_tested"] * tri_b + cs["instances_entered"] * 64
-        stream_bytes = cs["primary_rays"] * 48 + cs["shadow_rays"] * (32 + 32)
-        both_ms = (kernel_ms["ms_trace_primary"] + kernel_ms["ms_trace_shadow"]) / args.steps
-        achieved = (trav_bytes + stream_bytes) / (both_ms * 1e-3) / 1e9 if both_ms > 0 else 0.0
+        nf = max(timed_frames, 1)
+        n_prim, n_shad = cs["primary_rays"], cs["shadow_rays"]
+        alg = {
+            # nodes x 128 B + triangles x 48 B + instance records x 64 B + 48 B written per ray (origin, direction, hit) + 16 B accumulator clear
+            "k_primary": cs["nodes_visited"][0] * node_b + cs["tris_tested"][0] * tri_b + cs["instances_entered"][0] * 64 + n_prim * (48 + 16),
+            # + 32 B queue entry read per ray, 16 B contribution read and 32 B accumulator read-modify-write per unoccluded ray (counted for all)
+            "k_shadow": cs["nodes_visited"][2] * node_b + cs["tris_tested"][2] * tri_b + cs["instances_entered"][2] * 64 + n_shad * (32 + 16 + 32),
+            # per path: hit 16 + ray 32 read; per hit: RTTriangle 176 + material 96 + normal matrix 48; shadow-queue push 48 per shadow ray
+            "k_shade": n_prim * (16 + 32) + n_prim * (176 + 96 + 48) + n_shad * 48,
+        }
+        ms = {"k_primary": kernel_ms["ms_trace_primary"] / nf, "k_shadow": kernel_ms["ms_trace_shadow"] / nf, "k_shade": kernel_ms["ms_shade"] / nf}
+        dom = max(ms, key=lambda k: ms[k])
+        gbs = {k: (alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in alg}
+        achieved = gbs[dom]
+        traffic = pmc_traffic(dom)
+        rays_local_f = max(rays_local, 1)
         out = {
             "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
@@ -127,13 +144,13 @@ def main():
                        "rays_per_frame": int(rays_total), "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_primary+k_shadow (BVH4 traversal)", "dominant": dom,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
-                         "bytes_per_ray": round((trav_bytes + stream_bytes) / max(rays_local, 1), 1),
-                         "nodes_per_ray": round(cs["nodes_visited"] / max(rays_local, 1), 2),
-                         "tris_per_ray": round(cs["tris_tested"] / max(rays_local, 1), 2),
-                         "kernel_ms": {k: round(v / args.steps, 4) for k, v in kernel_ms.items()}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(ms[dom], 4),
+                         "per_kernel": {k: {"ms": round(ms[k], 4), "alg_GBps": round(gbs[k], 1), "frac": round(gbs[k] / HBM_PEAK_GBS, 4)} for k in alg},
+                         "nodes_per_ray": {"primary": round(cs["nodes_visited"][0] / max(n_prim, 1), 2), "shadow": round(cs["nodes_visited"][2] / max(n_shad, 1), 2)},
+                         "tris_per_ray": {"primary": round(cs["tris_tested"][0] / max(n_prim, 1), 2), "shadow": round(cs["tris_tested"][2] / max(n_shad, 1), 2)},
+                         "frame_ms_events": round(kernel_ms["ms_total"] / nf, 4)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, w, h, args.cpu_seconds)
@@ -142,6 +159,24 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     be.close()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this workload (profiles/*_pmc.json,
+    written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes; gfx950 correction applied).
+    Counters cannot be read from inside this process, so this is the latest committed measurement, or null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        for name, v in k.items():
+            if name.startswith(kernel) and "<true>" not in name:
+                return v["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(scene, view, w, h, budget_s):

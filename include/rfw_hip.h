@@ -71,9 +71,10 @@ typedef struct {
     uint64_t primary_rays;
     uint64_t extension_rays;
     uint64_t shadow_rays;
-    uint64_t nodes_visited;     /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
-    uint64_t tris_tested;       /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
-    uint64_t instances_entered; /* only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
+    /* traversal work per kernel kind [0 primary, 1 extension, 2 shadow]; only with RFW_HIP_FLAG_COUNT_TRAVERSAL */
+    uint64_t nodes_visited[3];
+    uint64_t tris_tested[3];
+    uint64_t instances_entered[3];
     float ms_total;             /* hipEvent span of the whole frame on the instance's stream */
     float ms_trace_primary;
     float ms_trace_extend;
@@ -153,6 +154,9 @@ RFW_HIP_API int rfw_hip_read_framebuffer(void* instance, float* rgba, uint64_t n
 /* raw accumulator (acPixels), RGBA32F sums */
 RFW_HIP_API int rfw_hip_read_accumulator(void* instance, float* rgba, uint64_t n_floats);
 RFW_HIP_API int rfw_hip_get_frame_stats(void* instance, rfw_hip_frame_stats* out);
+/* Sums the per-kernel HIP-event timings of every frame rendered since the previous drain (at most 64 frames are kept)
+ * into `sum` (ms_* fields only) and reports how many frames that was.  One stream synchronisation per call, none per frame. */
+RFW_HIP_API int rfw_hip_drain_timing(void* instance, rfw_hip_frame_stats* sum, uint32_t* frames);
 RFW_HIP_API int rfw_hip_get_scene_stats(void* instance, rfw_hip_scene_stats* out);
 /* launch all work on this hipStream_t (NULL = the instance's own stream) */
 RFW_HIP_API int rfw_hip_set_stream(void* instance, void* hip_stream);

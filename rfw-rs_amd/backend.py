@@ -21,7 +21,7 @@ EXPORTS = [
     "rfw_hip_render", "rfw_hip_resize", "rfw_hip_set_point_lights", "rfw_hip_set_spot_lights",
     "rfw_hip_set_area_lights", "rfw_hip_set_directional_lights", "rfw_hip_set_skybox", "rfw_hip_set_skins",
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
-    "rfw_hip_get_frame_stats", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_device_synchronize",
+    "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read",
 ]
@@ -71,6 +71,7 @@ def hip_lib():
         l.rfw_hip_read_accumulator.argtypes = [vp, vp, u64]
         l.rfw_hip_get_frame_stats.argtypes = [vp, C.POINTER(pod.FrameStats)]
         l.rfw_hip_get_scene_stats.argtypes = [vp, C.POINTER(pod.SceneStats)]
+        l.rfw_hip_drain_timing.argtypes = [vp, C.POINTER(pod.FrameStats), C.POINTER(u32)]
         l.rfw_hip_set_stream.argtypes = [vp, vp]
         l.rfw_hip_device_synchronize.argtypes = [vp]
         l.rfw_hip_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
@@ -212,7 +213,13 @@ class HipBackend:
     def frame_stats(self):
         s = pod.FrameStats()
         self._check(self._l.rfw_hip_get_frame_stats(self._h, C.byref(s)))
-        return {n: getattr(s, n) for n, _ in pod.FrameStats._fields_}
+        return {n: (list(getattr(s, n)) if n in ("nodes_visited", "tris_tested", "instances_entered") else getattr(s, n)) for n, _ in pod.FrameStats._fields_}
+
+    def drain_timing(self):
+        """Summed per-kernel HIP-event milliseconds of the frames rendered since the last drain, and their count."""
+        s, n = pod.FrameStats(), C.c_uint32(0)
+        self._check(self._l.rfw_hip_drain_timing(self._h, C.byref(s), C.byref(n)))
+        return {k: getattr(s, k) for k, _ in pod.FrameStats._fields_ if k.startswith("ms_")}, int(n.value)
 
     def scene_stats(self):
         s = pod.SceneStats()

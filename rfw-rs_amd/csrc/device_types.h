@@ -75,7 +75,8 @@ struct CameraParams {
 struct QueueCounters {
     uint32_t ext[8];
     uint32_t shadow[8];
-    unsigned long long nodes_visited, tris_tested, instances_entered, pad;
+    unsigned long long trav[3][3]; // [kind: 0 primary, 1 extend, 2 shadow][0 nodes visited, 1 triangles tested, 2 instances entered]
+    unsigned long long overflow, pad;
 };
 
 enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };

@@ -56,7 +56,7 @@ RFW_DI SceneView scene_view(const SceneDev& sc)
     return v;
 }
 
-template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCounters& tc)
+template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCounters& tc, const int kind)
 {
     if (!COUNT) return;
     // wave reduction, then one atomic per wave
@@ -67,9 +67,9 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
         i += __shfl_down(i, off);
     }
     if ((threadIdx.x & 63u) == 0) {
-        atomicAdd(&qc->nodes_visited, n);
-        atomicAdd(&qc->tris_tested, t);
-        atomicAdd(&qc->instances_entered, i);
+        atomicAdd(&qc->trav[kind][0], n);
+        atomicAdd(&qc->trav[kind][1], t);
+        atomicAdd(&qc->trav[kind][2], i);
     }
 }
 
@@ -183,7 +183,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock) void k_primary(c
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     }
-    flush_counters<COUNT>(sc.counters, tc);
+    flush_counters<COUNT>(sc.counters, tc, 0);
 }
 
 // ---------------------------------------------------------------- ray_extend.comp:245-268
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(const CameraParams cam, 
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[half][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     }
-    flush_counters<COUNT>(sc.counters, tc);
+    flush_counters<COUNT>(sc.counters, tc, 1);
 }
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(const CameraParams cam, 
             p.acc[slot] = a;
         }
     }
-    flush_counters<COUNT>(sc.counters, tc);
+    flush_counters<COUNT>(sc.counters, tc, 2);
 }
 
 // ---------------------------------------------------------------- shade.comp:70-266

@@ -62,6 +62,7 @@ enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, st
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
 constexpr int kNumEvents = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce + 1);
+constexpr int kTimingRing = 64; // frames whose events can be pending before rfw_hip_drain_timing must be called
 
 struct Instance {
     std::mutex mu;
@@ -119,7 +120,11 @@ struct Instance {
     uint32_t sample_count = 0;
     bool have_last_view = false;
     rfw_camera_view_3d last_view{};
-    hipEvent_t events[kNumEvents] = {};
+    hipEvent_t ring[kTimingRing][kNumEvents] = {};
+    hipEvent_t* events = ring[0]; // event set of the current frame
+    uint64_t frame_index = 0, drained_index = 0;
+    uint32_t ring_bounces[kTimingRing] = {};
+    bool ring_nee[kTimingRing] = {};
     uint32_t last_bounces = 0;
     bool frame_recorded = false;
     bool last_count_flag = false;
@@ -444,6 +449,8 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
     const bool count = (I->flags & RFW_HIP_FLAG_COUNT_TRAVERSAL) != 0;
     hipStream_t s = I->stream;
     const bool tm = I->timing;
+    const int slot = (int)(I->frame_index % kTimingRing);
+    I->events = I->ring[slot];
     auto rec = [&](int ev) { if (tm) (void)hipEventRecord(I->events[ev], s); };
 
     rec(EV_FRAME0);
@@ -471,6 +478,10 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
     rec(EV_FRAME1);
     HIP_TRY(I, hipGetLastError());
     I->last_bounces = bounces;
+    I->ring_bounces[slot] = tm ? bounces : 0;
+    I->ring_nee[slot] = !(I->flags & RFW_HIP_FLAG_NO_NEE);
+    I->frame_index++;
+    if (I->frame_index - I->drained_index > kTimingRing) I->drained_index = I->frame_index - kTimingRing;
     I->frame_recorded = tm;
     I->last_count_flag = count;
     return RFW_HIP_OK;
@@ -536,8 +547,9 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     if ((e = hipSetDevice(dev)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&I->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     I->stream = I->own_stream;
-    for (int i = 0; i < kNumEvents; i++)
-        if ((e = hipEventCreate(&I->events[i])) != hipSuccess) return bail("hipEventCreate", e);
+    for (int r = 0; r < kTimingRing; r++)
+        for (int i = 0; i < kNumEvents; i++)
+            if ((e = hipEventCreate(&I->ring[r][i])) != hipSuccess) return bail("hipEventCreate", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
         delete I;
@@ -561,8 +573,9 @@ void rfw_hip_destroy(void* inst)
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release();
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
         I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
-        for (int i = 0; i < kNumEvents; i++)
-            if (I->events[i]) (void)hipEventDestroy(I->events[i]);
+        for (int r = 0; r < kTimingRing; r++)
+            for (int i = 0; i < kNumEvents; i++)
+                if (I->ring[r][i]) (void)hipEventDestroy(I->ring[r][i]);
         if (I->own_stream) (void)hipStreamDestroy(I->own_stream);
     }
     delete I;
@@ -750,15 +763,17 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     QueueCounters qc;
     HIP_TRY(I, hipMemcpy(&qc, I->d_counters.ptr, sizeof(qc), hipMemcpyDeviceToHost));
-    if (qc.pad) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
+    if (qc.overflow) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
     const uint32_t nb = I->last_bounces;
     out->primary_rays = nb ? I->local_pixels : 0;
     for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc.ext[b];
     if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
         for (uint32_t b = 0; b < nb; b++) out->shadow_rays += qc.shadow[b];
-    out->nodes_visited = qc.nodes_visited;
-    out->tris_tested = qc.tris_tested;
-    out->instances_entered = qc.instances_entered;
+    for (int k = 0; k < 3; k++) {
+        out->nodes_visited[k] = qc.trav[k][0];
+        out->tris_tested[k] = qc.trav[k][1];
+        out->instances_entered[k] = qc.trav[k][2];
+    }
     out->sample_count = I->sample_count;
     out->bounces = nb;
     if (I->frame_recorded) {
@@ -772,6 +787,35 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
         }
         out->ms_other = el(kEvBlit, kEvBlit + 1);
     }
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_drain_timing(void* inst, rfw_hip_frame_stats* sum, uint32_t* frames)
+{
+    LOCK(inst);
+    if (!sum || !frames) return fail(I, RFW_HIP_E_INVALID, "drain_timing: null out");
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    std::memset(sum, 0, sizeof(*sum));
+    uint32_t n = 0;
+    for (uint64_t f = I->drained_index; f < I->frame_index; f++) {
+        const int slot = (int)(f % kTimingRing);
+        const uint32_t nb = I->ring_bounces[slot];
+        if (!nb) continue;
+        hipEvent_t* ev = I->ring[slot];
+        auto el = [&](int a, int b) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
+        sum->ms_total += el(EV_FRAME0, EV_FRAME1);
+        for (uint32_t b = 0; b < nb; b++) {
+            const float tr = el(ev_index(b, 0, 0), ev_index(b, 0, 1));
+            if (b == 0) sum->ms_trace_primary += tr; else sum->ms_trace_extend += tr;
+            sum->ms_shade += el(ev_index(b, 1, 0), ev_index(b, 1, 1));
+            if (I->ring_nee[slot]) sum->ms_trace_shadow += el(ev_index(b, 2, 0), ev_index(b, 2, 1));
+        }
+        sum->ms_other += el(kEvBlit, kEvBlit + 1);
+        n++;
+    }
+    I->drained_index = I->frame_index;
+    *frames = n;
     return RFW_HIP_OK;
 }
 

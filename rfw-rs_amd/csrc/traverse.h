@@ -64,7 +64,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     auto push = [&](uint32_t v) {
         if (sp < kStackLds) lds_stack[sp * kTraceBlock + lane_slot] = v;
         else if (sp < kStackLds + kStackSpill) sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot] = v;
-        else sc.counters->pad = 1ull; // overflow: reported by the host, never silently dropped
+        else sc.counters->overflow = 1ull; // overflow: reported by the host, never silently dropped
         sp++;
     };
     auto pop = [&]() -> uint32_t {

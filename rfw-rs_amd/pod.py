@@ -115,8 +115,8 @@ class HipOptions(C.Structure):
 
 class FrameStats(C.Structure):
     _fields_ = [
-        ("primary_rays", u64), ("extension_rays", u64), ("shadow_rays", u64), ("nodes_visited", u64), ("tris_tested", u64),
-        ("instances_entered", u64), ("ms_total", f32), ("ms_trace_primary", f32), ("ms_trace_extend", f32), ("ms_trace_shadow", f32),
+        ("primary_rays", u64), ("extension_rays", u64), ("shadow_rays", u64), ("nodes_visited", u64 * 3), ("tris_tested", u64 * 3),
+        ("instances_entered", u64 * 3), ("ms_total", f32), ("ms_trace_primary", f32), ("ms_trace_extend", f32), ("ms_trace_shadow", f32),
         ("ms_shade", f32), ("ms_other", f32), ("sample_count", u32), ("bounces", u32),
     ]
 
