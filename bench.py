@@ -22,7 +22,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell"])
+    ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell", "spheres10k"],
+                    help="atrium1m = headline (C4 geometry, primary+shadow); atrium262k = C2; spheres10k = C3 (atrium262k + 10 000 "
+                         "animated icosphere instances, synchronize() every frame); cornell = C1 geometry")
+    ap.add_argument("--max-path-length", type=int, default=1, help="1 = primary+shadow (the metric); 3 = the reference's path tracer (C4)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -36,22 +39,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif not torch.cuda.is_available():
+    if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    dev = local_rank if world > 1 else 0
+    # RFW_BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets two ranks share one GPU (RCCL refuses duplicate devices) so the
+    # N > 1 code path can be exercised on a 1-GPU box; slabs are then staged through host memory.  Default: nccl (= RCCL).
+    dist_backend = os.environ.get("RFW_BENCH_DIST_BACKEND", "nccl")
+    dev = (local_rank % torch.cuda.device_count()) if world > 1 else 0
     torch.cuda.set_device(dev)
+    if world > 1:
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(dist_backend)
 
     from rfw_rs_amd import HipBackend, Scene
 
     w, h = args.width, args.height
-    tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0}[args.workload]
+    tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267}[args.workload]
     scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 0, 0.0, 0xC0FFEE)
+    animated = args.workload == "spheres10k"
+    if animated:
+        scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
-    be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=1, rank=rank, world=world)
+    be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank, world=world)
     # a real (non-null) torch stream: the library launches on it, so does RCCL's all-gather ordering, and the HIP events
     # that time the kernels are recorded on it
     stream = torch.cuda.Stream(device=dev)
@@ -68,11 +79,25 @@ def main():
         gathered = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
         be.set_slab_output(gathered[rank].data_ptr())
 
+    frame_no = [0]
+    sync_ms = [0.0]
+
     def step():
+        if animated:  # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
+            t_s = time.perf_counter()
+            scene.animate(frame_no[0] / 60.0)
+            frame_no[0] += 1
+            scene.sync(be)
+            sync_ms[0] += (time.perf_counter() - t_s) * 1e3
         be.reset_accumulation()
         be.render(view)
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), gathered[rank])
+            if dist_backend == "nccl":
+                dist.all_gather_into_tensor(gathered.view(-1), gathered[rank])  # the ONE collective per frame (RCCL over xGMI)
+            else:
+                host = torch.empty(gathered.shape, dtype=gathered.dtype)
+                dist.all_gather_into_tensor(host.view(-1), gathered[rank].cpu())
+                gathered.copy_(host)
             be.assemble_frame(gathered.data_ptr())
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
@@ -91,6 +116,7 @@ def main():
     kernel_ms = {"ms_trace_primary": 0.0, "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
     be.drain_timing()
     timed_frames = 0
+    sync_ms[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
@@ -107,7 +133,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
@@ -143,7 +169,9 @@ def main():
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles, {w}x{h}, 1 spp primary+shadow (max path length 1), static BVH4",
                        "rays_per_frame": int(rays_total), "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
-                       "synchronize_s": round(sync_s, 2)},
+                       "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
+                       "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
+                       "per_frame_synchronize_ms": round(sync_ms[0] / args.steps, 3) if animated else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(ms[dom], 4),

@@ -1,0 +1,43 @@
+// lbvh.h — device-side BVH construction: Morton-ordered LBVH (Karras 2012) -> bottom-up fit -> 4-wide collapse,
+// emitting the same Node4 layout the traversal kernels read.  Used for the TLAS every synchronize() (the
+// reference rebuilds it on the CPU and re-uploads it, backends/gpu-rt/src/lib.rs:1576-1581,1617-1632) and,
+// with builder = DEVICE_LBVH, for the per-mesh BLAS (the reference: rayon over rtbvh builds, :1345-1383).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_types.h"
+
+namespace rfwhip {
+
+// primitive bounds on the device: lo.xyz / hi.xyz (w unused)
+struct DevBox {
+    float lo[4], hi[4];
+};
+
+struct LbvhWorkspace {
+    void* base = nullptr;
+    size_t bytes = 0;
+};
+
+// bytes of scratch lbvh_build needs for n primitives (allocate once for the largest n)
+size_t lbvh_workspace_bytes(uint32_t n);
+
+// Builds a BVH4 over boxes[0..n) entirely on `stream`.  nodes_out needs room for max(n, 1) nodes; prim_order_out for n
+// entries (leaf refs index into it; one primitive per leaf).  No host synchronisation.  Returns hipSuccess or the first error.
+hipError_t lbvh_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
+                      uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */);
+
+// world-space boxes of instances: box k = local_aabb(mesh of gid[k]) through matrix gid[k], padded
+void launch_instance_boxes(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const DevBox* mesh_local_boxes,
+                           const uint32_t* valid_gids, uint32_t n_valid, DevBox* out);
+// tlas_prims[k] = valid_gids[order[k]]
+void launch_gather_u32(hipStream_t s, const uint32_t* src, const uint32_t* order, uint32_t n, uint32_t* dst);
+// triangle boxes (padded) from the boundary's RTTriangle array
+void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, DevBox* out);
+// leaf-ordered traversal packets: packet k = triangle order[k]; tri_id = order[k] + id_offset
+void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out);
+
+} // namespace rfwhip

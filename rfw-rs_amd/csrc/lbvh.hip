@@ -1,0 +1,386 @@
+// lbvh.hip — device BVH build: scene bounds -> 30-bit Morton keys -> radix sort (hipCUB) -> Karras hierarchy ->
+// bottom-up box fit (agent-scope release/acquire hand-off between the two children of a node) -> every even-depth
+// internal node becomes one 4-wide Node4 whose children are its grandchildren.  One primitive per leaf.
+#include "lbvh.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace rfwhip {
+namespace {
+
+constexpr int kBlock = 256;
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Layout {
+    size_t bounds, keys_in, keys_out, vals_in, left, right, parent, flags, nbox, flag4, idx4, cub, total;
+    size_t cub_bytes;
+};
+
+Layout make_layout(uint32_t n, size_t cub_bytes)
+{
+    Layout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t m = n > 0 ? n : 1;
+    L.bounds = take(8 * sizeof(uint32_t));
+    L.keys_in = take(m * 4);
+    L.keys_out = take(m * 4);
+    L.vals_in = take(m * 4);
+    L.left = take(m * 4);
+    L.right = take(m * 4);
+    L.parent = take(2 * m * 4);
+    L.flags = take(m * 4);
+    L.nbox = take(2 * m * sizeof(DevBox));
+    L.flag4 = take(m * 4);
+    L.idx4 = take(m * 4);
+    L.cub = take(cub_bytes);
+    L.cub_bytes = cub_bytes;
+    L.total = off;
+    return L;
+}
+
+size_t cub_temp_bytes(uint32_t n)
+{
+    size_t a = 0, b = 0;
+    const uint32_t m = n > 0 ? n : 1;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)m, 0, 30);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)m);
+    return (a > b ? a : b) + 256;
+}
+
+__device__ inline uint32_t f_order(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float f_unorder(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void k_init_bounds(uint32_t* bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0xffffffffu;      // min
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;          // max
+}
+
+__global__ void k_scene_bounds(const DevBox* __restrict__ boxes, uint32_t n, uint32_t* bounds)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < n) {
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+            lo[a] = c;
+            hi[a] = c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&bounds[a], f_order(lo[a]));
+            atomicMax(&bounds[3 + a], f_order(hi[a]));
+        }
+}
+
+__device__ inline uint32_t expand10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void k_morton(const DevBox* __restrict__ boxes, uint32_t n, const uint32_t* __restrict__ bounds, uint32_t* keys, uint32_t* vals)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = f_unorder(bounds[a]), hi = f_unorder(bounds[3 + a]);
+        const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+        const float ext = hi - lo;
+        float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint32_t)t;
+    }
+    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    vals[i] = i;
+}
+
+// longest common prefix of keys i and j (ties broken by index), -1 outside the array
+__device__ inline int delta(const uint32_t* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clz(a ^ b);
+}
+
+// child encoding in left/right: >= 0 internal node index, < 0 leaf ~index
+__global__ void k_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, int32_t* left, int32_t* right, uint32_t* parent)
+{
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    const int ni = (int)n;
+    if (i >= ni - 1) return;
+    const int d = (delta(keys, ni, i, i + 1) - delta(keys, ni, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, ni, i, i - d);
+    int lmax = 2;
+    while (delta(keys, ni, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, ni, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, ni, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, ni, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const bool left_leaf = lo == gamma, right_leaf = hi == gamma + 1;
+    left[i] = left_leaf ? ~gamma : gamma;
+    right[i] = right_leaf ? ~(gamma + 1) : gamma + 1;
+    parent[left_leaf ? (ni - 1 + gamma) : gamma] = (uint32_t)i;
+    parent[right_leaf ? (ni - 1 + gamma + 1) : gamma + 1] = (uint32_t)i;
+    if (i == 0) parent[0] = 0xffffffffu;
+}
+
+__device__ inline uint32_t node_slot(int32_t child, uint32_t n) { return child < 0 ? (n - 1 + (uint32_t)(~child)) : (uint32_t)child; }
+
+// bottom-up fit.  nbox[slot]: slot < n-1 internal node, slot >= n-1 leaf (n-1 + sorted position).
+__global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n, const int32_t* __restrict__ left,
+                      const int32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* flags, DevBox* nbox)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    DevBox b = boxes[order[i]];
+    uint32_t me = n - 1 + i;
+    nbox[me] = b;
+    uint32_t node = parent[me];
+    while (node != 0xffffffffu) {
+        // publish this subtree's box, then arrive: the second arrival at a node owns it and may read the sibling's box
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = atomicAdd(&flags[node], 1u);
+        if (old == 0u) return;
+        __threadfence();
+        const uint32_t ls = node_slot(left[node], n), rs = node_slot(right[node], n);
+        const uint32_t sib = ls == me ? rs : ls;
+        const volatile DevBox* sb = nbox + sib;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = fminf(b.lo[a], sb->lo[a]);
+            b.hi[a] = fmaxf(b.hi[a], sb->hi[a]);
+        }
+        nbox[node] = b;
+        me = node;
+        node = parent[node];
+    }
+}
+
+// internal nodes at even depth become Node4s
+__global__ void k_flag_even_depth(uint32_t n_internal, const uint32_t* __restrict__ parent, uint32_t* flag4)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_internal) return;
+    uint32_t depth = 0, p = parent[i];
+    while (p != 0xffffffffu) {
+        depth++;
+        p = parent[p];
+    }
+    flag4[i] = (depth & 1u) ? 0u : 1u;
+}
+
+__global__ void k_emit4(uint32_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right, const uint32_t* __restrict__ flag4,
+                        const uint32_t* __restrict__ idx4, const DevBox* __restrict__ nbox, Node4* __restrict__ nodes, uint32_t* node_count_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    if (i == n - 2 && node_count_out) *node_count_out = idx4[i] + flag4[i];
+    if (!flag4[i]) return;
+    int32_t kids[4];
+    int nk = 0;
+    const int32_t c2[2] = {left[i], right[i]};
+    for (int k = 0; k < 2; k++) {
+        if (c2[k] < 0) kids[nk++] = c2[k];
+        else {
+            kids[nk++] = left[c2[k]];
+            kids[nk++] = right[c2[k]];
+        }
+    }
+    Node4 out;
+    for (int k = 0; k < 4; k++) {
+        if (k < nk) {
+            const DevBox b = nbox[node_slot(kids[k], n)];
+            out.lox[k] = b.lo[0]; out.loy[k] = b.lo[1]; out.loz[k] = b.lo[2];
+            out.hix[k] = b.hi[0]; out.hiy[k] = b.hi[1]; out.hiz[k] = b.hi[2];
+            out.child[k] = kids[k] < 0 ? make_leaf((uint32_t)(~kids[k]), 1u) : idx4[kids[k]];
+        } else {
+            out.lox[k] = out.loy[k] = out.loz[k] = INFINITY;
+            out.hix[k] = out.hiy[k] = out.hiz[k] = -INFINITY;
+            out.child[k] = kInvalidRef;
+        }
+        out.pad[k] = 0;
+    }
+    nodes[idx4[i]] = out;
+}
+
+// n == 0 / n == 1: a root with no / one leaf child
+__global__ void k_tiny_tree(const DevBox* __restrict__ boxes, uint32_t n, Node4* nodes, uint32_t* order, uint32_t* node_count_out)
+{
+    Node4 out;
+    for (int k = 0; k < 4; k++) {
+        out.lox[k] = out.loy[k] = out.loz[k] = INFINITY;
+        out.hix[k] = out.hiy[k] = out.hiz[k] = -INFINITY;
+        out.child[k] = kInvalidRef;
+        out.pad[k] = 0;
+    }
+    if (n == 1) {
+        out.lox[0] = boxes[0].lo[0]; out.loy[0] = boxes[0].lo[1]; out.loz[0] = boxes[0].lo[2];
+        out.hix[0] = boxes[0].hi[0]; out.hiy[0] = boxes[0].hi[1]; out.hiz[0] = boxes[0].hi[2];
+        out.child[0] = make_leaf(0u, 1u);
+        order[0] = 0;
+    }
+    nodes[0] = out;
+    if (node_count_out) *node_count_out = 1;
+}
+
+__global__ void k_instance_boxes(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                                 const DevBox* __restrict__ mesh_local, const uint32_t* __restrict__ valid_gids, uint32_t n, DevBox* out)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t gid = valid_gids[k];
+    const float* m = matrices[gid].m;
+    const DevBox lb = mesh_local[mesh_of_instance[gid]];
+    DevBox b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+    for (int c = 0; c < 8; c++) {
+        const float x = (c & 1) ? lb.hi[0] : lb.lo[0], y = (c & 2) ? lb.hi[1] : lb.lo[1], z = (c & 4) ? lb.hi[2] : lb.lo[2];
+        const float w[3] = {m[0] * x + m[4] * y + m[8] * z + m[12], m[1] * x + m[5] * y + m[9] * z + m[13], m[2] * x + m[6] * y + m[10] * z + m[14]};
+        for (int a = 0; a < 3; a++) { b.lo[a] = fminf(b.lo[a], w[a]); b.hi[a] = fmaxf(b.hi[a], w[a]); }
+    }
+    // pad for the transform's rounding and the BLAS' own padding (conservative traversal)
+    for (int a = 0; a < 3; a++) {
+        const float ext = b.hi[a] - b.lo[a];
+        const float e = 2e-4f + 1e-5f * fmaxf(fabsf(b.lo[a]), fabsf(b.hi[a])) + 1e-5f * ext;
+        b.lo[a] -= e;
+        b.hi[a] += e;
+    }
+    b.lo[3] = 0.0f; b.hi[3] = 0.0f;
+    out[k] = b;
+}
+
+__global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ order, uint32_t n, uint32_t* dst)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) dst[k] = src[order[k]];
+}
+
+__global__ void k_triangle_boxes(const rfw_rt_triangle* __restrict__ tris, uint32_t n, DevBox* out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* tp = reinterpret_cast<const float4*>(tris + i);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    DevBox bx;
+    const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {c.x, c.y, c.z};
+    for (int k = 0; k < 3; k++) {
+        float lo = fminf(va[k], fminf(vb[k], vc[k])), hi = fmaxf(va[k], fmaxf(vb[k], vc[k]));
+        const float e = 1e-4f + 4e-6f * fmaxf(fabsf(lo), fabsf(hi));
+        bx.lo[k] = lo - e;
+        bx.hi[k] = hi + e;
+    }
+    bx.lo[3] = 0.0f; bx.hi[3] = 0.0f;
+    out[i] = bx;
+}
+
+__global__ void k_make_packets(const rfw_rt_triangle* __restrict__ tris, const uint32_t* __restrict__ order, uint32_t n, uint32_t id_offset,
+                               TriPacket* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t id = order[k];
+    const float4* tp = reinterpret_cast<const float4*>(tris + id);
+    const float4 a = tp[0], b = tp[1], c = tp[2], g = tp[3];
+    TriPacket p;
+    p.v0x = a.x; p.v0y = a.y; p.v0z = a.z;
+    p.tri_id = id + id_offset;
+    // single IEEE subtractions / one division: the same arithmetic the host builder and the oracle perform (-ffp-contract=off)
+    p.e1x = b.x - a.x; p.e1y = b.y - a.y; p.e1z = b.z - a.z;
+    p.e2x = c.x - a.x; p.e2y = c.y - a.y; p.e2z = c.z - a.z;
+    p.inv_gn2 = 1.0f / (g.x * g.x + g.y * g.y + g.z * g.z);
+    p.pad = 0.0f;
+    out[k] = p;
+}
+
+inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+} // namespace
+
+size_t lbvh_workspace_bytes(uint32_t n) { return make_layout(n, cub_temp_bytes(n)).total; }
+
+hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out, uint32_t* order_out,
+                      uint32_t* node_count_out)
+{
+    if (n < 2) {
+        hipLaunchKernelGGL(k_tiny_tree, dim3(1), dim3(1), 0, s, boxes, n, nodes_out, order_out, node_count_out);
+        return hipGetLastError();
+    }
+    const Layout L = make_layout(n, cub_temp_bytes(n));
+    if (L.total > workspace_bytes) return hipErrorInvalidValue;
+    char* w = static_cast<char*>(workspace);
+    uint32_t* bounds = (uint32_t*)(w + L.bounds);
+    uint32_t* keys_in = (uint32_t*)(w + L.keys_in);
+    uint32_t* keys_out = (uint32_t*)(w + L.keys_out);
+    uint32_t* vals_in = (uint32_t*)(w + L.vals_in);
+    int32_t* left = (int32_t*)(w + L.left);
+    int32_t* right = (int32_t*)(w + L.right);
+    uint32_t* parent = (uint32_t*)(w + L.parent);
+    uint32_t* flags = (uint32_t*)(w + L.flags);
+    DevBox* nbox = (DevBox*)(w + L.nbox);
+    uint32_t* flag4 = (uint32_t*)(w + L.flag4);
+    uint32_t* idx4 = (uint32_t*)(w + L.idx4);
+    void* cub = w + L.cub;
+    size_t cub_bytes = L.cub_bytes;
+
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, bounds);
+    hipLaunchKernelGGL(k_scene_bounds, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, n, bounds);
+    hipLaunchKernelGGL(k_morton, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, n, bounds, keys_in, vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, keys_in, keys_out, vals_in, order_out, (int)n, 0, 30, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(flags, 0, (size_t)n * 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks(n - 1)), dim3(kBlock), 0, s, keys_out, n, left, right, parent);
+    hipLaunchKernelGGL(k_fit, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
+    hipLaunchKernelGGL(k_flag_even_depth, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n - 1, parent, flag4);
+    cub_bytes = L.cub_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag4, idx4, (int)(n - 1), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_emit4, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n, left, right, flag4, idx4, nbox, nodes_out, node_count_out);
+    return hipGetLastError();
+}
+
+void launch_instance_boxes(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const DevBox* mesh_local_boxes,
+                           const uint32_t* valid_gids, uint32_t n_valid, DevBox* out)
+{
+    if (n_valid) hipLaunchKernelGGL(k_instance_boxes, dim3(blocks(n_valid)), dim3(kBlock), 0, s, matrices, mesh_of_instance, mesh_local_boxes, valid_gids, n_valid, out);
+}
+void launch_gather_u32(hipStream_t s, const uint32_t* src, const uint32_t* order, uint32_t n, uint32_t* dst)
+{
+    if (n) hipLaunchKernelGGL(k_gather_u32, dim3(blocks(n)), dim3(kBlock), 0, s, src, order, n, dst);
+}
+void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, DevBox* out)
+{
+    if (n) hipLaunchKernelGGL(k_triangle_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, tris, n, out);
+}
+void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out)
+{
+    if (n) hipLaunchKernelGGL(k_make_packets, dim3(blocks(n)), dim3(kBlock), 0, s, tris, order, n, id_offset, out);
+}
+
+} // namespace rfwhip

@@ -17,6 +17,7 @@
 #include "../../include/rfw_hip.h"
 #include "bvh_host.h"
 #include "kernels.h"
+#include "lbvh.h"
 #include "traverse.h"
 
 using namespace rfwhip;
@@ -73,7 +74,7 @@ struct Instance {
     uint32_t max_path_length = 3;
     float clamp_value = 10.0f;
     uint32_t rank = 0, world = 1, tile_size = 64;
-    uint32_t builder = RFW_HIP_BUILDER_HOST_SAH;
+    uint32_t builder = RFW_HIP_BUILDER_AUTO;
     uint32_t flags = 0;
     float sky[3] = {0, 0, 0};
     bool timing = true;
@@ -105,6 +106,16 @@ struct Instance {
     DevBuf<rfw_spot_light> d_spot;
     DevBuf<rfw_directional_light> d_dir;
     DevBuf<uint32_t> d_spill;
+    DevBuf<uint32_t> d_valid_gids, d_tlas_order, d_node_count;
+    DevBuf<DevBox> d_inst_boxes, d_mesh_local, d_tri_boxes;
+    DevBuf<char> d_lbvh_ws;
+    DevBuf<uint32_t> d_blas_order;
+    // pinned staging for the per-frame instance upload (truly asynchronous H2D; guarded by stage_event)
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t stage_event = nullptr;
+    bool stage_pending = false;
+    bool tlas_on_device = true, blas_on_device = false;
     DevBuf<QueueCounters> d_counters;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
@@ -268,115 +279,239 @@ void build_mesh(Instance* I, MeshHost& m)
     m.dirty = false;
 }
 
+int ensure_stage(Instance* I, size_t bytes)
+{
+    if (bytes <= I->stage_bytes) return RFW_HIP_OK;
+    if (I->stage) (void)hipHostFree(I->stage);
+    I->stage = nullptr;
+    I->stage_bytes = 0;
+    const size_t want = std::max<size_t>(bytes * 2, 1 << 20);
+    HIP_TRY(I, hipHostMalloc(&I->stage, want, hipHostMallocDefault));
+    I->stage_bytes = want;
+    return RFW_HIP_OK;
+}
+
+int ensure_lbvh_ws(Instance* I, uint32_t n)
+{
+    const size_t need = lbvh_workspace_bytes(n);
+    HIP_TRY(I, I->d_lbvh_ws.ensure(need));
+    return RFW_HIP_OK;
+}
+
+// BLAS for every mesh on the device (builder = DEVICE_LBVH): upload the triangles, then boxes -> LBVH -> packets, all on-stream
+int build_blas_device(Instance* I)
+{
+    I->mesh_records.clear();
+    I->mesh_index.clear();
+    uint32_t tri_total = 0, node_total = 0;
+    for (auto& kv : I->meshes) {
+        MeshRecord r;
+        r.tri_base = tri_total;
+        r.tri_count = (uint32_t)kv.second.tris.size();
+        r.node_base = node_total;
+        r.node_count = std::max<uint32_t>(r.tri_count, 1u); // worst case (one primitive per leaf => at most n - 1 wide nodes)
+        tri_total += r.tri_count;
+        node_total += r.node_count;
+        I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        kv.second.dirty = false;
+    }
+    HIP_TRY(I, I->d_triangles.ensure(tri_total));
+    HIP_TRY(I, I->d_packets.ensure(tri_total));
+    HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
+    HIP_TRY(I, I->d_blas_order.ensure(tri_total));
+    uint32_t max_n = 0;
+    size_t k = 0;
+    for (auto& kv : I->meshes) {
+        const MeshRecord& r = I->mesh_records[k++];
+        max_n = std::max(max_n, r.tri_count);
+        if (r.tri_count)
+            HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle),
+                                      hipMemcpyHostToDevice, I->stream));
+    }
+    HIP_TRY(I, I->d_tri_boxes.ensure(max_n));
+    int rc;
+    if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
+    for (const MeshRecord& r : I->mesh_records) {
+        launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_nodes.ptr + r.node_base,
+                              I->d_blas_order.ptr + r.tri_base, nullptr));
+        launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base,
+                            I->d_packets.ptr + r.tri_base);
+    }
+    HIP_TRY(I, hipGetLastError());
+    I->n_tris = tri_total;
+    I->n_blas_nodes = node_total;
+    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    return RFW_HIP_OK;
+}
+
+// BLAS on the host cores (binned SAH, multi-threaded), flattened into the mega-buffers (gpu-rt/src/lib.rs:1387-1548)
+int build_blas_host(Instance* I)
+{
+    for (auto& kv : I->meshes)
+        if (kv.second.dirty) build_mesh(I, kv.second);
+    I->mesh_records.clear();
+    I->mesh_index.clear();
+    std::vector<Node4> nodes;
+    std::vector<TriPacket> packets;
+    std::vector<rfw_rt_triangle> tris;
+    for (auto& kv : I->meshes) {
+        MeshHost& m = kv.second;
+        MeshRecord r;
+        r.node_base = (uint32_t)nodes.size();
+        r.node_count = (uint32_t)m.bvh.nodes.size();
+        r.tri_base = (uint32_t)tris.size();
+        r.tri_count = (uint32_t)m.tris.size();
+        I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        nodes.insert(nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
+        const size_t p0 = packets.size();
+        packets.insert(packets.end(), m.packets.begin(), m.packets.end());
+        for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
+        tris.insert(tris.end(), m.tris.begin(), m.tris.end());
+    }
+    I->n_tris = tris.size();
+    I->n_blas_nodes = nodes.size();
+    int rc;
+    if ((rc = upload(I, I->d_blas_nodes, nodes.data(), nodes.size()))) return rc;
+    if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
+    if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
+    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+    HIP_TRY(I, hipStreamSynchronize(I->stream)); // the host vectors above go out of scope
+    return RFW_HIP_OK;
+}
+
+// instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
+int build_instances(Instance* I)
+{
+    // sizes first, then ONE pinned staging block: [matrices | mesh_of | valid_gids | mesh_local]
+    size_t n_all = 0;
+    for (auto& kv : I->inst_lists) n_all += kv.second.matrices.size();
+    const size_t n_mesh = I->mesh_records.size();
+    const size_t off_mats = 0, off_meshof = off_mats + n_all * sizeof(rfw_mat4), off_valid = off_meshof + n_all * 4,
+                 off_local = (off_valid + n_all * 4 + 63) / 64 * 64, total = off_local + std::max<size_t>(n_mesh, 1) * sizeof(DevBox);
+    if (I->stage_pending) { // the previous frame's async upload must have left the staging block
+        HIP_TRY(I, hipEventSynchronize(I->stage_event));
+        I->stage_pending = false;
+    }
+    int rc;
+    if ((rc = ensure_stage(I, total))) return rc;
+    char* st = static_cast<char*>(I->stage);
+    rfw_mat4* mats = reinterpret_cast<rfw_mat4*>(st + off_mats);
+    uint32_t* mesh_of = reinterpret_cast<uint32_t*>(st + off_meshof);
+    uint32_t* valid = reinterpret_cast<uint32_t*>(st + off_valid);
+    DevBox* local = reinterpret_cast<DevBox*>(st + off_local);
+    std::memset(local, 0, std::max<size_t>(n_mesh, 1) * sizeof(DevBox));
+    uint32_t gid = 0, n_valid = 0;
+    for (auto& kv : I->inst_lists) {
+        const auto mit = I->mesh_index.find(kv.first);
+        const bool mesh_ok = mit != I->mesh_index.end() && I->mesh_records[mit->second].tri_count > 0;
+        if (mesh_ok) {
+            DevBox& lb = local[mit->second];
+            for (int a = 0; a < 3; a++) { lb.lo[a] = kv.second.local_aabb.min[a]; lb.hi[a] = kv.second.local_aabb.max[a]; }
+        }
+        const size_t cnt = kv.second.matrices.size();
+        if (cnt) std::memcpy(mats + gid, kv.second.matrices.data(), cnt * sizeof(rfw_mat4));
+        for (size_t s = 0; s < cnt; s++, gid++) {
+            mesh_of[gid] = mesh_ok ? mit->second : 0xffffffffu;
+            if (mesh_ok && !is_zero_matrix(kv.second.matrices[s])) valid[n_valid++] = gid; // zero matrix = removed slot (instances_3d.rs:79-86)
+        }
+    }
+    I->n_instances = n_all;
+    I->n_valid_instances = n_valid;
+    HIP_TRY(I, I->d_matrices.ensure(n_all));
+    HIP_TRY(I, I->d_mesh_of_instance.ensure(n_all));
+    HIP_TRY(I, I->d_valid_gids.ensure(n_all));
+    HIP_TRY(I, I->d_mesh_local.ensure(std::max<size_t>(n_mesh, 1)));
+    HIP_TRY(I, I->d_xforms.ensure(n_all));
+    HIP_TRY(I, I->d_normals.ensure(n_all));
+    HIP_TRY(I, I->d_tlas_prims.ensure(n_all));
+    HIP_TRY(I, I->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, I->d_node_count.ensure(1));
+    hipStream_t s = I->stream;
+    if (n_all) {
+        HIP_TRY(I, hipMemcpyAsync(I->d_matrices.ptr, mats, n_all * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(I->d_mesh_of_instance.ptr, mesh_of, n_all * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(I->d_valid_gids.ptr, valid, n_all * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(I, hipMemcpyAsync(I->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
+    launch_prepare_instances(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)n_all, I->d_xforms.ptr, I->d_normals.ptr);
+    if (I->tlas_on_device) {
+        HIP_TRY(I, I->d_inst_boxes.ensure(std::max<size_t>(n_valid, 1)));
+        HIP_TRY(I, I->d_tlas_order.ensure(std::max<size_t>(n_valid, 1)));
+        if ((rc = ensure_lbvh_ws(I, n_valid))) return rc;
+        launch_instance_boxes(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_local.ptr, I->d_valid_gids.ptr, n_valid, I->d_inst_boxes.ptr);
+        HIP_TRY(I, lbvh_build(s, I->d_inst_boxes.ptr, n_valid, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_tlas_nodes.ptr, I->d_tlas_order.ptr,
+                              I->d_node_count.ptr));
+        launch_gather_u32(s, I->d_valid_gids.ptr, I->d_tlas_order.ptr, n_valid, I->d_tlas_prims.ptr);
+        HIP_TRY(I, hipGetLastError());
+        I->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
+        HIP_TRY(I, hipEventRecord(I->stage_event, s));
+        I->stage_pending = true;
+    } else {
+        // host TLAS (builder = HOST_SAH): boxes on the host, binned SAH, upload
+        std::vector<PrimBox> boxes(n_valid);
+        for (uint32_t k = 0; k < n_valid; k++) {
+            const rfw_mat4& m = mats[valid[k]];
+            const DevBox& lb = local[mesh_of[valid[k]]];
+            PrimBox b;
+            for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            for (int c = 0; c < 8; c++) {
+                const float x = (c & 1) ? lb.hi[0] : lb.lo[0], y = (c & 2) ? lb.hi[1] : lb.lo[1], z = (c & 4) ? lb.hi[2] : lb.lo[2];
+                const float w[3] = {m.m[0] * x + m.m[4] * y + m.m[8] * z + m.m[12], m.m[1] * x + m.m[5] * y + m.m[9] * z + m.m[13],
+                                    m.m[2] * x + m.m[6] * y + m.m[10] * z + m.m[14]};
+                for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], w[a]); b.hi[a] = std::max(b.hi[a], w[a]); }
+            }
+            for (int a = 0; a < 3; a++) {
+                const float ext = b.hi[a] - b.lo[a];
+                const float e = 2e-4f + 1e-5f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + 1e-5f * ext;
+                b.lo[a] -= e;
+                b.hi[a] += e;
+            }
+            boxes[k] = b;
+        }
+        HostBvh4 tlas;
+        build_bvh4_host(boxes, 1, I->build_threads, tlas);
+        std::vector<uint32_t> prims(tlas.prim_order.size());
+        for (size_t k = 0; k < prims.size(); k++) prims[k] = valid[tlas.prim_order[k]];
+        I->n_tlas_nodes = tlas.nodes.size();
+        if ((rc = upload(I, I->d_tlas_nodes, tlas.nodes.data(), tlas.nodes.size()))) return rc;
+        if ((rc = upload(I, I->d_tlas_prims, prims.data(), prims.size()))) return rc;
+        HIP_TRY(I, hipGetLastError());
+        HIP_TRY(I, hipStreamSynchronize(s));
+    }
+    return RFW_HIP_OK;
+}
+
 int do_synchronize(Instance* I)
 {
     HIP_TRY(I, hipSetDevice(I->device));
     bool any_change = false;
-    // ---- BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383) and the flattened mega-buffers (:1387-1548)
-    if (I->meshes_dirty) {
+    int rc;
+    if (I->meshes_dirty) { // BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383)
         const auto t0 = std::chrono::steady_clock::now();
-        for (auto& kv : I->meshes)
-            if (kv.second.dirty) build_mesh(I, kv.second);
-        I->mesh_records.clear();
-        I->mesh_index.clear();
-        std::vector<Node4> nodes;
-        std::vector<TriPacket> packets;
-        std::vector<rfw_rt_triangle> tris;
-        for (auto& kv : I->meshes) {
-            MeshHost& m = kv.second;
-            MeshRecord r;
-            r.node_base = (uint32_t)nodes.size();
-            r.node_count = (uint32_t)m.bvh.nodes.size();
-            r.tri_base = (uint32_t)tris.size();
-            r.tri_count = (uint32_t)m.tris.size();
-            I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
-            I->mesh_records.push_back(r);
-            nodes.insert(nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
-            const size_t p0 = packets.size();
-            packets.insert(packets.end(), m.packets.begin(), m.packets.end());
-            for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
-            tris.insert(tris.end(), m.tris.begin(), m.tris.end());
-        }
-        I->n_tris = tris.size();
-        I->n_blas_nodes = nodes.size();
-        int rc;
-        if ((rc = upload(I, I->d_blas_nodes, nodes.data(), nodes.size()))) return rc;
-        if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
-        if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
-        if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
-        HIP_TRY(I, hipStreamSynchronize(I->stream)); // the host vectors above go out of scope
+        if ((rc = I->blas_on_device ? build_blas_device(I) : build_blas_host(I))) return rc;
         I->ms_blas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         I->meshes_dirty = false;
         I->instances_dirty = true;
         any_change = true;
     }
-    // ---- instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
     if (I->instances_dirty) {
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<rfw_mat4> mats;
-        std::vector<uint32_t> mesh_of;
-        std::vector<PrimBox> boxes;
-        std::vector<uint32_t> box_gid;
-        for (auto& kv : I->inst_lists) {
-            const auto mit = I->mesh_index.find(kv.first);
-            const bool mesh_ok = mit != I->mesh_index.end() && I->mesh_records[mit->second].tri_count > 0;
-            for (size_t s = 0; s < kv.second.matrices.size(); s++) {
-                const rfw_mat4& m = kv.second.matrices[s];
-                const uint32_t gid = (uint32_t)mats.size();
-                mats.push_back(m);
-                mesh_of.push_back(mesh_ok ? mit->second : 0xffffffffu);
-                if (!mesh_ok || is_zero_matrix(m)) continue; // removed slot (crates/rfw-scene/src/instances_3d.rs:79-86)
-                PrimBox b;
-                for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
-                const rfw_aabb& lb = kv.second.local_aabb;
-                for (int c = 0; c < 8; c++) {
-                    const float x = (c & 1) ? lb.max[0] : lb.min[0], y = (c & 2) ? lb.max[1] : lb.min[1], z = (c & 4) ? lb.max[2] : lb.min[2];
-                    const float w[3] = {m.m[0] * x + m.m[4] * y + m.m[8] * z + m.m[12], m.m[1] * x + m.m[5] * y + m.m[9] * z + m.m[13],
-                                        m.m[2] * x + m.m[6] * y + m.m[10] * z + m.m[14]};
-                    for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], w[a]); b.hi[a] = std::max(b.hi[a], w[a]); }
-                }
-                // the mesh-local box holds unpadded vertices; pad for the transform's rounding and the BLAS padding
-                for (int a = 0; a < 3; a++) {
-                    const float ext = b.hi[a] - b.lo[a];
-                    const float e = 2e-4f + 1e-5f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + 1e-5f * ext;
-                    b.lo[a] -= e;
-                    b.hi[a] += e;
-                }
-                boxes.push_back(b);
-                box_gid.push_back(gid);
-            }
-        }
-        I->n_instances = mats.size();
-        I->n_valid_instances = boxes.size();
-        HostBvh4 tlas;
-        build_bvh4_host(boxes, 1, I->build_threads, tlas);
-        std::vector<uint32_t> prims(tlas.prim_order.size());
-        for (size_t k = 0; k < prims.size(); k++) prims[k] = box_gid[tlas.prim_order[k]];
-        I->n_tlas_nodes = tlas.nodes.size();
-        int rc;
-        if ((rc = upload(I, I->d_matrices, mats.data(), mats.size()))) return rc;
-        if ((rc = upload(I, I->d_mesh_of_instance, mesh_of.data(), mesh_of.size()))) return rc;
-        if ((rc = upload(I, I->d_tlas_nodes, tlas.nodes.data(), tlas.nodes.size()))) return rc;
-        if ((rc = upload(I, I->d_tlas_prims, prims.data(), prims.size()))) return rc;
-        HIP_TRY(I, I->d_xforms.ensure(mats.size()));
-        HIP_TRY(I, I->d_normals.ensure(mats.size()));
-        launch_prepare_instances(I->stream, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)mats.size(),
-                                 I->d_xforms.ptr, I->d_normals.ptr);
-        HIP_TRY(I, hipGetLastError());
-        HIP_TRY(I, hipStreamSynchronize(I->stream));
-        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if ((rc = build_instances(I))) return rc;
+        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); // host-side time; the device part is asynchronous
         I->instances_dirty = false;
         any_change = true;
     }
     if (I->materials_dirty) {
-        int rc;
         if ((rc = upload(I, I->d_materials, I->materials.data(), I->materials.size()))) return rc;
         HIP_TRY(I, hipStreamSynchronize(I->stream));
         I->materials_dirty = false;
         any_change = true;
     }
     if (I->lights_dirty) {
-        int rc;
         if ((rc = upload(I, I->d_area, I->area_lights.data(), I->area_lights.size()))) return rc;
         if ((rc = upload(I, I->d_point, I->point_lights.data(), I->point_lights.size()))) return rc;
         if ((rc = upload(I, I->d_spot, I->spot_lights.data(), I->spot_lights.size()))) return rc;
@@ -531,11 +666,10 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         delete I;
         return nullptr;
     }
-    if (I->builder == RFW_HIP_BUILDER_DEVICE_LBVH) {
-        g_create_error = "builder DEVICE_LBVH is not available in this build";
-        delete I;
-        return nullptr;
-    }
+    // AUTO: BLAS by binned SAH on the host cores (built once per mesh change, best traversal quality), TLAS by LBVH on the device
+    // (rebuilt every synchronize()).  HOST_SAH / DEVICE_LBVH force one builder for both levels.
+    I->blas_on_device = I->builder == RFW_HIP_BUILDER_DEVICE_LBVH;
+    I->tlas_on_device = I->builder != RFW_HIP_BUILDER_HOST_SAH;
     if (dev < 0) (void)hipGetDevice(&dev);
     I->device = dev;
     I->build_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -550,6 +684,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     for (int r = 0; r < kTimingRing; r++)
         for (int i = 0; i < kNumEvents; i++)
             if ((e = hipEventCreate(&I->ring[r][i])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&I->stage_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
         delete I;
@@ -571,6 +706,10 @@ void rfw_hip_destroy(void* inst)
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release();
+        I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
+        I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
+        if (I->stage) (void)hipHostFree(I->stage);
+        if (I->stage_event) (void)hipEventDestroy(I->stage_event);
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
         I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
         for (int r = 0; r < kTimingRing; r++)
@@ -826,6 +965,12 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
     out->triangles = I->n_tris;
     out->instances = I->n_valid_instances;
     out->blas_nodes = I->n_blas_nodes;
+    if (I->tlas_on_device && I->d_node_count.ptr && I->synchronized) {
+        uint32_t nc = 0;
+        (void)hipSetDevice(I->device);
+        (void)hipStreamSynchronize(I->stream);
+        if (hipMemcpy(&nc, I->d_node_count.ptr, 4, hipMemcpyDeviceToHost) == hipSuccess) I->n_tlas_nodes = nc;
+    }
     out->tlas_nodes = I->n_tlas_nodes;
     out->node_bytes = sizeof(Node4);
     out->tri_bytes = sizeof(TriPacket);
