@@ -3,7 +3,9 @@
 // All buffers are structure-of-arrays of 16-byte elements so that a wavefront reading element
 // `lane` of an array issues one coalesced dwordx4 load (1 KiB per wave-instruction).
 #pragma once
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include "../../include/rfw_pod.h"
 
@@ -24,6 +26,75 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafFirstMask = 0x07ffffffu;
 constexpr int kMaxLeafTris = 8;
 inline __host__ __device__ uint32_t make_leaf(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 27) | first; }
+
+// The node the traversal kernels actually read: the same 4 child boxes quantised to 8 bits per plane relative to the
+// node's own origin with power-of-two scales (floor for lo, ceil for hi => conservative), 64 B = 4 dwordx4 per lane
+// instead of 7.  The trace kernels are bound by the L1/TA data-return path (16 cycles per dwordx4 wave-instruction,
+// profiles/), so bytes per node visit are what matters.  plane = origin + q * scale, scale = 2^(exp - 127).
+struct Node4Q {
+    float ox, oy, oz;
+    uint32_t exps;      // byte a = biased exponent of the scale of axis a
+    uint32_t qlo[3];    // byte i of qlo[a] = quantised lower plane of child i on axis a
+    uint32_t qhi[3];
+    uint32_t pad[2];
+    uint32_t child[4];  // as Node4::child
+};
+static_assert(sizeof(Node4Q) == 64, "Node4Q must be half a 128-B line");
+
+inline __host__ __device__ uint32_t rfw_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline __host__ __device__ float rfw_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+inline __host__ __device__ Node4Q quantize_node(const Node4& n)
+{
+    Node4Q q;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const float* nlo[3] = {n.lox, n.loy, n.loz};
+    const float* nhi[3] = {n.hix, n.hiy, n.hiz};
+    for (int i = 0; i < 4; i++) {
+        if (n.child[i] == 0xffffffffu) continue;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = nlo[a][i] < lo[a] ? nlo[a][i] : lo[a];
+            hi[a] = nhi[a][i] > hi[a] ? nhi[a][i] : hi[a];
+        }
+    }
+    uint32_t exps = 0;
+    float scale[3];
+    for (int a = 0; a < 3; a++) {
+        if (!(hi[a] >= lo[a])) { lo[a] = 0.0f; hi[a] = 0.0f; } // node without children
+        // smallest power of two s with 255 * s >= extent (biased exponent clamped to the normal range)
+        const float want = (hi[a] - lo[a]) * (1.0f / 255.0f);
+        uint32_t e = (rfw_f2bits(want) >> 23) & 0xffu;
+        if ((rfw_f2bits(want) & 0x007fffffu) != 0u) e += 1u;
+        if (e < 1u) e = 1u;
+        if (e > 254u) e = 254u;
+        scale[a] = rfw_bits2f(e << 23);
+        if (255.0f * scale[a] < (hi[a] - lo[a]) && e < 254u) { e += 1u; scale[a] = rfw_bits2f(e << 23); }
+        exps |= e << (8 * a);
+    }
+    q.ox = lo[0]; q.oy = lo[1]; q.oz = lo[2];
+    q.exps = exps;
+    for (int a = 0; a < 3; a++) { q.qlo[a] = 0u; q.qhi[a] = 0u; }
+    for (int i = 0; i < 4; i++) {
+        q.child[i] = n.child[i];
+        for (int a = 0; a < 3; a++) {
+            uint32_t ql = 255u, qh = 0u; // empty slot: inverted
+            if (n.child[i] != 0xffffffffu) {
+                const float inv = 1.0f / scale[a];
+                float fl = floorf((nlo[a][i] - lo[a]) * inv), fh = ceilf((nhi[a][i] - lo[a]) * inv);
+                fl = fl < 0.0f ? 0.0f : (fl > 255.0f ? 255.0f : fl);
+                fh = fh < 0.0f ? 0.0f : (fh > 255.0f ? 255.0f : fh);
+                ql = (uint32_t)fl;
+                qh = (uint32_t)fh;
+                while (ql > 0u && lo[a] + (float)ql * scale[a] > nlo[a][i]) ql--;   // decoded planes must enclose the original box
+                while (qh < 255u && lo[a] + (float)qh * scale[a] < nhi[a][i]) qh++;
+            }
+            q.qlo[a] |= ql << (8 * i);
+            q.qhi[a] |= qh << (8 * i);
+        }
+    }
+    q.pad[0] = 0u; q.pad[1] = 0u;
+    return q;
+}
 
 // Triangle packet for traversal, 48 B, stored in BLAS leaf order (no index indirection in the leaf loop):
 //   p0 = (v0.xyz, bits(global triangle id)), p1 = (edge1.xyz, 1/dot(gn,gn)), p2 = (edge2.xyz, 0)
@@ -80,5 +151,6 @@ struct QueueCounters {
 };
 
 enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };
+
 
 } // namespace rfwhip

@@ -8,11 +8,11 @@
 namespace rfwhip {
 
 struct SceneDev {
-    const Node4* tlas_nodes;
+    const Node4Q* tlas_nodes;
     const uint32_t* tlas_prims;
     const InstanceXform* instances;
     const InstanceNormal* instance_normals;
-    const Node4* blas_nodes;
+    const Node4Q* blas_nodes;
     const TriPacket* tri_packets;
     const rfw_rt_triangle* triangles; // shading attributes, global triangle id order
     const rfw_device_material* materials;
@@ -47,6 +47,7 @@ void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, 
 void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n);
 void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples);
 void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples);

@@ -12,6 +12,10 @@
 #include "shade_device.h"
 #include "traverse.h"
 
+#ifndef RFW_TRACE_WAVES
+#define RFW_TRACE_WAVES 5 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves)
+#endif
+
 namespace rfwhip {
 
 // ---------------------------------------------------------------- shard / slab indexing
@@ -160,11 +164,23 @@ RFW_DI void generate_eye_ray(const CameraParams& cam, f3& O, f3& D, uint32_t sx,
     D = normalize(pointOnPixel - O);
 }
 
+// ---------------------------------------------------------------- XCD-aware block mapping
+// Workgroups are dealt round-robin over the 8 XCDs (launch indices b and b + 8 share an XCD and its 4 MiB L2).  The launch
+// index is remapped so that the 64 wavefronts of one 64x64-pixel tile (64 consecutive queue blocks) run on ONE XCD, and the
+// tiles are dealt round-robin to the XCDs: an XCD's L2 then holds the BVH working set of its own tiles instead of every L2
+// replicating all of them, while the load stays balanced tile by tile.  Speed only: each block is still visited exactly once.
+// Launch grids are padded to a multiple of 512 (8 tiles x 64 blocks).
+RFW_DI uint32_t xcd_block(const uint32_t b)
+{
+    return (((b >> 9) << 3) + (b & 7u)) * 64u + ((b & 511u) >> 3);
+}
+
 // ---------------------------------------------------------------- ray_gen.comp:39-70
-template <bool COUNT> __global__ __launch_bounds__(kTraceBlock) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
+template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
-    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
     TravCounters tc{0, 0, 0};
     uint32_t px = 0, py = 0;
     const bool valid = idx < p.capacity && slab_to_pixel(cam, idx, px, py);
@@ -188,12 +204,13 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock) void k_primary(c
 
 // ---------------------------------------------------------------- ray_extend.comp:245-268
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
-    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t count = sc.counters->ext[bounce - 1];
-    if (blockIdx.x * kTraceBlock >= count) return;
+    if (block * kTraceBlock >= count) return;
     TravCounters tc{0, 0, 0};
     const uint32_t half = bounce & 1u;
     if (idx < count) {
@@ -211,12 +228,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(const CameraParams cam, 
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
-    const uint32_t idx = blockIdx.x * kTraceBlock + threadIdx.x;
     const uint32_t count = sc.counters->shadow[bounce];
-    if (blockIdx.x * kTraceBlock >= count) return;
+    // the queue is filled in path order: an eighth of it per XCD keeps each XCD on its own region
+    const uint32_t block = xcd_block(blockIdx.x);
+    if (block * kTraceBlock >= count) return;
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
     TravCounters tc{0, 0, 0};
     if (idx < count) {
         const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
@@ -499,6 +518,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     occluded[idx] = occ ? 1 : 0;
 }
 
+__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = quantize_node(in[i]);
+}
+
 // ---------------------------------------------------------------- launch wrappers
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
@@ -510,13 +535,13 @@ void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uin
 }
 void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count)
 {
-    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
     if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, s, cam, sc, p);
     else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, s, cam, sc, p);
 }
 void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
-    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
     if (count) hipLaunchKernelGGL(k_extend<true>, grid, block, 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL(k_extend<false>, grid, block, 0, s, cam, sc, p, bounce);
 }
@@ -526,9 +551,13 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
-    const dim3 grid(ceil_div(p.capacity, kTraceBlock)), block(kTraceBlock);
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
     if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, s, cam, sc, p, bounce);
+}
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n)
+{
+    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);
 }
 void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples)
 {

@@ -92,7 +92,8 @@ struct Instance {
     bool synchronized = false;
 
     // device scene
-    DevBuf<Node4> d_blas_nodes, d_tlas_nodes;
+    DevBuf<Node4Q> d_blas_nodes, d_tlas_nodes;   // what the kernels traverse
+    DevBuf<Node4> d_blas_raw, d_tlas_raw;        // device-built trees before quantisation
     DevBuf<TriPacket> d_packets;
     DevBuf<rfw_rt_triangle> d_triangles;
     DevBuf<MeshRecord> d_mesh_records;
@@ -319,6 +320,7 @@ int build_blas_device(Instance* I)
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
+    HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
     uint32_t max_n = 0;
     size_t k = 0;
@@ -334,11 +336,12 @@ int build_blas_device(Instance* I)
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
     for (const MeshRecord& r : I->mesh_records) {
         launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
-        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_nodes.ptr + r.node_base,
+        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
                               I->d_blas_order.ptr + r.tri_base, nullptr));
         launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base,
                             I->d_packets.ptr + r.tri_base);
     }
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, node_total);
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
@@ -375,7 +378,9 @@ int build_blas_host(Instance* I)
     I->n_tris = tris.size();
     I->n_blas_nodes = nodes.size();
     int rc;
-    if ((rc = upload(I, I->d_blas_nodes, nodes.data(), nodes.size()))) return rc;
+    std::vector<Node4Q> qnodes(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
+    if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
     if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
     if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
@@ -429,6 +434,7 @@ int build_instances(Instance* I)
     HIP_TRY(I, I->d_normals.ensure(n_all));
     HIP_TRY(I, I->d_tlas_prims.ensure(n_all));
     HIP_TRY(I, I->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, I->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, I->d_node_count.ensure(1));
     hipStream_t s = I->stream;
     if (n_all) {
@@ -443,8 +449,9 @@ int build_instances(Instance* I)
         HIP_TRY(I, I->d_tlas_order.ensure(std::max<size_t>(n_valid, 1)));
         if ((rc = ensure_lbvh_ws(I, n_valid))) return rc;
         launch_instance_boxes(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_local.ptr, I->d_valid_gids.ptr, n_valid, I->d_inst_boxes.ptr);
-        HIP_TRY(I, lbvh_build(s, I->d_inst_boxes.ptr, n_valid, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_tlas_nodes.ptr, I->d_tlas_order.ptr,
+        HIP_TRY(I, lbvh_build(s, I->d_inst_boxes.ptr, n_valid, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_tlas_raw.ptr, I->d_tlas_order.ptr,
                               I->d_node_count.ptr));
+        launch_quantize_nodes(s, I->d_tlas_raw.ptr, I->d_tlas_nodes.ptr, std::max<uint32_t>(n_valid, 1u));
         launch_gather_u32(s, I->d_valid_gids.ptr, I->d_tlas_order.ptr, n_valid, I->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         I->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
@@ -477,7 +484,9 @@ int build_instances(Instance* I)
         std::vector<uint32_t> prims(tlas.prim_order.size());
         for (size_t k = 0; k < prims.size(); k++) prims[k] = valid[tlas.prim_order[k]];
         I->n_tlas_nodes = tlas.nodes.size();
-        if ((rc = upload(I, I->d_tlas_nodes, tlas.nodes.data(), tlas.nodes.size()))) return rc;
+        std::vector<Node4Q> qn(tlas.nodes.size());
+        for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
+        if ((rc = upload(I, I->d_tlas_nodes, qn.data(), qn.size()))) return rc;
         if ((rc = upload(I, I->d_tlas_prims, prims.data(), prims.size()))) return rc;
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));
@@ -702,7 +711,7 @@ void rfw_hip_destroy(void* inst)
         std::lock_guard<std::mutex> g(I->mu);
         (void)hipSetDevice(I->device);
         (void)hipDeviceSynchronize();
-        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_packets.release(); I->d_triangles.release();
+        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release();
@@ -972,7 +981,7 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
         if (hipMemcpy(&nc, I->d_node_count.ptr, 4, hipMemcpyDeviceToHost) == hipSuccess) I->n_tlas_nodes = nc;
     }
     out->tlas_nodes = I->n_tlas_nodes;
-    out->node_bytes = sizeof(Node4);
+    out->node_bytes = sizeof(Node4Q);
     out->tri_bytes = sizeof(TriPacket);
     out->ms_blas_build = I->ms_blas_build;
     out->ms_tlas_build = I->ms_tlas_build;
