@@ -59,6 +59,7 @@ typedef struct {
     uint32_t tile_size;        /* shard tile edge in pixels; 0 = default 64 */
     uint32_t builder;          /* RFW_HIP_BUILDER_*; acceleration-structure builder for meshes */
     uint32_t flags;            /* RFW_HIP_FLAG_* */
+    uint32_t streams;          /* sub-shards (HIP streams) one frame is split into on this GPU; 0 = default 1, max 8 */
 } rfw_hip_options;
 
 enum {
@@ -75,7 +76,7 @@ typedef struct {
     uint64_t nodes_visited[3];
     uint64_t tris_tested[3];
     uint64_t instances_entered[3];
-    float ms_total;             /* hipEvent span of the whole frame on the instance's stream */
+    float ms_total;             /* hipEvent span of the whole frame on the instance's stream (wall time, sub-shards overlap) */
     float ms_trace_primary;
     float ms_trace_extend;
     float ms_trace_shadow;
@@ -83,6 +84,8 @@ typedef struct {
     float ms_other;
     uint32_t sample_count;      /* samples accumulated so far */
     uint32_t bounces;
+    uint32_t substreams;        /* launches per kernel per frame: the ms_* kernel figures are sums over them */
+    uint32_t pad;
 } rfw_hip_frame_stats;
 
 /* Sizes of the device-resident acceleration structures (for DESIGN.md byte accounting). */

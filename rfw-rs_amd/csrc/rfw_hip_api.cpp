@@ -63,7 +63,8 @@ enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, st
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
 constexpr int kNumEvents = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce + 1);
-constexpr int kTimingRing = 64; // frames whose events can be pending before rfw_hip_drain_timing must be called
+constexpr int kTimingRing = 32;
+constexpr int kMaxSub = 8;      // sub-shards (HIP streams) a frame is split into on one GPU // frames whose events can be pending before rfw_hip_drain_timing must be called
 
 struct Instance {
     std::mutex mu;
@@ -132,8 +133,12 @@ struct Instance {
     uint32_t sample_count = 0;
     bool have_last_view = false;
     rfw_camera_view_3d last_view{};
-    hipEvent_t ring[kTimingRing][kNumEvents] = {};
-    hipEvent_t* events = ring[0]; // event set of the current frame
+    std::vector<hipEvent_t> ring;  // [kTimingRing][substreams][kNumEvents]
+    hipEvent_t* events = nullptr;   // event set of the current frame, sub-shard 0
+    uint32_t substreams = 1;        // the frame's tiles are dealt to this many sub-shards, each traced on its own stream
+    hipStream_t sub[kMaxSub] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
+    uint32_t local_tiles_v = 0, cap_v = 0; // per sub-shard
     uint64_t frame_index = 0, drained_index = 0;
     uint32_t ring_bounces[kTimingRing] = {};
     bool ring_nee[kTimingRing] = {};
@@ -173,13 +178,18 @@ template <typename T> int upload(Instance* I, DevBuf<T>& buf, const T* src, size
 
 void compute_shard(Instance* I)
 {
+    // virtual sharding: world x substreams virtual ranks; virtual rank rank*S + s belongs to this instance's sub-shard s
+    const uint32_t S = I->substreams, wv = I->world * S;
     I->tiles_x = (I->width + I->tile_size - 1) / I->tile_size;
     I->tiles_y = (I->height + I->tile_size - 1) / I->tile_size;
     const uint32_t total = I->tiles_x * I->tiles_y;
-    I->local_tiles = (total + I->world - 1) / I->world; // slab is padded to the same size on every rank
-    I->capacity = I->local_tiles * I->tile_size * I->tile_size;
+    I->local_tiles_v = (total + wv - 1) / wv; // every sub-slab is padded to the same size on every rank
+    I->cap_v = I->local_tiles_v * I->tile_size * I->tile_size;
+    I->local_tiles = I->local_tiles_v * S;
+    I->capacity = I->cap_v * S;
     uint64_t px = 0;
-    for (uint32_t t = I->rank; t < total; t += I->world) {
+    for (uint32_t t = 0; t < total; t++) {
+        if ((t % wv) / S != I->rank) continue;
         const uint32_t tx = t % I->tiles_x, ty = t / I->tiles_x;
         const uint32_t w = std::min(I->tile_size, I->width - tx * I->tile_size), h = std::min(I->tile_size, I->height - ty * I->tile_size);
         px += (uint64_t)w * h;
@@ -208,8 +218,8 @@ int alloc_paths(Instance* I)
     HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
     HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
     HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * std::max<size_t>(n, 65536)));
-    HIP_TRY(I, I->d_counters.ensure(1));
-    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, sizeof(QueueCounters), I->stream));
+    HIP_TRY(I, I->d_counters.ensure(kMaxSub));
+    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, kMaxSub * sizeof(QueueCounters), I->stream));
     I->sample_count = 0;
     return RFW_HIP_OK;
 }
@@ -534,7 +544,7 @@ int do_synchronize(Instance* I)
     return RFW_HIP_OK;
 }
 
-CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v)
+CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint32_t sub = 0)
 {
     CameraParams c;
     std::memset(&c, 0, sizeof(c));
@@ -552,32 +562,35 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v)
     c.spot_light_count = (uint32_t)I->spot_lights.size();
     c.directional_light_count = (uint32_t)I->directional_lights.size();
     c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
-    c.rank = I->rank; c.world = I->world; c.local_tiles = I->local_tiles;
+    c.rank = I->rank * I->substreams + sub; c.world = I->world * I->substreams; c.local_tiles = I->local_tiles_v;
     c.flags = I->flags;
     c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
     return c;
 }
 
-PathDev path_dev(Instance* I)
+PathDev path_dev(Instance* I, uint32_t sub = 0)
 {
     PathDev p;
+    const size_t off = (size_t)sub * I->cap_v;
     for (int h = 0; h < 2; h++) {
-        p.ray_o[h] = I->d_ray_o[h].ptr;
-        p.ray_d[h] = I->d_ray_d[h].ptr;
-        p.thr[h] = I->d_thr[h].ptr;
-        p.hit[h] = I->d_hit[h].ptr;
+        p.ray_o[h] = I->d_ray_o[h].ptr + off;
+        p.ray_d[h] = I->d_ray_d[h].ptr + off;
+        p.thr[h] = I->d_thr[h].ptr + off;
+        p.hit[h] = I->d_hit[h].ptr + off;
     }
-    p.sh_o = I->d_sh_o.ptr;
-    p.sh_d = I->d_sh_d.ptr;
-    p.sh_e = I->d_sh_e.ptr;
-    p.acc = I->external_slab ? (float4*)I->external_slab : I->d_acc_slab.ptr;
-    p.capacity = I->capacity;
+    p.sh_o = I->d_sh_o.ptr + off;
+    p.sh_d = I->d_sh_d.ptr + off;
+    p.sh_e = I->d_sh_e.ptr + off;
+    p.acc = (I->external_slab ? (float4*)I->external_slab : I->d_acc_slab.ptr) + off;
+    p.capacity = I->cap_v;
     return p;
 }
 
 inline int ev_index(uint32_t bounce, int kernel, int end) { return EV_KERNEL_BASE + 2 * ((int)bounce * kKernelsPerBounce + kernel) + end; }
 constexpr int kEvBlit = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce);
+
+hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.data() + ((size_t)slot * I->substreams + sub) * kNumEvents; }
 
 int do_render(Instance* I, const rfw_camera_view_3d& view)
 {
@@ -587,43 +600,73 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
     I->last_view = view;
     I->have_last_view = true;
 
-    CameraParams cam = camera_params(I, view);
-    const SceneDev sc = scene_dev(I);
-    const PathDev p = path_dev(I);
+    const uint32_t S = I->substreams;
     const bool count = (I->flags & RFW_HIP_FLAG_COUNT_TRAVERSAL) != 0;
-    hipStream_t s = I->stream;
+    const bool nee = !(I->flags & RFW_HIP_FLAG_NO_NEE);
+    hipStream_t main = I->stream;
     const bool tm = I->timing;
     const int slot = (int)(I->frame_index % kTimingRing);
-    I->events = I->ring[slot];
-    auto rec = [&](int ev) { if (tm) (void)hipEventRecord(I->events[ev], s); };
-
-    rec(EV_FRAME0);
-    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, sizeof(QueueCounters), s));
+    I->events = ring_events(I, slot, 0);
     const uint32_t bounces = std::min<uint32_t>(I->max_path_length, kMaxBounces);
-    for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back
-        cam.path_length = b;
-        rec(ev_index(b, 0, 0));
-        if (b == 0) launch_primary(s, cam, sc, p, count);
-        else launch_extend(s, cam, sc, p, b, count);
-        rec(ev_index(b, 0, 1));
-        rec(ev_index(b, 1, 0));
-        launch_shade(s, cam, sc, p, b);
-        rec(ev_index(b, 1, 1));
-        if (!(I->flags & RFW_HIP_FLAG_NO_NEE)) {
-            rec(ev_index(b, 2, 0));
-            launch_shadow(s, cam, sc, p, b, count);
-            rec(ev_index(b, 2, 1));
-        }
+
+    if (tm) (void)hipEventRecord(I->events[EV_FRAME0], main);
+    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, S * sizeof(QueueCounters), main));
+    // The frame's tiles are dealt to S sub-shards, each with its own queues, counters and accumulator slab, each traced on its
+    // own stream: the long tail of one sub-shard's trace kernel (the slowest wavefront bounds a launch) overlaps the other
+    // sub-shards' kernels.  Fork from / join into the caller's stream with events.
+    if (S > 1) HIP_TRY(I, hipEventRecord(I->ev_fork, main));
+    SceneDev sc[kMaxSub];
+    PathDev p[kMaxSub];
+    CameraParams cam[kMaxSub];
+    hipStream_t st[kMaxSub];
+    for (uint32_t s = 0; s < S; s++) {
+        st[s] = S > 1 ? I->sub[s] : main;
+        if (S > 1) HIP_TRY(I, hipStreamWaitEvent(st[s], I->ev_fork, 0));
+        sc[s] = scene_dev(I);
+        sc[s].counters = I->d_counters.ptr + s;
+        sc[s].spill = I->d_spill.ptr + (size_t)s * I->cap_v;
+        p[s] = path_dev(I, s);
+        cam[s] = camera_params(I, view, s);
     }
+    for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back; stage by stage across the sub-shards
+        for (uint32_t s = 0; s < S; s++) {
+            hipEvent_t* ev = ring_events(I, slot, s);
+            cam[s].path_length = b;
+            if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
+            if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
+            else launch_extend(st[s], cam[s], sc[s], p[s], b, count);
+            if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 1)], st[s]);
+        }
+        for (uint32_t s = 0; s < S; s++) {
+            hipEvent_t* ev = ring_events(I, slot, s);
+            if (tm) (void)hipEventRecord(ev[ev_index(b, 1, 0)], st[s]);
+            launch_shade(st[s], cam[s], sc[s], p[s], b);
+            if (tm) (void)hipEventRecord(ev[ev_index(b, 1, 1)], st[s]);
+        }
+        if (nee)
+            for (uint32_t s = 0; s < S; s++) {
+                hipEvent_t* ev = ring_events(I, slot, s);
+                if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 0)], st[s]);
+                launch_shadow(st[s], cam[s], sc[s], p[s], b, count);
+                if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 1)], st[s]);
+            }
+    }
+    if (S > 1)
+        for (uint32_t s = 0; s < S; s++) {
+            HIP_TRY(I, hipEventRecord(I->ev_join[s], st[s]));
+            HIP_TRY(I, hipStreamWaitEvent(main, I->ev_join[s], 0));
+        }
     I->sample_count += 1;
-    rec(kEvBlit);
-    if (I->world <= 1) launch_blit(s, cam, p.acc, I->d_frame_acc.ptr, I->d_frame_out.ptr, I->sample_count);
-    rec(kEvBlit + 1);
-    rec(EV_FRAME1);
+    if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
+    if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
+        launch_assemble(main, cam[0], I->external_slab ? (const float4*)I->external_slab : I->d_acc_slab.ptr, I->cap_v, I->d_frame_acc.ptr,
+                        I->d_frame_out.ptr, I->sample_count);
+    if (tm) (void)hipEventRecord(I->events[kEvBlit + 1], main);
+    if (tm) (void)hipEventRecord(I->events[EV_FRAME1], main);
     HIP_TRY(I, hipGetLastError());
     I->last_bounces = bounces;
     I->ring_bounces[slot] = tm ? bounces : 0;
-    I->ring_nee[slot] = !(I->flags & RFW_HIP_FLAG_NO_NEE);
+    I->ring_nee[slot] = nee;
     I->frame_index++;
     if (I->frame_index - I->drained_index > kTimingRing) I->drained_index = I->frame_index - kTimingRing;
     I->frame_recorded = tm;
@@ -669,6 +712,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->tile_size) I->tile_size = o->tile_size;
         if (o->builder) I->builder = o->builder;
         I->flags = o->flags;
+        if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
     }
     if (I->rank >= I->world || (I->tile_size % 8) != 0) {
         g_create_error = "invalid shard options (rank >= world, or tile_size not a multiple of 8)";
@@ -690,9 +734,15 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     if ((e = hipSetDevice(dev)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&I->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     I->stream = I->own_stream;
-    for (int r = 0; r < kTimingRing; r++)
-        for (int i = 0; i < kNumEvents; i++)
-            if ((e = hipEventCreate(&I->ring[r][i])) != hipSuccess) return bail("hipEventCreate", e);
+    I->ring.assign((size_t)kTimingRing * I->substreams * kNumEvents, nullptr);
+    for (auto& ev : I->ring)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    I->events = I->ring.data();
+    if ((e = hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (uint32_t k = 0; k < I->substreams; k++) {
+        if ((e = hipStreamCreateWithFlags(&I->sub[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&I->ev_join[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     if ((e = hipEventCreateWithFlags(&I->stage_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
@@ -721,9 +771,13 @@ void rfw_hip_destroy(void* inst)
         if (I->stage_event) (void)hipEventDestroy(I->stage_event);
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
         I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
-        for (int r = 0; r < kTimingRing; r++)
-            for (int i = 0; i < kNumEvents; i++)
-                if (I->ring[r][i]) (void)hipEventDestroy(I->ring[r][i]);
+        for (auto& ev : I->ring)
+            if (ev) (void)hipEventDestroy(ev);
+        if (I->ev_fork) (void)hipEventDestroy(I->ev_fork);
+        for (int k = 0; k < kMaxSub; k++) {
+            if (I->ev_join[k]) (void)hipEventDestroy(I->ev_join[k]);
+            if (I->sub[k]) (void)hipStreamDestroy(I->sub[k]);
+        }
         if (I->own_stream) (void)hipStreamDestroy(I->own_stream);
     }
     delete I;
@@ -902,6 +956,24 @@ int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
     return RFW_HIP_OK;
 }
 
+static void add_frame_timing(Instance* I, int slot, uint32_t nb, bool nee, rfw_hip_frame_stats* out)
+{
+    hipEvent_t* e0 = ring_events(I, slot, 0);
+    auto el = [&](hipEvent_t a, hipEvent_t b) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, a, b); return ms; };
+    out->ms_total += el(e0[EV_FRAME0], e0[EV_FRAME1]);
+    out->ms_other += el(e0[kEvBlit], e0[kEvBlit + 1]);
+    // per-kernel figures are SUMS over the sub-shard launches (which overlap in time on different streams)
+    for (uint32_t s = 0; s < I->substreams; s++) {
+        hipEvent_t* ev = ring_events(I, slot, s);
+        for (uint32_t b = 0; b < nb; b++) {
+            const float tr = el(ev[ev_index(b, 0, 0)], ev[ev_index(b, 0, 1)]);
+            if (b == 0) out->ms_trace_primary += tr; else out->ms_trace_extend += tr;
+            out->ms_shade += el(ev[ev_index(b, 1, 0)], ev[ev_index(b, 1, 1)]);
+            if (nee) out->ms_trace_shadow += el(ev[ev_index(b, 2, 0)], ev[ev_index(b, 2, 1)]);
+        }
+    }
+}
+
 int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
 {
     LOCK(inst);
@@ -909,32 +981,25 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
     HIP_TRY(I, hipSetDevice(I->device));
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
-    QueueCounters qc;
-    HIP_TRY(I, hipMemcpy(&qc, I->d_counters.ptr, sizeof(qc), hipMemcpyDeviceToHost));
-    if (qc.overflow) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
+    QueueCounters qc[kMaxSub];
+    HIP_TRY(I, hipMemcpy(qc, I->d_counters.ptr, I->substreams * sizeof(QueueCounters), hipMemcpyDeviceToHost));
     const uint32_t nb = I->last_bounces;
     out->primary_rays = nb ? I->local_pixels : 0;
-    for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc.ext[b];
-    if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
-        for (uint32_t b = 0; b < nb; b++) out->shadow_rays += qc.shadow[b];
-    for (int k = 0; k < 3; k++) {
-        out->nodes_visited[k] = qc.trav[k][0];
-        out->tris_tested[k] = qc.trav[k][1];
-        out->instances_entered[k] = qc.trav[k][2];
+    for (uint32_t s = 0; s < I->substreams; s++) {
+        if (qc[s].overflow) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
+        for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc[s].ext[b];
+        if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
+            for (uint32_t b = 0; b < nb; b++) out->shadow_rays += qc[s].shadow[b];
+        for (int k = 0; k < 3; k++) {
+            out->nodes_visited[k] += qc[s].trav[k][0];
+            out->tris_tested[k] += qc[s].trav[k][1];
+            out->instances_entered[k] += qc[s].trav[k][2];
+        }
     }
     out->sample_count = I->sample_count;
     out->bounces = nb;
-    if (I->frame_recorded) {
-        auto el = [&](int a, int b) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, I->events[a], I->events[b]); return ms; };
-        out->ms_total = el(EV_FRAME0, EV_FRAME1);
-        for (uint32_t b = 0; b < nb; b++) {
-            const float tr = el(ev_index(b, 0, 0), ev_index(b, 0, 1));
-            if (b == 0) out->ms_trace_primary += tr; else out->ms_trace_extend += tr;
-            out->ms_shade += el(ev_index(b, 1, 0), ev_index(b, 1, 1));
-            if (!(I->flags & RFW_HIP_FLAG_NO_NEE)) out->ms_trace_shadow += el(ev_index(b, 2, 0), ev_index(b, 2, 1));
-        }
-        out->ms_other = el(kEvBlit, kEvBlit + 1);
-    }
+    out->substreams = I->substreams;
+    if (I->frame_recorded && nb) add_frame_timing(I, (int)((I->frame_index - 1) % kTimingRing), nb, !(I->flags & RFW_HIP_FLAG_NO_NEE), out);
     return RFW_HIP_OK;
 }
 
@@ -950,18 +1015,10 @@ int rfw_hip_drain_timing(void* inst, rfw_hip_frame_stats* sum, uint32_t* frames)
         const int slot = (int)(f % kTimingRing);
         const uint32_t nb = I->ring_bounces[slot];
         if (!nb) continue;
-        hipEvent_t* ev = I->ring[slot];
-        auto el = [&](int a, int b) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
-        sum->ms_total += el(EV_FRAME0, EV_FRAME1);
-        for (uint32_t b = 0; b < nb; b++) {
-            const float tr = el(ev_index(b, 0, 0), ev_index(b, 0, 1));
-            if (b == 0) sum->ms_trace_primary += tr; else sum->ms_trace_extend += tr;
-            sum->ms_shade += el(ev_index(b, 1, 0), ev_index(b, 1, 1));
-            if (I->ring_nee[slot]) sum->ms_trace_shadow += el(ev_index(b, 2, 0), ev_index(b, 2, 1));
-        }
-        sum->ms_other += el(kEvBlit, kEvBlit + 1);
+        add_frame_timing(I, slot, nb, I->ring_nee[slot], sum);
         n++;
     }
+    sum->substreams = I->substreams;
     I->drained_index = I->frame_index;
     *frames = n;
     return RFW_HIP_OK;
@@ -1026,7 +1083,8 @@ int rfw_hip_assemble_frame(void* inst, const void* gathered)
     if (!gathered) return fail(I, RFW_HIP_E_INVALID, "assemble_frame: null buffer");
     HIP_TRY(I, hipSetDevice(I->device));
     const CameraParams cam = camera_params(I, I->last_view);
-    launch_assemble(I->stream, cam, (const float4*)gathered, I->capacity, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
+    // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]
+    launch_assemble(I->stream, cam, (const float4*)gathered, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
     HIP_TRY(I, hipGetLastError());
     return RFW_HIP_OK;
 }

@@ -7,43 +7,48 @@ pixel_to_slab); `slab_index_map` restates them in numpy so that host code and te
 import numpy as np
 
 
-def shard_geometry(width, height, world, tile_size=64):
+def shard_geometry(width, height, world, tile_size=64, streams=1):
+    """`streams` = sub-shards per rank (rfw_hip_options.streams): tiles are dealt round-robin to world * streams virtual ranks,
+    virtual rank r * streams + s being sub-shard s of rank r; a rank's slab is its sub-slabs back to back."""
     tiles_x = (width + tile_size - 1) // tile_size
     tiles_y = (height + tile_size - 1) // tile_size
     total = tiles_x * tiles_y
-    local_tiles = (total + world - 1) // world
-    return {"tiles_x": tiles_x, "tiles_y": tiles_y, "tiles_total": total, "tiles_local": local_tiles,
-            "slab_elems": local_tiles * tile_size * tile_size}
+    wv = world * streams
+    local_v = (total + wv - 1) // wv
+    return {"tiles_x": tiles_x, "tiles_y": tiles_y, "tiles_total": total, "tiles_local": local_v * streams,
+            "sub_elems": local_v * tile_size * tile_size, "slab_elems": local_v * streams * tile_size * tile_size}
 
 
-def slab_index_map(width, height, world, tile_size=64):
+def slab_index_map(width, height, world, tile_size=64, streams=1):
     """owner[y, x] = rank that renders pixel (x, y); slot[y, x] = its index in that rank's slab."""
     ys, xs = np.mgrid[0:height, 0:width]
-    g = shard_geometry(width, height, world, tile_size)
+    g = shard_geometry(width, height, world, tile_size, streams)
     tx, ty = xs // tile_size, ys // tile_size
     tile = ty * g["tiles_x"] + tx
-    owner = tile % world
-    lt = tile // world
+    wv = world * streams
+    vowner = tile % wv
+    owner, sub = vowner // streams, vowner % streams
+    lt = tile // wv
     ix, iy = xs - tx * tile_size, ys - ty * tile_size
     block = (iy >> 3) * (tile_size >> 3) + (ix >> 3)
-    slot = lt * tile_size * tile_size + block * 64 + ((iy & 7) << 3) + (ix & 7)
+    slot = sub * g["sub_elems"] + lt * tile_size * tile_size + block * 64 + ((iy & 7) << 3) + (ix & 7)
     return owner.astype(np.int64), slot.astype(np.int64)
 
 
-def extract_slab(frame, rank, world, tile_size=64):
+def extract_slab(frame, rank, world, tile_size=64, streams=1):
     """The slab rank `rank` would produce for a full frame (H, W, C): used by the CPU tests as a stand-in renderer."""
     h, w, c = frame.shape
-    owner, slot = slab_index_map(w, h, world, tile_size)
-    slab = np.zeros((shard_geometry(w, h, world, tile_size)["slab_elems"], c), dtype=frame.dtype)
+    owner, slot = slab_index_map(w, h, world, tile_size, streams)
+    slab = np.zeros((shard_geometry(w, h, world, tile_size, streams)["slab_elems"], c), dtype=frame.dtype)
     m = owner == rank
     slab[slot[m]] = frame[m]
     return slab
 
 
-def assemble(gathered, width, height, tile_size=64):
+def assemble(gathered, width, height, tile_size=64, streams=1):
     """gathered: (world, slab_elems, C) -> frame (H, W, C); the numpy twin of the k_assemble kernel."""
     world = gathered.shape[0]
-    owner, slot = slab_index_map(width, height, world, tile_size)
+    owner, slot = slab_index_map(width, height, world, tile_size, streams)
     return gathered[owner, slot]
 
 

@@ -109,7 +109,7 @@ class SkinData(C.Structure):
 class HipOptions(C.Structure):
     _fields_ = [
         ("struct_size", u32), ("device", i32), ("max_path_length", u32), ("clamp_value", f32), ("rank", u32), ("world", u32),
-        ("tile_size", u32), ("builder", u32), ("flags", u32),
+        ("tile_size", u32), ("builder", u32), ("flags", u32), ("streams", u32),
     ]
 
 
@@ -117,7 +117,7 @@ class FrameStats(C.Structure):
     _fields_ = [
         ("primary_rays", u64), ("extension_rays", u64), ("shadow_rays", u64), ("nodes_visited", u64 * 3), ("tris_tested", u64 * 3),
         ("instances_entered", u64 * 3), ("ms_total", f32), ("ms_trace_primary", f32), ("ms_trace_extend", f32), ("ms_trace_shadow", f32),
-        ("ms_shade", f32), ("ms_other", f32), ("sample_count", u32), ("bounces", u32),
+        ("ms_shade", f32), ("ms_other", f32), ("sample_count", u32), ("bounces", u32), ("substreams", u32), ("pad", u32),
     ]
 
 

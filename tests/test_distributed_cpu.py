@@ -17,14 +17,14 @@ import numpy as np, torch, torch.distributed as dist
 from rfw_rs_amd import dist as rd
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['RFW_PORT']}", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
-w, h, ts = 200, 136, 32
+w, h, ts, streams = 200, 136, 32, 4
 rng = np.random.default_rng(42)
 frame = rng.random((h, w, 4), dtype=np.float32)           # the frame every rank would agree on
-slab = torch.from_numpy(rd.extract_slab(frame, rank, world, ts))  # what THIS rank renders
+slab = torch.from_numpy(rd.extract_slab(frame, rank, world, ts, streams))  # what THIS rank renders (4 sub-shards back to back)
 gathered = rd.all_gather_slabs(slab)                       # the one collective per frame
-out = rd.assemble(gathered.numpy(), w, h, ts)
+out = rd.assemble(gathered.numpy(), w, h, ts, streams)
 assert gathered.shape[0] == world and np.array_equal(out, frame), "assembled frame differs"
-owner, slot = rd.slab_index_map(w, h, world, ts)
+owner, slot = rd.slab_index_map(w, h, world, ts, streams)
 assert set(np.unique(owner)) == set(range(world))
 # every (owner, slot) pair addresses a distinct slab element: no two pixels collide
 assert len(np.unique(owner * gathered.shape[1] + slot)) == w * h

@@ -16,7 +16,7 @@ def make(kind, w, h, a=0, b=0, c=0.0, seed=1, **opts):
     from rfw_rs_amd import HipBackend, Scene
     scene = Scene().build(kind, a, b, c, seed)
     scene.set_aspect(w / h)
-    be = HipBackend.init(w, h, 1.0, **{k: v for k, v in opts.items() if k in ("max_path_length", "flags", "builder")})
+    be = HipBackend.init(w, h, 1.0, **{k: v for k, v in opts.items() if k in ("max_path_length", "flags", "builder", "streams")})
     scene.sync(be)
     orc = Oracle(w, h, threads=8)
     if "max_path_length" in opts:
@@ -281,3 +281,18 @@ def test_device_lbvh_on_large_mesh_matches_host_sah():
         assert st["triangles"] > 250000 and st["blas_nodes"] > 0
         be.close()
     assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("streams", [1, 3, 8])
+def test_substreams_do_not_change_the_image(streams):
+    """A frame split into sub-shards on separate HIP streams is the same frame."""
+    w, h = 200, 136
+    scene, be, orc = make("soup", w, h, 1200, 5, seed=17, max_path_length=3, streams=streams)
+    view = scene.view(w, h)
+    for _ in range(2):
+        be.render(view)
+        orc.render(view)
+    assert be.frame_stats()["substreams"] == streams
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    s, o = be.frame_stats(), orc.stats()
+    assert s["primary_rays"] == w * h
