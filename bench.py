@@ -6,6 +6,7 @@ metric's target is quoted on, BASELINE.json north_star; SURVEY.md §8d C4 geomet
 inputs resident in HBM.  For N > 1 the frame is sharded by 64x64 tiles across ranks and the accumulator slabs are
 all-gathered with RCCL once per frame (strong scaling: the frame is fixed)."""
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -28,6 +29,9 @@ def main():
     ap.add_argument("--max-path-length", type=int, default=1, help="1 = primary+shadow (the metric); 3 = the reference's path tracer (C4)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="renderer instances used round-robin, each on its own stream: frame k+1 is traced while frame k's tail, "
+                         "all-gather and assemble finish (1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -62,44 +66,54 @@ def main():
         scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
-    be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank, world=world,
-                         streams=int(os.environ.get("RFW_STREAMS", "0")))
-    # a real (non-null) torch stream: the library launches on it, so does RCCL's all-gather ordering, and the HIP events
-    # that time the kernels are recorded on it
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    be.set_stream(stream.cuda_stream)
+    F = max(1, args.frames_in_flight)
+    bes, streams, gathers = [], [], []
     t0 = time.time()
-    scene.sync(be)
-    sync_s = time.time() - t0
+    for f in range(F):
+        be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank, world=world,
+                             streams=int(os.environ.get("RFW_STREAMS", "0")))
+        # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created: HIP deals streams to
+        # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
+        # all-gather is ordered against the kernels and the HIP events that time them are recorded on the launch stream
+        st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
+        scene.mark_all_changed()
+        scene.sync(be)
+        g = None
+        if world > 1:
+            slab = be.shard_info()["slab_floats"]
+            g = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
+            be.set_slab_output(g[rank].data_ptr())
+        bes.append(be); streams.append(st); gathers.append(g)
+    sync_s = (time.time() - t0) / F
+    be = bes[0]
     sstats = be.scene_stats()
-
-    gathered = None
-    if world > 1:
-        slab = be.shard_info()["slab_floats"]
-        gathered = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
-        be.set_slab_output(gathered[rank].data_ptr())
+    torch.cuda.synchronize()
 
     frame_no = [0]
     sync_ms = [0.0]
+    step_no = [0]
 
     def step():
-        if animated:  # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
-            t_s = time.perf_counter()
-            scene.animate(frame_no[0] / 60.0)
-            frame_no[0] += 1
-            scene.sync(be)
-            sync_ms[0] += (time.perf_counter() - t_s) * 1e3
-        be.reset_accumulation()
-        be.render(view)
-        if world > 1:
-            if dist_backend == "nccl":
-                dist.all_gather_into_tensor(gathered.view(-1), gathered[rank])  # the ONE collective per frame (RCCL over xGMI)
-            else:
-                host = torch.empty(gathered.shape, dtype=gathered.dtype)
-                dist.all_gather_into_tensor(host.view(-1), gathered[rank].cpu())
-                gathered.copy_(host)
-            be.assemble_frame(gathered.data_ptr())
+        k = step_no[0] % F
+        step_no[0] += 1
+        b, g = bes[k], gathers[k]
+        with (torch.cuda.stream(streams[k]) if world > 1 else contextlib.nullcontext()):  # the library already launches on streams[k]
+            if animated:  # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
+                t_s = time.perf_counter()
+                scene.animate(frame_no[0] / 60.0)
+                frame_no[0] += 1
+                scene.sync(b)
+                sync_ms[0] += (time.perf_counter() - t_s) * 1e3
+            b.reset_accumulation()
+            b.render(view)
+            if world > 1:
+                if dist_backend == "nccl":
+                    dist.all_gather_into_tensor(g.view(-1), g[rank])  # the ONE collective per frame (RCCL over xGMI)
+                else:
+                    host = torch.empty(g.shape, dtype=g.dtype)
+                    dist.all_gather_into_tensor(host.view(-1), g[rank].cpu())
+                    g.copy_(host)
+                b.assemble_frame(g.data_ptr())
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
     be.set_option("count_traversal", 1)
@@ -115,19 +129,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = {"ms_trace_primary": 0.0, "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
-    be.drain_timing()
+    for b in bes:
+        b.drain_timing()
     timed_frames = 0
     sync_ms[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
-        if (i + 1) % 48 == 0 or i + 1 == args.steps:
+        if (i + 1) % (24 * F) == 0 or i + 1 == args.steps:
             # per-kernel HIP-event durations, recorded inside render() on the launch stream for EVERY timed frame and
-            # read back in batches (one stream sync per 48 frames instead of one per frame)
-            ms, n = be.drain_timing()
-            timed_frames += n
-            for k in kernel_ms:
-                kernel_ms[k] += ms[k]
+            # read back in batches (one stream sync per 24 frames per instance instead of one per frame)
+            for b in bes:
+                ms, n = b.drain_timing()
+                timed_frames += n
+                for k in kernel_ms:
+                    kernel_ms[k] += ms[k]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -172,7 +188,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles, {w}x{h}, 1 spp primary+shadow (max path length 1), static BVH4",
-                       "rays_per_frame": int(rays_total), "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
@@ -191,7 +207,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    be.close()
+    for b in bes:
+        b.close()
 
 
 def pmc_traffic(kernel):

@@ -163,6 +163,8 @@ RFW_HIP_API int rfw_hip_drain_timing(void* instance, rfw_hip_frame_stats* sum, u
 RFW_HIP_API int rfw_hip_get_scene_stats(void* instance, rfw_hip_scene_stats* out);
 /* launch all work on this hipStream_t (NULL = the instance's own stream) */
 RFW_HIP_API int rfw_hip_set_stream(void* instance, void* hip_stream);
+/* the hipStream_t all work of this instance is launched on (its own stream unless rfw_hip_set_stream replaced it) */
+RFW_HIP_API void* rfw_hip_get_stream(void* instance);
 RFW_HIP_API int rfw_hip_device_synchronize(void* instance);
 
 /* Multi-GPU tile sharding.  With world > 1 an instance renders only the

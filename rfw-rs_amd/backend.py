@@ -21,7 +21,7 @@ EXPORTS = [
     "rfw_hip_render", "rfw_hip_resize", "rfw_hip_set_point_lights", "rfw_hip_set_spot_lights",
     "rfw_hip_set_area_lights", "rfw_hip_set_directional_lights", "rfw_hip_set_skybox", "rfw_hip_set_skins",
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
-    "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_device_synchronize",
+    "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read",
 ]
@@ -74,6 +74,8 @@ def hip_lib():
         l.rfw_hip_drain_timing.argtypes = [vp, C.POINTER(pod.FrameStats), C.POINTER(u32)]
         l.rfw_hip_set_stream.argtypes = [vp, vp]
         l.rfw_hip_device_synchronize.argtypes = [vp]
+        l.rfw_hip_get_stream.argtypes = [vp]
+        l.rfw_hip_get_stream.restype = vp
         l.rfw_hip_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
         l.rfw_hip_set_slab_output.argtypes = [vp, vp]
         l.rfw_hip_assemble_frame.argtypes = [vp, vp]
@@ -228,6 +230,10 @@ class HipBackend:
 
     def set_stream(self, stream_handle):
         self._check(self._l.rfw_hip_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def stream_handle(self):
+        """hipStream_t of this instance as an integer (wrap with torch.cuda.ExternalStream to order torch work against it)."""
+        return int(self._l.rfw_hip_get_stream(self._h) or 0)
 
     def device_synchronize(self):
         self._check(self._l.rfw_hip_device_synchronize(self._h))

@@ -739,7 +739,9 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     I->events = I->ring.data();
     if ((e = hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    for (uint32_t k = 0; k < I->substreams; k++) {
+    // HIP maps streams to a handful of hardware queues in creation order and two streams sharing a queue serialise, so no
+    // stream is created that is not used: sub-shard streams only when the frame is actually split
+    for (uint32_t k = 0; k < I->substreams && I->substreams > 1; k++) {
         if ((e = hipStreamCreateWithFlags(&I->sub[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
         if ((e = hipEventCreateWithFlags(&I->ev_join[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
@@ -1052,6 +1054,14 @@ int rfw_hip_set_stream(void* inst, void* stream)
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     I->stream = stream ? (hipStream_t)stream : I->own_stream;
     return RFW_HIP_OK;
+}
+
+void* rfw_hip_get_stream(void* inst)
+{
+    if (!inst) return nullptr;
+    Instance* I = static_cast<Instance*>(inst);
+    std::lock_guard<std::mutex> g(I->mu);
+    return (void*)I->stream;
 }
 
 int rfw_hip_device_synchronize(void* inst)
