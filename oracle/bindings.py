@@ -43,6 +43,7 @@ def lib():
         l.orc_generate_primary_rays.argtypes = [C.c_void_p, C.POINTER(pod.CameraView3D), C.c_uint32, C.c_void_p, C.c_void_p]
         l.orc_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         l.orc_detmath_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        l.orc_sample_texture.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]
         l.orc_wang_hash.argtypes = [C.c_uint32]
         l.orc_wang_hash.restype = C.c_uint32
         l.orc_randi.argtypes = [C.POINTER(C.c_uint32)]
@@ -83,7 +84,7 @@ class Oracle:
         t = BackendTable()
         t.instance = self._h
         for name in ("set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
-                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights"):
+                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox"):
             setattr(t, name, C.cast(getattr(self._l, "orc_" + name), C.c_void_p))
         return t
 
@@ -128,6 +129,11 @@ class Oracle:
         d = np.empty((n, 3), dtype=np.float32)
         self._l.orc_generate_primary_rays(self._h, C.byref(view), sample, o.ctypes.data, d.ctypes.data)
         return o, d
+
+    def sample_texture(self, tex, u, v, lod, trilinear=False):
+        out = (C.c_float * 4)()
+        self._l.orc_sample_texture(self._h, tex, u, v, lod, 1 if trilinear else 0, out)
+        return np.array(out[:], dtype=np.float32)
 
     def stats(self):
         s = OrcStats()

@@ -42,6 +42,7 @@ inline vec3 operator-(vec3 a) { return vec3{-a.x, -a.y, -a.z}; }
 inline vec4 operator+(vec4 a, vec4 b) { return vec4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 inline vec4 operator*(vec4 a, float s) { return vec4{a.x * s, a.y * s, a.z * s, a.w * s}; }
 inline vec4 operator*(float s, vec4 a) { return vec4{s * a.x, s * a.y, s * a.z, s * a.w}; }
+inline vec3 operator-(vec3 a, float s) { return vec3{a.x - s, a.y - s, a.z - s}; }
 inline vec2 operator+(vec2 a, vec2 b) { return vec2{a.x + b.x, a.y + b.y}; }
 inline vec2 operator*(vec2 a, float s) { return vec2{a.x * s, a.y * s}; }
 

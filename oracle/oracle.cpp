@@ -37,9 +37,13 @@
  *   D2  equal-t ties between triangles are resolved to the lowest (instance, triangle) id
  *       instead of "first encountered in traversal order" so that the answer is a function
  *       of the scene, not of the tree (option "tie_break"=0 restores the literal rule).
- *   D3  textures (diffuse/normal/... maps) and the skybox image are not sampled: materials
- *       are flat, a miss adds the constant sky colour (default black = gpu-rt's
- *       zero-initialised 64x64 skybox, backends/gpu-rt/src/lib.rs:424-436).
+ *   D3  texture filtering is implementation-defined in GLSL/Vulkan (weight precision, rounding), so one meaning is
+ *       fixed here and in the kernels (texture_sample below): the sampler of gpu-rt/src/lib.rs:1026-1038 — repeat
+ *       addressing, linear filter at LOD 0 (magnification), nearest at LOD >= 1 — with f32 weights and
+ *       byte * (1/255) unorm decoding; textures are sampled at the size and mip count the trait hands over (gpu-rt
+ *       resamples every texture to 1024^2 x 5 mips on the host first, lib.rs:1230-1246: not restated).  With no
+ *       skybox set a miss adds the constant sky colour (default black = gpu-rt's zero-initialised 64x64 skybox,
+ *       lib.rs:424-436).
  *   D4  instance ids follow the live API numbering mesh_base[mesh] + slot.
  */
 #include <atomic>
@@ -417,8 +421,16 @@ struct Hit {
     float t = 0.0f, u = 0.0f, v = 0.0f;
 };
 
+struct Tex {
+    uint32_t w = 0, h = 0, mips = 0, format = 0;
+    std::vector<uint8_t> bytes;
+};
+
 struct Oracle {
     uint32_t width = 0, height = 0;
+    std::vector<Tex> textures;
+    Tex skybox;
+    float spread_angle = 0.0f; // camera.spread_angle of the frame being rendered
     std::map<uint32_t, Mesh> meshes;
     std::map<uint32_t, InstanceList> instance_lists;
     std::vector<rfw_device_material> materials;
@@ -929,6 +941,56 @@ static vec3 RandomPointOnLight(const Oracle& o, float r0, float /*r1*/, vec3 I, 
     return I - 1000.0f * L;
 }
 
+// ---------------------------------------------------------------- texture sampling (shade.comp:268-281; sampler: gpu-rt/src/lib.rs:1026-1038)
+static inline vec4 texel_at(const Tex& t, uint32_t level, int32_t x, int32_t y)
+{
+    uint32_t w = t.w, h = t.h;
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; l++) { // TextureData::offset_for_level (crates/rfw-backend/src/structs.rs:80-88)
+        off += (size_t)w * h;
+        w >>= 1; h >>= 1;
+    }
+    // repeat addressing
+    int32_t xi = x % (int32_t)w, yi = y % (int32_t)h;
+    if (xi < 0) xi += (int32_t)w;
+    if (yi < 0) yi += (int32_t)h;
+    const uint8_t* p = &t.bytes[(off + (size_t)yi * w + (size_t)xi) * 4];
+    const float c0 = (float)p[0] * (1.0f / 255.0f), c1 = (float)p[1] * (1.0f / 255.0f), c2 = (float)p[2] * (1.0f / 255.0f), c3 = (float)p[3] * (1.0f / 255.0f);
+    return t.format == RFW_FORMAT_BGRA8 ? vec4{c2, c1, c0, c3} : vec4{c0, c1, c2, c3};
+}
+static inline vec4 mix4(vec4 a, vec4 b, float t) { return a * (1.0f - t) + b * t; }
+// textureLod(sampler2D..., uv, LOD): LOD clamped to [0, mips-1]; level 0 = bilinear, level >= 1 = nearest
+static vec4 texture_sample(const Tex& t, float u, float v, float LOD)
+{
+    if (t.mips == 0 || t.w == 0 || t.h == 0) return vec4{0.0f, 0.0f, 0.0f, 0.0f};
+    int32_t level = f2i(LOD);
+    if (level < 0) level = 0;
+    if (level > (int32_t)t.mips - 1) level = (int32_t)t.mips - 1;
+    const uint32_t w = t.w >> level, h = t.h >> level;
+    if (level == 0) {
+        const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+        const float x0 = std::floor(x), y0 = std::floor(y);
+        const float fx = x - x0, fy = y - y0;
+        const int32_t ix = f2i(x0), iy = f2i(y0);
+        const vec4 t00 = texel_at(t, 0, ix, iy), t10 = texel_at(t, 0, ix + 1, iy), t01 = texel_at(t, 0, ix, iy + 1), t11 = texel_at(t, 0, ix + 1, iy + 1);
+        return mix4(mix4(t00, t10, fx), mix4(t01, t11, fx), fy);
+    }
+    return texel_at(t, (uint32_t)level, f2i(std::floor(u * (float)w)), f2i(std::floor(v * (float)h)));
+}
+// shade.comp:273-281
+static vec4 fetchTexelTrilinear(const Tex& t, float lambda, float u, float v)
+{
+    const int32_t MIPLEVELCOUNT = (int32_t)t.mips; // reference: 5 for every (resampled) texture
+    int32_t level0 = f2i(lambda);
+    if (level0 > MIPLEVELCOUNT - 1) level0 = MIPLEVELCOUNT - 1;
+    int32_t level1 = level0 + 1;
+    if (level1 > MIPLEVELCOUNT - 1) level1 = MIPLEVELCOUNT - 1;
+    const float f = lambda - std::floor(lambda);
+    const vec4 p0 = texture_sample(t, u, v, (float)level0);
+    const vec4 p1 = texture_sample(t, u, v, (float)level1);
+    return (1.0f - f) * p0 + f * p1;
+}
+
 // ---------------------------------------------------------------- one path = ray_gen -> [shade -> shadow -> extend]*
 struct PathState { // structs.glsl:4-9
     int32_t inst, tri;
@@ -950,8 +1012,14 @@ static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec
     const float bsdfPdf = path_length == 0 ? 1.0f : st.pdf;
     const uint32_t PATH_ID = st.path_id;
 
-    if (st.inst < 0) { // shade.comp:90-96 (D3: constant sky)
-        vec3 contribution = throughput * o.sky * (1.0f / bsdfPdf);
+    if (st.inst < 0) { // shade.comp:90-96
+        vec3 sky = o.sky;
+        if (o.skybox.mips) {
+            const float su = 0.5f * (1.0f + rfw_atan2f(D.x, -D.z) * (1.0f / 3.14159265359f));
+            const float sv = 1.0f - rfw_acosf(D.y) * (1.0f / 3.14159265359f);
+            sky = xyz(texture_sample(o.skybox, su, sv, (float)(int)path_length));
+        }
+        vec3 contribution = throughput * sky * (1.0f / bsdfPdf);
         CLAMPINTENSITY(contribution, o.clamp_value);
         acc.x += contribution.x; acc.y += contribution.y; acc.z += contribution.z; acc.w += 0.0f;
         return 0;
@@ -981,8 +1049,12 @@ static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec
     const vec3 B = cross(N, xyz(T)) * T.w;
     const vec3 P = O + st.t * D;
 
-    // shade.comp:128-160 hit a light (D3: no emissive maps)
-    if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) {
+    const uint32_t flags = mat.flags;
+    const bool any_map = (flags & 63u) != 0u; // HAS_DIFFUSE|NORMAL|ROUGHNESS|METALLIC|EMISSIVE|SHEEN_MAP (structs.glsl:210-215)
+
+    // shade.comp:128-160 hit a light; a material with an emissive map is NOT treated as a light (the branch's inner
+    // HAS_EMISSIVE_MAP fetch at :131-133 is unreachable)
+    if ((sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) && !(flags & RFW_MAT_HAS_EMISSIVE_MAP)) {
         vec3 contribution = V3(0.0f);
         const float DdotNL = -dot(D, N);
         if (DdotNL > 0.0f) {
@@ -998,6 +1070,18 @@ static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec
         }
         acc.x += contribution.x; acc.y += contribution.y; acc.z += contribution.z; acc.w += 0.0f;
         return 0;
+    }
+
+    if (any_map) { // shade.comp:162-175
+        const float lambda = std::sqrt(tri.lod) + rfw_log2f(o.spread_angle * (1.0f / gl_abs(dot(D, N))));
+        const float tu = w * tri.u0 + u * tri.u1 + v * tri.u2;
+        const float tv = w * tri.v0 + u * tri.v1 + v * tri.v2;
+        if ((flags & RFW_MAT_HAS_DIFFUSE_MAP) && mat.diffuse_map >= 0 && (size_t)mat.diffuse_map < o.textures.size())
+            sd.color = sd.color * xyz(fetchTexelTrilinear(o.textures[mat.diffuse_map], lambda, tu, tv));
+        if ((flags & RFW_MAT_HAS_NORMAL_MAP) && mat.normal_map >= 0 && (size_t)mat.normal_map < o.textures.size()) {
+            const vec3 m = (xyz(texture_sample(o.textures[mat.normal_map], tu, tv, (float)f2i(lambda))) - V3(0.5f)) * 2.0f;
+            N = normalize((xyz(T) * m.x + B * m.y) + N * m.z); // mat3(T, B, N) * m
+        }
     }
 
     const bool backFacing = dot(D, gN) >= 0.0f;
@@ -1145,6 +1229,38 @@ ORC_API int orc_set_point_lights(void* p, const rfw_point_light* l, uint32_t n, 
 ORC_API int orc_set_spot_lights(void* p, const rfw_spot_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->spot_lights.assign(l, l + n); return 0; }
 ORC_API int orc_set_directional_lights(void* p, const rfw_directional_light* l, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->directional_lights.assign(l, l + n); return 0; }
 
+static void copy_tex(Tex& t, const rfw_texture_data* d)
+{
+    t = Tex();
+    if (!d || !d->bytes || d->width == 0 || d->height == 0) return;
+    t.w = d->width; t.h = d->height; t.format = d->format;
+    uint32_t w = d->width, h = d->height, levels = 0;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < (d->mip_levels ? d->mip_levels : 1u) && w > 0 && h > 0; l++) {
+        texels += (size_t)w * h;
+        w >>= 1; h >>= 1;
+        levels++;
+    }
+    t.mips = levels;
+    t.bytes.assign(d->bytes, d->bytes + texels * 4);
+}
+ORC_API int orc_set_textures(void* p, const rfw_texture_data* t, uint32_t n, const uint32_t* /*changed*/)
+{
+    Oracle& o = *(Oracle*)p;
+    o.textures.resize(n);
+    for (uint32_t i = 0; i < n; i++) copy_tex(o.textures[i], t + i);
+    return 0;
+}
+ORC_API int orc_set_skybox(void* p, const rfw_texture_data* t) { copy_tex(((Oracle*)p)->skybox, t); return 0; }
+ORC_API int orc_sample_texture(void* p, int32_t tex /* -1 = skybox */, float u, float v, float lod, int trilinear, float* rgba)
+{
+    Oracle& o = *(Oracle*)p;
+    const Tex& t = tex < 0 ? o.skybox : o.textures.at((size_t)tex);
+    const vec4 c = trilinear ? fetchTexelTrilinear(t, lod, u, v) : texture_sample(t, u, v, lod);
+    rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = c.w;
+    return 0;
+}
+
 ORC_API int orc_set_option(void* p, const char* key, double value)
 {
     Oracle& o = *(Oracle*)p;
@@ -1247,6 +1363,7 @@ ORC_API int orc_render(void* p, const rfw_camera_view_3d* view)
 {
     Oracle& o = *(Oracle*)p;
     const rfw_camera_view_3d cam = *view;
+    o.spread_angle = cam.spread_angle;
     const int nt = o.threads;
     std::vector<Counters> cs(nt);
     if (nt <= 1) {

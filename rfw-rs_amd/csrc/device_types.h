@@ -122,6 +122,16 @@ struct InstanceNormal {
     float n_r0[4], n_r1[4], n_r2[4];
 };
 
+// A texture as handed over by set_textures / set_skybox (crates/rfw-backend/src/structs.rs:69-121): texels of all mip levels
+// back to back in one device array of 4-byte texels.
+struct TexDesc {
+    uint32_t offset;  // first texel of level 0 in tex_data
+    uint32_t w, h, mips;
+    uint32_t format;  // RFW_FORMAT_BGRA8 / RFW_FORMAT_RGBA8
+    uint32_t pad[3];
+};
+static_assert(sizeof(TexDesc) == 32, "TexDesc");
+
 struct MeshRecord {
     uint32_t node_base, node_count;
     uint32_t tri_base, tri_count; // tri_base doubles as the global triangle id offset (same concatenation order)

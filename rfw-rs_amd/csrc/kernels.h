@@ -20,6 +20,10 @@ struct SceneDev {
     const rfw_point_light* point_lights;
     const rfw_spot_light* spot_lights;
     const rfw_directional_light* directional_lights;
+    const uint32_t* tex_data;   // all textures' texels (set_textures), then the skybox's
+    const TexDesc* tex_desc;
+    uint32_t n_textures;
+    TexDesc skybox;             // mips == 0: no skybox image, a miss adds the constant sky colour
     uint32_t* spill;
     uint32_t spill_stride;
     QueueCounters* counters;

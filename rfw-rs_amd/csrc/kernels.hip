@@ -298,8 +298,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         const uint32_t TRI_ID = S.y;
         const float T_VAL = bitsf(S.z);
 
-        if (INST_ID < 0) { // shade.comp:90-96, constant sky (textures/skybox image: SURVEY §8f rank 4)
-            f3 contribution = throughput * mk3(cam.sky[0], cam.sky[1], cam.sky[2]) * (1.0f / bsdfPdf);
+        if (INST_ID < 0) { // shade.comp:90-96: lat-long skybox lookup at LOD = path length (constant sky colour when none is set)
+            f3 sky = mk3(cam.sky[0], cam.sky[1], cam.sky[2]);
+            if (sc.skybox.mips) {
+                const float su = 0.5f * (1.0f + rfw_atan2f(D.x, -D.z) * (1.0f / 3.14159265359f));
+                const float sv = 1.0f - rfw_acosf(D.y) * (1.0f / 3.14159265359f);
+                const f4 c = texture_sample(sc.tex_data, sc.skybox, su, sv, (float)(int)path_length);
+                sky = mk3(c.x, c.y, c.z);
+            }
+            f3 contribution = throughput * sky * (1.0f / bsdfPdf);
             CLAMPINTENSITY(contribution, cam.clamp_value);
             float4 a = p.acc[slot];
             a.x += contribution.x; a.y += contribution.y; a.z += contribution.z; a.w += 0.0f;
@@ -333,7 +340,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
             const f3 B = cross(N, T) * Tw;
             const f3 P = O + T_VAL * D;
 
-            if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) { // shade.comp:128-160 hit a light
+            const bool any_map = (sd.flags & 63u) != 0u;
+            // shade.comp:128-160 hit a light (a material with an emissive map is shaded as a surface instead)
+            if ((sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f) && !(sd.flags & RFW_MAT_HAS_EMISSIVE_MAP)) {
                 f3 contribution = mk3(0.0f);
                 const float DdotNL = -dot(D, N);
                 bool add = true;
@@ -355,6 +364,21 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                     p.acc[slot] = a;
                 }
             } else {
+                if (any_map) { // shade.comp:162-175
+                    const float lambda = __builtin_sqrtf(bitsf(q10.z)) + rfw_log2f(cam.spread_angle * (1.0f / gl_abs(dot(D, N))));
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    const float tu = w * q0.w + u * q1.w + v * q2.w;   // u0, u1, u2 ride in the .w of the vertex slots
+                    const float tv = w * q3.w + u * q4.w + v * q5.w;   // v0, v1, v2 in the .w of normal / n0 / n1
+                    if ((sd.flags & RFW_MAT_HAS_DIFFUSE_MAP) && sd.diffuse_map >= 0 && (uint32_t)sd.diffuse_map < sc.n_textures) {
+                        const f4 c = fetchTexelTrilinear(sc.tex_data, sc.tex_desc[sd.diffuse_map], lambda, tu, tv);
+                        sd.color = sd.color * mk3(c.x, c.y, c.z);
+                    }
+                    if ((sd.flags & RFW_MAT_HAS_NORMAL_MAP) && sd.normal_map >= 0 && (uint32_t)sd.normal_map < sc.n_textures) {
+                        const f4 c = texture_sample(sc.tex_data, sc.tex_desc[sd.normal_map], tu, tv, (float)f2i(lambda));
+                        const f3 m = (mk3(c.x, c.y, c.z) - mk3(0.5f)) * 2.0f;
+                        N = normalize((T * m.x + B * m.y) + N * m.z); // mat3(T, B, N) * m
+                    }
+                }
                 const bool backFacing = dot(D, gN) >= 0.0f;
                 if (backFacing) {
                     N = N * -1.0f;

@@ -54,6 +54,10 @@ struct MeshHost {
     std::vector<TriPacket> packets; // leaf order
     bool dirty = true;
 };
+struct TexHost {
+    uint32_t w = 0, h = 0, mips = 0, format = 0;
+    std::vector<uint32_t> texels; // all levels back to back
+};
 struct InstList {
     rfw_aabb local_aabb{};
     std::vector<rfw_mat4> matrices;
@@ -89,7 +93,9 @@ struct Instance {
     std::vector<rfw_point_light> point_lights;
     std::vector<rfw_spot_light> spot_lights;
     std::vector<rfw_directional_light> directional_lights;
-    bool meshes_dirty = true, instances_dirty = true, materials_dirty = true, lights_dirty = true;
+    std::vector<TexHost> textures;
+    TexHost skybox;
+    bool meshes_dirty = true, instances_dirty = true, materials_dirty = true, lights_dirty = true, textures_dirty = true;
     bool synchronized = false;
 
     // device scene
@@ -108,6 +114,10 @@ struct Instance {
     DevBuf<rfw_spot_light> d_spot;
     DevBuf<rfw_directional_light> d_dir;
     DevBuf<uint32_t> d_spill;
+    DevBuf<uint32_t> d_tex_data;
+    DevBuf<TexDesc> d_tex_desc;
+    TexDesc skybox_desc{};
+    uint32_t n_textures = 0;
     DevBuf<uint32_t> d_valid_gids, d_tlas_order, d_node_count;
     DevBuf<DevBox> d_inst_boxes, d_mesh_local, d_tri_boxes;
     DevBuf<char> d_lbvh_ws;
@@ -241,6 +251,10 @@ SceneDev scene_dev(Instance* I)
     s.point_lights = I->d_point.ptr;
     s.spot_lights = I->d_spot.ptr;
     s.directional_lights = I->d_dir.ptr;
+    s.tex_data = I->d_tex_data.ptr;
+    s.tex_desc = I->d_tex_desc.ptr;
+    s.n_textures = I->n_textures;
+    s.skybox = I->skybox_desc;
     s.spill = I->d_spill.ptr;
     s.spill_stride = spill_stride(I);
     s.counters = I->d_counters.ptr;
@@ -530,6 +544,26 @@ int do_synchronize(Instance* I)
         I->materials_dirty = false;
         any_change = true;
     }
+    if (I->textures_dirty) { // texels of every texture, then the skybox, in one array + descriptor table
+        std::vector<uint32_t> data;
+        std::vector<TexDesc> desc(I->textures.size());
+        auto put = [&](const TexHost& t) {
+            TexDesc d;
+            std::memset(&d, 0, sizeof(d));
+            d.offset = (uint32_t)data.size();
+            d.w = t.w; d.h = t.h; d.mips = t.mips; d.format = t.format;
+            data.insert(data.end(), t.texels.begin(), t.texels.end());
+            return d;
+        };
+        for (size_t k = 0; k < I->textures.size(); k++) desc[k] = put(I->textures[k]);
+        I->skybox_desc = put(I->skybox);
+        I->n_textures = (uint32_t)desc.size();
+        if ((rc = upload(I, I->d_tex_data, data.data(), data.size()))) return rc;
+        if ((rc = upload(I, I->d_tex_desc, desc.data(), desc.size()))) return rc;
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->textures_dirty = false;
+        any_change = true;
+    }
     if (I->lights_dirty) {
         if ((rc = upload(I, I->d_area, I->area_lights.data(), I->area_lights.size()))) return rc;
         if ((rc = upload(I, I->d_point, I->point_lights.data(), I->point_lights.size()))) return rc;
@@ -766,7 +800,7 @@ void rfw_hip_destroy(void* inst)
         I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
-        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release();
+        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         if (I->stage) (void)hipHostFree(I->stage);
@@ -839,9 +873,33 @@ int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, 
     return RFW_HIP_OK;
 }
 
-int rfw_hip_set_textures(void* inst, const rfw_texture_data*, uint32_t, const uint32_t*)
+static bool copy_texture(TexHost& t, const rfw_texture_data* d)
 {
-    LOCK(inst); // accepted; texture sampling is a "next" row — materials shade with their flat colour
+    t = TexHost();
+    if (!d || !d->bytes || d->width == 0 || d->height == 0) return true; // an empty texture samples as zero
+    if (d->format != RFW_FORMAT_BGRA8 && d->format != RFW_FORMAT_RGBA8) return false;
+    t.w = d->width; t.h = d->height; t.format = d->format;
+    uint32_t w = d->width, h = d->height, levels = 0;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < (d->mip_levels ? d->mip_levels : 1u) && w > 0 && h > 0; l++) { // structs.rs:79-121: level l is (w >> l) x (h >> l)
+        texels += (size_t)w * h;
+        w >>= 1; h >>= 1;
+        levels++;
+    }
+    t.mips = levels;
+    t.texels.resize(texels);
+    std::memcpy(t.texels.data(), d->bytes, texels * 4); // copy: the borrow ends with this call
+    return true;
+}
+
+int rfw_hip_set_textures(void* inst, const rfw_texture_data* textures, uint32_t n, const uint32_t* /*changed*/)
+{
+    LOCK(inst);
+    if (n && !textures) return fail(I, RFW_HIP_E_INVALID, "set_textures: null data");
+    I->textures.resize(n);
+    for (uint32_t k = 0; k < n; k++)
+        if (!copy_texture(I->textures[k], textures + k)) return fail(I, RFW_HIP_E_INVALID, "set_textures: unknown texel format");
+    I->textures_dirty = true;
     return RFW_HIP_OK;
 }
 
@@ -902,9 +960,11 @@ int rfw_hip_set_directional_lights(void* inst, const rfw_directional_light* l, u
     return RFW_HIP_OK;
 }
 
-int rfw_hip_set_skybox(void* inst, const rfw_texture_data*)
+int rfw_hip_set_skybox(void* inst, const rfw_texture_data* skybox)
 {
-    LOCK(inst); // accepted; the skybox image is a "next" row — a miss adds the constant sky colour (option sky_r/g/b, default black)
+    LOCK(inst);
+    if (!copy_texture(I->skybox, skybox)) return fail(I, RFW_HIP_E_INVALID, "set_skybox: unknown texel format");
+    I->textures_dirty = true;
     return RFW_HIP_OK;
 }
 int rfw_hip_set_skins(void* inst, const rfw_skin_data*, uint32_t, const uint32_t*)

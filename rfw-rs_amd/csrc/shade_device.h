@@ -75,6 +75,8 @@ struct ShadingData {
     f3 color, absorption, specular;
     float metallic, subsurface, specular_f, roughness, specular_tint, anisotropic, sheen, sheen_tint;
     float clearcoat, clearcoat_gloss, transmission, eta;
+    uint32_t flags;
+    int32_t diffuse_map, normal_map;
 };
 RFW_DI float CHAR2FLT(uint32_t x, int s) { return (float)((x >> s) & 255u) * (1.0f / 255.0f); }
 RFW_DI ShadingData extractParameters(const rfw_device_material* m)
@@ -84,6 +86,10 @@ RFW_DI ShadingData extractParameters(const rfw_device_material* m)
     const float4 c = mp[0], a = mp[1], s = mp[2];
     const uint4 p = *reinterpret_cast<const uint4*>(mp + 3);
     ShadingData d;
+    const uint4 q = *reinterpret_cast<const uint4*>(mp + 4);
+    d.flags = q.x;
+    d.diffuse_map = (int32_t)q.y;
+    d.normal_map = (int32_t)q.z;
     d.color = mk3(c.x, c.y, c.z);
     d.absorption = mk3(a.x, a.y, a.z);
     d.specular = mk3(s.x, s.y, s.z);
@@ -304,6 +310,62 @@ RFW_DI f3 SampleBSDF(const ShadingData& sd, f3 iN, f3 N, f3 T, f3 B, f3 wo, floa
     int type = BSDF_TYPE_REFLECTED;
     BSDFSample(sd, T, B, N, wo, wi, pdf, type, r3, r4);
     return BSDFEval(sd, iN, wo, wi, t, backfacing);
+}
+
+// ---- texture sampling (shade.comp:268-281) with the sampler of gpu-rt/src/lib.rs:1026-1038: repeat addressing, linear at LOD 0,
+// nearest at LOD >= 1, f32 weights, byte * (1/255) decoding — the one meaning fixed for parity (oracle.cpp texture_sample)
+struct f4 {
+    float x, y, z, w;
+};
+RFW_DI f4 operator+(f4 a, f4 b) { return f4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+RFW_DI f4 operator*(f4 a, float s) { return f4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+RFW_DI f4 operator*(float s, f4 a) { return f4{s * a.x, s * a.y, s * a.z, s * a.w}; }
+RFW_DI f4 mix4(f4 a, f4 b, float t) { return a * (1.0f - t) + b * t; }
+RFW_DI f4 texel_at(const uint32_t* __restrict__ data, const TexDesc& t, uint32_t level, int32_t x, int32_t y)
+{
+    uint32_t w = t.w, h = t.h, off = t.offset;
+    for (uint32_t l = 0; l < level; l++) {
+        off += w * h;
+        w >>= 1; h >>= 1;
+    }
+    int32_t xi = x % (int32_t)w, yi = y % (int32_t)h;
+    if (xi < 0) xi += (int32_t)w;
+    if (yi < 0) yi += (int32_t)h;
+    const uint32_t p = data[off + (uint32_t)yi * w + (uint32_t)xi];
+    const float c0 = (float)(p & 255u) * (1.0f / 255.0f), c1 = (float)((p >> 8) & 255u) * (1.0f / 255.0f),
+                c2 = (float)((p >> 16) & 255u) * (1.0f / 255.0f), c3 = (float)(p >> 24) * (1.0f / 255.0f);
+    return t.format == RFW_FORMAT_BGRA8 ? f4{c2, c1, c0, c3} : f4{c0, c1, c2, c3};
+}
+RFW_DI f4 texture_sample(const uint32_t* __restrict__ data, const TexDesc& t, float u, float v, float LOD)
+{
+    if (t.mips == 0 || t.w == 0 || t.h == 0) return f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int32_t level = f2i(LOD);
+    if (level < 0) level = 0;
+    if (level > (int32_t)t.mips - 1) level = (int32_t)t.mips - 1;
+    const uint32_t w = t.w >> level, h = t.h >> level;
+    if (level == 0) {
+        const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+        const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+        const float fx = x - x0, fy = y - y0;
+        const int32_t ix = f2i(x0), iy = f2i(y0);
+        const f4 t00 = texel_at(data, t, 0, ix, iy), t10 = texel_at(data, t, 0, ix + 1, iy), t01 = texel_at(data, t, 0, ix, iy + 1),
+                 t11 = texel_at(data, t, 0, ix + 1, iy + 1);
+        return mix4(mix4(t00, t10, fx), mix4(t01, t11, fx), fy);
+    }
+    return texel_at(data, t, (uint32_t)level, f2i(__builtin_floorf(u * (float)w)), f2i(__builtin_floorf(v * (float)h)));
+}
+// shade.comp:273-281
+RFW_DI f4 fetchTexelTrilinear(const uint32_t* __restrict__ data, const TexDesc& t, float lambda, float u, float v)
+{
+    const int32_t MIPLEVELCOUNT = (int32_t)t.mips;
+    int32_t level0 = f2i(lambda);
+    if (level0 > MIPLEVELCOUNT - 1) level0 = MIPLEVELCOUNT - 1;
+    int32_t level1 = level0 + 1;
+    if (level1 > MIPLEVELCOUNT - 1) level1 = MIPLEVELCOUNT - 1;
+    const float f = lambda - __builtin_floorf(lambda);
+    const f4 p0 = texture_sample(data, t, u, v, (float)level0);
+    const f4 p1 = texture_sample(data, t, u, v, (float)level1);
+    return (1.0f - f) * p0 + f * p1;
 }
 
 // ---- shade.comp:283-528 (uniform light pick: ISLIGHTS undefined) ----

@@ -206,6 +206,35 @@ void InstanceList3D::make_invalid(size_t slot)
     flags[slot] = RFW_INSTANCE_TRANSFORMED;
 }
 
+rfw_texture_data Texture::as_data() const
+{
+    rfw_texture_data d;
+    d.width = width; d.height = height; d.mip_levels = mip_levels; d.bytes = bytes.data(); d.format = format;
+    return d;
+}
+void Texture::generate_mipmaps(uint32_t levels)
+{
+    bytes.resize((size_t)width * height * 4);
+    mip_levels = 1;
+    size_t src_off = 0;
+    uint32_t w = width, h = height;
+    for (uint32_t l = 1; l < levels && (w >> 1) > 0 && (h >> 1) > 0; l++) {
+        const uint32_t nw = w >> 1, nh = h >> 1;
+        const size_t dst_off = bytes.size();
+        bytes.resize(dst_off + (size_t)nw * nh * 4);
+        for (uint32_t y = 0; y < nh; y++)
+            for (uint32_t x = 0; x < nw; x++)
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t s = bytes[src_off + ((size_t)(2 * y) * w + 2 * x) * 4 + c] + bytes[src_off + ((size_t)(2 * y) * w + 2 * x + 1) * 4 + c] +
+                                       bytes[src_off + ((size_t)(2 * y + 1) * w + 2 * x) * 4 + c] + bytes[src_off + ((size_t)(2 * y + 1) * w + 2 * x + 1) * 4 + c];
+                    bytes[dst_off + ((size_t)y * nw + x) * 4 + c] = (uint8_t)((s + 2) / 4);
+                }
+        src_off = dst_off;
+        w = nw; h = nh;
+        mip_levels++;
+    }
+}
+
 // ------------------------------------------------------------------ Camera3D::get_view (camera/mod.rs:77-115, 246-252)
 rfw_camera_view_3d Camera3D::get_view(uint32_t width, uint32_t height) const
 {
@@ -384,6 +413,18 @@ void synchronize_system(Scene& scene, Backend& renderer)
         renderer.set_3d_instances(kv.first, d);
         for (auto& f : kv.second.flags) f = 0;
         scene.instances_changed[kv.first] = false;
+        changed = true;
+    }
+    if (scene.textures_changed) { // :118-136
+        std::vector<rfw_texture_data> t;
+        for (const Texture& x : scene.textures) t.push_back(x.as_data());
+        renderer.set_textures(t, nullptr);
+        scene.textures_changed = false;
+        changed = true;
+    }
+    if (scene.skybox_changed) {
+        renderer.set_skybox(scene.skybox.as_data());
+        scene.skybox_changed = false;
         changed = true;
     }
     if (scene.materials_changed) { // :138-147
@@ -898,6 +939,83 @@ void build_soup(Scene& scene, Camera3D& cam, uint32_t triangles, uint32_t instan
     cam.focal_distance = 1.0f;
 }
 
+namespace {
+Texture make_texture(uint32_t w, uint32_t h, uint32_t seed, int kind)
+{
+    Texture t;
+    t.width = w; t.height = h; t.format = RFW_FORMAT_BGRA8;
+    t.bytes.resize((size_t)w * h * 4);
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint8_t* px = &t.bytes[((size_t)y * w + x) * 4];
+            if (kind == 0) { // checker with noise (albedo), BGRA
+                const bool c = (((x * 8) / w) + ((y * 8) / h)) & 1;
+                const float n = vnoise(x * 0.37f, y * 0.37f, seed);
+                px[0] = (uint8_t)(c ? 60 + 40 * n : 200 + 50 * n);
+                px[1] = (uint8_t)(c ? 90 + 60 * n : 190 + 40 * n);
+                px[2] = (uint8_t)(c ? 200 + 50 * n : 120 + 60 * n);
+                px[3] = 255;
+            } else if (kind == 1) { // normal map: bumps, tangent-space (r = x, g = y, b = z) stored BGRA
+                const float fx = std::sin(x * 6.2831853f * 4.0f / w) * 0.35f, fy = std::cos(y * 6.2831853f * 3.0f / h) * 0.35f;
+                const float fz = std::sqrt(std::max(0.0f, 1.0f - fx * fx - fy * fy));
+                px[2] = (uint8_t)((fx * 0.5f + 0.5f) * 255.0f);
+                px[1] = (uint8_t)((fy * 0.5f + 0.5f) * 255.0f);
+                px[0] = (uint8_t)((fz * 0.5f + 0.5f) * 255.0f);
+                px[3] = 255;
+            } else { // sky: vertical gradient + a bright band, RGBA order to exercise the second format
+                const float v = (float)y / (float)h;
+                t.format = RFW_FORMAT_RGBA8;
+                px[0] = (uint8_t)(60 + 120 * v);
+                px[1] = (uint8_t)(110 + 100 * v);
+                px[2] = (uint8_t)(235 - 60 * v);
+                px[3] = 255;
+                if (((x * 16) / w) % 5 == 0 && v < 0.45f) { px[0] = 250; px[1] = 240; px[2] = 200; }
+            }
+        }
+    t.generate_mipmaps(5);
+    return t;
+}
+} // namespace
+
+void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed)
+{
+    scene.textures.push_back(make_texture(64, 64, seed, 0));       // 0 albedo checker
+    scene.textures.push_back(make_texture(32, 64, seed + 1, 1));   // 1 normal map (non-square)
+    scene.textures.push_back(make_texture(16, 16, seed + 2, 0));   // 2 small albedo (few mips)
+    scene.skybox = make_texture(128, 64, seed + 3, 2);
+    scene.textures_changed = true;
+    scene.skybox_changed = true;
+    Material plain; plain.color[0] = 0.75f; plain.color[1] = 0.7f; plain.color[2] = 0.6f; plain.roughness = 0.9f;
+    Material tex = plain; tex.color[0] = tex.color[1] = tex.color[2] = 1.0f; tex.diffuse_tex = 0; tex.roughness = 0.6f;
+    Material bump = plain; bump.diffuse_tex = 2; bump.normal_tex = 1; bump.roughness = 0.35f; bump.metallic = 0.0f; bump.clearcoat = 0.5f;
+    Material emap = plain; emap.color[0] = 4.0f; emap.color[1] = 3.0f; emap.color[2] = 2.0f; emap.emissive_tex = 0; // emissive map: shaded, not a light (shade.comp:128)
+    Material light = plain; light.color[0] = 14.0f; light.color[1] = 13.0f; light.color[2] = 11.0f;
+    const int m_plain = (int)scene.add_material(plain), m_tex = (int)scene.add_material(tex), m_bump = (int)scene.add_material(bump),
+              m_emap = (int)scene.add_material(emap), m_light = (int)scene.add_material(light);
+    Builder b;
+    b.d.name = "gallery";
+    b.surface([&](float u, float v) { return v3(-3 + 6 * u, 0.0f, -3 + 6 * v); }, 6, 6, m_tex, true);                  // textured floor
+    b.surface([&](float u, float v) { return v3(-3 + 6 * u, 3 * v, 3.0f); }, 5, 3, m_bump, true);                      // bump-mapped back wall
+    b.surface([&](float u, float v) { return v3(-3.0f, 3 * v, -3 + 6 * u); }, 4, 3, m_tex, false);                     // left wall
+    b.quad(v3(3, 0.3f, -1.5f), v3(3, 0.3f, 1.5f), v3(3, 2.4f, 1.5f), v3(3, 2.4f, -1.5f), m_emap);                       // emissive-mapped panel
+    const float t0[3] = {0.6f, 0.5f, 0.4f}, ax[3] = {0.2f, 1, 0.1f};
+    rfw_mat4 xf = mat4_from_trs(t0, ax, 0.6f, 1.0f);
+    b.box(v3(-0.5f, -0.5f, -0.5f), v3(0.5f, 0.5f, 0.5f), m_bump, &xf);
+    b.quad(v3(-1, 2.95f, -1), v3(1, 2.95f, -1), v3(1, 2.95f, 1), v3(-1, 2.95f, 1), m_light);                            // lamp, faces down
+    b.quad(v3(-1.6f, 0.0f, -2.4f), v3(-0.4f, 0.0f, -2.4f), v3(-0.4f, 1.1f, -2.4f), v3(-1.6f, 1.1f, -2.4f), m_plain);
+    const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
+    scene.add_instance(mesh, mat4_identity());
+    const float t1[3] = {-1.6f, 0.0f, 0.9f}, ay[3] = {0, 1, 0};
+    scene.add_instance(scene.add_mesh(Mesh3D::from(make_icosphere(2, (uint32_t)m_bump))), mat4_from_trs(t1, ay, 0.4f, 0.6f));
+    scene.update_lights();
+    cam = Camera3D();
+    cam.pos[0] = 0.4f; cam.pos[1] = 1.5f; cam.pos[2] = -5.5f;
+    const V3 d = normalize(v3(-0.05f, -0.05f, 1.0f));
+    cam.direction[0] = d.x; cam.direction[1] = d.y; cam.direction[2] = d.z;
+    cam.fov = 60.0f;
+    cam.aperture = 0.0f;
+}
+
 } // namespace rfw
 
 // ==================================================================== C exports (for the Python tests / bench)
@@ -923,6 +1041,8 @@ struct rfwhost_backend_table {
     int (*set_spot_lights)(void*, const rfw_spot_light*, uint32_t, const uint32_t*);
     int (*set_area_lights)(void*, const rfw_area_light*, uint32_t, const uint32_t*);
     int (*set_directional_lights)(void*, const rfw_directional_light*, uint32_t, const uint32_t*);
+    int (*set_textures)(void*, const rfw_texture_data*, uint32_t, const uint32_t*);
+    int (*set_skybox)(void*, const rfw_texture_data*);
 };
 struct TableBackend : rfw::Backend {
     rfwhost_backend_table t;
@@ -941,7 +1061,10 @@ struct TableBackend : rfw::Backend {
     {
         acc(t.set_materials(t.instance, m.data(), (uint32_t)m.size(), nullptr));
     }
-    void set_textures(const std::vector<rfw_texture_data>&, const std::vector<uint32_t>*) override {}
+    void set_textures(const std::vector<rfw_texture_data>& t, const std::vector<uint32_t>*) override
+    {
+        if (this->t.set_textures) acc(this->t.set_textures(this->t.instance, t.data(), (uint32_t)t.size(), nullptr));
+    }
     void synchronize() override { acc(t.synchronize(t.instance)); }
     void render(const rfw_mat4&, const rfw_camera_view_3d&, uint32_t) override {}
     void resize(uint32_t, uint32_t, double) override {}
@@ -961,7 +1084,10 @@ struct TableBackend : rfw::Backend {
     {
         acc(t.set_directional_lights(t.instance, l.data(), (uint32_t)l.size(), nullptr));
     }
-    void set_skybox(const rfw_texture_data&) override {}
+    void set_skybox(const rfw_texture_data& s) override
+    {
+        if (t.set_skybox) acc(t.set_skybox(t.instance, &s));
+    }
     void set_skins(const std::vector<rfw_skin_data>&, const std::vector<uint32_t>*) override {}
 };
 } // namespace
@@ -976,6 +1102,7 @@ HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, fl
     if (k == "cornell") rfw::build_cornell_box(h.scene, h.cam);
     else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed);
     else if (k == "soup") rfw::build_soup(h.scene, h.cam, a, b, seed);
+    else if (k == "gallery") rfw::build_gallery(h.scene, h.cam, seed);
     else if (k == "spheres") {
         rfw::add_sphere_grid(h.scene, a, b, c);
         h.grid_mesh = h.scene.meshes_3d.rbegin()->first;
@@ -1006,6 +1133,8 @@ HOST_API int rfwhost_mark_all_changed(void* p)
     for (auto& kv : h.scene.instances_3d) h.scene.instances_changed[kv.first] = true;
     h.scene.materials_changed = true;
     h.scene.lights_changed = true;
+    h.scene.textures_changed = !h.scene.textures.empty();
+    h.scene.skybox_changed = h.scene.skybox.width != 0;
     return 0;
 }
 // runs rfw::synchronize_system against a table of C entry points (rfw_hip_* or orc_*)

@@ -168,7 +168,20 @@ struct Camera3D {
     rfw_camera_view_3d get_view(uint32_t width, uint32_t height) const;
 };
 
+// crates/rfw-backend/src/structs.rs:69-121 TextureData: 4 bytes per texel, mip levels concatenated (level i is (w >> i) x (h >> i))
+struct Texture {
+    uint32_t width = 0, height = 0, mip_levels = 1;
+    uint32_t format = RFW_FORMAT_BGRA8;
+    std::vector<uint8_t> bytes;
+    rfw_texture_data as_data() const;
+    // box-filtered mip chain appended to level 0 (what l3d's Texture::generate_mipmaps hands the trait)
+    void generate_mipmaps(uint32_t levels);
+};
+
 struct Scene {
+    std::vector<Texture> textures;
+    Texture skybox;
+    bool textures_changed = false, skybox_changed = false;
     std::map<uint32_t, Mesh3D> meshes_3d;
     std::map<uint32_t, InstanceList3D> instances_3d;
     std::vector<Material> materials;
@@ -207,5 +220,6 @@ void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32
 void add_sphere_grid(Scene& scene, uint32_t nx, uint32_t nz, float spacing);       // C3: instances of a 320-tri icosphere
 void animate_sphere_grid(Scene& scene, uint32_t mesh, uint32_t nx, uint32_t nz, float spacing, float time); // examples/animated/src/main.rs:197-219
 void build_soup(Scene& scene, Camera3D& cam, uint32_t triangles, uint32_t instances, uint32_t seed); // random soups for BVH equivalence tests
+void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox
 
 } // namespace rfw

@@ -14,7 +14,7 @@ class BackendTable(C.Structure):
     """Table of C entry points with the rfw_hip_* signatures (see rfw_host.cpp rfwhost_backend_table)."""
     _fields_ = [("instance", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
-        "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights")]
+        "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox")]
 
 
 _lib = None

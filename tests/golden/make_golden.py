@@ -16,6 +16,7 @@ CASES = {
     "cornell_primary_shadow": ("cornell", 0, 0, 1, 64, 64, 1, 1),
     "cornell_path3_4spp": ("cornell", 0, 0, 1, 64, 64, 3, 4),
     "soup_instanced_path3_2spp": ("soup", 900, 5, 11, 64, 48, 3, 2),
+    "gallery_textured_path3_2spp": ("gallery", 0, 0, 5, 96, 64, 3, 2),
 }
 
 

@@ -105,7 +105,7 @@ def test_edge_cases_empty_and_removed_instances():
     assert set(np.unique(g["inst"])) <= {-1, 0, 2}
 
 
-@pytest.mark.parametrize("kind,a,b,mpl,spp", [("cornell", 0, 0, 1, 1), ("cornell", 0, 0, 3, 4), ("soup", 1500, 6, 3, 2)])
+@pytest.mark.parametrize("kind,a,b,mpl,spp", [("cornell", 0, 0, 1, 1), ("cornell", 0, 0, 3, 4), ("soup", 1500, 6, 3, 2), ("gallery", 0, 0, 3, 3)])
 def test_radiance_matches_oracle(kind, a, b, mpl, spp):
     w, h = 96, 64
     scene, be, orc = make(kind, w, h, a, b, seed=9, max_path_length=mpl)

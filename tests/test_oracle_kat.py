@@ -155,3 +155,35 @@ def test_material_packing_bytes():
     assert m.parameters[0] == (0 | (255 << 8) | (127 << 16) | (63 << 24))
     assert (m.parameters[2] >> 24) == 255                      # eta 1.5 clamps to 255
     assert m.color[0] == 2.0 and m.flags == 0 and m.diffuse_map == -1
+
+
+def test_texture_sampler_known_answers():
+    # sampler of backends/gpu-rt/src/lib.rs:1026-1038: repeat, linear at LOD 0, nearest at LOD >= 1; fetchTexelTrilinear shade.comp:273-281
+    import ctypes as C
+    o = Oracle(8, 8)
+    w, h = 4, 2
+    lvl0 = np.zeros((h, w, 4), np.uint8)
+    for y in range(h):
+        for x in range(w):
+            lvl0[y, x] = (10 * x, 100 * y, 255, 51)          # B, G, R, A  (BGRA8)
+    lvl1 = np.full((1, 2, 4), 255, np.uint8)
+    lvl1[0, 1] = (0, 0, 0, 0)
+    data = np.concatenate([lvl0.ravel(), lvl1.ravel()])
+    td = pod.TextureData(w, h, 2, data.ctypes.data_as(C.POINTER(C.c_uint8)), 0)
+    o._l.orc_set_textures(o._h, C.byref(td), 1, None)
+    f = np.float32
+    # texel centres reproduce the texel (BGRA -> rgba)
+    c = o.sample_texture(0, (1 + 0.5) / w, (1 + 0.5) / h, 0.0)
+    assert np.array_equal(c, f([255, 100, 10, 51]) * f(1.0 / 255.0))
+    # halfway between texel 0 and 1 of row 0: exact average in f32 weights
+    c = o.sample_texture(0, 1.0 / w, 0.5 / h, 0.0)
+    assert abs(c[2] - (0 + 10) / 2 / 255) < 1e-7 and c[0] == 1.0
+    # repeat addressing: u = -0.125 is texel 3 of the previous period
+    assert np.array_equal(o.sample_texture(0, -0.5 / w, 0.5 / h, 0.0), o.sample_texture(0, 3.5 / w, 0.5 / h, 0.0))
+    # LOD >= 1: nearest texel of that level; LOD beyond the chain clamps to the last level
+    assert np.array_equal(o.sample_texture(0, 0.2, 0.3, 1.0), f([1, 1, 1, 1]))
+    assert np.array_equal(o.sample_texture(0, 0.7, 0.3, 7.0), f([0, 0, 0, 0]))
+    # trilinear: (1 - f) * level0 + f * level1 with f = fract(lambda)
+    a, b = o.sample_texture(0, 0.2, 0.3, 0.0), o.sample_texture(0, 0.2, 0.3, 1.0)
+    got = o.sample_texture(0, 0.2, 0.3, 0.25, trilinear=True)
+    assert np.allclose(got, f(0.75) * a + f(0.25) * b, atol=1e-7)
