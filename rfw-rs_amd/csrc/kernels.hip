@@ -13,7 +13,7 @@
 #include "traverse.h"
 
 #ifndef RFW_TRACE_WAVES
-#define RFW_TRACE_WAVES 5 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves)
+#define RFW_TRACE_WAVES 6 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves); 6 measured best with frames in flight (5: -6 %, 8: -2 %)
 #endif
 
 namespace rfwhip {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const C
 }
 
 // ---------------------------------------------------------------- shade.comp:70-266
-constexpr int kShadeBlock = 256;
+constexpr int kShadeBlock = 512; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -439,41 +439,45 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         }
     }
 
-    // ---- queue compaction: ballot + prefix inside the wavefront, one atomic per wave and queue
-    const uint32_t lane = threadIdx.x & 63u;
-    {
-        const unsigned long long m = __ballot(push_shadow);
-        if (m) {
-            const uint32_t n = (uint32_t)__popcll(m);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&sc.counters->shadow[bounce], n);
-            base = __shfl(base, leader);
-            if (push_shadow) {
-                const uint32_t j = base + rank;
-                p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_ID));
-                p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
-                p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
-            }
-        }
+    // ---- queue compaction: ballot + mbcnt prefix inside each wavefront, wave totals combined through LDS, ONE atomic per
+    // workgroup and queue (the reference issues one global atomic per thread, shade.comp:250,261; one per wavefront still
+    // serialised 32 k returning atomics on a single address)
+    __shared__ uint32_t s_cnt[2][kShadeBlock / 64];
+    __shared__ uint32_t s_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m_sh = __ballot(push_shadow), m_ex = __ballot(push_ext);
+    const uint32_t n_sh = (uint32_t)__popcll(m_sh), n_ex = (uint32_t)__popcll(m_ex);
+    const uint32_t r_sh = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_sh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_sh, 0u));
+    const uint32_t r_ex = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_ex, 0u));
+    if (lane == 0) {
+        s_cnt[0][wave] = n_sh;
+        s_cnt[1][wave] = n_ex;
     }
-    {
-        const unsigned long long m = __ballot(push_ext);
-        if (m) {
-            const uint32_t n = (uint32_t)__popcll(m);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&sc.counters->ext[bounce], n);
-            base = __shfl(base, leader);
-            if (push_ext) {
-                const uint32_t j = base + rank;
-                p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_ID));
-                p.ray_d[next_half][j] = make_float4(ext_d.x, ext_d.y, ext_d.z, bitsf(ext_normal));
-                p.thr[next_half][j] = make_float4(ext_thr.x, ext_thr.y, ext_thr.z, ext_pdf);
-            }
-        }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t tot = 0;
+        for (int k = 0; k < kShadeBlock / 64; k++) tot += s_cnt[threadIdx.x][k];
+        uint32_t base = 0;
+        if (tot) base = atomicAdd(threadIdx.x == 0 ? &sc.counters->shadow[bounce] : &sc.counters->ext[bounce], tot);
+        s_base[threadIdx.x] = base;
+    }
+    __syncthreads();
+    uint32_t off_sh = s_base[0], off_ex = s_base[1];
+    for (uint32_t k = 0; k < wave; k++) {
+        off_sh += s_cnt[0][k];
+        off_ex += s_cnt[1][k];
+    }
+    if (push_shadow) {
+        const uint32_t j = off_sh + r_sh;
+        p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_ID));
+        p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
+        p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
+    }
+    if (push_ext) {
+        const uint32_t j = off_ex + r_ex;
+        p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_ID));
+        p.ray_d[next_half][j] = make_float4(ext_d.x, ext_d.y, ext_d.z, bitsf(ext_normal));
+        p.thr[next_half][j] = make_float4(ext_thr.x, ext_thr.y, ext_thr.z, ext_pdf);
     }
 }
 
