@@ -153,9 +153,10 @@ struct CameraParams {
 
 // Device-side queue counters; one slot per bounce so nothing has to be reset or read back between bounces
 // (the reference reads extensionId/shadowId back to the host every bounce: gpu-rt/src/lib.rs:2052-2069).
+constexpr int kShadowBuckets = 8; // shadow rays are queued per light bucket (light index & 7): a wavefront's rays aim at one light
 struct QueueCounters {
     uint32_t ext[8];
-    uint32_t shadow[8];
+    uint32_t shadow[8][kShadowBuckets]; // [bounce][bucket]
     unsigned long long trav[3][3]; // [kind: 0 primary, 1 extend, 2 shadow][0 nodes visited, 1 triangles tested, 2 instances entered]
     unsigned long long overflow, pad;
 };

@@ -231,19 +231,33 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
-    const uint32_t count = sc.counters->shadow[bounce];
-    // the queue is filled in path order: an eighth of it per XCD keeps each XCD on its own region
-    const uint32_t block = xcd_block(blockIdx.x);
-    if (block * kTraceBlock >= count) return;
-    const uint32_t idx = block * kTraceBlock + threadIdx.x;
+    // the queue is bucketed by light (shade pushes into region light & 7): walk the buckets, each padded to whole wavefronts, so
+    // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
+    uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t spill_slot = block * kTraceBlock + threadIdx.x;
+    uint32_t bucket = 0, count = 0;
+    {
+        bool found = false;
+        for (int k = 0; k < kShadowBuckets; k++) {
+            const uint32_t c = sc.counters->shadow[bounce][k];
+            const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
+            if (!found) {
+                if (block < nb) { found = true; bucket = (uint32_t)k; count = c; }
+                else block -= nb;
+            }
+        }
+        if (!found) return;
+    }
+    const uint32_t local = block * kTraceBlock + threadIdx.x;
+    const uint32_t idx = bucket * p.capacity + local;
     TravCounters tc{0, 0, 0};
-    if (idx < count) {
+    if (local < count) {
         const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
         const f3 O = mk3(o4.x, o4.y, o4.z), D = mk3(d4.x, d4.y, d4.z);
         float t = d4.w - 0.0001f, hu, hv;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
-        const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {
             const float4 e = p.sh_e[idx];
             const uint32_t pixel = fbits(o4.w);
@@ -273,6 +287,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     if (live && bounce == 0) live = slab_to_pixel(cam, idx, px, py);
 
     bool push_ext = false, push_shadow = false;
+    int light_bucket = 0;
     f3 ext_o = mk3(0.0f), ext_d = mk3(0.0f), ext_thr = mk3(0.0f);
     float ext_pdf = 0.0f;
     uint32_t ext_normal = 0;
@@ -404,7 +419,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                         lv.n_spot = (int)cam.spot_light_count; lv.n_directional = (int)cam.directional_light_count;
                         f3 lightColor = mk3(0.0f);
                         float pickProb = 0.0f, lightPdf = 0.0f;
-                        f3 L = RandomPointOnLight(lv, r3, P, N, pickProb, lightPdf, lightColor) - P;
+                        int picked = 0;
+                        f3 L = RandomPointOnLight(lv, r3, P, N, pickProb, lightPdf, lightColor, picked) - P;
                         const float dist = length(L);
                         L = L * (1.0f / dist);
                         const float NdotL = dot(L, N);
@@ -420,6 +436,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                                     sh_dist = dist - 1e-4f;
                                     sh_e = contribution;
                                     push_shadow = true;
+                                    light_bucket = picked & (kShadowBuckets - 1);
                                 }
                             }
                         }
@@ -442,39 +459,41 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     // ---- queue compaction: ballot + mbcnt prefix inside each wavefront, wave totals combined through LDS, ONE atomic per
     // workgroup and queue (the reference issues one global atomic per thread, shade.comp:250,261; one per wavefront still
     // serialised 32 k returning atomics on a single address)
-    __shared__ uint32_t s_cnt[2][kShadeBlock / 64];
-    __shared__ uint32_t s_base[2];
+    constexpr int kQ = kShadowBuckets + 1; // queues: one shadow region per light bucket + the extension queue
+    __shared__ uint32_t s_cnt[kQ][kShadeBlock / 64];
+    __shared__ uint32_t s_base[kQ];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long m_sh = __ballot(push_shadow), m_ex = __ballot(push_ext);
-    const uint32_t n_sh = (uint32_t)__popcll(m_sh), n_ex = (uint32_t)__popcll(m_ex);
-    const uint32_t r_sh = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_sh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_sh, 0u));
-    const uint32_t r_ex = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_ex, 0u));
-    if (lane == 0) {
-        s_cnt[0][wave] = n_sh;
-        s_cnt[1][wave] = n_ex;
+    uint32_t my_rank = 0;
+    for (int q = 0; q < kShadowBuckets; q++) {
+        const bool mine = push_shadow && light_bucket == q;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) s_cnt[q][wave] = (uint32_t)__popcll(m);
+        if (mine) my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }
+    const unsigned long long m_ex = __ballot(push_ext);
+    if (lane == 0) s_cnt[kShadowBuckets][wave] = (uint32_t)__popcll(m_ex);
+    const uint32_t r_ex = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_ex, 0u));
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < kQ) {
         uint32_t tot = 0;
         for (int k = 0; k < kShadeBlock / 64; k++) tot += s_cnt[threadIdx.x][k];
         uint32_t base = 0;
-        if (tot) base = atomicAdd(threadIdx.x == 0 ? &sc.counters->shadow[bounce] : &sc.counters->ext[bounce], tot);
+        if (tot) base = atomicAdd(threadIdx.x < kShadowBuckets ? &sc.counters->shadow[bounce][threadIdx.x] : &sc.counters->ext[bounce], tot);
         s_base[threadIdx.x] = base;
     }
     __syncthreads();
-    uint32_t off_sh = s_base[0], off_ex = s_base[1];
-    for (uint32_t k = 0; k < wave; k++) {
-        off_sh += s_cnt[0][k];
-        off_ex += s_cnt[1][k];
-    }
     if (push_shadow) {
-        const uint32_t j = off_sh + r_sh;
+        uint32_t off = s_base[light_bucket];
+        for (uint32_t k = 0; k < wave; k++) off += s_cnt[light_bucket][k];
+        const size_t j = (size_t)light_bucket * p.capacity + off + my_rank;
         p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_ID));
         p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
         p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
     }
     if (push_ext) {
-        const uint32_t j = off_ex + r_ex;
+        uint32_t off = s_base[kShadowBuckets];
+        for (uint32_t k = 0; k < wave; k++) off += s_cnt[kShadowBuckets][k];
+        const uint32_t j = off + r_ex;
         p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_ID));
         p.ray_d[next_half][j] = make_float4(ext_d.x, ext_d.y, ext_d.z, bitsf(ext_normal));
         p.thr[next_half][j] = make_float4(ext_thr.x, ext_thr.y, ext_thr.z, ext_pdf);
@@ -579,7 +598,7 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
-    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + kShadowBuckets + 511u) & ~511u), block(kTraceBlock);
     if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, s, cam, sc, p, bounce);
 }

@@ -68,6 +68,7 @@ constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
 constexpr int kNumEvents = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce + 1);
 constexpr int kTimingRing = 32;
+constexpr size_t kSpillMargin = 65536; // extra per-thread spill slots per sub-shard for padded launch grids
 constexpr int kMaxSub = 8;      // sub-shards (HIP streams) a frame is split into on one GPU // frames whose events can be pending before rfw_hip_drain_timing must be called
 
 struct Instance {
@@ -217,9 +218,9 @@ int alloc_paths(Instance* I)
         HIP_TRY(I, I->d_thr[h].ensure(n));
         HIP_TRY(I, I->d_hit[h].ensure(n));
     }
-    HIP_TRY(I, I->d_sh_o.ensure(n));
-    HIP_TRY(I, I->d_sh_d.ensure(n));
-    HIP_TRY(I, I->d_sh_e.ensure(n));
+    HIP_TRY(I, I->d_sh_o.ensure(n * kShadowBuckets));
+    HIP_TRY(I, I->d_sh_d.ensure(n * kShadowBuckets));
+    HIP_TRY(I, I->d_sh_e.ensure(n * kShadowBuckets));
     HIP_TRY(I, I->d_acc_slab.ensure(n));
     HIP_TRY(I, hipMemsetAsync(I->d_acc_slab.ptr, 0, n * sizeof(float4), I->stream));
     const size_t px = (size_t)I->width * I->height;
@@ -227,7 +228,8 @@ int alloc_paths(Instance* I)
     HIP_TRY(I, I->d_frame_out.ensure(px));
     HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
     HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
-    HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * std::max<size_t>(n, 65536)));
+    // per-thread overflow slots: launch grids are padded (XCD tiling, shadow buckets), so leave a margin per sub-shard
+    HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * I->substreams * ((size_t)I->cap_v + kSpillMargin)));
     HIP_TRY(I, I->d_counters.ensure(kMaxSub));
     HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, kMaxSub * sizeof(QueueCounters), I->stream));
     I->sample_count = 0;
@@ -613,9 +615,9 @@ PathDev path_dev(Instance* I, uint32_t sub = 0)
         p.thr[h] = I->d_thr[h].ptr + off;
         p.hit[h] = I->d_hit[h].ptr + off;
     }
-    p.sh_o = I->d_sh_o.ptr + off;
-    p.sh_d = I->d_sh_d.ptr + off;
-    p.sh_e = I->d_sh_e.ptr + off;
+    p.sh_o = I->d_sh_o.ptr + off * kShadowBuckets;
+    p.sh_d = I->d_sh_d.ptr + off * kShadowBuckets;
+    p.sh_e = I->d_sh_e.ptr + off * kShadowBuckets;
     p.acc = (I->external_slab ? (float4*)I->external_slab : I->d_acc_slab.ptr) + off;
     p.capacity = I->cap_v;
     return p;
@@ -658,7 +660,7 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
         if (S > 1) HIP_TRY(I, hipStreamWaitEvent(st[s], I->ev_fork, 0));
         sc[s] = scene_dev(I);
         sc[s].counters = I->d_counters.ptr + s;
-        sc[s].spill = I->d_spill.ptr + (size_t)s * I->cap_v;
+        sc[s].spill = I->d_spill.ptr + (size_t)s * (I->cap_v + kSpillMargin);
         p[s] = path_dev(I, s);
         cam[s] = camera_params(I, view, s);
     }
@@ -1051,7 +1053,8 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
         if (qc[s].overflow) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
         for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc[s].ext[b];
         if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
-            for (uint32_t b = 0; b < nb; b++) out->shadow_rays += qc[s].shadow[b];
+            for (uint32_t b = 0; b < nb; b++)
+                for (int k = 0; k < kShadowBuckets; k++) out->shadow_rays += qc[s].shadow[b][k];
         for (int k = 0; k < 3; k++) {
             out->nodes_visited[k] += qc[s].trav[k][0];
             out->tris_tested[k] += qc[s].trav[k][1];

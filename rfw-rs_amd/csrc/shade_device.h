@@ -400,7 +400,7 @@ RFW_DI f3 RandomBarycentrics(float r0)
 }
 
 // shade.comp:413-528
-RFW_DI f3 RandomPointOnLight(const LightView& lv, float r0, f3 I, f3 N, float& pickProb, float& lightPdf, f3& lightColor)
+RFW_DI f3 RandomPointOnLight(const LightView& lv, float r0, f3 I, f3 N, float& pickProb, float& lightPdf, f3& lightColor, int& pickedLight)
 {
     const int AREA = lv.n_area, POINT = lv.n_point, SPOT = lv.n_spot;
     const uint32_t lightCount = (uint32_t)(lv.n_area + lv.n_point + lv.n_spot + lv.n_directional);
@@ -408,6 +408,7 @@ RFW_DI f3 RandomPointOnLight(const LightView& lv, float r0, f3 I, f3 N, float& p
     pickProb = 1.0f / (float)lightCount;
     int lightIdx = f2i(r0 * (float)lightCount);
     lightIdx = lightIdx < 0 ? 0 : (lightIdx > (int)lightCount - 1 ? (int)lightCount - 1 : lightIdx);
+    pickedLight = lightIdx;
     if (lightIdx < AREA) {
         const rfw_area_light* al = lv.area + lightIdx;
         lightColor = ld3(al->radiance);
