@@ -76,13 +76,17 @@ def main():
         # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
         # all-gather is ordered against the kernels and the HIP events that time them are recorded on the launch stream
         st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
+        for key in ("sah_max_leaf", "sah_trav_cost"):  # builder experiments
+            if os.environ.get("RFW_" + key.upper()):
+                be.set_option(key, float(os.environ["RFW_" + key.upper()]))
         scene.mark_all_changed()
         scene.sync(be)
         g = None
         if world > 1:
-            slab = be.shard_info()["slab_floats"]
-            g = torch.zeros(world, slab, dtype=torch.float32, device="cuda")
-            be.set_slab_output(g[rank].data_ptr())
+            nslab = be.shard_info()["slab_floats"]
+            send = torch.zeros(nslab, dtype=torch.float32, device="cuda")          # this rank's tiles (written by render())
+            g = (send, torch.zeros(world, nslab, dtype=torch.float32, device="cuda"))  # (send buffer, all ranks' slabs)
+            be.set_slab_output(send.data_ptr())
         bes.append(be); streams.append(st); gathers.append(g)
     sync_s = (time.time() - t0) / F
     be = bes[0]
@@ -107,13 +111,14 @@ def main():
             b.reset_accumulation()
             b.render(view)
             if world > 1:
+                send, recv = g
                 if dist_backend == "nccl":
-                    dist.all_gather_into_tensor(g.view(-1), g[rank])  # the ONE collective per frame (RCCL over xGMI)
+                    dist.all_gather_into_tensor(recv.view(-1), send)  # the ONE collective per frame (RCCL over xGMI)
                 else:
-                    host = torch.empty(g.shape, dtype=g.dtype)
-                    dist.all_gather_into_tensor(host.view(-1), g[rank].cpu())
-                    g.copy_(host)
-                b.assemble_frame(g.data_ptr())
+                    host = torch.empty(recv.shape, dtype=recv.dtype)
+                    dist.all_gather_into_tensor(host.view(-1), send.cpu())
+                    recv.copy_(host)
+                b.assemble_frame(recv.data_ptr())
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
     be.set_option("count_traversal", 1)

@@ -115,6 +115,9 @@ RFW_HIP_API void rfw_hip_destroy(void* instance);
 /* instance may be NULL: returns the message of the last failed rfw_hip_create on this thread. */
 RFW_HIP_API const char* rfw_hip_last_error(void* instance);
 RFW_HIP_API uint32_t rfw_hip_abi_version(void);
+/* Host-only self test of the CPU-side builder + node quantiser (no GPU needed): boxes6 = n x (lo.xyz, hi.xyz); returns the
+ * number of structural violations (0 = pass). */
+RFW_HIP_API int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf, uint32_t threads, uint32_t* out_nodes);
 
 /* ---- Backend trait, in declaration order (crates/rfw-backend/src/lib.rs:36-81) ---- */
 /* :36 set_2d_mesh / :39 set_2d_instances — accepted and ignored; gpu-rt `unimplemented!()`s them

@@ -47,6 +47,7 @@ struct Builder2 {
     std::atomic<uint32_t> next_node{1};
     int max_leaf;
     int max_par_depth;
+    float trav_cost = 1.0f;
 
     Builder2(const std::vector<PrimBox>& b, int ml, int threads) : boxes(b), max_leaf(ml)
     {
@@ -117,7 +118,7 @@ struct Builder2 {
         uint32_t mid = 0;
         const float leaf_cost = (float)count * node.box.half_area();
         // traversal step ~ 1 triangle test: split when SAH says so, or when the leaf would be too fat
-        if (best_axis >= 0 && (best_cost + node.box.half_area() < leaf_cost || (int)count > max_leaf)) {
+        if (best_axis >= 0 && (best_cost + trav_cost * node.box.half_area() < leaf_cost || (int)count > max_leaf)) {
             const float lo = cb.lo[best_axis], hi = cb.hi[best_axis];
             const float scale = (float)kBinCount / (hi - lo);
             uint32_t* begin = &order[first];
@@ -166,7 +167,7 @@ inline Node4 empty_node4()
 
 } // namespace
 
-void build_bvh4_host(const std::vector<PrimBox>& boxes, int max_leaf, int threads, HostBvh4& out)
+void build_bvh4_host(const std::vector<PrimBox>& boxes, int max_leaf, int threads, HostBvh4& out, float trav_cost)
 {
     out.nodes.clear();
     out.prim_order.clear();
@@ -175,6 +176,7 @@ void build_bvh4_host(const std::vector<PrimBox>& boxes, int max_leaf, int thread
     if (n == 0) return;
     max_leaf = std::min(std::max(max_leaf, 1), kMaxLeafTris);
     Builder2 b2(boxes, max_leaf, std::max(threads, 1));
+    b2.trav_cost = trav_cost;
     b2.build(0, 0, n, 0);
     out.prim_order = b2.order;
     const std::vector<Node2>& n2 = b2.nodes;

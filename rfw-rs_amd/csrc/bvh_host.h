@@ -19,7 +19,8 @@ struct HostBvh4 {
 };
 
 // Builds a 4-wide BVH over `boxes` (already padded by the caller).  max_leaf <= kMaxLeafTris.
-void build_bvh4_host(const std::vector<PrimBox>& boxes, int max_leaf, int threads, HostBvh4& out);
+// trav_cost: cost of one node step in units of one primitive test (SAH termination: split iff cost_split + trav_cost * area < cost_leaf)
+void build_bvh4_host(const std::vector<PrimBox>& boxes, int max_leaf, int threads, HostBvh4& out, float trav_cost = 1.0f);
 
 // Structural self-check used by the CPU tests: every primitive in exactly one leaf, child boxes contain their subtree.
 uint64_t validate_bvh4(const HostBvh4& bvh, const std::vector<PrimBox>& boxes);

@@ -85,6 +85,8 @@ struct Instance {
     float sky[3] = {0, 0, 0};
     bool timing = true;
     int build_threads = 8;
+    int sah_max_leaf = 8;
+    float sah_trav_cost = 1.0f;
 
     // host-side scene copies (the trait's borrows end with each call)
     std::map<uint32_t, MeshHost> meshes;
@@ -287,7 +289,7 @@ void build_mesh(Instance* I, MeshHost& m)
         }
         pad_box(boxes[i]);
     }
-    build_bvh4_host(boxes, 4, I->build_threads, m.bvh);
+    build_bvh4_host(boxes, I->sah_max_leaf, I->build_threads, m.bvh, I->sah_trav_cost);
     m.packets.resize(n);
     for (size_t k = 0; k < n; k++) {
         const uint32_t id = m.bvh.prim_order[k];
@@ -722,6 +724,38 @@ extern "C" {
 
 uint32_t rfw_hip_abi_version(void) { return RFW_HIP_ABI_VERSION; }
 
+// Host-only self test of the acceleration-structure code that runs on the CPU (no HIP call): builds the 4-wide binned-SAH BVH over
+// `n` boxes (6 floats each: lo.xyz, hi.xyz), validates it (every primitive in exactly one leaf, child boxes contain their
+// subtree), quantises every node and checks that the decoded 8-bit planes still enclose the f32 boxes.  Returns the number of
+// violations (0 = pass), or a negative code on bad arguments.
+int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf, uint32_t threads, uint32_t* out_nodes)
+{
+    if (n && !boxes6) return RFW_HIP_E_INVALID;
+    std::vector<PrimBox> boxes(n);
+    for (uint32_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) { boxes[i].lo[a] = boxes6[6 * i + a]; boxes[i].hi[a] = boxes6[6 * i + 3 + a]; }
+    HostBvh4 bvh;
+    build_bvh4_host(boxes, (int)(max_leaf ? max_leaf : 4), (int)(threads ? threads : 1), bvh);
+    int64_t errors = (int64_t)validate_bvh4(bvh, boxes);
+    for (const Node4& nd : bvh.nodes) {
+        const Node4Q q = quantize_node(nd);
+        const float o[3] = {q.ox, q.oy, q.oz};
+        const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+        const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+        for (int i = 0; i < 4; i++) {
+            if (q.child[i] != nd.child[i]) errors++;
+            if (nd.child[i] == kInvalidRef) continue;
+            for (int a = 0; a < 3; a++) {
+                const float scale = rfw_bits2f(((q.exps >> (8 * a)) & 0xffu) << 23);
+                const float dlo = o[a] + (float)((q.qlo[a] >> (8 * i)) & 0xffu) * scale, dhi = o[a] + (float)((q.qhi[a] >> (8 * i)) & 0xffu) * scale;
+                if (dlo > lo[a][i] || dhi < hi[a][i]) errors++;
+            }
+        }
+    }
+    if (out_nodes) *out_nodes = (uint32_t)bvh.nodes.size();
+    return errors;
+}
+
 void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rfw_hip_options* o)
 {
     int ndev = 0;
@@ -996,6 +1030,8 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "sky_r") I->sky[0] = (float)value;
     else if (k == "sky_g") I->sky[1] = (float)value;
     else if (k == "sky_b") I->sky[2] = (float)value;
+    else if (k == "sah_max_leaf") I->sah_max_leaf = std::max(1, std::min((int)value, kMaxLeafTris));
+    else if (k == "sah_trav_cost") I->sah_trav_cost = (float)value;
     else if (k == "build_threads") I->build_threads = std::max(1, (int)value);
     else return fail(I, RFW_HIP_E_INVALID, "set_option: unknown key " + k);
     return RFW_HIP_OK;

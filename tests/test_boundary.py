@@ -62,3 +62,22 @@ def test_product_never_touches_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
+
+
+def test_host_bvh_builder_and_quantiser_selftest():
+    """The product's CPU-side builder (binned SAH -> 4-wide collapse) and the 8-bit node quantiser, without a GPU."""
+    import numpy as np
+    from rfw_rs_amd import hip_lib
+    lib = hip_lib()
+    rng = np.random.default_rng(3)
+    for n, leaf, threads in [(0, 4, 1), (1, 4, 1), (2, 4, 1), (7, 1, 2), (5000, 4, 4), (20000, 8, 8)]:
+        c = rng.uniform(-50, 50, size=(n, 3)).astype(np.float32)
+        e = rng.uniform(0.0, 2.0, size=(n, 3)).astype(np.float32)
+        if n > 10:
+            e[:10] = 0.0                      # degenerate (point) boxes
+            c[10:20] = c[10]                  # coincident centroids
+        boxes = np.ascontiguousarray(np.concatenate([c - e, c + e], axis=1))
+        nodes = C.c_uint32(0)
+        err = lib.rfw_hip_selftest_bvh(boxes.ctypes.data, n, leaf, threads, C.byref(nodes))
+        assert err == 0, (n, leaf, err)
+        assert nodes.value >= 1

@@ -1,0 +1,123 @@
+"""Behaviour of the drop-in boundary on a real device: the call sequences the reference's host makes
+(rfw/src/system/mod.rs:19-206 synchronize_system, rfw/src/lib.rs:411-430 render_system incl. resize), error reporting,
+threading, and scene edits — each checked against the oracle driven through the same calls."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(kind, w, h, a=0, b=0, seed=1, mpl=2):
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build(kind, a, b, 0.0, seed)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=mpl)
+    orc = Oracle(w, h, threads=4, max_path_length=mpl)
+    scene.sync(be)
+    scene.mark_all_changed()
+    scene.sync(orc)
+    return scene, be, orc
+
+
+def same(be, orc):
+    return np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+
+
+def test_resize_restarts_accumulation_and_matches_fresh_instance():
+    from oracle.bindings import Oracle
+    scene, be, orc = pair("cornell", 48, 32)
+    be.render(scene.view(48, 32))
+    be.resize((80, 56), 1.0)                      # render_system handles a resize before get_view (rfw/src/lib.rs:415-421)
+    scene.set_aspect(80 / 56)
+    view = scene.view(80, 56)
+    be.render(view)
+    assert be.frame_stats()["sample_count"] == 1 and be.accumulator().shape == (56, 80, 4)
+    orc2 = Oracle(80, 56, threads=4, max_path_length=2)
+    scene.mark_all_changed()
+    scene.sync(orc2)
+    orc2.render(view)
+    assert same(be, orc2)
+
+
+def test_material_and_light_edits_take_effect():
+    from rfw_rs_amd import into_device_material
+    scene, be, orc = pair("cornell", 64, 48)
+    view = scene.view(64, 48)
+    be.render(view); orc.render(view)
+    before = be.accumulator().copy()
+    assert same(be, orc)
+    mats = [into_device_material([0.2, 0.3, 0.9, 1.0], [0, 0, 0.5, 0.9] + [0] * 4 + [0, 1, 0, 1] + [0] * 4),
+            into_device_material([0.9, 0.1, 0.1, 1.0], [1.0, 0, 0.5, 0.2] + [0] * 4 + [0, 1, 0, 1] + [0] * 4),
+            into_device_material([0.1, 0.8, 0.1, 1.0], [0, 0, 0.5, 1.0] + [0] * 4 + [1.0, 0.5, 0, 1] + [0] * 4),
+            into_device_material([12.0, 12.0, 9.0, 1.0], [0] * 16)]
+    be.set_materials(mats)
+    be.synchronize()
+    arr = (type(mats[0]) * 4)(*mats)
+    orc._l.orc_set_materials(orc._h, arr, 4, None)
+    orc.reset()
+    be.render(view); orc.render(view)
+    assert be.frame_stats()["sample_count"] == 1       # synchronize() with changes restarted the accumulation
+    assert same(be, orc) and not np.array_equal(before, be.accumulator())
+
+
+def test_unload_mesh_removes_its_instances():
+    scene, be, orc = pair("gallery", 64, 48, seed=3)
+    view = scene.view(64, 48)
+    be.render(view); orc.render(view)
+    assert same(be, orc) and be.scene_stats()["instances"] == 2
+    be.unload_3d_meshes([1])                             # the icosphere mesh and its instance list
+    be.synchronize()
+    ids = (C.c_uint32 * 1)(1)
+    orc._l.orc_unload_3d_meshes(orc._h, ids, 1)
+    orc._l.orc_synchronize(orc._h)
+    orc.reset()
+    be.render(view); orc.render(view)
+    assert be.scene_stats()["instances"] == 1 and same(be, orc)
+
+
+def test_errors_are_reported_not_thrown():
+    from rfw_rs_amd import BackendError, HipBackend, hip_lib
+    lib = hip_lib()
+    with pytest.raises(BackendError):
+        HipBackend.init(0, 16)
+    with pytest.raises(BackendError):
+        HipBackend.init(16, 16, 1.0, rank=2, world=2)
+    be = HipBackend.init(16, 16)
+    assert lib.rfw_hip_set_3d_mesh(be._h, 0, None) < 0 and b"null" in lib.rfw_hip_last_error(be._h)
+    assert lib.rfw_hip_render(be._h, None, None, 0) < 0
+    assert lib.rfw_hip_set_option(be._h, b"no_such_option", 1.0) < 0 and b"unknown" in lib.rfw_hip_last_error(be._h)
+    assert lib.rfw_hip_read_framebuffer(be._h, None, 4) < 0
+    assert lib.rfw_hip_set_2d_mesh(be._h, 0, None, 0, -1) == 0 and lib.rfw_hip_set_2d_instances(be._h, 0, None, 0) == 0  # accepted, ignored
+    assert lib.rfw_hip_set_3d_mesh(None, 0, None) < 0      # null instance
+    o = np.zeros((4, 3), np.float32)
+    with pytest.raises(BackendError):
+        be.intersect(o, o + 1)                             # scene not synchronized yet
+
+
+def test_calls_from_other_threads():
+    """bevy runs synchronize_system / render_system on arbitrary workers (rfw/src/system/mod.rs:16-17): the library must not
+    depend on the calling thread (it sets the device on entry and serialises on one mutex)."""
+    scene, be, orc = pair("cornell", 48, 48)
+    view = scene.view(48, 48)
+    errs = []
+
+    def work():
+        try:
+            for _ in range(3):
+                be.render(view)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work) for _ in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and be.frame_stats()["sample_count"] == 9
+    for _ in range(9):
+        orc.render(view)
+    assert same(be, orc)
