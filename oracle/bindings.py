@@ -84,7 +84,7 @@ class Oracle:
         t = BackendTable()
         t.instance = self._h
         for name in ("set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
-                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox"):
+                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox", "set_skins"):
             setattr(t, name, C.cast(getattr(self._l, "orc_" + name), C.c_void_p))
         return t
 
@@ -134,6 +134,15 @@ class Oracle:
         out = (C.c_float * 4)()
         self._l.orc_sample_texture(self._h, tex, u, v, lod, 1 if trilinear else 0, out)
         return np.array(out[:], dtype=np.float32)
+
+    def triangles(self):
+        """All triangles after synchronize as raw 176-byte records (n, 44) float32: static meshes, then skinned copies."""
+        self._l.orc_read_triangles.restype = C.c_uint64
+        self._l.orc_read_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        n = int(self._l.orc_read_triangles(self._h, None, 0))
+        out = np.zeros((n, 44), dtype=np.float32)
+        self._l.orc_read_triangles(self._h, out.ctypes.data, n)
+        return out
 
     def stats(self):
         s = OrcStats()

@@ -45,6 +45,11 @@
  *       skybox set a miss adds the constant sky colour (default black = gpu-rt's zero-initialised 64x64 skybox,
  *       lib.rs:424-436).
  *   D4  instance ids follow the live API numbering mesh_base[mesh] + slot.
+ *   D5  skinning (crates/rfw-backend/src/structs.rs:820-877, used by gpu-rt/src/lib.rs:1318-1336): triangle i is skinned with the
+ *       joint data of its own vertices 3i, 3i+1, 3i+2 (the reference indexes skin_data[i/3], [i+1], [i+2] — an indexing bug,
+ *       not inherited); every (mesh, skin) pair referenced by an instance becomes its own mesh, appended after the static
+ *       meshes in (mesh id, skin id) order, so skinned instances of one mesh with different skins differ (gpu-rt keeps one
+ *       skinned copy per mesh: the last instance's skin wins).
  */
 #include <atomic>
 #include <cmath>
@@ -391,6 +396,7 @@ static inline vec3 SampleBSDF(const ShadingData& sd, vec3 iN, vec3 N, vec3 T, ve
 struct Mesh {
     bool present = false;
     std::vector<rfw_rt_triangle> tris;
+    std::vector<rfw_joint_data> skin_data; // per vertex, 3 per triangle; empty = not skinnable
     BVH bvh;
     MBVH mbvh;
     uint32_t tri_offset = 0; // into the concatenated triangle array (gpu-rt/src/lib.rs:1387-1461)
@@ -398,6 +404,7 @@ struct Mesh {
 struct InstanceList {
     rfw_aabb local_aabb{};
     std::vector<rfw_mat4> matrices;
+    std::vector<int32_t> skin_ids;
 };
 // structs.glsl:110-122 (offsets replaced by a mesh index; the arithmetic is the same)
 struct InstanceDescriptor {
@@ -433,6 +440,8 @@ struct Oracle {
     float spread_angle = 0.0f; // camera.spread_angle of the frame being rendered
     std::map<uint32_t, Mesh> meshes;
     std::map<uint32_t, InstanceList> instance_lists;
+    std::vector<std::vector<mat4>> skins;                         // joint matrices per skin
+    std::map<std::pair<uint32_t, int32_t>, Mesh> derived;         // (mesh id, skin id) -> skinned copy with its own BVH
     std::vector<rfw_device_material> materials;
     std::vector<rfw_area_light> area_lights;
     std::vector<rfw_point_light> point_lights;
@@ -495,6 +504,45 @@ static mat4 transpose(const mat4& a)
     mat4 o;
     std::memcpy(&o, t, 64);
     return o;
+}
+
+// ---------------------------------------------------------------- SkinnedTriangles3D::apply (crates/rfw-backend/src/structs.rs:820-877)
+static mat4 blend_joints(const rfw_joint_data& jd, const std::vector<mat4>& joints)
+{
+    auto J = [&](int k) -> const mat4& { const uint32_t j = jd.joint[k]; return joints[j < joints.size() ? j : joints.size() - 1]; };
+    auto scale = [](float w, const mat4& m) { mat4 r; for (int c = 0; c < 4; c++) r.c[c] = w * m.c[c]; return r; };
+    auto add = [](const mat4& a, const mat4& b) { mat4 r; for (int c = 0; c < 4; c++) r.c[c] = a.c[c] + b.c[c]; return r; };
+    const float w[4] = {jd.weight.x, jd.weight.y, jd.weight.z, jd.weight.w};
+    mat4 m = scale(w[0], J(0));
+    m = add(m, scale(w[1], J(1)));
+    m = add(m, scale(w[2], J(2)));
+    m = add(m, scale(w[3], J(3)));
+    return m;
+}
+static void skin_triangles(const Mesh& src, const std::vector<mat4>& joints, std::vector<rfw_rt_triangle>& out)
+{
+    out = src.tris;
+    if (joints.empty()) return;
+    for (size_t i = 0; i < out.size(); i++) {
+        rfw_rt_triangle& t = out[i];
+        rfw_vec3* vs[3] = {&t.vertex0, &t.vertex1, &t.vertex2};
+        rfw_vec3* ns[3] = {&t.n0, &t.n1, &t.n2};
+        rfw_vec4* ts[3] = {&t.tangent0, &t.tangent1, &t.tangent2};
+        const float tw = t.tangent2.w; // every tangent takes tangent2[3] (structs.rs:838-840, 851-853, 864-866)
+        for (int k = 0; k < 3; k++) {
+            const mat4 m = blend_joints(src.skin_data[3 * i + k], joints);
+            const mat4 nm = transpose(inverse(m));
+            const vec3 v = xyz(mul(m, vec4{vs[k]->x, vs[k]->y, vs[k]->z, 1.0f}));
+            const vec3 n = xyz(mul(nm, vec4{ns[k]->x, ns[k]->y, ns[k]->z, 0.0f}));
+            const vec3 tg = xyz(mul(nm, vec4{ts[k]->x, ts[k]->y, ts[k]->z, 0.0f}));
+            *vs[k] = rfw_vec3{v.x, v.y, v.z};
+            *ns[k] = rfw_vec3{n.x, n.y, n.z};
+            *ts[k] = rfw_vec4{tg.x, tg.y, tg.z, tw};
+        }
+        const vec3 v0 = V3(t.vertex0.x, t.vertex0.y, t.vertex0.z), v1 = V3(t.vertex1.x, t.vertex1.y, t.vertex1.z), v2 = V3(t.vertex2.x, t.vertex2.y, t.vertex2.z);
+        const vec3 gn = normalize(cross(v1 - v0, v2 - v0)); // RTTriangle::normal (structs.rs:970-975)
+        t.normal = rfw_vec3{gn.x, gn.y, gn.z};
+    }
 }
 
 // ---------------------------------------------------------------- intersection.glsl:1-38
@@ -1205,6 +1253,9 @@ ORC_API int orc_set_3d_mesh(void* p, uint32_t id, const rfw_mesh_data_3d* data)
     Mesh& m = o.meshes[id];
     m.present = true;
     m.tris.assign(data->triangles, data->triangles + data->num_triangles);
+    m.skin_data.clear();
+    if (data->skin_data && data->num_skin_data == 3u * data->num_triangles && (data->flags & RFW_MESH_ALLOW_SKINNING))
+        m.skin_data.assign(data->skin_data, data->skin_data + data->num_skin_data);
     m.bvh = BVH();
     m.mbvh = MBVH();
     return 0;
@@ -1221,6 +1272,19 @@ ORC_API int orc_set_3d_instances(void* p, uint32_t mesh, const rfw_instances_dat
     InstanceList& l = o.instance_lists[mesh];
     l.local_aabb = data->local_aabb;
     l.matrices.assign(data->matrices, data->matrices + data->num_matrices);
+    l.skin_ids.assign(data->num_matrices, -1);
+    if (data->skin_ids)
+        for (uint32_t i = 0; i < data->num_matrices && i < data->num_skin_ids; i++) l.skin_ids[i] = data->skin_ids[i];
+    return 0;
+}
+ORC_API int orc_set_skins(void* p, const rfw_skin_data* skins, uint32_t n, const uint32_t* /*changed*/)
+{
+    Oracle& o = *(Oracle*)p;
+    o.skins.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        o.skins[i].resize(skins[i].num_joint_matrices);
+        if (skins[i].num_joint_matrices) std::memcpy(o.skins[i].data(), skins[i].joint_matrices, (size_t)skins[i].num_joint_matrices * 64);
+    }
     return 0;
 }
 ORC_API int orc_set_materials(void* p, const rfw_device_material* m, uint32_t n, const uint32_t* /*changed*/) { ((Oracle*)p)->materials.assign(m, m + n); return 0; }
@@ -1289,30 +1353,49 @@ ORC_API int orc_synchronize(void* p)
 {
     Oracle& o = *(Oracle*)p;
     o.all_tris.clear();
+    auto build = [&](Mesh& m) {
+        std::vector<Box> boxes(m.tris.size());
+        std::vector<float> centers(3 * m.tris.size());
+        for (size_t i = 0; i < m.tris.size(); i++) {
+            const rfw_rt_triangle& t = m.tris[i];
+            boxes[i].reset();
+            boxes[i].grow(&t.vertex0.x);
+            boxes[i].grow(&t.vertex1.x);
+            boxes[i].grow(&t.vertex2.x);
+            // AABB_EPSILON (crates/rfw-scene/src/constants.rs:2): boxes are padded so that a slab test can never cull a
+            // triangle whose Moeller-Trumbore t differs from the box's entry distance by rounding only
+            for (int a = 0; a < 3; a++) { boxes[i].mn[a] -= 1e-4f; boxes[i].mx[a] += 1e-4f; }
+            // RTTriangle::center (crates/rfw-backend/src/structs.rs:985-988)
+            centers[3 * i + 0] = (t.vertex0.x + t.vertex1.x + t.vertex2.x) * (1.0f / 3.0f);
+            centers[3 * i + 1] = (t.vertex0.y + t.vertex1.y + t.vertex2.y) * (1.0f / 3.0f);
+            centers[3 * i + 2] = (t.vertex0.z + t.vertex1.z + t.vertex2.z) * (1.0f / 3.0f);
+        }
+        build_binned_sah(boxes, centers, m.bvh);
+        collapse_mbvh(m.bvh, m.mbvh);
+    };
     for (auto& kv : o.meshes) {
         Mesh& m = kv.second;
         m.tri_offset = (uint32_t)o.all_tris.size();
         o.all_tris.insert(o.all_tris.end(), m.tris.begin(), m.tris.end());
-        if (m.bvh.nodes.empty()) {
-            std::vector<Box> boxes(m.tris.size());
-            std::vector<float> centers(3 * m.tris.size());
-            for (size_t i = 0; i < m.tris.size(); i++) {
-                const rfw_rt_triangle& t = m.tris[i];
-                boxes[i].reset();
-                boxes[i].grow(&t.vertex0.x);
-                boxes[i].grow(&t.vertex1.x);
-                boxes[i].grow(&t.vertex2.x);
-                // AABB_EPSILON (crates/rfw-scene/src/constants.rs:2): boxes are padded so that a slab test can never cull a
-                // triangle whose Moeller-Trumbore t differs from the box's entry distance by rounding only
-                for (int a = 0; a < 3; a++) { boxes[i].mn[a] -= 1e-4f; boxes[i].mx[a] += 1e-4f; }
-                // RTTriangle::center (crates/rfw-backend/src/structs.rs:985-988)
-                centers[3 * i + 0] = (t.vertex0.x + t.vertex1.x + t.vertex2.x) * (1.0f / 3.0f);
-                centers[3 * i + 1] = (t.vertex0.y + t.vertex1.y + t.vertex2.y) * (1.0f / 3.0f);
-                centers[3 * i + 2] = (t.vertex0.z + t.vertex1.z + t.vertex2.z) * (1.0f / 3.0f);
-            }
-            build_binned_sah(boxes, centers, m.bvh);
-            collapse_mbvh(m.bvh, m.mbvh);
+        if (m.bvh.nodes.empty()) build(m);
+    }
+    // D5: one skinned copy per (mesh, skin) pair referenced by an instance, appended after the static meshes
+    o.derived.clear();
+    for (auto& kv : o.instance_lists) {
+        const auto mit = o.meshes.find(kv.first);
+        if (mit == o.meshes.end() || mit->second.skin_data.empty()) continue;
+        for (size_t s2 = 0; s2 < kv.second.matrices.size(); s2++) {
+            const int32_t sk = kv.second.skin_ids[s2];
+            if (sk < 0 || (size_t)sk >= o.skins.size() || o.skins[sk].empty() || is_zero_matrix(kv.second.matrices[s2])) continue;
+            o.derived[std::make_pair(kv.first, sk)];
         }
+    }
+    for (auto& kv : o.derived) {
+        Mesh& d = kv.second;
+        skin_triangles(o.meshes[kv.first.first], o.skins[kv.first.second], d.tris);
+        d.tri_offset = (uint32_t)o.all_tris.size();
+        o.all_tris.insert(o.all_tris.end(), d.tris.begin(), d.tris.end());
+        build(d);
     }
     // instances: global id = mesh_base[mesh] + slot over mesh ids in ascending order (D4)
     o.instances.clear();
@@ -1331,14 +1414,22 @@ ORC_API int orc_synchronize(void* p)
             InstanceDescriptor d;
             d.mesh = mesh_id;
             d.meshp = &o.meshes[mesh_id];
+            rfw_aabb lb = l.local_aabb;
+            const int32_t sk = s < l.skin_ids.size() ? l.skin_ids[s] : -1;
+            const auto dit = o.derived.find(std::make_pair(mesh_id, sk));
+            if (sk >= 0 && dit != o.derived.end()) { // skinned instance: its own geometry and the bounds of the deformed triangles
+                d.meshp = &dit->second;
+                Box sb; sb.reset();
+                for (const rfw_rt_triangle& t : dit->second.tris) { sb.grow(&t.vertex0.x); sb.grow(&t.vertex1.x); sb.grow(&t.vertex2.x); }
+                for (int a = 0; a < 3; a++) { lb.min[a] = sb.mn[a]; lb.max[a] = sb.mx[a]; }
+            }
             std::memcpy(&d.matrix, &l.matrices[s], 64);
             d.inverse = inverse(d.matrix);
             d.normal = transpose(d.inverse);
             // world bounds: the 8 corners of the mesh-local AABB through the matrix
             Box b; b.reset();
             for (int c = 0; c < 8; c++) {
-                const vec4 corner{(c & 1) ? l.local_aabb.max[0] : l.local_aabb.min[0], (c & 2) ? l.local_aabb.max[1] : l.local_aabb.min[1],
-                                  (c & 4) ? l.local_aabb.max[2] : l.local_aabb.min[2], 1.0f};
+                const vec4 corner{(c & 1) ? lb.max[0] : lb.min[0], (c & 2) ? lb.max[1] : lb.min[1], (c & 4) ? lb.max[2] : lb.min[2], 1.0f};
                 const vec4 w = mul(d.matrix, corner);
                 const float pt[3] = {w.x, w.y, w.z};
                 b.grow(pt);
@@ -1455,6 +1546,15 @@ struct orc_stats {
     uint64_t n_tris, n_instances, n_mesh_mbvh_nodes, n_top_mbvh_nodes;
     uint32_t sample_count, pad;
 };
+// the concatenated triangle array after orc_synchronize: static meshes in mesh-id order, then the skinned copies (D5)
+ORC_API uint64_t orc_read_triangles(void* p, rfw_rt_triangle* dst, uint64_t max_tris)
+{
+    Oracle& o = *(Oracle*)p;
+    const uint64_t n = o.all_tris.size() < max_tris ? o.all_tris.size() : max_tris;
+    if (dst && n) std::memcpy(dst, o.all_tris.data(), n * sizeof(rfw_rt_triangle));
+    return o.all_tris.size();
+}
+
 ORC_API int orc_get_stats(void* p, orc_stats* s)
 {
     Oracle& o = *(Oracle*)p;

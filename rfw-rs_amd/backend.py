@@ -136,7 +136,7 @@ class HipBackend:
         t = BackendTable()
         t.instance = self._h
         for name in ("set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
-                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox"):
+                     "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox", "set_skins"):
             setattr(t, name, C.cast(getattr(self._l, "rfw_hip_" + name), C.c_void_p))
         return t
 

@@ -40,4 +40,11 @@ void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t 
 // leaf-ordered traversal packets: packet k = triangle order[k]; tri_id = order[k] + id_offset
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out);
 
+// SkinnedTriangles3D::apply (crates/rfw-backend/src/structs.rs:820-877) on the device: triangle i of `src` blended with the joint
+// matrices selected by the joint data of its own three vertices (skin[3i..3i+2]); writes the deformed triangle to dst[i]
+void launch_skin_triangles(hipStream_t s, const rfw_rt_triangle* src, const rfw_joint_data* skin, const rfw_mat4* joints, uint32_t n_joints,
+                           uint32_t n_tris, rfw_rt_triangle* dst);
+// bounds of n triangles' vertices -> out (one DevBox); scratch = 6 uint32
+void launch_mesh_bounds(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, uint32_t* scratch, DevBox* out);
+
 } // namespace rfwhip

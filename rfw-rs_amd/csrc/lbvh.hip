@@ -318,6 +318,99 @@ __global__ void k_make_packets(const rfw_rt_triangle* __restrict__ tris, const u
     out[k] = p;
 }
 
+// explicit 4x4 inverse, term by term the expansion of k_prepare_instances / oracle.cpp inverse() (-ffp-contract=off)
+__device__ inline void mat4_inverse(const float* m, float* inv)
+{
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    det = 1.0f / det;
+    for (int k = 0; k < 16; k++) inv[k] = inv[k] * det;
+}
+
+__global__ void k_skin_triangles(const rfw_rt_triangle* __restrict__ src, const rfw_joint_data* __restrict__ skin, const rfw_mat4* __restrict__ joints,
+                                 uint32_t n_joints, uint32_t n, rfw_rt_triangle* __restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    rfw_rt_triangle t = src[i];
+    float* vs[3] = {&t.vertex0.x, &t.vertex1.x, &t.vertex2.x};
+    float* ns[3] = {&t.n0.x, &t.n1.x, &t.n2.x};
+    float* ts[3] = {&t.tangent0.x, &t.tangent1.x, &t.tangent2.x};
+    const float tw = t.tangent2.w; // every tangent takes tangent2[3] (structs.rs:838-840, 851-853, 864-866)
+    for (int k = 0; k < 3; k++) {
+        const rfw_joint_data jd = skin[3 * i + k];
+        const float w[4] = {jd.weight.x, jd.weight.y, jd.weight.z, jd.weight.w};
+        float m[16], inv[16];
+        for (int j = 0; j < 4; j++) { // M = w0*J0, then M = M + w_j*J_j, element by element
+            const uint32_t ji = jd.joint[j] < n_joints ? jd.joint[j] : n_joints - 1;
+            const float* J = joints[ji].m;
+            for (int e = 0; e < 16; e++) m[e] = j == 0 ? w[0] * J[e] : m[e] + w[j] * J[e];
+        }
+        mat4_inverse(m, inv);
+        const float x = vs[k][0], y = vs[k][1], z = vs[k][2];
+        const float nx = ns[k][0], ny = ns[k][1], nz = ns[k][2];
+        const float tx = ts[k][0], ty = ts[k][1], tz = ts[k][2];
+        for (int r = 0; r < 3; r++) {
+            vs[k][r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * 1.0f;                       // M * (v, 1)
+            ns[k][r] = ((inv[4 * r] * nx + inv[4 * r + 1] * ny) + inv[4 * r + 2] * nz) + inv[4 * r + 3] * 0.0f; // transpose(inverse(M)) * (n, 0)
+            ts[k][r] = ((inv[4 * r] * tx + inv[4 * r + 1] * ty) + inv[4 * r + 2] * tz) + inv[4 * r + 3] * 0.0f;
+        }
+        ts[k][3] = tw;
+    }
+    // RTTriangle::normal (structs.rs:970-975): normalize(cross(v1 - v0, v2 - v0)), normalize(v) = v * (1 / sqrt(dot))
+    const float ax = t.vertex1.x - t.vertex0.x, ay = t.vertex1.y - t.vertex0.y, az = t.vertex1.z - t.vertex0.z;
+    const float bx = t.vertex2.x - t.vertex0.x, by = t.vertex2.y - t.vertex0.y, bz = t.vertex2.z - t.vertex0.z;
+    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    const float il = 1.0f / __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
+    t.normal.x = cx * il; t.normal.y = cy * il; t.normal.z = cz * il;
+    dst[i] = t;
+}
+
+__global__ void k_bounds_init(uint32_t* scratch)
+{
+    if (threadIdx.x < 3) scratch[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) scratch[threadIdx.x] = 0u;
+}
+__global__ void k_bounds_reduce(const rfw_rt_triangle* __restrict__ tris, uint32_t n, uint32_t* scratch)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < n) {
+        const float4* tp = reinterpret_cast<const float4*>(tris + i);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {c.x, c.y, c.z};
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(va[k], fminf(vb[k], vc[k])); hi[k] = fmaxf(va[k], fmaxf(vb[k], vc[k])); }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_down(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off)); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; k++) { atomicMin(&scratch[k], f_order(lo[k])); atomicMax(&scratch[3 + k], f_order(hi[k])); }
+}
+__global__ void k_bounds_store(const uint32_t* scratch, DevBox* out)
+{
+    if (threadIdx.x == 0) {
+        DevBox b;
+        for (int k = 0; k < 3; k++) { b.lo[k] = f_unorder(scratch[k]); b.hi[k] = f_unorder(scratch[3 + k]); }
+        b.lo[3] = 0.0f; b.hi[3] = 0.0f;
+        *out = b;
+    }
+}
+
 inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 } // namespace
@@ -381,6 +474,18 @@ void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t 
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out)
 {
     if (n) hipLaunchKernelGGL(k_make_packets, dim3(blocks(n)), dim3(kBlock), 0, s, tris, order, n, id_offset, out);
+}
+
+void launch_skin_triangles(hipStream_t s, const rfw_rt_triangle* src, const rfw_joint_data* skin, const rfw_mat4* joints, uint32_t n_joints,
+                           uint32_t n_tris, rfw_rt_triangle* dst)
+{
+    if (n_tris && n_joints) hipLaunchKernelGGL(k_skin_triangles, dim3(blocks(n_tris)), dim3(kBlock), 0, s, src, skin, joints, n_joints, n_tris, dst);
+}
+void launch_mesh_bounds(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, uint32_t* scratch, DevBox* out)
+{
+    hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, scratch);
+    if (n) hipLaunchKernelGGL(k_bounds_reduce, dim3(blocks(n)), dim3(kBlock), 0, s, tris, n, scratch);
+    hipLaunchKernelGGL(k_bounds_store, dim3(1), dim3(64), 0, s, scratch, out);
 }
 
 } // namespace rfwhip

@@ -52,7 +52,15 @@ struct MeshHost {
     std::vector<rfw_rt_triangle> tris;
     HostBvh4 bvh;
     std::vector<TriPacket> packets; // leaf order
+    std::vector<rfw_joint_data> skin; // per vertex (3 per triangle); empty = not skinnable
     bool dirty = true;
+};
+// one skinned copy of a mesh per (mesh id, skin id) pair some instance references (gpu-rt/src/lib.rs:1318-1336 skins the
+// mesh in place; keeping a copy per pair lets two instances of one mesh wear different skins)
+struct DerivedMesh {
+    uint32_t record = 0;      // index in mesh_records (after the static meshes, in (mesh id, skin id) order)
+    uint32_t src_record = 0;  // the static record holding the bind-pose triangles
+    size_t skin_offset = 0;   // first rfw_joint_data of the source mesh in d_skin_data
 };
 struct TexHost {
     uint32_t w = 0, h = 0, mips = 0, format = 0;
@@ -61,6 +69,7 @@ struct TexHost {
 struct InstList {
     rfw_aabb local_aabb{};
     std::vector<rfw_mat4> matrices;
+    std::vector<int32_t> skin_ids; // per slot, -1 = none
 };
 
 enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
@@ -98,6 +107,13 @@ struct Instance {
     std::vector<rfw_directional_light> directional_lights;
     std::vector<TexHost> textures;
     TexHost skybox;
+    std::vector<std::vector<rfw_mat4>> skins; // joint matrices per skin id
+    std::map<std::pair<uint32_t, int32_t>, DerivedMesh> derived;
+    DevBuf<rfw_joint_data> d_skin_data;
+    DevBuf<rfw_mat4> d_joints;
+    DevBuf<uint32_t> d_bounds_scratch;
+    uint32_t raw_node_origin = 0; // d_blas_raw[0] holds node raw_node_origin of the mega-buffer
+    uint32_t max_derived_tris = 0;
     bool meshes_dirty = true, instances_dirty = true, materials_dirty = true, lights_dirty = true, textures_dirty = true;
     bool synchronized = false;
 
@@ -327,6 +343,63 @@ int ensure_lbvh_ws(Instance* I, uint32_t n)
     return RFW_HIP_OK;
 }
 
+// the (mesh id, skin id) pairs that need a skinned copy: the mesh carries joint data, the skin exists and the slot is live
+std::map<std::pair<uint32_t, int32_t>, DerivedMesh> wanted_derived(const Instance* I)
+{
+    std::map<std::pair<uint32_t, int32_t>, DerivedMesh> out;
+    for (const auto& kv : I->inst_lists) {
+        const auto mit = I->meshes.find(kv.first);
+        if (mit == I->meshes.end() || mit->second.skin.empty()) continue;
+        for (size_t s = 0; s < kv.second.matrices.size(); s++) {
+            const int32_t sk = s < kv.second.skin_ids.size() ? kv.second.skin_ids[s] : -1;
+            if (sk < 0 || (size_t)sk >= I->skins.size() || I->skins[sk].empty() || is_zero_matrix(kv.second.matrices[s])) continue;
+            out[std::make_pair(kv.first, sk)];
+        }
+    }
+    return out;
+}
+
+// Appends one record per skinned copy after the static meshes, reserves their regions of the mega-buffers and uploads the joint
+// data of the source meshes.  The triangles, BVH and packets of these records are (re)built on the device by build_instances.
+int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
+{
+    const uint32_t static_nodes = node_total;
+    I->derived = wanted_derived(I);
+    I->max_derived_tris = 0;
+    std::vector<rfw_joint_data> skin_all;
+    std::map<uint32_t, size_t> skin_off;
+    for (auto& kv : I->derived) {
+        DerivedMesh& d = kv.second;
+        d.src_record = I->mesh_index[kv.first.first];
+        const MeshHost& src = I->meshes[kv.first.first];
+        auto so = skin_off.find(kv.first.first);
+        if (so == skin_off.end()) {
+            so = skin_off.emplace(kv.first.first, skin_all.size()).first;
+            skin_all.insert(skin_all.end(), src.skin.begin(), src.skin.end());
+        }
+        d.skin_offset = so->second;
+        MeshRecord r;
+        r.tri_base = tri_total;
+        r.tri_count = (uint32_t)src.tris.size();
+        r.node_base = node_total;
+        r.node_count = std::max<uint32_t>(r.tri_count, 1u);
+        tri_total += r.tri_count;
+        node_total += r.node_count;
+        d.record = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        I->max_derived_tris = std::max(I->max_derived_tris, r.tri_count);
+    }
+    if (I->derived.empty()) return RFW_HIP_OK;
+    if (!I->blas_on_device) { // the host path has no raw-node buffer of its own: keep one for the skinned records only
+        I->raw_node_origin = static_nodes;
+        HIP_TRY(I, I->d_blas_raw.ensure(node_total - static_nodes));
+    }
+    HIP_TRY(I, I->d_blas_order.ensure(tri_total));
+    HIP_TRY(I, I->d_tri_boxes.ensure(I->max_derived_tris));
+    HIP_TRY(I, I->d_bounds_scratch.ensure(8));
+    return upload(I, I->d_skin_data, skin_all.data(), skin_all.size());
+}
+
 // BLAS for every mesh on the device (builder = DEVICE_LBVH): upload the triangles, then boxes -> LBVH -> packets, all on-stream
 int build_blas_device(Instance* I)
 {
@@ -345,6 +418,11 @@ int build_blas_device(Instance* I)
         I->mesh_records.push_back(r);
         kv.second.dirty = false;
     }
+    const uint32_t static_tris = tri_total, static_nodes = node_total;
+    const size_t n_static = I->mesh_records.size();
+    I->raw_node_origin = 0;
+    int rc;
+    if ((rc = layout_derived(I, tri_total, node_total))) return rc;
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
@@ -359,17 +437,18 @@ int build_blas_device(Instance* I)
             HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle),
                                       hipMemcpyHostToDevice, I->stream));
     }
-    HIP_TRY(I, I->d_tri_boxes.ensure(max_n));
-    int rc;
+    HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
-    for (const MeshRecord& r : I->mesh_records) {
+    for (size_t q = 0; q < n_static; q++) {
+        const MeshRecord& r = I->mesh_records[q];
         launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
         HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
                               I->d_blas_order.ptr + r.tri_base, nullptr));
         launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base,
                             I->d_packets.ptr + r.tri_base);
     }
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, node_total);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes);
+    (void)static_tris;
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
@@ -403,9 +482,14 @@ int build_blas_host(Instance* I)
         for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
         tris.insert(tris.end(), m.tris.begin(), m.tris.end());
     }
-    I->n_tris = tris.size();
-    I->n_blas_nodes = nodes.size();
+    uint32_t tri_total = (uint32_t)tris.size(), node_total = (uint32_t)nodes.size();
     int rc;
+    if ((rc = layout_derived(I, tri_total, node_total))) return rc;
+    I->n_tris = tri_total;
+    I->n_blas_nodes = node_total;
+    HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
+    HIP_TRY(I, I->d_packets.ensure(tri_total));
+    HIP_TRY(I, I->d_triangles.ensure(tri_total));
     std::vector<Node4Q> qnodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
     if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
@@ -424,7 +508,12 @@ int build_instances(Instance* I)
     for (auto& kv : I->inst_lists) n_all += kv.second.matrices.size();
     const size_t n_mesh = I->mesh_records.size();
     const size_t off_mats = 0, off_meshof = off_mats + n_all * sizeof(rfw_mat4), off_valid = off_meshof + n_all * 4,
-                 off_local = (off_valid + n_all * 4 + 63) / 64 * 64, total = off_local + std::max<size_t>(n_mesh, 1) * sizeof(DevBox);
+                 off_local = (off_valid + n_all * 4 + 63) / 64 * 64, off_joints = off_local + std::max<size_t>(n_mesh, 1) * sizeof(DevBox);
+    size_t n_joints = 0;
+    std::vector<size_t> joint_off(I->skins.size(), 0);
+    if (!I->derived.empty())
+        for (size_t k = 0; k < I->skins.size(); k++) { joint_off[k] = n_joints; n_joints += I->skins[k].size(); }
+    const size_t total = off_joints + n_joints * sizeof(rfw_mat4);
     if (I->stage_pending) { // the previous frame's async upload must have left the staging block
         HIP_TRY(I, hipEventSynchronize(I->stage_event));
         I->stage_pending = false;
@@ -436,7 +525,11 @@ int build_instances(Instance* I)
     uint32_t* mesh_of = reinterpret_cast<uint32_t*>(st + off_meshof);
     uint32_t* valid = reinterpret_cast<uint32_t*>(st + off_valid);
     DevBox* local = reinterpret_cast<DevBox*>(st + off_local);
+    rfw_mat4* joints = reinterpret_cast<rfw_mat4*>(st + off_joints);
     std::memset(local, 0, std::max<size_t>(n_mesh, 1) * sizeof(DevBox));
+    if (n_joints)
+        for (size_t k = 0; k < I->skins.size(); k++)
+            if (!I->skins[k].empty()) std::memcpy(joints + joint_off[k], I->skins[k].data(), I->skins[k].size() * sizeof(rfw_mat4));
     uint32_t gid = 0, n_valid = 0;
     for (auto& kv : I->inst_lists) {
         const auto mit = I->mesh_index.find(kv.first);
@@ -449,6 +542,11 @@ int build_instances(Instance* I)
         if (cnt) std::memcpy(mats + gid, kv.second.matrices.data(), cnt * sizeof(rfw_mat4));
         for (size_t s = 0; s < cnt; s++, gid++) {
             mesh_of[gid] = mesh_ok ? mit->second : 0xffffffffu;
+            const int32_t sk = s < kv.second.skin_ids.size() ? kv.second.skin_ids[s] : -1;
+            if (mesh_ok && sk >= 0 && !I->derived.empty()) { // skinned slot: its own record (geometry, BVH, bounds)
+                const auto dit = I->derived.find(std::make_pair(kv.first, sk));
+                if (dit != I->derived.end()) mesh_of[gid] = dit->second.record;
+            }
             if (mesh_ok && !is_zero_matrix(kv.second.matrices[s])) valid[n_valid++] = gid; // zero matrix = removed slot (instances_3d.rs:79-86)
         }
     }
@@ -471,6 +569,32 @@ int build_instances(Instance* I)
         HIP_TRY(I, hipMemcpyAsync(I->d_valid_gids.ptr, valid, n_all * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(I, hipMemcpyAsync(I->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
+    if (!I->derived.empty()) {
+        // skinned copies (structs.rs:820-877) and their BLAS, every synchronize: skin -> boxes -> LBVH -> packets -> bounds, all on-stream
+        HIP_TRY(I, I->d_joints.ensure(n_joints));
+        HIP_TRY(I, hipMemcpyAsync(I->d_joints.ptr, joints, n_joints * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
+        if ((rc = ensure_lbvh_ws(I, std::max<uint32_t>(I->max_derived_tris, n_valid)))) return rc;
+        for (const auto& kv : I->derived) {
+            const DerivedMesh& d = kv.second;
+            const MeshRecord& r = I->mesh_records[d.record];
+            const MeshRecord& src = I->mesh_records[d.src_record];
+            rfw_rt_triangle* tris = I->d_triangles.ptr + r.tri_base;
+            Node4* raw = I->d_blas_raw.ptr + (r.node_base - I->raw_node_origin);
+            launch_skin_triangles(s, I->d_triangles.ptr + src.tri_base, I->d_skin_data.ptr + d.skin_offset, I->d_joints.ptr + joint_off[kv.first.second],
+                                  (uint32_t)I->skins[kv.first.second].size(), r.tri_count, tris);
+            launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
+            HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, raw, I->d_blas_order.ptr + r.tri_base, nullptr));
+            launch_make_packets(s, tris, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, r.node_count);
+            launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, I->d_mesh_local.ptr + d.record);
+        }
+        HIP_TRY(I, hipGetLastError());
+        if (!I->tlas_on_device) { // the host TLAS needs the deformed bounds
+            HIP_TRY(I, hipStreamSynchronize(s));
+            for (const auto& kv : I->derived)
+                HIP_TRY(I, hipMemcpy(local + kv.second.record, I->d_mesh_local.ptr + kv.second.record, sizeof(DevBox), hipMemcpyDeviceToHost));
+        }
+    }
     launch_prepare_instances(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)n_all, I->d_xforms.ptr, I->d_normals.ptr);
     if (I->tlas_on_device) {
         HIP_TRY(I, I->d_inst_boxes.ensure(std::max<size_t>(n_valid, 1)));
@@ -527,6 +651,14 @@ int do_synchronize(Instance* I)
     HIP_TRY(I, hipSetDevice(I->device));
     bool any_change = false;
     int rc;
+    if (!I->meshes_dirty && I->instances_dirty) { // a new (mesh, skin) pair needs its region of the mega-buffers
+        const auto want = wanted_derived(I);
+        bool same = want.size() == I->derived.size();
+        if (same)
+            for (auto a = want.cbegin(), b = I->derived.cbegin(); a != want.cend(); ++a, ++b)
+                if (a->first != b->first) { same = false; break; }
+        if (!same) I->meshes_dirty = true;
+    }
     if (I->meshes_dirty) { // BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383)
         const auto t0 = std::chrono::steady_clock::now();
         if ((rc = I->blas_on_device ? build_blas_device(I) : build_blas_host(I))) return rc;
@@ -839,6 +971,7 @@ void rfw_hip_destroy(void* inst)
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
+        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release();
         if (I->stage) (void)hipHostFree(I->stage);
         if (I->stage_event) (void)hipEventDestroy(I->stage_event);
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
@@ -871,6 +1004,9 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
     if (d->num_triangles > kLeafFirstMask) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: more than 2^27 triangles in one mesh");
     MeshHost& m = I->meshes[id];
     m.tris.assign(d->triangles, d->triangles + d->num_triangles); // copy: the borrow ends with this call
+    m.skin.clear();
+    if (d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING))
+        m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
     m.dirty = true;
     I->meshes_dirty = true;
     return RFW_HIP_OK;
@@ -896,6 +1032,9 @@ int rfw_hip_set_3d_instances(void* inst, uint32_t mesh, const rfw_instances_data
     InstList& l = I->inst_lists[mesh];
     l.local_aabb = d->local_aabb;
     l.matrices.assign(d->matrices, d->matrices + d->num_matrices);
+    l.skin_ids.assign(d->num_matrices, -1);
+    if (d->skin_ids)
+        for (uint32_t i = 0; i < d->num_matrices && i < d->num_skin_ids; i++) l.skin_ids[i] = d->skin_ids[i];
     I->instances_dirty = true;
     return RFW_HIP_OK;
 }
@@ -1003,9 +1142,16 @@ int rfw_hip_set_skybox(void* inst, const rfw_texture_data* skybox)
     I->textures_dirty = true;
     return RFW_HIP_OK;
 }
-int rfw_hip_set_skins(void* inst, const rfw_skin_data*, uint32_t, const uint32_t*)
+int rfw_hip_set_skins(void* inst, const rfw_skin_data* skins, uint32_t n, const uint32_t* /*changed*/)
 {
-    LOCK(inst); // accepted and stored nowhere yet: GPU skinning is a "next" row
+    LOCK(inst);
+    if (n && !skins) return fail(I, RFW_HIP_E_INVALID, "set_skins: null data");
+    I->skins.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (skins[i].num_joint_matrices && !skins[i].joint_matrices) return fail(I, RFW_HIP_E_INVALID, "set_skins: null joint matrices");
+        I->skins[i].assign(skins[i].joint_matrices, skins[i].joint_matrices + skins[i].num_joint_matrices);
+    }
+    I->instances_dirty = true; // the skinned copies and their BLAS are rebuilt with the instances (gpu-rt/src/lib.rs:1318-1336)
     return RFW_HIP_OK;
 }
 
@@ -1285,6 +1431,7 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     else if (w == "counters") { src = I->d_counters.ptr; avail = sizeof(QueueCounters); }
     else if (w == "xforms") { src = I->d_xforms.ptr; avail = I->n_instances * sizeof(InstanceXform); }
     else if (w == "normals") { src = I->d_normals.ptr; avail = I->n_instances * sizeof(InstanceNormal); }
+    else if (w == "triangles") { src = I->d_triangles.ptr; avail = I->n_tris * sizeof(rfw_rt_triangle); } // static meshes, then the skinned copies
     else return fail(I, RFW_HIP_E_INVALID, "debug_read: unknown buffer " + w);
     const uint64_t n = std::min(bytes, avail);
     HIP_TRY(I, hipStreamSynchronize(I->stream));

@@ -187,7 +187,7 @@ rfw_mesh_data_3d Mesh3D::as_data() const
     d.vertices = vertices.data(); d.num_vertices = (uint32_t)vertices.size();
     d.triangles = triangles.data(); d.num_triangles = (uint32_t)triangles.size();
     d.ranges = ranges.data(); d.num_ranges = (uint32_t)ranges.size();
-    d.skin_data = nullptr; d.num_skin_data = 0;
+    d.skin_data = skin_data.empty() ? nullptr : skin_data.data(); d.num_skin_data = (uint32_t)skin_data.size();
     d.flags = flags;
     d.bounds = bounds;
     return d;
@@ -394,6 +394,15 @@ rfw_mat4 mat4_from_trs(const float t[3], const float axis_in[3], float angle, fl
 void synchronize_system(Scene& scene, Backend& renderer)
 {
     bool changed = false;
+    if (scene.skins_changed) { // :36 set_skins comes first
+        std::vector<rfw_skin_data> sk;
+        for (const Skin& k : scene.skins)
+            sk.push_back(rfw_skin_data{k.inverse_bind_matrices.data(), (uint32_t)k.inverse_bind_matrices.size(), k.joint_matrices.data(),
+                                       (uint32_t)k.joint_matrices.size()});
+        renderer.set_skins(sk, nullptr);
+        scene.skins_changed = false;
+        changed = true;
+    }
     for (auto& kv : scene.meshes_3d) { // :63-76 changed meshes
         if (!scene.mesh_changed[kv.first]) continue;
         renderer.set_3d_mesh(kv.first, kv.second.as_data());
@@ -1016,6 +1025,87 @@ void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed)
     cam.aperture = 0.0f;
 }
 
+void pose_skins(Scene& scene, float time)
+{
+    // joint k of skin s: rotate about z by an angle growing along the chain, pivoting at the joint's rest position (0, k * 0.5, 0)
+    for (size_t si = 0; si < scene.skins.size(); si++) {
+        Skin& sk = scene.skins[si];
+        rfw_mat4 acc = mat4_identity();
+        for (size_t k = 0; k < sk.joint_matrices.size(); k++) {
+            const float ang = (si == 0 ? 0.35f : -0.25f) * std::sin(time * (1.0f + 0.3f * (float)si) + 0.4f * (float)k);
+            const float piv[3] = {0.0f, 0.5f * (float)k, 0.0f};
+            // local = T(piv) * Rz(ang) * T(-piv); accumulate down the chain
+            const float c = std::cos(ang), sn = std::sin(ang);
+            rfw_mat4 l = mat4_identity();
+            l.m[0] = c; l.m[1] = sn; l.m[4] = -sn; l.m[5] = c;
+            l.m[12] = piv[0] - (c * piv[0] - sn * piv[1]);
+            l.m[13] = piv[1] - (sn * piv[0] + c * piv[1]);
+            rfw_mat4 r;
+            for (int col = 0; col < 4; col++)
+                for (int row = 0; row < 4; row++) {
+                    float v = 0.0f;
+                    for (int i = 0; i < 4; i++) v += acc.m[i * 4 + row] * l.m[col * 4 + i];
+                    r.m[col * 4 + row] = v;
+                }
+            acc = r;
+            sk.joint_matrices[k] = acc;
+        }
+    }
+    scene.skins_changed = true;
+}
+
+void build_skinned(Scene& scene, Camera3D& cam, uint32_t seed)
+{
+    (void)seed;
+    Material wall; wall.color[0] = 0.7f; wall.color[1] = 0.7f; wall.color[2] = 0.65f; wall.roughness = 0.9f;
+    Material skin_m; skin_m.color[0] = 0.85f; skin_m.color[1] = 0.45f; skin_m.color[2] = 0.3f; skin_m.roughness = 0.35f; skin_m.clearcoat = 0.4f;
+    Material light; light.color[0] = 15.0f; light.color[1] = 14.0f; light.color[2] = 12.0f;
+    const int m_wall = (int)scene.add_material(wall), m_skin = (int)scene.add_material(skin_m), m_light = (int)scene.add_material(light);
+    Builder room;
+    room.d.name = "room";
+    room.quad(v3(-4, 0, -4), v3(-4, 0, 4), v3(4, 0, 4), v3(4, 0, -4), m_wall);
+    room.quad(v3(-4, 0, 4), v3(-4, 4, 4), v3(4, 4, 4), v3(4, 0, 4), m_wall);
+    room.quad(v3(-1, 3.9f, -1), v3(1, 3.9f, -1), v3(1, 3.9f, 1), v3(-1, 3.9f, 1), m_light);
+    scene.add_instance(scene.add_mesh(Mesh3D::from(room.d)), mat4_identity());
+    // the tube: radius 0.18, height 2, 4 joints at y = 0, 0.5, 1.0, 1.5; each vertex blends the two nearest joints
+    Builder tube;
+    tube.d.name = "tube";
+    const float PI = 3.14159265358979323846f;
+    tube.surface([&](float u, float v) { const float a = 2 * PI * u; return v3(0.18f * std::cos(a), 2.0f * v, 0.18f * std::sin(a)); }, 14, 16, m_skin, true);
+    Mesh3D tm = Mesh3D::from(tube.d);
+    tm.skin_data.resize(tm.vertices.size());
+    for (size_t i = 0; i < tm.vertices.size(); i++) {
+        const float y = tm.vertices[i].vertex.y, f = std::min(std::max(y / 0.5f, 0.0f), 2.9999f);
+        const uint32_t j0 = (uint32_t)f;
+        const float w1 = f - (float)j0;
+        rfw_joint_data jd;
+        std::memset(&jd, 0, sizeof(jd));
+        jd.joint[0] = j0; jd.joint[1] = j0 + 1; jd.joint[2] = 0; jd.joint[3] = 0;
+        jd.weight = rfw_vec4{1.0f - w1, w1, 0.0f, 0.0f};
+        tm.skin_data[i] = jd;
+    }
+    const uint32_t mesh = scene.add_mesh(tm);
+    for (int k = 0; k < 2; k++) {
+        Skin sk;
+        sk.inverse_bind_matrices.assign(4, mat4_identity());
+        sk.joint_matrices.assign(4, mat4_identity());
+        scene.skins.push_back(sk);
+    }
+    const size_t i0 = scene.add_instance(mesh, mat4_from_translation(-1.2f, 0.0f, 0.5f));
+    const size_t i1 = scene.add_instance(mesh, mat4_from_translation(0.9f, 0.0f, 1.0f));
+    scene.add_instance(mesh, mat4_from_translation(2.4f, 0.0f, -0.5f)); // bind pose, unskinned
+    scene.instances_3d[mesh].skin_ids[i0] = 0;
+    scene.instances_3d[mesh].skin_ids[i1] = 1;
+    pose_skins(scene, 0.7f);
+    scene.update_lights();
+    cam = Camera3D();
+    cam.pos[0] = 0.3f; cam.pos[1] = 1.6f; cam.pos[2] = -5.0f;
+    const V3 d = normalize(v3(0.0f, -0.1f, 1.0f));
+    cam.direction[0] = d.x; cam.direction[1] = d.y; cam.direction[2] = d.z;
+    cam.fov = 55.0f;
+    cam.aperture = 0.0f;
+}
+
 } // namespace rfw
 
 // ==================================================================== C exports (for the Python tests / bench)
@@ -1043,6 +1133,7 @@ struct rfwhost_backend_table {
     int (*set_directional_lights)(void*, const rfw_directional_light*, uint32_t, const uint32_t*);
     int (*set_textures)(void*, const rfw_texture_data*, uint32_t, const uint32_t*);
     int (*set_skybox)(void*, const rfw_texture_data*);
+    int (*set_skins)(void*, const rfw_skin_data*, uint32_t, const uint32_t*);
 };
 struct TableBackend : rfw::Backend {
     rfwhost_backend_table t;
@@ -1088,7 +1179,10 @@ struct TableBackend : rfw::Backend {
     {
         if (t.set_skybox) acc(t.set_skybox(t.instance, &s));
     }
-    void set_skins(const std::vector<rfw_skin_data>&, const std::vector<uint32_t>*) override {}
+    void set_skins(const std::vector<rfw_skin_data>& s, const std::vector<uint32_t>*) override
+    {
+        if (t.set_skins) acc(t.set_skins(t.instance, s.data(), (uint32_t)s.size(), nullptr));
+    }
 };
 } // namespace
 
@@ -1103,6 +1197,7 @@ HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, fl
     else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed);
     else if (k == "soup") rfw::build_soup(h.scene, h.cam, a, b, seed);
     else if (k == "gallery") rfw::build_gallery(h.scene, h.cam, seed);
+    else if (k == "skinned") rfw::build_skinned(h.scene, h.cam, seed);
     else if (k == "spheres") {
         rfw::add_sphere_grid(h.scene, a, b, c);
         h.grid_mesh = h.scene.meshes_3d.rbegin()->first;
@@ -1115,6 +1210,13 @@ HOST_API int rfwhost_animate(void* p, float time)
     HostScene& h = *(HostScene*)p;
     if (h.grid_nx == 0) return -1;
     rfw::animate_sphere_grid(h.scene, h.grid_mesh, h.grid_nx, h.grid_nz, h.grid_spacing, time);
+    return 0;
+}
+HOST_API int rfwhost_pose(void* p, float time)
+{
+    HostScene& h = *(HostScene*)p;
+    if (h.scene.skins.empty()) return -1;
+    rfw::pose_skins(h.scene, time);
     return 0;
 }
 HOST_API int rfwhost_set_camera(void* p, const float* pos, const float* dir, float fov, float aperture, float aspect)
@@ -1135,6 +1237,7 @@ HOST_API int rfwhost_mark_all_changed(void* p)
     h.scene.lights_changed = true;
     h.scene.textures_changed = !h.scene.textures.empty();
     h.scene.skybox_changed = h.scene.skybox.width != 0;
+    h.scene.skins_changed = !h.scene.skins.empty();
     return 0;
 }
 // runs rfw::synchronize_system against a table of C entry points (rfw_hip_* or orc_*)

@@ -144,6 +144,7 @@ struct Mesh3D {
     std::vector<rfw_vertex_3d> vertices;
     std::vector<rfw_rt_triangle> triangles;
     std::vector<rfw_vertex_mesh> ranges;
+    std::vector<rfw_joint_data> skin_data; // per vertex (3 per triangle), empty = not skinnable
     std::vector<uint32_t> materials;
     rfw_aabb bounds;
     uint32_t flags = RFW_MESH_SHADOW_CASTER | RFW_MESH_ALLOW_SKINNING;
@@ -178,7 +179,14 @@ struct Texture {
     void generate_mipmaps(uint32_t levels);
 };
 
+// crates/rfw-backend/src/structs.rs:6-11 SkinData (the joint matrices are what SkinnedTriangles3D::apply consumes)
+struct Skin {
+    std::vector<rfw_mat4> inverse_bind_matrices, joint_matrices;
+};
+
 struct Scene {
+    std::vector<Skin> skins;
+    bool skins_changed = false;
     std::vector<Texture> textures;
     Texture skybox;
     bool textures_changed = false, skybox_changed = false;
@@ -220,6 +228,10 @@ void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32
 void add_sphere_grid(Scene& scene, uint32_t nx, uint32_t nz, float spacing);       // C3: instances of a 320-tri icosphere
 void animate_sphere_grid(Scene& scene, uint32_t mesh, uint32_t nx, uint32_t nz, float spacing, float time); // examples/animated/src/main.rs:197-219
 void build_soup(Scene& scene, Camera3D& cam, uint32_t triangles, uint32_t instances, uint32_t seed); // random soups for BVH equivalence tests
-void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox
+void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed);
+// a skinned tube (4 joints) instanced twice with two different skins + one unskinned instance of the same mesh, in a lit room;
+// pose_skins() bends the joints as a function of time (the graph/animation system of rfw-scene is what does this in the reference)
+void build_skinned(Scene& scene, Camera3D& cam, uint32_t seed);
+void pose_skins(Scene& scene, float time); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox
 
 } // namespace rfw

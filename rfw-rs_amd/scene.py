@@ -14,7 +14,7 @@ class BackendTable(C.Structure):
     """Table of C entry points with the rfw_hip_* signatures (see rfw_host.cpp rfwhost_backend_table)."""
     _fields_ = [("instance", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "set_3d_mesh", "unload_3d_meshes", "set_3d_instances", "set_materials", "synchronize",
-        "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox")]
+        "set_point_lights", "set_spot_lights", "set_area_lights", "set_directional_lights", "set_textures", "set_skybox", "set_skins")]
 
 
 _lib = None
@@ -30,6 +30,7 @@ def host_lib():
         l.rfwhost_scene_destroy.argtypes = [C.c_void_p]
         l.rfwhost_build.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
         l.rfwhost_animate.argtypes = [C.c_void_p, C.c_float]
+        l.rfwhost_pose.argtypes = [C.c_void_p, C.c_float]
         l.rfwhost_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]
         l.rfwhost_set_aspect.argtypes = [C.c_void_p, C.c_float]
         l.rfwhost_camera_view.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(pod.CameraView3D)]
@@ -68,6 +69,10 @@ class Scene:
     def animate(self, time):
         if self._l.rfwhost_animate(self._h, time) != 0:
             raise RuntimeError("scene has no animated instance grid")
+
+    def pose(self, time):
+        if self._l.rfwhost_pose(self._h, time) != 0:
+            raise RuntimeError("scene has no skins")
 
     def set_camera(self, pos, direction, fov=40.0, aperture=0.0, aspect=1.0):
         p = (C.c_float * 3)(*pos)

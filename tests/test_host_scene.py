@@ -38,3 +38,23 @@ def test_sphere_grid_animation_moves_instances():
     s = Scene().build("cornell").build("spheres", 4, 4, 1.0)
     assert s.counts()["instances"] == 17 and s.triangle_count == 36 + 16 * 320
     s.animate(0.5)
+
+
+def test_skinned_scene_poses_change_only_the_skinned_copies():
+    """build_skinned: a floor, a bind-pose tube and two instances of the same tube wearing different skins."""
+    import numpy as np
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import Scene
+    scene = Scene().build("skinned", 0, 0, 0.0, 3)
+    orc = Oracle(32, 24, threads=2)
+    scene.sync(orc)
+    assert orc.stats()["n_tris"] == 6 + 448 + 2 * 448 and orc.validate_bvh() == 0
+    a = orc.triangles().copy()
+    scene.pose(1.3)
+    scene.mark_all_changed()
+    scene.sync(orc)
+    b = orc.triangles()
+    assert orc.validate_bvh() == 0
+    assert np.array_equal(a[:454].view(np.uint32), b[:454].view(np.uint32))      # static meshes: unchanged
+    assert not np.array_equal(a[454:], b[454:])                                  # skinned copies: moved
+    assert not np.array_equal(b[454:902], b[902:])                               # two skins, two shapes

@@ -187,3 +187,82 @@ def test_texture_sampler_known_answers():
     a, b = o.sample_texture(0, 0.2, 0.3, 0.0), o.sample_texture(0, 0.2, 0.3, 1.0)
     got = o.sample_texture(0, 0.2, 0.3, 0.25, trilinear=True)
     assert np.allclose(got, f(0.75) * a + f(0.25) * b, atol=1e-7)
+
+
+def test_skinning_known_answers():
+    """SkinnedTriangles3D::apply (crates/rfw-backend/src/structs.rs:820-877): v' = M (v, 1), n' = transpose(inverse(M)) (n, 0) with
+    M = sum_k w_k J[joint_k]; every tangent takes tangent2.w; the geometric normal is recomputed.  Checked against numpy f64."""
+    rng = np.random.default_rng(4)
+    n_tris = 5
+
+    def rot(axis, a):
+        c, s = math.cos(a), math.sin(a)
+        r = np.eye(4)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+        return r
+
+    joints = [np.eye(4), rot(2, 0.6), rot(0, -0.4)]
+    joints[1][:3, 3] = (0.5, -0.25, 2.0)
+    joints[2][:3, 3] = (-1.0, 0.0, 0.125)
+    joints[2][:3, :3] *= 1.5                                   # non-rigid: normals need the inverse transpose
+    jm = (pod.Mat4 * 3)()
+    for k, j in enumerate(joints):
+        jm[k].m[:] = [float(x) for x in np.asarray(j, np.float32).T.ravel()]     # column-major
+    tris = (pod.RTTriangle * n_tris)()
+    skin = (pod.JointData * (3 * n_tris))()
+    raw = np.frombuffer(tris, dtype=np.float32).reshape(n_tris, 44)
+    raw[:] = rng.uniform(-1, 1, size=raw.shape).astype(np.float32)
+    for v in range(3 * n_tris):
+        w = rng.uniform(0.0, 1.0, 4)
+        w /= w.sum()
+        if v == 0:
+            w = np.array([1.0, 0, 0, 0])                       # vertex 0 of triangle 0: joint 0 = identity only
+        skin[v].joint[:] = [0, 1, 2, 7][: 4] if v else [0, 0, 0, 0]             # joint 7 is out of range -> clamped to the last joint
+        skin[v].weight = pod.Vec4(*[float(x) for x in np.float32(w)])
+    before = raw.copy()
+
+    o = Oracle(8, 8)
+    sd = pod.SkinData(None, 0, jm, 3)
+    assert o._l.orc_set_skins(o._h, C.byref(sd), 1, None) == 0
+    md = pod.MeshData3D()
+    md.triangles, md.num_triangles = tris, n_tris
+    md.skin_data, md.num_skin_data = skin, 3 * n_tris
+    md.flags = 2                                               # ALLOW_SKINNING
+    assert o._l.orc_set_3d_mesh(o._h, 0, C.byref(md)) == 0
+    ident = (pod.Mat4 * 2)()
+    for k in range(2):
+        ident[k].m[:] = [float(x) for x in np.eye(4).ravel()]
+    sid = (C.c_int32 * 2)(0, -1)                               # slot 0 wears skin 0, slot 1 is the bind pose
+    idata = pod.InstancesData3D()
+    idata.matrices, idata.num_matrices, idata.skin_ids, idata.num_skin_ids = ident, 2, sid, 2
+    assert o._l.orc_set_3d_instances(o._h, 0, C.byref(idata)) == 0
+    assert o._l.orc_synchronize(o._h) == 0
+    out = o.triangles()
+    assert out.shape == (2 * n_tris, 44)
+    assert np.array_equal(out[:n_tris].view(np.uint32), before.view(np.uint32))      # the static mesh is untouched
+    sk = out[n_tris:]
+
+    V, N, NRM, T = (0, 4, 8), (16, 20, 24), 12, (28, 32, 36)
+    for i in range(n_tris):
+        pos = []
+        for k in range(3):
+            jd = skin[3 * i + k]
+            w = np.array([jd.weight.x, jd.weight.y, jd.weight.z, jd.weight.w], np.float64)
+            M = sum(w[q] * np.asarray(np.float32(joints[min(jd.joint[q], 2)]), np.float64) for q in range(4))
+            NM = np.linalg.inv(M).T
+            v = M @ np.append(before[i, V[k]:V[k] + 3].astype(np.float64), 1.0)
+            nn = NM @ np.append(before[i, N[k]:N[k] + 3].astype(np.float64), 0.0)
+            tt = NM @ np.append(before[i, T[k]:T[k] + 3].astype(np.float64), 0.0)
+            assert np.allclose(sk[i, V[k]:V[k] + 3], v[:3], rtol=1e-5, atol=1e-5)
+            assert np.allclose(sk[i, N[k]:N[k] + 3], nn[:3], rtol=2e-4, atol=2e-5)
+            assert np.allclose(sk[i, T[k]:T[k] + 3], tt[:3], rtol=2e-4, atol=2e-5)
+            assert sk[i, T[k] + 3] == before[i, T[2] + 3]                        # tangent2.w everywhere
+            pos.append(sk[i, V[k]:V[k] + 3].astype(np.float64))
+        gn = np.cross(pos[1] - pos[0], pos[2] - pos[0])
+        assert np.allclose(sk[i, NRM:NRM + 3], gn / np.linalg.norm(gn), atol=1e-5)
+        # scalars riding in the padding lanes (uv, ids, lod, area) pass through
+        for lane in (3, 7, 11, 15, 19, 23, 27, 40, 41, 42, 43):
+            assert sk[i].view(np.uint32)[lane] == before[i].view(np.uint32)[lane]
+    # identity joint with weight 1: the vertex is reproduced exactly
+    assert np.array_equal(sk[0, 0:3], before[0, 0:3])
