@@ -17,6 +17,7 @@ CASES = {
     "cornell_path3_4spp": ("cornell", 0, 0, 1, 64, 64, 3, 4),
     "soup_instanced_path3_2spp": ("soup", 900, 5, 11, 64, 48, 3, 2),
     "gallery_textured_path3_2spp": ("gallery", 0, 0, 5, 96, 64, 3, 2),
+    "skinned_pose07_path3_2spp": ("skinned", 0, 0, 3, 96, 64, 3, 2),
 }
 
 
@@ -38,7 +39,10 @@ def run_case(case):
 
 def main():
     out = os.path.dirname(os.path.abspath(__file__))
+    only_missing = "--missing" in sys.argv
     for name, case in CASES.items():
+        if only_missing and os.path.exists(os.path.join(out, name + ".npz")):
+            continue
         acc, hits, st = run_case(case)
         np.savez_compressed(os.path.join(out, name + ".npz"), acc=acc, hit_inst=hits["inst"], hit_tri=hits["tri"], hit_t=hits["t"],
                             hit_u=hits["u"], hit_v=hits["v"], rays=np.array([st["primary"], st["extension"], st["shadow"]], dtype=np.int64))
