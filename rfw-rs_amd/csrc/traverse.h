@@ -32,19 +32,49 @@ struct SceneView {
     QueueCounters* counters;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 1 / direction for the slab test only (boxes are padded: an ulp does not matter; the triangle test keeps IEEE division)
+RFW_DI f3 slab_inv(const f3 d)
+{
+#ifdef RFW_SLAB_DIV
+    return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#else
+    return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+#endif
+}
+
 struct TravCounters {
     uint32_t nodes, tris, insts;
 };
 
-RFW_DI uint32_t sel4(const uint4 c, uint32_t i) { return i == 0 ? c.x : (i == 1 ? c.y : (i == 2 ? c.z : c.w)); }
+// child ref by 2-bit index as three selects (no branches)
+RFW_DI uint32_t sel4(const uint4 c, uint32_t i)
+{
+    const bool b0 = (i & 1u) != 0u, b1 = (i & 2u) != 0u;
+    const uint32_t lo = b0 ? c.y : c.x, hi = b0 ? c.w : c.z;
+    return b1 ? hi : lo;
+}
 
-#define RFW_CSWAP(a, b)                       \
-    {                                         \
-        const float lo_ = __builtin_fminf(a, b); \
-        const float hi_ = __builtin_fmaxf(a, b); \
-        a = lo_;                              \
-        b = hi_;                              \
+// Compare-exchange of two sort keys (entry distance bits with the child index in the 2 LSBs; never NaN).
+// FLOAT_ORDER: raw v_min_f32 / v_max_f32 (through asm: the builtin would canonicalise both operands first); otherwise
+// signed-integer order, which is the float order for non-negative keys and puts the children the ray starts inside of
+// (negative entry distance) first in some order.  Either order is a valid traversal order; which one the any-hit and the
+// closest-hit kernels use was chosen by measurement: it changes the generated code, not the answer.
+template <bool FLOAT_ORDER> RFW_DI void cswap(int32_t& a, int32_t& b)
+{
+    int32_t lo, hi;
+    if (FLOAT_ORDER) {
+        asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+        asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    } else {
+        lo = a < b ? a : b;
+        hi = a < b ? b : a;
     }
+    a = lo;
+    b = hi;
+}
+#define RFW_CSWAP(a, b) cswap<ANY_HIT>(a, b);
 
 // Closest hit (ANY_HIT = false): on return t/hu/hv/hit_inst/hit_tri describe the nearest accepted hit, ties resolved
 // to the lowest (instance, triangle) id.  Any hit (ANY_HIT = true): returns true as soon as one triangle has
@@ -54,7 +84,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                      int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
 {
     f3 o = O, d = D;
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 inv = slab_inv(d);
     int sp = 0;
     int blas_sp = -1;          // stack height at BLAS entry; -1 = currently in the TLAS
     int32_t cur_inst = -1;
@@ -84,8 +114,31 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const float Ax = bitsf((w0.w & 0xffu) << 23) * inv.x, Ay = bitsf(((w0.w >> 8) & 0xffu) << 23) * inv.y,
                         Az = bitsf(((w0.w >> 16) & 0xffu) << 23) * inv.z;
             const float Bx = (bitsf(w0.x) - o.x) * inv.x, By = (bitsf(w0.y) - o.y) * inv.y, Bz = (bitsf(w0.z) - o.z) * inv.z;
-            float key[4];
+            int32_t key[4];
             uint32_t nhit = 0;
+#ifndef RFW_SLAB_V1
+            // the ray's direction signs pick the near and the far plane of each axis, so a child costs 6 conversions, 3 packed
+            // FMAs (near, far share scale and offset), one max3 and one min3.  A NaN (0 * inf on an axis-parallel ray) is ignored
+            // by max3 / min3 and only drops that axis' constraint: conservative.
+            const bool mx = inv.x < 0.0f, my = inv.y < 0.0f, mz = inv.z < 0.0f;
+            const uint32_t nxw = mx ? w1.w : w1.x, fxw = mx ? w1.x : w1.w;
+            const uint32_t nyw = my ? w2.x : w1.y, fyw = my ? w1.y : w2.x;
+            const uint32_t nzw = mz ? w2.y : w1.z, fzw = mz ? w1.z : w2.y;
+            const v2f Ax2 = {Ax, Ax}, Ay2 = {Ay, Ay}, Az2 = {Az, Az}, Bx2 = {Bx, Bx}, By2 = {By, By}, Bz2 = {Bz, Bz};
+#define RFW_SLAB(i, CH)                                                                                                               \
+    {                                                                                                                                 \
+        const v2f qx = {(float)((nxw >> (8 * i)) & 0xffu), (float)((fxw >> (8 * i)) & 0xffu)};                                        \
+        const v2f qy = {(float)((nyw >> (8 * i)) & 0xffu), (float)((fyw >> (8 * i)) & 0xffu)};                                        \
+        const v2f qz = {(float)((nzw >> (8 * i)) & 0xffu), (float)((fzw >> (8 * i)) & 0xffu)};                                        \
+        const v2f tx = __builtin_elementwise_fma(qx, Ax2, Bx2), ty = __builtin_elementwise_fma(qy, Ay2, By2),                         \
+                  tz = __builtin_elementwise_fma(qz, Az2, Bz2);                                                                       \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x);                                                          \
+        const float tf = __builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y);                                                          \
+        const bool h = (tf >= tn) & (tn <= t) & (tf >= 0.0f) & (CH != kInvalidRef);                                                   \
+        nhit += h ? 1u : 0u;                                                                                                          \
+        key[i] = h ? (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : (int32_t)(0x7f7ffffcu | (uint32_t)i);                       \
+    }
+#else
 #define RFW_SLAB(i, CH)                                                                                                               \
     {                                                                                                                                 \
         const float ax = __builtin_fmaf((float)((w1.x >> (8 * i)) & 0xffu), Ax, Bx), bx = __builtin_fmaf((float)((w1.w >> (8 * i)) & 0xffu), Ax, Bx); \
@@ -93,10 +146,11 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         const float az = __builtin_fmaf((float)((w1.z >> (8 * i)) & 0xffu), Az, Bz), bz = __builtin_fmaf((float)((w2.y >> (8 * i)) & 0xffu), Az, Bz); \
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)); \
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)); \
-        const bool h = (tf >= tn) && (tn <= t) && (tf >= 0.0f) && (CH != kInvalidRef);                                                \
+        const bool h = (tf >= tn) & (tn <= t) & (tf >= 0.0f) & (CH != kInvalidRef);                                                   \
         nhit += h ? 1u : 0u;                                                                                                          \
-        key[i] = h ? bitsf((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : bitsf(0x7f7ffffcu | (uint32_t)i);                               \
+        key[i] = h ? (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : (int32_t)(0x7f7ffffcu | (uint32_t)i);                       \
     }
+#endif
             RFW_SLAB(0, ch.x)
             RFW_SLAB(1, ch.y)
             RFW_SLAB(2, ch.z)
@@ -111,10 +165,25 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                 RFW_CSWAP(key[0], key[2])
                 RFW_CSWAP(key[1], key[3])
                 RFW_CSWAP(key[1], key[2])
-                if (nhit > 3) push(sel4(ch, fbits(key[3]) & 3u));
-                if (nhit > 2) push(sel4(ch, fbits(key[2]) & 3u));
-                if (nhit > 1) push(sel4(ch, fbits(key[1]) & 3u));
-                cur = sel4(ch, fbits(key[0]) & 3u);
+                cur = sel4(ch, (uint32_t)key[0] & 3u);
+                if (nhit > 1) {
+                    const uint32_t c1 = sel4(ch, (uint32_t)key[1] & 3u), c2 = sel4(ch, (uint32_t)key[2] & 3u), c3 = sel4(ch, (uint32_t)key[3] & 3u);
+                    const int extra = (int)nhit - 1;
+                    if (sp + 3 <= kStackLds) {
+                        // far children go on first: child j (1..3 in sorted order) lands in slot sp + extra - j.  Straight LDS writes,
+                        // no per-push capacity branches; with fewer than 4 hits the third write lands above the new top (never read)
+                        lds_stack[(sp + extra - 1) * kTraceBlock + lane_slot] = c1;
+                        if (nhit > 2) {
+                            lds_stack[(sp + extra - 2) * kTraceBlock + lane_slot] = c2;
+                            lds_stack[(sp + (3 <= extra ? 0 : 2)) * kTraceBlock + lane_slot] = c3;
+                        }
+                        sp += extra;
+                    } else {
+                        if (nhit > 3) push(c3);
+                        if (nhit > 2) push(c2);
+                        push(c1);
+                    }
+                }
                 continue;
             }
         } else if (blas_sp >= 0) {
@@ -122,7 +191,11 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const uint32_t first = cur & kLeafFirstMask, count = ((cur >> 27) & 15u) + 1u;
             const float4* tp = reinterpret_cast<const float4*>(sc.tri_packets + tri_base + first);
             for (uint32_t k = 0; k < count; k++) {
-                const float4 p0 = tp[3 * k], p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
+                float4 p0 = tp[3 * k];
+                const float4 p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
+#ifdef RFW_P0_PIN
+                asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z)); // keep the v0 load next to the edge loads (one round trip, not two)
+#endif
                 if (COUNT) tc.tris++;
                 const f3 v0 = mk3(p0.x, p0.y, p0.z), edge1 = mk3(p1.x, p1.y, p1.z), edge2 = mk3(p2.x, p2.y, p2.z);
                 const f3 h = cross(d, edge2);
@@ -163,7 +236,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             // ray into object space with the inverse instance matrix; direction NOT renormalised (ray_gen.comp:340-341)
             o = xform_rows(r0, r1, r2, O, 1.0f);
             d = xform_rows(r0, r1, r2, D, 0.0f);
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            inv = slab_inv(d);
             node_base = meta.x;
             tri_base = meta.y;
             cur_inst = (int32_t)gid;
@@ -177,7 +250,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             blas_sp = -1;
             o = O;
             d = D;
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            inv = slab_inv(d);
             nodes = sc.tlas_nodes;
             node_base = 0;
         }
