@@ -37,11 +37,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // 1 / direction for the slab test only (boxes are padded: an ulp does not matter; the triangle test keeps IEEE division)
 RFW_DI f3 slab_inv(const f3 d)
 {
-#ifdef RFW_SLAB_DIV
-    return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-#else
     return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-#endif
 }
 
 struct TravCounters {
@@ -116,7 +112,6 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const float Bx = (bitsf(w0.x) - o.x) * inv.x, By = (bitsf(w0.y) - o.y) * inv.y, Bz = (bitsf(w0.z) - o.z) * inv.z;
             int32_t key[4];
             uint32_t nhit = 0;
-#ifndef RFW_SLAB_V1
             // the ray's direction signs pick the near and the far plane of each axis, so a child costs 6 conversions, 3 packed
             // FMAs (near, far share scale and offset), one max3 and one min3.  A NaN (0 * inf on an axis-parallel ray) is ignored
             // by max3 / min3 and only drops that axis' constraint: conservative.
@@ -138,19 +133,6 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         nhit += h ? 1u : 0u;                                                                                                          \
         key[i] = h ? (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : (int32_t)(0x7f7ffffcu | (uint32_t)i);                       \
     }
-#else
-#define RFW_SLAB(i, CH)                                                                                                               \
-    {                                                                                                                                 \
-        const float ax = __builtin_fmaf((float)((w1.x >> (8 * i)) & 0xffu), Ax, Bx), bx = __builtin_fmaf((float)((w1.w >> (8 * i)) & 0xffu), Ax, Bx); \
-        const float ay = __builtin_fmaf((float)((w1.y >> (8 * i)) & 0xffu), Ay, By), by = __builtin_fmaf((float)((w2.x >> (8 * i)) & 0xffu), Ay, By); \
-        const float az = __builtin_fmaf((float)((w1.z >> (8 * i)) & 0xffu), Az, Bz), bz = __builtin_fmaf((float)((w2.y >> (8 * i)) & 0xffu), Az, Bz); \
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz)); \
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz)); \
-        const bool h = (tf >= tn) & (tn <= t) & (tf >= 0.0f) & (CH != kInvalidRef);                                                   \
-        nhit += h ? 1u : 0u;                                                                                                          \
-        key[i] = h ? (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : (int32_t)(0x7f7ffffcu | (uint32_t)i);                       \
-    }
-#endif
             RFW_SLAB(0, ch.x)
             RFW_SLAB(1, ch.y)
             RFW_SLAB(2, ch.z)
@@ -191,11 +173,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const uint32_t first = cur & kLeafFirstMask, count = ((cur >> 27) & 15u) + 1u;
             const float4* tp = reinterpret_cast<const float4*>(sc.tri_packets + tri_base + first);
             for (uint32_t k = 0; k < count; k++) {
-                float4 p0 = tp[3 * k];
-                const float4 p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
-#ifdef RFW_P0_PIN
-                asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z)); // keep the v0 load next to the edge loads (one round trip, not two)
-#endif
+                const float4 p0 = tp[3 * k], p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
                 if (COUNT) tc.tris++;
                 const f3 v0 = mk3(p0.x, p0.y, p0.z), edge1 = mk3(p1.x, p1.y, p1.z), edge2 = mk3(p2.x, p2.y, p2.z);
                 const f3 h = cross(d, edge2);
