@@ -1,0 +1,632 @@
+// gltf.cpp — glTF 2.0 (.gltf + external/embedded buffers, .glb) -> rfw::Scene.
+//
+// The reference imports glTF through the third-party crate l3d 0.3 (crates/rfw-scene/src/loaders/gltf.rs:26-90 calls
+// l3d::LoadInstance and receives MeshDescriptors, Materials and a node list); l3d is not vendored in /root/reference, so
+// this file restates what that hand-over contains, from the glTF 2.0 specification and from how the reference consumes it:
+//   * every glTF mesh -> one MeshDescriptor, all TRIANGLES primitives concatenated and de-indexed (3 vertices per triangle),
+//     per-vertex material id (gltf.rs:77-83 remaps them into the scene's material list), then Mesh3D::from
+//     (crates/rfw-scene/src/objects_3d/mod.rs:673-895: normals generated when absent, RTTriangle lod/area, ranges);
+//   * pbrMetallicRoughness -> Material {color, metallic, roughness}; emissiveFactor (x KHR_materials_emissive_strength)
+//     replaces the colour when it is non-zero, which is how the scene recognises lights (material/list.rs:492-515: rgb > 1);
+//   * the node hierarchy is flattened: every node with a mesh becomes one instance with the node's world matrix
+//     (loaders/gltf.rs:86-88 + graph/mod.rs keep the hierarchy for animation; animation stays outside the backend path);
+//   * JOINTS_0/WEIGHTS_0 -> JointData per vertex, skins -> SkinData with joint_matrices = world(joint) * inverseBind
+//     (graph/mod.rs:592-608), and skinned instances carry the skin id; as glTF prescribes, the transform of a skinned
+//     mesh's own node is ignored (instance matrix = identity).
+// Not read: images/textures (no image decoder in this tree: texture ids stay -1), animations, sparse accessors, morph
+// targets, cameras other than the first perspective one, non-triangle primitive modes.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+
+#include "rfw_host.hpp"
+
+namespace rfw {
+namespace {
+
+// ---------------------------------------------------------------- JSON
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+
+    const Json* get(const char* key) const
+    {
+        if (kind != Obj) return nullptr;
+        for (const auto& kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    bool has(const char* key) const { return get(key) != nullptr; }
+    double number(const char* key, double dflt) const
+    {
+        const Json* j = get(key);
+        return j && j->kind == Num ? j->num : dflt;
+    }
+    int64_t integer(const char* key, int64_t dflt) const
+    {
+        const Json* j = get(key);
+        return j && j->kind == Num ? (int64_t)j->num : dflt;
+    }
+    std::string string(const char* key, const std::string& dflt = "") const
+    {
+        const Json* j = get(key);
+        return j && j->kind == Str ? j->str : dflt;
+    }
+    size_t size() const { return kind == Arr ? arr.size() : 0; }
+};
+
+struct JsonParser {
+    const char* p;
+    const char* end;
+    std::string err;
+    int depth = 0;
+
+    void ws()
+    {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+    }
+    bool fail(const char* m)
+    {
+        if (err.empty()) err = m;
+        return false;
+    }
+    bool parse_string(std::string& out)
+    {
+        if (p >= end || *p != '"') return fail("json: expected string");
+        p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return fail("json: bad escape");
+                switch (*p) {
+                case 'n': out += '\n'; break;
+                case 't': out += '\t'; break;
+                case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'u': {
+                    if (end - p < 5) return fail("json: bad \\u escape");
+                    unsigned v = 0;
+                    for (int k = 1; k <= 4; k++) {
+                        const char c = p[k];
+                        v = v * 16 + (c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f' ? c - 'a' + 10 : (c >= 'A' && c <= 'F' ? c - 'A' + 10 : 0)));
+                    }
+                    p += 4;
+                    if (v < 0x80) out += (char)v;
+                    else if (v < 0x800) { out += (char)(0xC0 | (v >> 6)); out += (char)(0x80 | (v & 0x3F)); }
+                    else { out += (char)(0xE0 | (v >> 12)); out += (char)(0x80 | ((v >> 6) & 0x3F)); out += (char)(0x80 | (v & 0x3F)); }
+                    break;
+                }
+                default: out += *p; break;
+                }
+                p++;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) return fail("json: unterminated string");
+        p++;
+        return true;
+    }
+    bool parse(Json& out)
+    {
+        if (++depth > 64) return fail("json: nesting too deep");
+        ws();
+        if (p >= end) return fail("json: unexpected end");
+        bool ok = true;
+        if (*p == '{') {
+            out.kind = Json::Obj;
+            p++;
+            ws();
+            if (p < end && *p == '}') { p++; }
+            else {
+                for (;;) {
+                    ws();
+                    std::string key;
+                    if (!parse_string(key)) { ok = false; break; }
+                    ws();
+                    if (p >= end || *p != ':') { ok = fail("json: expected ':'"); break; }
+                    p++;
+                    out.obj.emplace_back(key, Json());
+                    if (!parse(out.obj.back().second)) { ok = false; break; }
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == '}') { p++; break; }
+                    ok = fail("json: expected ',' or '}'");
+                    break;
+                }
+            }
+        } else if (*p == '[') {
+            out.kind = Json::Arr;
+            p++;
+            ws();
+            if (p < end && *p == ']') { p++; }
+            else {
+                for (;;) {
+                    out.arr.emplace_back();
+                    if (!parse(out.arr.back())) { ok = false; break; }
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == ']') { p++; break; }
+                    ok = fail("json: expected ',' or ']'");
+                    break;
+                }
+            }
+        } else if (*p == '"') {
+            out.kind = Json::Str;
+            ok = parse_string(out.str);
+        } else if (end - p >= 4 && !std::strncmp(p, "true", 4)) { out.kind = Json::Bool; out.b = true; p += 4; }
+        else if (end - p >= 5 && !std::strncmp(p, "false", 5)) { out.kind = Json::Bool; out.b = false; p += 5; }
+        else if (end - p >= 4 && !std::strncmp(p, "null", 4)) { out.kind = Json::Null; p += 4; }
+        else {
+            const char* q = p;
+            while (q < end && *q != '\0' && (std::strchr("+-0123456789.eE", *q) != nullptr)) q++;
+            if (q == p) ok = fail("json: unexpected character");
+            else {
+                const std::string tok(p, q);
+                char* e = nullptr;
+                out.kind = Json::Num;
+                out.num = std::strtod(tok.c_str(), &e);
+                if (e == tok.c_str()) ok = fail("json: bad number");
+                p = q;
+            }
+        }
+        depth--;
+        return ok;
+    }
+};
+
+// ---------------------------------------------------------------- small helpers
+bool read_file(const std::string& path, std::vector<uint8_t>& out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    if (n < 0) return false;
+    f.seekg(0);
+    out.resize((size_t)n);
+    if (n) f.read(reinterpret_cast<char*>(out.data()), n);
+    return (bool)f;
+}
+
+bool base64_decode(const std::string& s, size_t from, std::vector<uint8_t>& out)
+{
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = from; i < s.size(); i++) {
+        const char c = s[i];
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=') break;
+        else if (c == '\n' || c == '\r' || c == ' ') continue;
+        else return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((uint8_t)((acc >> bits) & 0xffu));
+        }
+    }
+    return true;
+}
+
+std::string dir_of(const std::string& path)
+{
+    const size_t k = path.find_last_of("/\\");
+    return k == std::string::npos ? std::string() : path.substr(0, k + 1);
+}
+
+// column-major 4x4 helpers (double for the hierarchy, rounded once at the end)
+struct M4 {
+    double m[16];
+};
+M4 m4_identity()
+{
+    M4 r{};
+    r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
+    return r;
+}
+M4 m4_mul(const M4& a, const M4& b)
+{
+    M4 r{};
+    for (int c = 0; c < 4; c++)
+        for (int row = 0; row < 4; row++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += a.m[k * 4 + row] * b.m[c * 4 + k];
+            r.m[c * 4 + row] = s;
+        }
+    return r;
+}
+M4 m4_trs(const double t[3], const double q[4], const double s[3])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    M4 r = m4_identity();
+    r.m[0] = (1 - 2 * (y * y + z * z)) * s[0]; r.m[1] = (2 * (x * y + z * w)) * s[0]; r.m[2] = (2 * (x * z - y * w)) * s[0];
+    r.m[4] = (2 * (x * y - z * w)) * s[1]; r.m[5] = (1 - 2 * (x * x + z * z)) * s[1]; r.m[6] = (2 * (y * z + x * w)) * s[1];
+    r.m[8] = (2 * (x * z + y * w)) * s[2]; r.m[9] = (2 * (y * z - x * w)) * s[2]; r.m[10] = (1 - 2 * (x * x + y * y)) * s[2];
+    r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+    return r;
+}
+rfw_mat4 to_f32(const M4& a)
+{
+    rfw_mat4 r;
+    for (int i = 0; i < 16; i++) r.m[i] = (float)a.m[i];
+    return r;
+}
+
+// ---------------------------------------------------------------- the document
+struct Doc {
+    Json root;
+    std::vector<std::vector<uint8_t>> buffers;
+    std::string err;
+
+    bool fail(const std::string& m)
+    {
+        if (err.empty()) err = m;
+        return false;
+    }
+
+    static int components(const std::string& type)
+    {
+        if (type == "SCALAR") return 1;
+        if (type == "VEC2") return 2;
+        if (type == "VEC3") return 3;
+        if (type == "VEC4") return 4;
+        if (type == "MAT4") return 16;
+        return 0;
+    }
+    static int component_bytes(int64_t ct)
+    {
+        switch (ct) {
+        case 5120: case 5121: return 1;
+        case 5122: case 5123: return 2;
+        case 5125: case 5126: return 4;
+        default: return 0;
+        }
+    }
+
+    // accessor -> count x ncomp doubles (integers converted; normalised integers mapped to [0,1] / [-1,1] when `normalise`)
+    bool read_accessor(int64_t index, int want_comp, bool normalise, std::vector<double>& out, size_t& count)
+    {
+        const Json* accs = root.get("accessors");
+        if (!accs || index < 0 || (size_t)index >= accs->size()) return fail("gltf: accessor index out of range");
+        const Json& a = accs->arr[(size_t)index];
+        if (a.has("sparse")) return fail("gltf: sparse accessors are not supported");
+        const int nc = components(a.string("type"));
+        const int64_t ct = a.integer("componentType", 0);
+        const int cb = component_bytes(ct);
+        if (nc == 0 || cb == 0) return fail("gltf: unsupported accessor type");
+        if (want_comp && nc != want_comp) return fail("gltf: accessor has the wrong number of components");
+        count = (size_t)a.integer("count", 0);
+        const bool norm = normalise || (a.get("normalized") && a.get("normalized")->b);
+        out.assign(count * (size_t)nc, 0.0);
+        const int64_t bv_index = a.integer("bufferView", -1);
+        if (bv_index < 0) return true; // all zeros
+        const Json* bvs = root.get("bufferViews");
+        if (!bvs || (size_t)bv_index >= bvs->size()) return fail("gltf: bufferView index out of range");
+        const Json& bv = bvs->arr[(size_t)bv_index];
+        const int64_t bi = bv.integer("buffer", -1);
+        if (bi < 0 || (size_t)bi >= buffers.size()) return fail("gltf: buffer index out of range");
+        const std::vector<uint8_t>& buf = buffers[(size_t)bi];
+        const size_t elem = (size_t)nc * (size_t)cb;
+        size_t stride = (size_t)bv.integer("byteStride", 0);
+        if (stride == 0) stride = elem;
+        const size_t base = (size_t)bv.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0);
+        const size_t view_len = (size_t)bv.integer("byteLength", 0), in_view = (size_t)a.integer("byteOffset", 0);
+        if (count && (stride < elem || in_view + (count - 1) * stride + elem > view_len || base + (count - 1) * stride + elem > buf.size()))
+            return fail("gltf: accessor reads past the end of its buffer view");
+        for (size_t i = 0; i < count; i++) {
+            const uint8_t* src = buf.data() + base + i * stride;
+            for (int c = 0; c < nc; c++) {
+                double v = 0.0;
+                switch (ct) {
+                case 5120: { int8_t x; std::memcpy(&x, src + c, 1); v = norm ? std::max((double)x / 127.0, -1.0) : (double)x; break; }
+                case 5121: { uint8_t x; std::memcpy(&x, src + c, 1); v = norm ? (double)x / 255.0 : (double)x; break; }
+                case 5122: { int16_t x; std::memcpy(&x, src + 2 * c, 2); v = norm ? std::max((double)x / 32767.0, -1.0) : (double)x; break; }
+                case 5123: { uint16_t x; std::memcpy(&x, src + 2 * c, 2); v = norm ? (double)x / 65535.0 : (double)x; break; }
+                case 5125: { uint32_t x; std::memcpy(&x, src + 4 * c, 4); v = (double)x; break; }
+                default: { float x; std::memcpy(&x, src + 4 * c, 4); v = (double)x; break; }
+                }
+                out[i * (size_t)nc + (size_t)c] = v;
+            }
+        }
+        return true;
+    }
+};
+
+bool open_document(const std::string& path, Doc& doc)
+{
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return doc.fail("gltf: cannot read " + path);
+    std::vector<uint8_t> glb_bin;
+    bool have_glb_bin = false;
+    const char* json_begin = reinterpret_cast<const char*>(file.data());
+    size_t json_len = file.size();
+    if (file.size() >= 12 && !std::memcmp(file.data(), "glTF", 4)) { // binary container: header, JSON chunk, optional BIN chunk
+        uint32_t version, total;
+        std::memcpy(&version, file.data() + 4, 4);
+        std::memcpy(&total, file.data() + 8, 4);
+        if (version != 2 || total > file.size()) return doc.fail("gltf: bad GLB header");
+        size_t off = 12;
+        bool have_json = false;
+        while (off + 8 <= total) {
+            uint32_t len, type;
+            std::memcpy(&len, file.data() + off, 4);
+            std::memcpy(&type, file.data() + off + 4, 4);
+            off += 8;
+            if (off + len > total) return doc.fail("gltf: GLB chunk runs past the end of the file");
+            if (type == 0x4E4F534Au && !have_json) { json_begin = reinterpret_cast<const char*>(file.data() + off); json_len = len; have_json = true; }
+            else if (type == 0x004E4942u && !have_glb_bin) { glb_bin.assign(file.begin() + (long)off, file.begin() + (long)(off + len)); have_glb_bin = true; }
+            off += (len + 3u) & ~3u;
+        }
+        if (!have_json) return doc.fail("gltf: GLB without a JSON chunk");
+    }
+    JsonParser jp{json_begin, json_begin + json_len, std::string()};
+    if (!jp.parse(doc.root) || doc.root.kind != Json::Obj) return doc.fail(jp.err.empty() ? "gltf: the document is not a JSON object" : jp.err);
+    const Json* asset = doc.root.get("asset");
+    if (!asset || asset->string("version").substr(0, 1) != "2") return doc.fail("gltf: asset.version 2.x required");
+    const Json* bufs = doc.root.get("buffers");
+    const std::string dir = dir_of(path);
+    for (size_t i = 0; bufs && i < bufs->size(); i++) {
+        const Json& b = bufs->arr[i];
+        std::vector<uint8_t> data;
+        const std::string uri = b.string("uri");
+        if (uri.empty()) {
+            if (i != 0 || !have_glb_bin) return doc.fail("gltf: buffer without uri outside a GLB");
+            data = glb_bin;
+        } else if (uri.compare(0, 5, "data:") == 0) {
+            const size_t comma = uri.find(',');
+            if (comma == std::string::npos || !base64_decode(uri, comma + 1, data)) return doc.fail("gltf: bad data: uri");
+        } else {
+            if (uri.find("..") != std::string::npos || uri[0] == '/') return doc.fail("gltf: buffer uri must stay below the document's directory");
+            if (!read_file(dir + uri, data)) return doc.fail("gltf: cannot read buffer " + uri);
+        }
+        if (data.size() < (size_t)b.integer("byteLength", 0)) return doc.fail("gltf: buffer shorter than its byteLength");
+        doc.buffers.push_back(std::move(data));
+    }
+    return true;
+}
+
+} // namespace
+
+// Adds the document's materials, meshes, instances and skins to `scene` (on top of what it already holds) and, when the
+// document has a perspective camera and `cam` is given, aims `cam` like it.  Returns false and sets `err` on any malformed input.
+bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string& err)
+{
+    Doc doc;
+    if (!open_document(path, doc)) { err = doc.err; return false; }
+    const Json& root = doc.root;
+    auto arr = [&](const char* key) -> const std::vector<Json>& {
+        static const std::vector<Json> empty;
+        const Json* j = root.get(key);
+        return j && j->kind == Json::Arr ? j->arr : empty;
+    };
+
+    // ---- materials (pbrMetallicRoughness; index materials.size() = the glTF default material, created on demand)
+    std::vector<uint32_t> mat_ids;
+    for (const Json& m : arr("materials")) {
+        Material mat;
+        mat.metallic = 1.0f; mat.roughness = 1.0f; // glTF defaults
+        if (const Json* pbr = m.get("pbrMetallicRoughness")) {
+            if (const Json* c = pbr->get("baseColorFactor"))
+                for (size_t k = 0; k < 4 && k < c->size(); k++) mat.color[k] = (float)c->arr[k].num;
+            mat.metallic = (float)pbr->number("metallicFactor", 1.0);
+            mat.roughness = (float)pbr->number("roughnessFactor", 1.0);
+        }
+        double strength = 1.0;
+        if (const Json* ext = m.get("extensions"))
+            if (const Json* es = ext->get("KHR_materials_emissive_strength")) strength = es->number("emissiveStrength", 1.0);
+        if (const Json* e = m.get("emissiveFactor")) {
+            double ev[3] = {0, 0, 0};
+            for (size_t k = 0; k < 3 && k < e->size(); k++) ev[k] = e->arr[k].num * strength;
+            if (ev[0] > 0.0 || ev[1] > 0.0 || ev[2] > 0.0) // an emitter: radiance goes into the colour (material/list.rs:492-515 keys on rgb > 1)
+                for (int k = 0; k < 3; k++) mat.color[k] = (float)ev[k];
+        }
+        if (const Json* ext = m.get("extensions")) {
+            if (const Json* ior = ext->get("KHR_materials_ior")) mat.eta = (float)ior->number("ior", 1.5);
+            if (const Json* tr = ext->get("KHR_materials_transmission")) mat.transmission = (float)tr->number("transmissionFactor", 0.0);
+        }
+        mat_ids.push_back(scene.add_material(mat));
+    }
+    int64_t default_mat = -1;
+    auto material_of = [&](int64_t gltf_index) -> int32_t {
+        if (gltf_index >= 0 && (size_t)gltf_index < mat_ids.size()) return (int32_t)mat_ids[(size_t)gltf_index];
+        if (default_mat < 0) {
+            Material mat;
+            mat.metallic = 1.0f; mat.roughness = 1.0f;
+            default_mat = scene.add_material(mat);
+        }
+        return (int32_t)default_mat;
+    };
+
+    // ---- meshes
+    std::vector<int64_t> mesh_ids; // glTF mesh index -> scene mesh id (-1 = no triangles)
+    for (const Json& m : arr("meshes")) {
+        MeshDescriptor desc;
+        desc.name = m.string("name");
+        std::vector<rfw_joint_data> joints;
+        bool any_normals = false, any_tangents = false, all_skinned = true;
+        const Json* prims = m.get("primitives");
+        for (size_t pi = 0; prims && pi < prims->size(); pi++) {
+            const Json& prim = prims->arr[pi];
+            if (prim.integer("mode", 4) != 4) continue; // points / lines / strips / fans are not part of the path
+            const Json* attrs = prim.get("attributes");
+            if (!attrs || !attrs->has("POSITION")) continue;
+            std::vector<double> pos, nor, uv, tan, jnt, wgt, idx;
+            size_t n_pos = 0, n = 0;
+            if (!doc.read_accessor(attrs->integer("POSITION", -1), 3, false, pos, n_pos)) { err = doc.err; return false; }
+            const bool has_n = attrs->has("NORMAL"), has_uv = attrs->has("TEXCOORD_0"), has_t = attrs->has("TANGENT");
+            const bool has_j = attrs->has("JOINTS_0") && attrs->has("WEIGHTS_0");
+            if (has_n && (!doc.read_accessor(attrs->integer("NORMAL", -1), 3, false, nor, n) || n != n_pos)) { err = doc.err.empty() ? "gltf: NORMAL count differs from POSITION" : doc.err; return false; }
+            if (has_uv && (!doc.read_accessor(attrs->integer("TEXCOORD_0", -1), 2, true, uv, n) || n != n_pos)) { err = doc.err.empty() ? "gltf: TEXCOORD_0 count differs from POSITION" : doc.err; return false; }
+            if (has_t && (!doc.read_accessor(attrs->integer("TANGENT", -1), 4, false, tan, n) || n != n_pos)) { err = doc.err.empty() ? "gltf: TANGENT count differs from POSITION" : doc.err; return false; }
+            if (has_j) {
+                if (!doc.read_accessor(attrs->integer("JOINTS_0", -1), 4, false, jnt, n) || n != n_pos) { err = doc.err.empty() ? "gltf: JOINTS_0 count differs from POSITION" : doc.err; return false; }
+                if (!doc.read_accessor(attrs->integer("WEIGHTS_0", -1), 4, true, wgt, n) || n != n_pos) { err = doc.err.empty() ? "gltf: WEIGHTS_0 count differs from POSITION" : doc.err; return false; }
+            }
+            size_t n_idx = 0;
+            if (prim.has("indices")) {
+                if (!doc.read_accessor(prim.integer("indices", -1), 1, false, idx, n_idx)) { err = doc.err; return false; }
+            } else {
+                n_idx = n_pos;
+                idx.resize(n_pos);
+                for (size_t i = 0; i < n_pos; i++) idx[i] = (double)i;
+            }
+            n_idx -= n_idx % 3;
+            const int32_t mat = material_of(prim.integer("material", -1));
+            // earlier primitives of this mesh without the optional attribute get zeros (normals: the whole mesh is then regenerated)
+            if (has_n && !any_normals) { desc.normals.assign(desc.vertices.size(), rfw_vec3{0, 0, 0}); any_normals = true; }
+            if (has_t && !any_tangents) { desc.tangents.assign(desc.vertices.size(), rfw_vec4{0, 0, 0, 0}); any_tangents = true; }
+            for (size_t k = 0; k < n_idx; k++) {
+                const double di = idx[k];
+                if (!(di >= 0.0) || (size_t)di >= n_pos) { err = "gltf: index out of range"; return false; }
+                const size_t i = (size_t)di;
+                desc.vertices.push_back(rfw_vec4{(float)pos[3 * i], (float)pos[3 * i + 1], (float)pos[3 * i + 2], 1.0f});
+                if (any_normals) desc.normals.push_back(has_n ? rfw_vec3{(float)nor[3 * i], (float)nor[3 * i + 1], (float)nor[3 * i + 2]} : rfw_vec3{0, 0, 0});
+                desc.uvs.push_back(has_uv ? rfw_vec2{(float)uv[2 * i], (float)uv[2 * i + 1]} : rfw_vec2{0, 0});
+                if (any_tangents) desc.tangents.push_back(has_t ? rfw_vec4{(float)tan[4 * i], (float)tan[4 * i + 1], (float)tan[4 * i + 2], (float)tan[4 * i + 3]} : rfw_vec4{0, 0, 0, 0});
+                desc.material_ids.push_back(mat);
+                rfw_joint_data jd{};
+                if (has_j) {
+                    for (int c = 0; c < 4; c++) jd.joint[c] = (uint32_t)jnt[4 * i + (size_t)c];
+                    jd.weight = rfw_vec4{(float)wgt[4 * i], (float)wgt[4 * i + 1], (float)wgt[4 * i + 2], (float)wgt[4 * i + 3]};
+                }
+                joints.push_back(jd);
+            }
+            all_skinned = all_skinned && has_j;
+        }
+        if (desc.vertices.empty()) { mesh_ids.push_back(-1); continue; }
+        if (!any_normals) desc.normals.assign(desc.vertices.size(), rfw_vec3{0, 0, 0}); // Mesh3D::from generates them (objects_3d/mod.rs:680-711)
+        else {
+            // a primitive without normals inside a mesh that has some: zero the first normal so the whole mesh is regenerated consistently
+            bool missing = false;
+            for (const rfw_vec3& nrm : desc.normals) missing = missing || (nrm.x == 0.0f && nrm.y == 0.0f && nrm.z == 0.0f);
+            if (missing) desc.normals.assign(desc.vertices.size(), rfw_vec3{0, 0, 0});
+        }
+        Mesh3D mesh = Mesh3D::from(desc);
+        if (all_skinned && joints.size() == mesh.vertices.size()) mesh.skin_data = joints;
+        mesh_ids.push_back((int64_t)scene.add_mesh(mesh));
+    }
+
+    // ---- node hierarchy -> world matrices
+    const std::vector<Json>& nodes = arr("nodes");
+    std::vector<M4> world(nodes.size(), m4_identity());
+    std::vector<char> visited(nodes.size(), 0);
+    auto local_of = [&](const Json& nd) {
+        if (const Json* mj = nd.get("matrix")) {
+            M4 r = m4_identity();
+            for (size_t k = 0; k < 16 && k < mj->size(); k++) r.m[k] = mj->arr[k].num;
+            return r;
+        }
+        double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+        if (const Json* j = nd.get("translation")) for (size_t k = 0; k < 3 && k < j->size(); k++) t[k] = j->arr[k].num;
+        if (const Json* j = nd.get("rotation")) for (size_t k = 0; k < 4 && k < j->size(); k++) q[k] = j->arr[k].num;
+        if (const Json* j = nd.get("scale")) for (size_t k = 0; k < 3 && k < j->size(); k++) s[k] = j->arr[k].num;
+        return m4_trs(t, q, s);
+    };
+    std::vector<std::pair<size_t, M4>> stack;
+    std::vector<size_t> order; // nodes reachable from the scene, parents first
+    {
+        std::vector<size_t> roots;
+        const std::vector<Json>& scenes = arr("scenes");
+        const size_t si = (size_t)root.integer("scene", 0);
+        if (si < scenes.size()) {
+            if (const Json* rn = scenes[si].get("nodes"))
+                for (const Json& j : rn->arr)
+                    if (j.kind == Json::Num && j.num >= 0 && (size_t)j.num < nodes.size()) roots.push_back((size_t)j.num);
+        } else {
+            std::vector<char> is_child(nodes.size(), 0);
+            for (const Json& nd : nodes)
+                if (const Json* ch = nd.get("children"))
+                    for (const Json& j : ch->arr)
+                        if (j.kind == Json::Num && j.num >= 0 && (size_t)j.num < nodes.size()) is_child[(size_t)j.num] = 1;
+            for (size_t i = 0; i < nodes.size(); i++)
+                if (!is_child[i]) roots.push_back(i);
+        }
+        for (auto it = roots.rbegin(); it != roots.rend(); ++it) stack.emplace_back(*it, m4_identity());
+    }
+    while (!stack.empty()) {
+        const auto [ni, parent] = stack.back();
+        stack.pop_back();
+        if (visited[ni]) continue; // a node graph with a cycle or a shared child is invalid glTF: visit once
+        visited[ni] = 1;
+        world[ni] = m4_mul(parent, local_of(nodes[ni]));
+        order.push_back(ni);
+        if (const Json* ch = nodes[ni].get("children"))
+            for (auto it = ch->arr.rbegin(); it != ch->arr.rend(); ++it)
+                if (it->kind == Json::Num && it->num >= 0 && (size_t)it->num < nodes.size()) stack.emplace_back((size_t)it->num, world[ni]);
+    }
+
+    // ---- skins: joint_matrices = world(joint) * inverseBind
+    std::vector<int32_t> skin_ids;
+    for (const Json& sk : arr("skins")) {
+        Skin skin;
+        const Json* js = sk.get("joints");
+        const size_t nj = js ? js->size() : 0;
+        std::vector<double> ibm;
+        size_t n_ibm = 0;
+        if (sk.has("inverseBindMatrices") && !doc.read_accessor(sk.integer("inverseBindMatrices", -1), 16, false, ibm, n_ibm)) { err = doc.err; return false; }
+        for (size_t j = 0; j < nj; j++) {
+            M4 inv_bind = m4_identity();
+            if (j < n_ibm) std::memcpy(inv_bind.m, ibm.data() + 16 * j, sizeof(inv_bind.m));
+            const double jn = js->arr[j].kind == Json::Num ? js->arr[j].num : -1.0;
+            const M4 jw = (jn >= 0 && (size_t)jn < nodes.size()) ? world[(size_t)jn] : m4_identity();
+            skin.inverse_bind_matrices.push_back(to_f32(inv_bind));
+            skin.joint_matrices.push_back(to_f32(m4_mul(jw, inv_bind)));
+        }
+        skin_ids.push_back((int32_t)scene.skins.size());
+        scene.skins.push_back(std::move(skin));
+        scene.skins_changed = true;
+    }
+
+    // ---- instances, camera
+    bool cam_set = false;
+    for (const size_t ni : order) {
+        const Json& nd = nodes[ni];
+        const int64_t mi = nd.integer("mesh", -1);
+        if (mi >= 0 && (size_t)mi < mesh_ids.size() && mesh_ids[(size_t)mi] >= 0) {
+            const uint32_t mesh = (uint32_t)mesh_ids[(size_t)mi];
+            const int64_t si = nd.integer("skin", -1);
+            const bool skinned = si >= 0 && (size_t)si < skin_ids.size() && !scene.meshes_3d[mesh].skin_data.empty();
+            const size_t slot = scene.add_instance(mesh, skinned ? mat4_identity() : to_f32(world[ni]));
+            if (skinned) {
+                InstanceList3D& l = scene.instances_3d[mesh];
+                if (l.skin_ids.size() <= slot) l.skin_ids.resize(slot + 1, -1);
+                l.skin_ids[slot] = skin_ids[(size_t)si];
+            }
+        }
+        const int64_t ci = nd.integer("camera", -1);
+        if (cam && !cam_set && ci >= 0 && (size_t)ci < arr("cameras").size()) {
+            const Json& cj = arr("cameras")[(size_t)ci];
+            if (const Json* persp = cj.get("perspective")) {
+                const M4& w = world[ni];
+                cam->pos[0] = (float)w.m[12]; cam->pos[1] = (float)w.m[13]; cam->pos[2] = (float)w.m[14];
+                double dz[3] = {-w.m[8], -w.m[9], -w.m[10]}; // a glTF camera looks down its local -Z
+                const double len = std::sqrt(dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2]);
+                if (len > 0.0)
+                    for (int k = 0; k < 3; k++) cam->direction[k] = (float)(dz[k] / len);
+                cam->fov = (float)(persp->number("yfov", 0.6981317) * 180.0 / 3.14159265358979323846);
+                if (persp->has("aspectRatio")) cam->aspect_ratio = (float)persp->number("aspectRatio", 1.0);
+                cam->aperture = 0.0f;
+                cam_set = true;
+            }
+        }
+    }
+    scene.update_lights(); // emissive triangles -> area lights (crates/rfw-scene/src/lib.rs:575-648)
+    return true;
+}
+
+} // namespace rfw

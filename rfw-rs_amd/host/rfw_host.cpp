@@ -1117,6 +1117,7 @@ struct HostScene {
     std::vector<rfw_device_material> dev_mats;
     uint32_t grid_mesh = 0, grid_nx = 0, grid_nz = 0;
     float grid_spacing = 1.0f;
+    std::string error;
 };
 // Backend over a table of C function pointers with the rfw_hip_* signatures: lets the tests drive the product
 // library and the oracle through the SAME synchronize_system.
@@ -1205,6 +1206,21 @@ HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, fl
     } else return -1;
     return 0;
 }
+// glTF 2.0 file (.gltf or .glb) added to the scene; 0 on success, -1 with the message in rfwhost_last_error
+HOST_API int rfwhost_load_gltf(void* p, const char* path, int use_camera)
+{
+    HostScene& h = *(HostScene*)p;
+    if (!path) { h.error = "load_gltf: null path"; return -1; }
+    try {
+        std::string err;
+        if (!rfw::load_gltf(path, h.scene, use_camera ? &h.cam : nullptr, err)) { h.error = err; return -1; }
+    } catch (const std::exception& e) {
+        h.error = std::string("load_gltf: ") + e.what();
+        return -1;
+    }
+    return 0;
+}
+HOST_API const char* rfwhost_last_error(void* p) { return ((HostScene*)p)->error.c_str(); }
 HOST_API int rfwhost_animate(void* p, float time)
 {
     HostScene& h = *(HostScene*)p;

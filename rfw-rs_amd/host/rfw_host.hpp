@@ -232,6 +232,8 @@ void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed);
 // a skinned tube (4 joints) instanced twice with two different skins + one unskinned instance of the same mesh, in a lit room;
 // pose_skins() bends the joints as a function of time (the graph/animation system of rfw-scene is what does this in the reference)
 void build_skinned(Scene& scene, Camera3D& cam, uint32_t seed);
+// glTF 2.0 (.gltf / .glb) -> meshes, materials, instances, skins (gltf.cpp; crates/rfw-scene/src/loaders/gltf.rs:26-90 via l3d)
+bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string& err);
 void pose_skins(Scene& scene, float time); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox
 
 } // namespace rfw

@@ -30,6 +30,9 @@ def host_lib():
         l.rfwhost_scene_destroy.argtypes = [C.c_void_p]
         l.rfwhost_build.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
         l.rfwhost_animate.argtypes = [C.c_void_p, C.c_float]
+        l.rfwhost_load_gltf.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        l.rfwhost_last_error.argtypes = [C.c_void_p]
+        l.rfwhost_last_error.restype = C.c_char_p
         l.rfwhost_pose.argtypes = [C.c_void_p, C.c_float]
         l.rfwhost_set_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float]
         l.rfwhost_set_aspect.argtypes = [C.c_void_p, C.c_float]
@@ -64,6 +67,12 @@ class Scene:
         rc = self._l.rfwhost_build(self._h, kind.encode(), a, b, c, seed)
         if rc != 0:
             raise ValueError(f"unknown scene kind {kind}")
+        return self
+
+    def load_gltf(self, path, use_camera=True):
+        """Adds a glTF 2.0 file (.gltf or .glb) to the scene: meshes, materials, instances, skins, first perspective camera."""
+        if self._l.rfwhost_load_gltf(self._h, os.fsencode(path), 1 if use_camera else 0) != 0:
+            raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
         return self
 
     def animate(self, time):

@@ -1,0 +1,162 @@
+"""Writes small glTF 2.0 documents for the loader tests (authored here, not taken from any asset)."""
+import base64
+import json
+import struct
+
+import numpy as np
+
+
+def cube():
+    """24 vertices with face normals and uvs, 36 indices (two triangles per face), unit cube centred at the origin."""
+    pos, nor, uv, idx = [], [], [], []
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            n = np.zeros(3); n[axis] = sign
+            u = np.zeros(3); u[(axis + 1) % 3] = 1.0
+            v = np.cross(n, u)
+            base = len(pos)
+            for a, b in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+                pos.append(0.5 * (n + a * u + b * v)); nor.append(n); uv.append(((a + 1) / 2, (b + 1) / 2))
+            idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+    return np.array(pos, np.float32), np.array(nor, np.float32), np.array(uv, np.float32), np.array(idx, np.uint16)
+
+
+def quat_y(angle):
+    return [0.0, float(np.sin(angle / 2)), 0.0, float(np.cos(angle / 2))]
+
+
+def build_document(embed=None):
+    """Returns (json dict, binary blob).  A lit room in miniature: a floor quad (no normals, no indices), a scaled / rotated /
+    translated cube under a parent node, and a downward-facing emissive quad (u32 indices) above them; one camera."""
+    cp, cn, cuv, ci = cube()
+    floor = np.array([[-4, 0, -4], [-4, 0, 4], [4, 0, 4], [-4, 0, -4], [4, 0, 4], [4, 0, -4]], np.float32)       # +y facing, 2 triangles, non-indexed
+    lamp = np.array([[-0.5, 0, -0.5], [0.5, 0, -0.5], [0.5, 0, 0.5], [-0.5, 0, 0.5]], np.float32)
+    lamp_idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)                                                       # -y facing (clockwise seen from above)
+    chunks, views, accessors = [], [], []
+    offset = 0
+
+    def add(arr, ctype, atype, target=None, minmax=False):
+        nonlocal offset
+        raw = np.ascontiguousarray(arr).tobytes()
+        pad = (-len(raw)) % 4
+        views.append({"buffer": 0, "byteOffset": offset, "byteLength": len(raw), **({"target": target} if target else {})})
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(arr.shape[0]), "type": atype}
+        if minmax:
+            acc["min"] = [float(x) for x in arr.min(axis=0)]
+            acc["max"] = [float(x) for x in arr.max(axis=0)]
+        accessors.append(acc)
+        chunks.append(raw + b"\0" * pad)
+        offset += len(raw) + pad
+        return len(accessors) - 1
+
+    a_cp = add(cp, 5126, "VEC3", 34962, True); a_cn = add(cn, 5126, "VEC3", 34962); a_cuv = add(cuv, 5126, "VEC2", 34962)
+    a_ci = add(ci, 5123, "SCALAR", 34963)
+    a_fl = add(floor, 5126, "VEC3", 34962, True)
+    a_lp = add(lamp, 5126, "VEC3", 34962, True); a_li = add(lamp_idx, 5125, "SCALAR", 34963)
+    blob = b"".join(chunks)
+    doc = {
+        "asset": {"version": "2.0", "generator": "tests/gltf_util.py"},
+        "scene": 0,
+        "scenes": [{"nodes": [0, 3, 4, 5]}],
+        "nodes": [
+            {"name": "rig", "translation": [0.5, 0.0, 0.25], "rotation": quat_y(np.pi / 2), "scale": [2.0, 2.0, 2.0], "children": [1, 2]},
+            {"name": "cube", "mesh": 0, "translation": [0.0, 0.25, 0.5]},
+            {"name": "cube again", "mesh": 0, "matrix": [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, -0.75, 0.125, 0.0, 1]},
+            {"name": "floor", "mesh": 1},
+            {"name": "lamp", "mesh": 2, "translation": [0.0, 3.0, 0.0]},
+            {"name": "eye", "camera": 0, "translation": [0.0, 1.5, 6.0]},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.7, "znear": 0.01, "aspectRatio": 1.5}}],
+        "meshes": [
+            {"name": "cube", "primitives": [{"attributes": {"POSITION": a_cp, "NORMAL": a_cn, "TEXCOORD_0": a_cuv}, "indices": a_ci, "material": 0}]},
+            {"name": "floor", "primitives": [{"attributes": {"POSITION": a_fl}, "material": 1}]},
+            {"name": "lamp", "primitives": [{"attributes": {"POSITION": a_lp}, "indices": a_li, "material": 2, "mode": 4}]},
+        ],
+        "materials": [
+            {"name": "red", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.1, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.6}},
+            {"name": "grey", "pbrMetallicRoughness": {"baseColorFactor": [0.6, 0.6, 0.6, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.9}},
+            {"name": "emitter", "emissiveFactor": [1.0, 0.9, 0.8], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 12.0}}},
+        ],
+        "accessors": accessors,
+        "bufferViews": views,
+        "buffers": [{"byteLength": len(blob)}],
+    }
+    if embed == "base64":
+        doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    elif embed is None:
+        doc["buffers"][0]["uri"] = "scene.bin"
+    return doc, blob
+
+
+def write_gltf(directory, embed=None, mutate=None):
+    """embed: None -> scene.gltf + scene.bin, "base64" -> scene.gltf with a data: uri, "glb" -> scene.glb.  Returns the path."""
+    doc, blob = build_document(embed)
+    if mutate:
+        mutate(doc)
+    if embed == "glb":
+        js = json.dumps(doc).encode()
+        js += b" " * ((-len(js)) % 4)
+        bin_chunk = blob + b"\0" * ((-len(blob)) % 4)
+        total = 12 + 8 + len(js) + 8 + len(bin_chunk)
+        path = directory / "scene.glb"
+        with open(path, "wb") as f:
+            f.write(b"glTF" + struct.pack("<II", 2, total))
+            f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+            f.write(struct.pack("<II", len(bin_chunk), 0x004E4942) + bin_chunk)
+        return path
+    path = directory / "scene.gltf"
+    path.write_text(json.dumps(doc))
+    if embed is None:
+        (directory / "scene.bin").write_bytes(blob)
+    return path
+
+
+def write_skinned_gltf(directory, bend=0.6):
+    """A vertical strip (4 quads, x in [-0.2, 0.2], y in [0, 2]) bound to two joints: joint 0 at the origin, joint 1 at y = 1 (child
+    of joint 0) rotated by `bend` about z.  Vertices at y <= 0.5 follow joint 0, at y >= 1.5 joint 1, in between they blend linearly.
+    Returns (path, positions (n,3), joints (n,4) u8, weights (n,4), indices)."""
+    ys = np.linspace(0.0, 2.0, 5)
+    pos = np.array([[x, y, 0.0] for y in ys for x in (-0.2, 0.2)], np.float32)
+    idx = []
+    for k in range(4):
+        a, b, c, d = 2 * k, 2 * k + 1, 2 * k + 2, 2 * k + 3
+        idx += [a, b, d, a, d, c]
+    idx = np.array(idx, np.uint8)
+    w1 = np.clip((pos[:, 1] - 0.5) / 1.0, 0.0, 1.0).astype(np.float32)
+    weights = np.stack([1.0 - w1, w1, np.zeros_like(w1), np.zeros_like(w1)], axis=1).astype(np.float32)
+    joints = np.tile(np.array([0, 1, 0, 0], np.uint8), (len(pos), 1))
+    ibm = np.stack([np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)])
+    ibm[1][1, 3] = -1.0                                   # inverse bind of joint 1: translate by -1 in y
+    ibm_cm = np.stack([m.T for m in ibm]).astype(np.float32)   # column-major
+    chunks, views, accessors = [], [], []
+    offset = 0
+
+    def add(arr, ctype, atype):
+        nonlocal offset
+        raw = np.ascontiguousarray(arr).tobytes()
+        pad = (-len(raw)) % 4
+        views.append({"buffer": 0, "byteOffset": offset, "byteLength": len(raw)})
+        accessors.append({"bufferView": len(views) - 1, "componentType": ctype, "count": int(arr.shape[0]), "type": atype})
+        chunks.append(raw + b"\0" * pad)
+        offset += len(raw) + pad
+        return len(accessors) - 1
+
+    a_p = add(pos, 5126, "VEC3"); a_j = add(joints, 5121, "VEC4"); a_w = add(weights, 5126, "VEC4"); a_i = add(idx, 5121, "SCALAR")
+    a_m = add(ibm_cm.reshape(2, 16), 5126, "MAT4")
+    blob = b"".join(chunks)
+    doc = {
+        "asset": {"version": "2.0"},
+        "scenes": [{"nodes": [0, 1]}],
+        "nodes": [
+            {"name": "strip", "mesh": 0, "skin": 0, "translation": [5.0, 5.0, 5.0]},   # ignored for a skinned mesh, as glTF prescribes
+            {"name": "joint0", "children": [2]},
+            {"name": "joint1", "translation": [0.0, 1.0, 0.0], "rotation": [0.0, 0.0, float(np.sin(bend / 2)), float(np.cos(bend / 2))]},
+        ],
+        "skins": [{"joints": [1, 2], "inverseBindMatrices": a_m}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": a_p, "JOINTS_0": a_j, "WEIGHTS_0": a_w}, "indices": a_i}]}],
+        "accessors": accessors, "bufferViews": views,
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+    }
+    path = directory / "skinned.gltf"
+    path.write_text(json.dumps(doc))
+    return path, pos, joints, weights, idx

@@ -1,0 +1,101 @@
+"""glTF 2.0 import of the C++ host (rfw-rs_amd/host/gltf.cpp): the scene that reaches the boundary."""
+import numpy as np
+import pytest
+
+from gltf_util import cube, write_gltf
+from oracle.bindings import Oracle
+from rfw_rs_amd import Scene
+
+
+def load(path):
+    scene = Scene().load_gltf(str(path))
+    orc = Oracle(48, 32, threads=2)
+    scene.sync(orc)
+    return scene, orc
+
+
+def test_meshes_materials_instances_lights(tmp_path):
+    scene, orc = load(write_gltf(tmp_path))
+    c = scene.counts()
+    assert c["meshes"] == 3 and c["materials"] == 3
+    assert c["instances"] == 4                       # two cubes, floor, lamp
+    assert c["area_lights"] == 2                     # the lamp's two emissive triangles
+    assert orc.stats()["n_tris"] == 12 + 2 + 2 and orc.validate_bvh() == 0
+    tris = orc.triangles()                           # mesh-local, de-indexed, meshes in id order: cube, floor, lamp
+    cp, cn, _, ci = cube()
+    assert np.array_equal(tris[:12, [0, 1, 2]], cp[ci[0::3]]) and np.array_equal(tris[:12, [4, 5, 6]], cp[ci[1::3]])
+    assert np.array_equal(tris[:12, [16, 17, 18]], cn[ci[0::3]])          # vertex normals as given
+    assert np.allclose(tris[12:14, 12:15], [0, 1, 0])                      # floor: normals generated, +y
+    assert np.allclose(tris[14:16, 12:15], [0, -1, 0])                     # lamp faces down
+
+
+def test_node_hierarchy_places_the_instances(tmp_path):
+    scene, orc = load(write_gltf(tmp_path))
+    # world = T(.5,0,.25) * Ry(90deg) * S(2) * T(0,.25,.5) for the first cube: local (x,y,z) -> (2(z+.5) + .5, 2(y+.25), -2x + .25)
+    # => centre (1.5, 0.5, 0.25), edge 2: top face at y = 1.5.  Second cube: rig * (0.5 p + (-.75,.125,0)) => centre (0.5, 0.25, 1.75), edge 1: top at 0.75
+    o = np.array([[1.5, 10, 0.25], [0.5, 10, 1.75], [-3, 10, -3], [0.2, 10, 0.1]], np.float32)
+    d = np.tile(np.array([0, -1, 0], np.float32), (4, 1))
+    hit = orc.intersect(o, d, brute=True)
+    assert np.allclose(hit["t"], [8.5, 9.25, 10.0, 7.0], atol=1e-5)       # cube tops, floor, lamp (y = 3, seen from above)
+    assert list(hit["inst"]) == [0, 1, 2, 3]
+    v = scene.view(48, 32)
+    assert np.allclose([v.pos.x, v.pos.y, v.pos.z], [0, 1.5, 6])          # the document's camera
+
+
+@pytest.mark.parametrize("embed", ["base64", "glb"])
+def test_containers_give_the_same_scene(tmp_path, embed):
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    _, ref = load(write_gltf(tmp_path / "a"))
+    _, other = load(write_gltf(tmp_path / "b", embed))
+    assert np.array_equal(ref.triangles().view(np.uint32), other.triangles().view(np.uint32))
+    o = np.random.default_rng(1).uniform(-3, 3, (500, 3)).astype(np.float32); o[:, 1] = 8
+    d = np.tile(np.array([0, -1, 0], np.float32), (500, 1))
+    a, b = ref.intersect(o, d), other.intersect(o, d)
+    assert np.array_equal(a["tri"], b["tri"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))
+
+
+def test_malformed_documents_are_errors_not_crashes(tmp_path):
+    def expect(mutate, text, sub):
+        d = tmp_path / sub
+        d.mkdir()
+        with pytest.raises(ValueError, match=text):
+            Scene().load_gltf(str(write_gltf(d, mutate=mutate)))
+    expect(lambda doc: doc["accessors"][3].update(count=60), "past the end", "a")                 # index accessor longer than its view
+    expect(lambda doc: doc["meshes"][2]["primitives"][0].update(indices=3), "index out of range", "b")  # the cube's indices (0..23) on the 4-vertex lamp
+    expect(lambda doc: doc["asset"].update(version="1.0"), "version", "c")
+    expect(lambda doc: doc["buffers"][0].update(uri="../scene.bin"), "below the document", "d")
+    expect(lambda doc: doc["accessors"][0].update(sparse={"count": 1}), "sparse", "e")
+    bad = tmp_path / "bad.gltf"
+    bad.write_text('{"asset": {"version": "2.0"}, "meshes": [')
+    with pytest.raises(ValueError, match="json"):
+        Scene().load_gltf(str(bad))
+    with pytest.raises(ValueError, match="cannot read"):
+        Scene().load_gltf(str(tmp_path / "missing.gltf"))
+
+
+def test_skinned_document(tmp_path):
+    """JOINTS_0 / WEIGHTS_0 / skins -> JointData + SkinData; the skinned copy the backend sees is M v with
+    M = sum w_k (world(joint_k) * inverseBind_k)."""
+    from gltf_util import write_skinned_gltf
+    bend = 0.6
+    path, pos, joints, weights, idx = write_skinned_gltf(tmp_path, bend)
+    scene, orc = load(path)
+    assert scene.counts()["meshes"] == 1 and scene.counts()["instances"] == 1
+    tris = orc.triangles()
+    assert tris.shape[0] == 16                                   # 8 bind-pose triangles + their skinned copy
+    c, s = np.cos(bend), np.sin(bend)
+    j1 = np.array([[c, -s, 0, 0], [s, c, 0, 1], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)   # world(joint1) = T(0,1,0) Rz(bend)
+    ibm1 = np.eye(4); ibm1[1, 3] = -1.0
+    J = [np.eye(4), j1 @ ibm1]
+    want = []
+    for i in idx:
+        M = sum(float(weights[i, k]) * J[int(joints[i, k])] for k in range(4))
+        want.append((M @ np.append(pos[i].astype(np.float64), 1.0))[:3])
+    want = np.array(want).reshape(8, 3, 3)
+    got = tris[8:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(8, 3, 3)
+    assert np.allclose(got, want, atol=1e-6)
+    assert np.array_equal(tris[:8, [0, 1, 2]], pos[idx[0::3]])   # the bind pose stays as the static mesh
+    # the skinned mesh's own node transform (5,5,5) is ignored: a ray down the bent tip finds it near the origin, not at x = 5
+    tip = want[-1].mean(axis=0)
+    hit = orc.intersect(np.array([[tip[0], tip[1], 4.0]], np.float32), np.array([[0, 0, -1]], np.float32), brute=True)
+    assert hit["inst"][0] == 0 and abs(hit["t"][0] - 4.0) < 1e-4

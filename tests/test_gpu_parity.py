@@ -362,3 +362,29 @@ def test_skin_set_change_relayouts_the_scene():
     assert be.scene_stats()["triangles"] > n0
     assert be.scene_stats()["triangles"] == orc.stats()["n_tris"]
     assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+
+
+@pytest.mark.parametrize("which", ["room", "skinned"])
+def test_gltf_scenes_match_oracle(tmp_path, which):
+    """a glTF document through the C++ host's importer, then the same boundary calls into both backends."""
+    from gltf_util import write_gltf, write_skinned_gltf
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 96, 64
+    path = write_gltf(tmp_path, "glb") if which == "room" else write_skinned_gltf(tmp_path)[0]
+    scene = Scene().load_gltf(str(path))
+    if which == "skinned":
+        scene.build("cornell")                                  # something to light the strip
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3)
+    orc = Oracle(w, h, threads=4, max_path_length=3)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    o, d = random_rays(5000, 3, extent=3.0)
+    assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
+    for _ in range(2):
+        be.render(view); orc.render(view)
+    ga, ra = be.accumulator(), orc.accumulator()
+    assert ra[..., :3].max() > 0
+    assert rel_l2(ga, ra) <= TOL
+    assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
