@@ -21,8 +21,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell", "spheres10k"],
                     help="atrium1m = headline (C4 geometry, primary+shadow); atrium262k = C2; spheres10k = C3 (atrium262k + 10 000 "
                          "animated icosphere instances, synchronize() every frame); cornell = C1 geometry")

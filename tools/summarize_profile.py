@@ -48,6 +48,30 @@ def main():
         json.dump({"note": "means per launch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a "
                            "16-B-per-lane stream; uncalibrated for divergent gathers, so treat as an upper bound there)",
                    "kernels": res}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+    if len(sys.argv) >= 7:
+        # instruction mix: every SQ counter of the two extra passes, mean per launch, plus the derived figures DESIGN.md quotes
+        counters = collections.defaultdict(lambda: collections.defaultdict(list))
+        for d in sys.argv[5:7]:
+            for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+                if "rfwhip" in r["Kernel_Name"]:
+                    short = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rfwhip::", "")
+                    counters[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        res = {}
+        for k, c in sorted(counters.items()):
+            m = {n: sum(v) / len(v) for n, v in c.items()}
+            e = {n: int(v) for n, v in m.items()}
+            valu, waves, gui = m.get("SQ_INSTS_VALU", 0.0), m.get("SQ_WAVES", 0.0), m.get("GRBM_GUI_ACTIVE", 0.0)
+            if valu and waves:
+                e["valu_insts_per_wave"] = round(valu / waves, 1)
+            if valu and m.get("SQ_THREAD_CYCLES_VALU"):
+                e["valu_lane_utilisation"] = round(m["SQ_THREAD_CYCLES_VALU"] / (m.get("SQ_ACTIVE_INST_VALU", valu) * 64.0), 3)
+            if valu and gui:
+                # GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction occupies its SIMD16 for 4 cycles; 1024 SIMDs
+                e["valu_busy_fraction"] = round(valu * 4.0 / (gui / 8.0 * 1024.0), 3)
+            res[k] = e
+        json.dump({"note": "means per launch from two rocprofv3 --pmc passes (instruction counts; VALU activity). valu_busy_fraction = "
+                           "SQ_INSTS_VALU * 4 cycles / (kernel cycles * 1024 SIMDs); valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
+                   "kernels": res}, open(os.path.join(out, f"{tag}_pmc_valu.json"), "w"), indent=1)
     print("wrote profiles/", tag)
 
 
