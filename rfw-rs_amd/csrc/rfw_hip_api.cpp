@@ -142,16 +142,20 @@ struct Instance {
     DevBuf<char> d_lbvh_ws;
     DevBuf<uint32_t> d_blas_order;
     // pinned staging for the per-frame instance upload (truly asynchronous H2D; guarded by stage_event)
-    void* stage = nullptr;
-    size_t stage_bytes = 0;
-    hipEvent_t stage_event = nullptr;
-    bool stage_pending = false;
+    // two blocks used alternately, so the host fills the next frame's block while the previous frame's copy is still queued
+    static constexpr int kStages = 2;
+    void* stage_buf[kStages] = {};
+    size_t stage_cap[kStages] = {};
+    hipEvent_t stage_event[kStages] = {};
+    bool stage_pending[kStages] = {};
+    int stage_next = 0;
+    void* stage = nullptr; // the block of the current synchronize
     bool tlas_on_device = true, blas_on_device = false;
     DevBuf<QueueCounters> d_counters;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
-    float ms_blas_build = 0, ms_tlas_build = 0;
+    float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
 
     // device path state
     DevBuf<float4> d_ray_o[2], d_ray_d[2], d_thr[2], d_sh_o, d_sh_d, d_sh_e, d_acc_slab, d_frame_acc, d_frame_out;
@@ -326,13 +330,17 @@ void build_mesh(Instance* I, MeshHost& m)
 
 int ensure_stage(Instance* I, size_t bytes)
 {
-    if (bytes <= I->stage_bytes) return RFW_HIP_OK;
-    if (I->stage) (void)hipHostFree(I->stage);
+    const int k = I->stage_next;
+    I->stage = I->stage_buf[k];
+    if (bytes <= I->stage_cap[k]) return RFW_HIP_OK;
+    if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
+    I->stage_buf[k] = nullptr;
     I->stage = nullptr;
-    I->stage_bytes = 0;
+    I->stage_cap[k] = 0;
     const size_t want = std::max<size_t>(bytes * 2, 1 << 20);
-    HIP_TRY(I, hipHostMalloc(&I->stage, want, hipHostMallocDefault));
-    I->stage_bytes = want;
+    HIP_TRY(I, hipHostMalloc(&I->stage_buf[k], want, hipHostMallocDefault));
+    I->stage_cap[k] = want;
+    I->stage = I->stage_buf[k];
     return RFW_HIP_OK;
 }
 
@@ -503,6 +511,7 @@ int build_blas_host(Instance* I)
 // instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
 int build_instances(Instance* I)
 {
+    const auto wait0 = std::chrono::steady_clock::now();
     // sizes first, then ONE pinned staging block: [matrices | mesh_of | valid_gids | mesh_local]
     size_t n_all = 0;
     for (auto& kv : I->inst_lists) n_all += kv.second.matrices.size();
@@ -514,10 +523,12 @@ int build_instances(Instance* I)
     if (!I->derived.empty())
         for (size_t k = 0; k < I->skins.size(); k++) { joint_off[k] = n_joints; n_joints += I->skins[k].size(); }
     const size_t total = off_joints + n_joints * sizeof(rfw_mat4);
-    if (I->stage_pending) { // the previous frame's async upload must have left the staging block
-        HIP_TRY(I, hipEventSynchronize(I->stage_event));
-        I->stage_pending = false;
+    if (I->stage_pending[I->stage_next]) { // the upload that last used this block (two synchronizes ago) must have left it
+        HIP_TRY(I, hipEventSynchronize(I->stage_event[I->stage_next]));
+        I->stage_pending[I->stage_next] = false;
     }
+    // back-pressure, not work: a host that runs ahead of the GPU waits here for the copy of two synchronizes ago
+    I->ms_stage_wait = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wait0).count();
     int rc;
     if ((rc = ensure_stage(I, total))) return rc;
     char* st = static_cast<char*>(I->stage);
@@ -607,8 +618,9 @@ int build_instances(Instance* I)
         launch_gather_u32(s, I->d_valid_gids.ptr, I->d_tlas_order.ptr, n_valid, I->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         I->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
-        HIP_TRY(I, hipEventRecord(I->stage_event, s));
-        I->stage_pending = true;
+        HIP_TRY(I, hipEventRecord(I->stage_event[I->stage_next], s));
+        I->stage_pending[I->stage_next] = true;
+        I->stage_next = (I->stage_next + 1) % Instance::kStages;
     } else {
         // host TLAS (builder = HOST_SAH): boxes on the host, binned SAH, upload
         std::vector<PrimBox> boxes(n_valid);
@@ -670,7 +682,8 @@ int do_synchronize(Instance* I)
     if (I->instances_dirty) {
         const auto t0 = std::chrono::steady_clock::now();
         if ((rc = build_instances(I))) return rc;
-        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); // host-side time; the device part is asynchronous
+        // host-side work (the device part is asynchronous), without the time spent waiting for the GPU to release a staging block
+        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() - I->ms_stage_wait;
         I->instances_dirty = false;
         any_change = true;
     }
@@ -947,7 +960,8 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if ((e = hipStreamCreateWithFlags(&I->sub[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
         if ((e = hipEventCreateWithFlags(&I->ev_join[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
-    if ((e = hipEventCreateWithFlags(&I->stage_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (int k = 0; k < Instance::kStages; k++)
+        if ((e = hipEventCreateWithFlags(&I->stage_event[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
         delete I;
@@ -972,8 +986,10 @@ void rfw_hip_destroy(void* inst)
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release();
-        if (I->stage) (void)hipHostFree(I->stage);
-        if (I->stage_event) (void)hipEventDestroy(I->stage_event);
+        for (int k = 0; k < Instance::kStages; k++) {
+            if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
+            if (I->stage_event[k]) (void)hipEventDestroy(I->stage_event[k]);
+        }
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
         I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
         for (auto& ev : I->ring)
