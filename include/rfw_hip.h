@@ -191,6 +191,11 @@ RFW_HIP_API int rfw_hip_occludes(void* instance, const float* origins, const flo
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
 RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);
 
+/* Measured HBM roofline for this device in this job: a float4 device-to-device copy of `bytes` bytes
+ * (rounded down to 16), repeated `iterations` times on the instance's stream and timed with HIP events.
+ * *gb_per_s = 2 * bytes * iterations / time (bytes read + bytes written).  Allocates and frees 2 * bytes of HBM. */
+RFW_HIP_API int rfw_hip_bandwidth_probe(void* instance, uint64_t bytes, uint32_t iterations, double* gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ EXPORTS = [
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
     "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
-    "rfw_hip_debug_read",
+    "rfw_hip_debug_read", "rfw_hip_bandwidth_probe",
 ]
 
 _lib = None
@@ -84,6 +84,7 @@ def hip_lib():
         l.rfw_hip_intersect.argtypes = [vp, vp, vp, f32, f32, u64, vp]
         l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
+        l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
         _lib = l
     return _lib
 
@@ -267,6 +268,12 @@ class HipBackend:
         out = np.empty(len(o), dtype=np.uint8)
         self._check(self._l.rfw_hip_occludes(self._h, o.ctypes.data, d.ctypes.data, t_min, tm.ctypes.data, len(o), out.ctypes.data))
         return out
+
+    def bandwidth_probe(self, nbytes=1 << 30, iterations=20):
+        """Measured device copy bandwidth in GB/s (read + written bytes): the job's own HBM roofline."""
+        out = C.c_double(0.0)
+        self._check(self._l.rfw_hip_bandwidth_probe(self._h, nbytes, iterations, C.byref(out)))
+        return float(out.value)
 
     def debug_read(self, what, nbytes):
         buf = np.empty(nbytes, dtype=np.uint8)

@@ -602,6 +602,15 @@ void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
     if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, s, cam, sc, p, bounce);
 }
+// bandwidth probe: 16 B per lane per access, grid-stride, enough workgroups to cover the 256 CUs several times
+__global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, const uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) dst[i] = src[i];
+}
+void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
+{
+    if (n) hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, s, src, dst, n);
+}
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n)
 {
     if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);

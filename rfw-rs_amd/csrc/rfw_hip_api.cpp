@@ -1456,4 +1456,35 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     return RFW_HIP_OK;
 }
 
+int rfw_hip_bandwidth_probe(void* inst, uint64_t bytes, uint32_t iterations, double* gb_per_s)
+{
+    LOCK(inst);
+    if (!gb_per_s || bytes < 16 || iterations == 0) return fail(I, RFW_HIP_E_INVALID, "bandwidth_probe: bad arguments");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const uint64_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&a, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&b, n * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0x3c, n * 16, I->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        launch_copy_f4(I->stream, a, b, n); // warm
+        (void)hipEventRecord(e0, I->stream);
+        for (uint32_t k = 0; k < iterations; k++) launch_copy_f4(I->stream, (k & 1u) ? b : a, (k & 1u) ? a : b, n);
+        (void)hipEventRecord(e1, I->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e != hipSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("bandwidth_probe: ") + hipGetErrorString(e));
+    *gb_per_s = ms > 0.0f ? 2.0 * (double)(n * 16) * iterations / (ms * 1e-3) / 1e9 : 0.0;
+    return RFW_HIP_OK;
+}
+
 } // extern "C"

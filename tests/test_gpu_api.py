@@ -121,3 +121,13 @@ def test_calls_from_other_threads():
     for _ in range(9):
         orc.render(view)
     assert same(be, orc)
+
+
+def test_bandwidth_probe_reports_a_plausible_hbm_rate():
+    from rfw_rs_amd import HipBackend
+    be = HipBackend.init(64, 64, 1.0)
+    gbs = be.bandwidth_probe(1 << 28, 10)
+    assert 500.0 < gbs < 9000.0, gbs        # MI355X HBM3E: ~8 TB/s peak; a copy reaches a large fraction of it
+    with pytest.raises(Exception):
+        be.bandwidth_probe(0, 1)
+    be.close()
