@@ -256,6 +256,12 @@ def main():
                          "per_kernel": {k: {"ms_sum_per_frame": round(ms[k], 4), "alg_GBps": round(gbs[k], 1), "frac": round(gbs[k] / HBM_PEAK_GBS, 4)} for k in alg},
                          "nodes_per_ray": {"primary": round(cs["nodes_visited"][0] / max(n_prim, 1), 2), "shadow": round(cs["nodes_visited"][2] / max(n_shad, 1), 2)},
                          "tris_per_ray": {"primary": round(cs["tris_tested"][0] / max(n_prim, 1), 2), "shadow": round(cs["tris_tested"][2] / max(n_shad, 1), 2)},
+                         # SIMD efficiency of the traversal, from the instrumented frame: active lanes / 64 per execution of the node test
+                         # and of the triangle test, and what lanes that finished before their wavefront cost (nodes / (64 x max per wave))
+                         "lane_utilisation": {name: {"node_test": round(cs["nodes_visited"][k] / max(64 * cs["node_test_executions"][k], 1), 3),
+                                                     "triangle_test": round(cs["tris_tested"][k] / max(64 * cs["tri_test_executions"][k], 1), 3),
+                                                     "finished_lanes_bound": round(cs["nodes_visited"][k] / max(64 * cs["wave_max_nodes"][k], 1), 3)}
+                                              for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if cs["node_test_executions"][k]},
                          "frame_ms_events": round((iso_ms["ms_total"] / iso_frames) if (iso_ms is not None and iso_frames > 0) else kernel_ms["ms_total"] / nf, 4),
                          "measured": measured,
                          # the timed region as a whole: every kernel's algorithmic bytes of one frame over the wall time per frame

@@ -86,6 +86,12 @@ typedef struct {
     uint32_t bounces;
     uint32_t substreams;        /* launches per kernel per frame: the ms_* kernel figures are sums over them */
     uint32_t pad;
+    /* SIMD efficiency of the traversal per kernel kind, only with RFW_HIP_FLAG_COUNT_TRAVERSAL: how often a wavefront executed the
+     * node test / the triangle test (lane utilisation of the node test = nodes_visited / (64 * node_test_executions)), and the sum
+     * over wavefronts of the largest per-lane node count (nodes_visited / (64 * wave_max_nodes) = what idle finished lanes cost). */
+    uint64_t node_test_executions[3];
+    uint64_t tri_test_executions[3];
+    uint64_t wave_max_nodes[3];
 } rfw_hip_frame_stats;
 
 /* Sizes of the device-resident acceleration structures (for DESIGN.md byte accounting). */

@@ -159,6 +159,9 @@ struct QueueCounters {
     uint32_t shadow[8][kShadowBuckets]; // [bounce][bucket]
     unsigned long long trav[3][3]; // [kind: 0 primary, 1 extend, 2 shadow][0 nodes visited, 1 triangles tested, 2 instances entered]
     unsigned long long overflow, pad;
+    unsigned long long wave_max_nodes[3]; // COUNT mode: sum over wavefronts of the largest per-lane node count (lane utilisation = nodes / (64 * this))
+    unsigned long long wave_exec[3][2];   // COUNT mode: wavefront-level executions of the node test / of the triangle test
+    unsigned long long pad2;
 };
 
 enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };

@@ -64,9 +64,16 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
 {
     if (!COUNT) return;
     // wave reduction, then one atomic per wave
-    unsigned long long n = tc.nodes, t = tc.tris, i = tc.insts;
+    unsigned long long n = tc.nodes, t = tc.tris, i = tc.insts, wn = tc.wave_nodes, wt = tc.wave_tris;
+    uint32_t mx = tc.nodes;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_down(n, off);
+        wn += __shfl_down(wn, off);
+        wt += __shfl_down(wt, off);
         t += __shfl_down(t, off);
         i += __shfl_down(i, off);
     }
@@ -74,6 +81,9 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
         atomicAdd(&qc->trav[kind][0], n);
         atomicAdd(&qc->trav[kind][1], t);
         atomicAdd(&qc->trav[kind][2], i);
+        atomicAdd(&qc->wave_max_nodes[kind], (unsigned long long)mx);
+        atomicAdd(&qc->wave_exec[kind][0], wn);
+        atomicAdd(&qc->wave_exec[kind][1], wt);
     }
 }
 

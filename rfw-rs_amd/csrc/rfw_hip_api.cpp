@@ -1257,6 +1257,9 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
             out->nodes_visited[k] += qc[s].trav[k][0];
             out->tris_tested[k] += qc[s].trav[k][1];
             out->instances_entered[k] += qc[s].trav[k][2];
+            out->node_test_executions[k] += qc[s].wave_exec[k][0];
+            out->tri_test_executions[k] += qc[s].wave_exec[k][1];
+            out->wave_max_nodes[k] += qc[s].wave_max_nodes[k];
         }
     }
     out->sample_count = I->sample_count;

@@ -42,6 +42,9 @@ RFW_DI f3 slab_inv(const f3 d)
 
 struct TravCounters {
     uint32_t nodes, tris, insts;
+    // COUNT mode: times this lane was the first active lane of a node test / triangle test; summed over a wavefront = how often the
+    // wavefront executed that code (lane utilisation of the node test = nodes / (64 * wave_nodes))
+    uint32_t wave_nodes = 0, wave_tris = 0;
 };
 
 // child ref by 2-bit index as three selects (no branches)
@@ -100,12 +103,17 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         return sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot];
     };
 
+    uint32_t iteration = 0;
     for (;;) {
+        iteration++;
         if (!(cur & kLeafBit)) {
             // ---- interior node: 4-wide slab test on the quantised child boxes (64 B = 4 dwordx4 per lane)
             const uint4* np = reinterpret_cast<const uint4*>(nodes + node_base + cur);
             const uint4 w0 = np[0], w1 = np[1], w2 = np[2], ch = np[3];
-            if (COUNT) tc.nodes++;
+            if (COUNT) {
+                tc.nodes++;
+                if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) tc.wave_nodes++;
+            }
             // plane = origin + q * scale  =>  t = q * (scale * inv) + (origin - o) * inv : one cvt + one fma per plane
             const float Ax = bitsf((w0.w & 0xffu) << 23) * inv.x, Ay = bitsf(((w0.w >> 8) & 0xffu) << 23) * inv.y,
                         Az = bitsf(((w0.w >> 16) & 0xffu) << 23) * inv.z;
@@ -169,12 +177,18 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                 continue;
             }
         } else if (blas_sp >= 0) {
+            // Any-hit: the compiled loop takes one stack entry per lane per iteration in lock step, and only ~7 of 64 lanes hold a leaf
+            // at any one iteration (measured).  Leaves wait for the next even iteration, which batches their tests.
+            if (ANY_HIT && (iteration & 1u) != 0u) continue;
             // ---- BLAS leaf: Moeller-Trumbore over the packets (intersection.glsl:1-38 / 40-70)
             const uint32_t first = cur & kLeafFirstMask, count = ((cur >> 27) & 15u) + 1u;
             const float4* tp = reinterpret_cast<const float4*>(sc.tri_packets + tri_base + first);
             for (uint32_t k = 0; k < count; k++) {
                 const float4 p0 = tp[3 * k], p1 = tp[3 * k + 1], p2 = tp[3 * k + 2];
-                if (COUNT) tc.tris++;
+                if (COUNT) {
+                    tc.tris++;
+                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) tc.wave_tris++;
+                }
                 const f3 v0 = mk3(p0.x, p0.y, p0.z), edge1 = mk3(p1.x, p1.y, p1.z), edge2 = mk3(p2.x, p2.y, p2.z);
                 const f3 h = cross(d, edge2);
                 const float a = dot(edge1, h);
