@@ -119,6 +119,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                         Az = bitsf(((w0.w >> 16) & 0xffu) << 23) * inv.z;
             const float Bx = (bitsf(w0.x) - o.x) * inv.x, By = (bitsf(w0.y) - o.y) * inv.y, Bz = (bitsf(w0.z) - o.z) * inv.z;
             int32_t key[4];
+            bool hit[4];
             uint32_t nhit = 0;
             // the ray's direction signs pick the near and the far plane of each axis, so a child costs 6 conversions, 3 packed
             // FMAs (near, far share scale and offset), one max3 and one min3.  A NaN (0 * inf on an axis-parallel ray) is ignored
@@ -139,7 +140,8 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         const float tf = __builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y);                                                          \
         const bool h = (tf >= tn) & (tn <= t) & (tf >= 0.0f) & (CH != kInvalidRef);                                                   \
         nhit += h ? 1u : 0u;                                                                                                          \
-        key[i] = h ? (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i) : (int32_t)(0x7f7ffffcu | (uint32_t)i);                       \
+        hit[i] = h;                                                                                                                   \
+        key[i] = (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i);                                                                  \
     }
             RFW_SLAB(0, ch.x)
             RFW_SLAB(1, ch.y)
@@ -149,14 +151,17 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             if (nhit == 0) {
                 cur = kInvalidRef;
             } else {
-                // sort the 4 keys ascending (misses are FLT_MAX-class keys and sink to the end; +inf | idx would be a NaN); child index rides in the 2 LSBs
-                RFW_CSWAP(key[0], key[1])
-                RFW_CSWAP(key[2], key[3])
-                RFW_CSWAP(key[0], key[2])
-                RFW_CSWAP(key[1], key[3])
-                RFW_CSWAP(key[1], key[2])
-                cur = sel4(ch, (uint32_t)key[0] & 3u);
+                // one hit child (the common case near the leaves): it is the next node, no ordering needed
+                cur = hit[0] ? ch.x : (hit[1] ? ch.y : (hit[2] ? ch.z : ch.w));
                 if (nhit > 1) {
+                    // sort the 4 keys ascending (misses become FLT_MAX-class keys and sink to the end; +inf | idx would be a NaN); child index rides in the 2 LSBs
+                    for (int i = 0; i < 4; i++) key[i] = hit[i] ? key[i] : (int32_t)(0x7f7ffffcu | (uint32_t)i);
+                    RFW_CSWAP(key[0], key[1])
+                    RFW_CSWAP(key[2], key[3])
+                    RFW_CSWAP(key[0], key[2])
+                    RFW_CSWAP(key[1], key[3])
+                    RFW_CSWAP(key[1], key[2])
+                    cur = sel4(ch, (uint32_t)key[0] & 3u);
                     const uint32_t c1 = sel4(ch, (uint32_t)key[1] & 3u), c2 = sel4(ch, (uint32_t)key[2] & 3u), c3 = sel4(ch, (uint32_t)key[3] & 3u);
                     const int extra = (int)nhit - 1;
                     if (sp + 3 <= kStackLds) {
