@@ -42,7 +42,7 @@ enum {
 };
 
 /* BLAS/TLAS builder selection (rfw_hip_options.builder) */
-enum { RFW_HIP_BUILDER_AUTO = 0, RFW_HIP_BUILDER_HOST_SAH = 1, RFW_HIP_BUILDER_DEVICE_LBVH = 2 };
+enum { RFW_HIP_BUILDER_AUTO = 0, RFW_HIP_BUILDER_HOST_SAH = 1, RFW_HIP_BUILDER_DEVICE_LBVH = 2, RFW_HIP_BUILDER_DEVICE_SAH = 3 };
 
 /*
  * Creation options.  Zero-initialise, then set what you need; a NULL pointer
@@ -57,7 +57,8 @@ typedef struct {
     uint32_t rank;             /* tile shard of this instance (multi-GPU): rank in [0, world) */
     uint32_t world;            /* 0/1 = render the whole frame */
     uint32_t tile_size;        /* shard tile edge in pixels; 0 = default 64 */
-    uint32_t builder;          /* RFW_HIP_BUILDER_*; acceleration-structure builder for meshes */
+    uint32_t builder;          /* RFW_HIP_BUILDER_*: AUTO = meshes by binned SAH on the device, TLAS by LBVH on the device; HOST_SAH = both
+                                  levels by binned SAH on the host cores; DEVICE_LBVH = both levels by LBVH; DEVICE_SAH = as AUTO */
     uint32_t flags;            /* RFW_HIP_FLAG_* */
     uint32_t streams;          /* sub-shards (HIP streams) one frame is split into on this GPU; 0 = default 1, max 8 */
 } rfw_hip_options;

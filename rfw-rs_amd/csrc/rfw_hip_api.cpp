@@ -18,6 +18,7 @@
 #include "bvh_host.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "sah_build.h"
 #include "traverse.h"
 
 using namespace rfwhip;
@@ -150,7 +151,9 @@ struct Instance {
     bool stage_pending[kStages] = {};
     int stage_next = 0;
     void* stage = nullptr; // the block of the current synchronize
-    bool tlas_on_device = true, blas_on_device = false;
+    bool tlas_on_device = true, blas_on_device = false, blas_sah_on_device = false;
+    DevBuf<char> d_sah_ws;
+    DevBuf<uint32_t> d_mesh_node_counts;
     DevBuf<QueueCounters> d_counters;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
@@ -447,11 +450,18 @@ int build_blas_device(Instance* I)
     }
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
+    HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
     for (size_t q = 0; q < n_static; q++) {
         const MeshRecord& r = I->mesh_records[q];
         launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
-        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
-                              I->d_blas_order.ptr + r.tri_base, nullptr));
+        if (I->blas_sah_on_device) {
+            HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
+            HIP_TRY(I, sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                 I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost));
+        } else {
+            HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                  I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+        }
         launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base,
                             I->d_packets.ptr + r.tri_base);
     }
@@ -459,9 +469,13 @@ int build_blas_device(Instance* I)
     (void)static_tris;
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
-    I->n_blas_nodes = node_total;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    // nodes actually in use (the regions are sized for the worst case, one node per primitive); skinned copies count at their worst case
+    std::vector<uint32_t> counts(n_static, 0u);
+    if (n_static) HIP_TRY(I, hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
+    I->n_blas_nodes = node_total - static_nodes;
+    for (uint32_t c : counts) I->n_blas_nodes += c;
     return RFW_HIP_OK;
 }
 
@@ -936,7 +950,10 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     }
     // AUTO: BLAS by binned SAH on the host cores (built once per mesh change, best traversal quality), TLAS by LBVH on the device
     // (rebuilt every synchronize()).  HOST_SAH / DEVICE_LBVH force one builder for both levels.
-    I->blas_on_device = I->builder == RFW_HIP_BUILDER_DEVICE_LBVH;
+    // AUTO: meshes by binned SAH on the device (the host builder's tree quality at ~14x its speed), TLAS and skinned copies by LBVH
+    // (no host round trip, so they can be rebuilt every frame without draining the stream)
+    I->blas_on_device = I->builder != RFW_HIP_BUILDER_HOST_SAH;
+    I->blas_sah_on_device = I->builder == RFW_HIP_BUILDER_DEVICE_SAH || I->builder == RFW_HIP_BUILDER_AUTO;
     I->tlas_on_device = I->builder != RFW_HIP_BUILDER_HOST_SAH;
     if (dev < 0) (void)hipGetDevice(&dev);
     I->device = dev;
@@ -985,7 +1002,7 @@ void rfw_hip_destroy(void* inst)
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
-        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release();
+        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release();
         for (int k = 0; k < Instance::kStages; k++) {
             if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
             if (I->stage_event[k]) (void)hipEventDestroy(I->stage_event[k]);

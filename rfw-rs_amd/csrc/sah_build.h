@@ -1,0 +1,23 @@
+// sah_build.h — binned-SAH BVH construction on the device (sah_build.hip): the quality of the host builder (bvh_host.cpp) at
+// device speed, for static meshes and for meshes rebuilt every frame alike.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_types.h"
+#include "lbvh.h" // DevBox
+
+namespace rfwhip {
+
+// bytes of scratch sah_build needs for n primitives
+size_t sah_workspace_bytes(uint32_t n);
+
+// Builds a BVH4 over boxes[0..n) on `stream`.  nodes_out needs room for max(n, 1) nodes, prim_order_out for n entries (leaf refs
+// index into it).  Synchronises the stream once per level of the upper tree (a 4-byte read-back), so it is a blocking call.
+// max_leaf <= kMaxLeafTris; trav_cost as in build_bvh4_host.
+hipError_t sah_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
+                     uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */, int max_leaf, float trav_cost);
+
+} // namespace rfwhip

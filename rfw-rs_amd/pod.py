@@ -146,3 +146,4 @@ RFW_HIP_FLAG_COUNT_TRAVERSAL = 2
 RFW_HIP_BUILDER_AUTO = 0
 RFW_HIP_BUILDER_HOST_SAH = 1
 RFW_HIP_BUILDER_DEVICE_LBVH = 2
+RFW_HIP_BUILDER_DEVICE_SAH = 3

@@ -248,7 +248,7 @@ def test_animated_instances_match_oracle():
     assert be.scene_stats()["instances"] == 31
 
 
-@pytest.mark.parametrize("builder", [1, 2])  # HOST_SAH (both levels on the host), DEVICE_LBVH (both levels on the device); 0 = AUTO is the default elsewhere
+@pytest.mark.parametrize("builder", [1, 2, 3])  # DEVICE_SAH = 3 (BLAS by binned SAH on the device); HOST_SAH (both levels on the host), DEVICE_LBVH (both levels on the device); 0 = AUTO is the default elsewhere
 def test_builders_give_identical_answers(builder):
     """Metamorphic: the image and the ray queries are functions of the scene, not of the acceleration structure."""
     w, h = 96, 64
@@ -264,14 +264,14 @@ def test_builders_give_identical_answers(builder):
     assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
 
 
-def test_device_lbvh_on_large_mesh_matches_host_sah():
+def test_device_builders_on_large_mesh_match_host_sah():
     from rfw_rs_amd import HipBackend, Scene
     w, h = 480, 270
     scene = Scene().build("atrium", 262267, 0, 0.0, 0xC0FFEE)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
     accs = []
-    for builder in (1, 2):
+    for builder in (1, 2, 3):
         be = HipBackend.init(w, h, 1.0, max_path_length=2, builder=builder)
         scene.mark_all_changed()
         scene.sync(be)
@@ -280,7 +280,8 @@ def test_device_lbvh_on_large_mesh_matches_host_sah():
         st = be.scene_stats()
         assert st["triangles"] > 250000 and st["blas_nodes"] > 0
         be.close()
-    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))   # host SAH == device LBVH
+    assert np.array_equal(accs[0].view(np.uint32), accs[2].view(np.uint32))   # host SAH == device SAH
 
 
 @pytest.mark.parametrize("streams", [1, 3, 8])
