@@ -160,3 +160,22 @@ def write_skinned_gltf(directory, bend=0.6):
     path = directory / "skinned.gltf"
     path.write_text(json.dumps(doc))
     return path, pos, joints, weights, idx
+
+
+def write_duplicates_gltf(directory, copies=3000):
+    """One triangle repeated `copies` times (coincident centroids: no SAH plane separates them) next to a second, distinct one."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 0, 1], [3, 0, 1], [2, 1, 1]], np.float32)
+    idx = np.concatenate([np.tile(np.array([0, 1, 2], np.uint32), copies), np.array([3, 4, 5], np.uint32)])
+    raw_p, raw_i = pos.tobytes(), idx.tobytes()
+    blob = raw_p + raw_i
+    doc = {
+        "asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 6, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5125, "count": int(len(idx)), "type": "SCALAR"}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(raw_p)}, {"buffer": 0, "byteOffset": len(raw_p), "byteLength": len(raw_i)}],
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+    }
+    path = directory / "dups.gltf"
+    path.write_text(json.dumps(doc))
+    return path

@@ -389,3 +389,25 @@ def test_gltf_scenes_match_oracle(tmp_path, which):
     assert ra[..., :3].max() > 0
     assert rel_l2(ga, ra) <= TOL
     assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
+
+
+@pytest.mark.parametrize("builder", [1, 2, 3])
+def test_coincident_primitives_do_not_break_the_builders(tmp_path, builder):
+    """3000 copies of one triangle: every centroid in one bin on every axis, so the SAH builders fall back to halving ranges; the
+    closest hit is the lowest triangle id among the exact ties."""
+    from gltf_util import write_duplicates_gltf
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().load_gltf(str(write_duplicates_gltf(tmp_path)))
+    be = HipBackend.init(32, 32, 1.0, builder=builder)
+    orc = Oracle(32, 32, threads=2)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    assert be.scene_stats()["triangles"] == 3001
+    rng = np.random.default_rng(2)
+    o = np.stack([rng.uniform(-0.5, 3.5, 4000), rng.uniform(-0.5, 1.5, 4000), np.full(4000, -2.0)], axis=1).astype(np.float32)
+    d = np.tile(np.array([0, 0, 1], np.float32), (4000, 1))
+    g = be.intersect(o, d)
+    assert_hits_equal(g, orc.intersect(o, d, brute=True))
+    hit_dups = (g["tri"] >= 0) & (g["tri"] < 3000)
+    assert hit_dups.sum() > 100 and np.all(g["tri"][hit_dups] == 0)      # exact ties -> lowest id
+    assert (g["tri"] == 3000).sum() > 100
