@@ -1467,6 +1467,8 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     else if (w == "counters") { src = I->d_counters.ptr; avail = sizeof(QueueCounters); }
     else if (w == "xforms") { src = I->d_xforms.ptr; avail = I->n_instances * sizeof(InstanceXform); }
     else if (w == "normals") { src = I->d_normals.ptr; avail = I->n_instances * sizeof(InstanceNormal); }
+    else if (w == "blas_raw") { src = I->d_blas_raw.ptr; avail = (uint64_t)I->d_blas_raw.cap * sizeof(Node4); }       // device builders: f32 nodes before quantisation
+    else if (w == "blas_order") { src = I->d_blas_order.ptr; avail = (uint64_t)I->d_blas_order.cap * 4; }           // leaf-ordered primitive ids per mesh
     else if (w == "triangles") { src = I->d_triangles.ptr; avail = I->n_tris * sizeof(rfw_rt_triangle); } // static meshes, then the skinned copies
     else return fail(I, RFW_HIP_E_INVALID, "debug_read: unknown buffer " + w);
     const uint64_t n = std::min(bytes, avail);

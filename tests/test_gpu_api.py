@@ -131,3 +131,47 @@ def test_bandwidth_probe_reports_a_plausible_hbm_rate():
     with pytest.raises(Exception):
         be.bandwidth_probe(0, 1)
     be.close()
+
+
+@pytest.mark.parametrize("builder", [2, 3])
+def test_device_built_trees_are_structurally_valid(builder):
+    """Reads the device builders' f32 BVH4 back and checks it the way bvh_host.cpp's validate_bvh4 checks the host builder's: every
+    triangle in exactly one leaf, every child box inside its parent's and around its triangles' padded boxes."""
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("soup", 6000, 1, 0.0, 5)
+    be = HipBackend.init(32, 32, 1.0, builder=builder)
+    scene.sync(be)
+    n = be.scene_stats()["triangles"]
+    tris = be.debug_read("triangles", n * 176).view(np.float32).reshape(n, 44)
+    v = tris[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(n, 3, 3)
+    lo, hi = v.min(axis=1), v.max(axis=1)
+    e = np.float32(1e-4) + np.float32(4e-6) * np.maximum(np.abs(lo), np.abs(hi))
+    lo, hi = lo - e, hi + e                                        # the padding of launch_triangle_boxes
+    nodes = be.debug_read("blas_raw", n * 128).view(np.float32).reshape(-1, 32)
+    order = be.debug_read("blas_order", n * 4).view(np.uint32)
+    child = nodes[:, 24:28].view(np.uint32)
+    seen = np.zeros(n, np.int32)
+    stack = [(0, np.full(3, -np.inf, np.float32), np.full(3, np.inf, np.float32))]
+    visited = 0
+    while stack:
+        i, plo, phi = stack.pop()
+        visited += 1
+        for k in range(4):
+            c = int(child[i, k])
+            if c == 0xFFFFFFFF:
+                continue
+            clo = nodes[i, [0 + k, 8 + k, 16 + k]]
+            chi = nodes[i, [4 + k, 12 + k, 20 + k]]
+            assert np.all(clo >= plo) and np.all(chi <= phi), (i, k)
+            if c & 0x80000000:
+                first, count = c & 0x07FFFFFF, ((c >> 27) & 15) + 1
+                ids = order[first:first + count]
+                seen[ids] += 1
+                assert np.all(lo[ids] >= clo) and np.all(hi[ids] <= chi), (i, k)
+            else:
+                if builder == 3:
+                    assert c > i                                   # the SAH builder numbers children after their parents
+                stack.append((c, clo, chi))
+    assert np.all(seen == 1)
+    assert visited <= be.scene_stats()["blas_nodes"]
+    be.close()
