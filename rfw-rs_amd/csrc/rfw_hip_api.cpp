@@ -62,6 +62,9 @@ struct DerivedMesh {
     uint32_t record = 0;      // index in mesh_records (after the static meshes, in (mesh id, skin id) order)
     uint32_t src_record = 0;  // the static record holding the bind-pose triangles
     size_t skin_offset = 0;   // first rfw_joint_data of the source mesh in d_skin_data
+    // refit (every builder but DEVICE_LBVH): the tree is built once, by binned SAH over the first pose; afterwards only its boxes follow
+    bool topology_built = false;
+    uint32_t node_count = 0;  // 4-wide nodes of that tree
 };
 struct TexHost {
     uint32_t w = 0, h = 0, mips = 0, format = 0;
@@ -154,6 +157,7 @@ struct Instance {
     bool tlas_on_device = true, blas_on_device = false, blas_sah_on_device = false;
     DevBuf<char> d_sah_ws;
     DevBuf<uint32_t> d_mesh_node_counts;
+    DevBuf<uint32_t> d_refit_parent, d_refit_nint, d_refit_arrive; // per raw node of the skinned copies
     DevBuf<QueueCounters> d_counters;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
@@ -595,22 +599,51 @@ int build_instances(Instance* I)
     }
     HIP_TRY(I, hipMemcpyAsync(I->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
     if (!I->derived.empty()) {
-        // skinned copies (structs.rs:820-877) and their BLAS, every synchronize: skin -> boxes -> LBVH -> packets -> bounds, all on-stream
+        // skinned copies (structs.rs:820-877) and their BLAS, every synchronize, all on-stream: skin -> refit of the tree built over the
+        // first pose (gpu-rt: refit_bvh, lib.rs:1350-1352) -> packets -> bounds; with builder = DEVICE_LBVH: skin -> boxes -> LBVH rebuild
         HIP_TRY(I, I->d_joints.ensure(n_joints));
         HIP_TRY(I, hipMemcpyAsync(I->d_joints.ptr, joints, n_joints * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
         if ((rc = ensure_lbvh_ws(I, std::max<uint32_t>(I->max_derived_tris, n_valid)))) return rc;
-        for (const auto& kv : I->derived) {
-            const DerivedMesh& d = kv.second;
+        const bool refit = I->builder != RFW_HIP_BUILDER_DEVICE_LBVH; // DEVICE_LBVH keeps the rebuild-every-frame path
+        if (refit) {
+            const size_t raw_nodes = I->d_blas_raw.cap;
+            HIP_TRY(I, I->d_refit_parent.ensure(raw_nodes));
+            HIP_TRY(I, I->d_refit_nint.ensure(raw_nodes));
+            HIP_TRY(I, I->d_refit_arrive.ensure(raw_nodes));
+        }
+        for (auto& kv : I->derived) {
+            DerivedMesh& d = kv.second;
             const MeshRecord& r = I->mesh_records[d.record];
             const MeshRecord& src = I->mesh_records[d.src_record];
             rfw_rt_triangle* tris = I->d_triangles.ptr + r.tri_base;
-            Node4* raw = I->d_blas_raw.ptr + (r.node_base - I->raw_node_origin);
+            const size_t raw_off = r.node_base - I->raw_node_origin;
+            Node4* raw = I->d_blas_raw.ptr + raw_off;
+            uint32_t* order = I->d_blas_order.ptr + r.tri_base;
             launch_skin_triangles(s, I->d_triangles.ptr + src.tri_base, I->d_skin_data.ptr + d.skin_offset, I->d_joints.ptr + joint_off[kv.first.second],
                                   (uint32_t)I->skins[kv.first.second].size(), r.tri_count, tris);
-            launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
-            HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, raw, I->d_blas_order.ptr + r.tri_base, nullptr));
-            launch_make_packets(s, tris, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, r.node_count);
+            uint32_t quantise_count = r.node_count;
+            if (!refit) {
+                launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
+                HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, raw, order, nullptr));
+            } else if (!d.topology_built) {
+                // first pose of this (mesh, skin) pair: the tree, by binned SAH (blocking, once), and what a refit needs to climb it
+                launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
+                HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
+                HIP_TRY(I, I->d_node_count.ensure(1));
+                HIP_TRY(I, sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, I->d_node_count.ptr, I->sah_max_leaf,
+                                     I->sah_trav_cost));
+                HIP_TRY(I, hipMemcpyAsync(&d.node_count, I->d_node_count.ptr, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(I, hipStreamSynchronize(s));
+                if (d.node_count == 0 || d.node_count > r.node_count) return fail(I, RFW_HIP_E_STATE, "skinned BLAS: node count out of range");
+                launch_refit_setup(s, raw, d.node_count, I->d_refit_parent.ptr + raw_off, I->d_refit_nint.ptr + raw_off);
+                d.topology_built = true;
+                quantise_count = d.node_count;
+            } else {
+                launch_refit(s, raw, d.node_count, tris, order, I->d_refit_parent.ptr + raw_off, I->d_refit_nint.ptr + raw_off, I->d_refit_arrive.ptr + raw_off);
+                quantise_count = d.node_count;
+            }
+            launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, quantise_count);
             launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, I->d_mesh_local.ptr + d.record);
         }
         HIP_TRY(I, hipGetLastError());
@@ -1002,7 +1035,7 @@ void rfw_hip_destroy(void* inst)
         I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
-        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release();
+        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
         for (int k = 0; k < Instance::kStages; k++) {
             if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
             if (I->stage_event[k]) (void)hipEventDestroy(I->stage_event[k]);

@@ -20,4 +20,11 @@ size_t sah_workspace_bytes(uint32_t n);
 hipError_t sah_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
                      uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */, int max_leaf, float trav_cost);
 
+// ---- refit: new boxes for a tree whose topology stays (skinned meshes: the triangles move every frame)
+// parent_slot[i] = 4 * parent + child slot of node i (0xffffffff for the root), n_internal[i] = interior children of node i
+void launch_refit_setup(hipStream_t s, const Node4* nodes, uint32_t n_nodes, uint32_t* parent_slot, uint32_t* n_internal);
+// leaf boxes from the (moved) triangles, then bottom-up through the interior nodes; `arrive` is n_nodes words of scratch
+void launch_refit(hipStream_t s, Node4* nodes, uint32_t n_nodes, const rfw_rt_triangle* tris, const uint32_t* order, const uint32_t* parent_slot,
+                  const uint32_t* n_internal, uint32_t* arrive);
+
 } // namespace rfwhip

@@ -556,6 +556,74 @@ __global__ void k_emit_nodes(uint32_t n_nodes_cap, const Counters* __restrict__ 
     out_nodes[idx4[i]] = o;
 }
 
+// ---------------------------------------------------------------- refit
+__global__ void k_refit_setup(const Node4* __restrict__ nodes, uint32_t n_nodes, uint32_t* parent_slot, uint32_t* n_internal)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    if (i == 0) parent_slot[0] = kNone;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t c = nodes[i].child[k];
+        if (c == kInvalidRef || (c & kLeafBit)) continue;
+        parent_slot[c] = 4u * i + k;
+        cnt++;
+    }
+    n_internal[i] = cnt;
+}
+
+// boxes of the leaf children: the padded triangle boxes of launch_triangle_boxes, from the triangles as they are now
+__global__ void k_refit_leaves(Node4* nodes, uint32_t n_nodes, const rfw_rt_triangle* __restrict__ tris, const uint32_t* __restrict__ order)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = t >> 2, k = t & 3u;
+    if (i >= n_nodes) return;
+    const uint32_t c = nodes[i].child[k];
+    if (c == kInvalidRef || !(c & kLeafBit)) return;
+    const uint32_t first = c & kLeafFirstMask, count = ((c >> 27) & 15u) + 1u;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t j = 0; j < count; j++) {
+        const float4* tp = reinterpret_cast<const float4*>(tris + order[first + j]);
+        const float4 a = tp[0], b = tp[1], cc = tp[2];
+        const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {cc.x, cc.y, cc.z};
+        for (int d = 0; d < 3; d++) {
+            const float l = fminf(va[d], fminf(vb[d], vc[d])), h = fmaxf(va[d], fmaxf(vb[d], vc[d]));
+            const float e = 1e-4f + 4e-6f * fmaxf(fabsf(l), fabsf(h));
+            lo[d] = fminf(lo[d], l - e);
+            hi[d] = fmaxf(hi[d], h + e);
+        }
+    }
+    nodes[i].lox[k] = lo[0]; nodes[i].loy[k] = lo[1]; nodes[i].loz[k] = lo[2];
+    nodes[i].hix[k] = hi[0]; nodes[i].hiy[k] = hi[1]; nodes[i].hiz[k] = hi[2];
+}
+
+// interior boxes, bottom-up: a thread starts at every node without interior children, writes the node's box into its parent's
+// slot and carries on with the parent if it is the last of the parent's interior children to arrive
+__global__ void k_refit_up(Node4* nodes, uint32_t n_nodes, const uint32_t* __restrict__ parent_slot, const uint32_t* __restrict__ n_internal, uint32_t* arrive)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes || n_internal[i] != 0u) return;
+    for (;;) {
+        const uint32_t ps = parent_slot[i];
+        if (ps == kNone) return; // the root has no slot to fill
+        const volatile Node4* nd = nodes + i;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 4; k++) {
+            if (nd->child[k] == kInvalidRef) continue;
+            lo[0] = fminf(lo[0], nd->lox[k]); lo[1] = fminf(lo[1], nd->loy[k]); lo[2] = fminf(lo[2], nd->loz[k]);
+            hi[0] = fmaxf(hi[0], nd->hix[k]); hi[1] = fmaxf(hi[1], nd->hiy[k]); hi[2] = fmaxf(hi[2], nd->hiz[k]);
+        }
+        const uint32_t p = ps >> 2, k = ps & 3u;
+        nodes[p].lox[k] = lo[0]; nodes[p].loy[k] = lo[1]; nodes[p].loz[k] = lo[2];
+        nodes[p].hix[k] = hi[0]; nodes[p].hiy[k] = hi[1]; nodes[p].hiz[k] = hi[2];
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&arrive[p], 1u) + 1u != n_internal[p]) return;
+        __threadfence();
+        i = p;
+    }
+}
+
 struct Layout {
     size_t ctr, nodes, order[2], nop[2], active[2], small, bin_slot, is_big, splits, fill, bins, flag4, idx4, cub, total, cub_bytes;
     uint32_t node_cap, big_cap;
@@ -663,6 +731,19 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_nodes, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, ctr, nodes, flag4, idx4, nodes_out, node_count_out);
     return hipGetLastError();
+}
+
+void launch_refit_setup(hipStream_t s, const Node4* nodes, uint32_t n_nodes, uint32_t* parent_slot, uint32_t* n_internal)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_refit_setup, dim3(blocks(n_nodes)), dim3(kBlock), 0, s, nodes, n_nodes, parent_slot, n_internal);
+}
+void launch_refit(hipStream_t s, Node4* nodes, uint32_t n_nodes, const rfw_rt_triangle* tris, const uint32_t* order, const uint32_t* parent_slot,
+                  const uint32_t* n_internal, uint32_t* arrive)
+{
+    if (!n_nodes) return;
+    (void)hipMemsetAsync(arrive, 0, (size_t)n_nodes * 4, s);
+    hipLaunchKernelGGL(k_refit_leaves, dim3(blocks(4 * n_nodes)), dim3(kBlock), 0, s, nodes, n_nodes, tris, order);
+    hipLaunchKernelGGL(k_refit_up, dim3(blocks(n_nodes)), dim3(kBlock), 0, s, nodes, n_nodes, parent_slot, n_internal, arrive);
 }
 
 } // namespace rfwhip
