@@ -33,6 +33,7 @@ def main():
                     help="renderer instances used round-robin, each on its own stream: frame k+1 is traced while frame k's tail, "
                          "all-gather and assemble finish (1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--readback", action="store_true", help="copy every finished frame to host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline value)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -119,6 +120,8 @@ def main():
                     dist.all_gather_into_tensor(host.view(-1), send.cpu())
                     recv.copy_(host)
                 b.assemble_frame(recv.data_ptr())
+            if args.readback:
+                b.framebuffer()  # blocking device-to-host copy of the w x h RGBA32F frame
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
     be.set_option("count_traversal", 1)
@@ -242,7 +245,7 @@ def main():
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "readback_every_frame": bool(args.readback), "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
