@@ -13,8 +13,10 @@
 //   * JOINTS_0/WEIGHTS_0 -> JointData per vertex, skins -> SkinData with joint_matrices = world(joint) * inverseBind
 //     (graph/mod.rs:592-608), and skinned instances carry the skin id; as glTF prescribes, the transform of a skinned
 //     mesh's own node is ignored (instance matrix = identity).
-// Not read: images/textures (no image decoder in this tree: texture ids stay -1), animations, sparse accessors, morph
-// targets, cameras other than the first perspective one, non-triangle primitive modes.
+//   * images: PNG (8-bit, non-interlaced; zlib inflates, the rest is decoded here) -> BGRA8 textures with a 5-level mip chain;
+//     baseColor / normal / emissive / metallicRoughness texture references -> the material's texture ids.
+// Not read: JPEG and other image formats (their texture ids stay -1), animations, sparse accessors, morph targets, cameras other
+// than the first perspective one, non-triangle primitive modes.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +25,8 @@
 #include <map>
 #include <memory>
 #include <sstream>
+
+#include <zlib.h>
 
 #include "rfw_host.hpp"
 
@@ -267,11 +271,97 @@ rfw_mat4 to_f32(const M4& a)
     return r;
 }
 
+// ---------------------------------------------------------------- PNG (8-bit, non-interlaced) -> RGBA8
+// The inflate step is zlib's; chunk walk, scanline filters (PNG 1.2 §6) and the expansion to RGBA are below.
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+
+bool decode_png(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 || std::memcmp(data, sig, 8) != 0) { err = "png: bad signature"; return false; }
+    size_t off = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, colour = -1, interlace = 0;
+    std::vector<uint8_t> idat, palette, trns;
+    bool end = false;
+    while (!end && off + 12 <= size) {
+        const uint32_t len = be32(data + off);
+        const uint8_t* type = data + off + 4;
+        const uint8_t* body = data + off + 8;
+        if (off + 12 + (size_t)len > size) { err = "png: chunk runs past the end"; return false; }
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len < 13) { err = "png: short IHDR"; return false; }
+            w = be32(body); h = be32(body + 4); depth = body[8]; colour = body[9]; interlace = body[12];
+        } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(type, "IEND", 4)) end = true;
+        off += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || w > 16384 || h > 16384) { err = "png: bad dimensions"; return false; }
+    if (depth != 8 || interlace != 0) { err = "png: only 8-bit non-interlaced images are read"; return false; }
+    int channels;
+    switch (colour) {
+    case 0: channels = 1; break; // grey
+    case 2: channels = 3; break; // rgb
+    case 3: channels = 1; break; // palette
+    case 4: channels = 2; break; // grey + alpha
+    case 6: channels = 4; break; // rgba
+    default: err = "png: unknown colour type"; return false;
+    }
+    const size_t stride = (size_t)w * (size_t)channels;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "png: inflate failed"; return false; }
+    std::vector<uint8_t> img(stride * h);
+    const size_t bpp = (size_t)channels;
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t filter = raw[(stride + 1) * y];
+        const uint8_t* src = raw.data() + (stride + 1) * y + 1;
+        uint8_t* dst = img.data() + stride * y;
+        const uint8_t* up = y ? dst - stride : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int v = src[x];
+            switch (filter) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+            default: err = "png: bad filter"; return false;
+            }
+            dst[x] = (uint8_t)v;
+        }
+    }
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        uint8_t r, g, b, a = 255;
+        switch (colour) {
+        case 0: r = g = b = img[i]; break;
+        case 2: r = img[3 * i]; g = img[3 * i + 1]; b = img[3 * i + 2]; break;
+        case 3: {
+            const size_t k = img[i];
+            if (3 * k + 2 >= palette.size()) { err = "png: palette index out of range"; return false; }
+            r = palette[3 * k]; g = palette[3 * k + 1]; b = palette[3 * k + 2];
+            if (k < trns.size()) a = trns[k];
+            break;
+        }
+        case 4: r = g = b = img[2 * i]; a = img[2 * i + 1]; break;
+        default: r = img[4 * i]; g = img[4 * i + 1]; b = img[4 * i + 2]; a = img[4 * i + 3]; break;
+        }
+        rgba[4 * i] = r; rgba[4 * i + 1] = g; rgba[4 * i + 2] = b; rgba[4 * i + 3] = a;
+    }
+    width = w; height = h;
+    return true;
+}
+
 // ---------------------------------------------------------------- the document
 struct Doc {
     Json root;
     std::vector<std::vector<uint8_t>> buffers;
     std::string err;
+    std::string dir;
 
     bool fail(const std::string& m)
     {
@@ -380,6 +470,7 @@ bool open_document(const std::string& path, Doc& doc)
     if (!asset || asset->string("version").substr(0, 1) != "2") return doc.fail("gltf: asset.version 2.x required");
     const Json* bufs = doc.root.get("buffers");
     const std::string dir = dir_of(path);
+    doc.dir = dir;
     for (size_t i = 0; bufs && i < bufs->size(); i++) {
         const Json& b = bufs->arr[i];
         std::vector<uint8_t> data;
@@ -415,6 +506,57 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
         return j && j->kind == Json::Arr ? j->arr : empty;
     };
 
+    // ---- images -> scene textures (PNG only: BGRA8 with a 5-level mip chain, what l3d hands the trait); texture -> scene texture id
+    std::vector<int> image_tex; // glTF image index -> scene texture id, -1 = not readable here (JPEG, KTX, ...)
+    for (const Json& im : arr("images")) {
+        std::vector<uint8_t> file;
+        const std::string uri = im.string("uri");
+        bool have = false;
+        if (!uri.empty()) {
+            if (uri.compare(0, 5, "data:") == 0) {
+                const size_t comma = uri.find(',');
+                have = comma != std::string::npos && base64_decode(uri, comma + 1, file);
+            } else if (uri.find("..") == std::string::npos && uri[0] != '/') {
+                have = read_file(doc.dir + uri, file);
+            }
+        } else if (im.has("bufferView")) {
+            const Json* bvs = root.get("bufferViews");
+            const int64_t bi = im.integer("bufferView", -1);
+            if (bvs && bi >= 0 && (size_t)bi < bvs->size()) {
+                const Json& bv = bvs->arr[(size_t)bi];
+                const int64_t b = bv.integer("buffer", -1);
+                const size_t o = (size_t)bv.integer("byteOffset", 0), n = (size_t)bv.integer("byteLength", 0);
+                if (b >= 0 && (size_t)b < doc.buffers.size() && o + n <= doc.buffers[(size_t)b].size()) {
+                    file.assign(doc.buffers[(size_t)b].begin() + (long)o, doc.buffers[(size_t)b].begin() + (long)(o + n));
+                    have = true;
+                }
+            }
+        }
+        int tex_id = -1;
+        uint32_t w = 0, h = 0;
+        std::vector<uint8_t> rgba;
+        std::string perr;
+        if (have && decode_png(file.data(), file.size(), w, h, rgba, perr)) {
+            Texture t;
+            t.width = w; t.height = h; t.format = RFW_FORMAT_BGRA8;
+            t.bytes.resize(rgba.size());
+            for (size_t i = 0; i < (size_t)w * h; i++) { t.bytes[4 * i] = rgba[4 * i + 2]; t.bytes[4 * i + 1] = rgba[4 * i + 1]; t.bytes[4 * i + 2] = rgba[4 * i]; t.bytes[4 * i + 3] = rgba[4 * i + 3]; }
+            t.generate_mipmaps(5);
+            tex_id = (int)scene.textures.size();
+            scene.textures.push_back(std::move(t));
+            scene.textures_changed = true;
+        }
+        image_tex.push_back(tex_id);
+    }
+    auto texture_of = [&](const Json* ref) -> int { // {"index": glTF texture} -> scene texture id
+        if (!ref) return -1;
+        const int64_t ti = ref->integer("index", -1);
+        const std::vector<Json>& texs = arr("textures");
+        if (ti < 0 || (size_t)ti >= texs.size()) return -1;
+        const int64_t src = texs[(size_t)ti].integer("source", -1);
+        return (src >= 0 && (size_t)src < image_tex.size()) ? image_tex[(size_t)src] : -1;
+    };
+
     // ---- materials (pbrMetallicRoughness; index materials.size() = the glTF default material, created on demand)
     std::vector<uint32_t> mat_ids;
     for (const Json& m : arr("materials")) {
@@ -425,7 +567,11 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
                 for (size_t k = 0; k < 4 && k < c->size(); k++) mat.color[k] = (float)c->arr[k].num;
             mat.metallic = (float)pbr->number("metallicFactor", 1.0);
             mat.roughness = (float)pbr->number("roughnessFactor", 1.0);
+            mat.diffuse_tex = texture_of(pbr->get("baseColorTexture"));
+            mat.metallic_roughness_tex = texture_of(pbr->get("metallicRoughnessTexture"));
         }
+        mat.normal_tex = texture_of(m.get("normalTexture"));
+        mat.emissive_tex = texture_of(m.get("emissiveTexture"));
         double strength = 1.0;
         if (const Json* ext = m.get("extensions"))
             if (const Json* es = ext->get("KHR_materials_emissive_strength")) strength = es->number("emissiveStrength", 1.0);
@@ -509,6 +655,29 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             all_skinned = all_skinned && has_j;
         }
         if (desc.vertices.empty()) { mesh_ids.push_back(-1); continue; }
+        // tangents: taken from the document when every primitive has them, else one per triangle from the uv derivatives (first edge
+        // when the uvs are degenerate) with handedness +1 — the frame the shading code builds its bitangent from must never be zero
+        {
+            bool have_all = any_tangents;
+            for (const rfw_vec4& tg : desc.tangents) have_all = have_all && (tg.x != 0.0f || tg.y != 0.0f || tg.z != 0.0f);
+            if (!have_all) {
+                desc.tangents.assign(desc.vertices.size(), rfw_vec4{1, 0, 0, 1});
+                for (size_t t3 = 0; t3 + 2 < desc.vertices.size(); t3 += 3) {
+                    const rfw_vec4 &a = desc.vertices[t3], &b = desc.vertices[t3 + 1], &c = desc.vertices[t3 + 2];
+                    const float e1[3] = {b.x - a.x, b.y - a.y, b.z - a.z}, e2[3] = {c.x - a.x, c.y - a.y, c.z - a.z};
+                    const float du1 = desc.uvs[t3 + 1].x - desc.uvs[t3].x, dv1 = desc.uvs[t3 + 1].y - desc.uvs[t3].y;
+                    const float du2 = desc.uvs[t3 + 2].x - desc.uvs[t3].x, dv2 = desc.uvs[t3 + 2].y - desc.uvs[t3].y;
+                    const float det = du1 * dv2 - du2 * dv1;
+                    float tv[3];
+                    for (int k = 0; k < 3; k++) tv[k] = std::fabs(det) > 1e-12f ? (e1[k] * dv2 - e2[k] * dv1) * (1.0f / det) : e1[k];
+                    float len2 = tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2];
+                    if (!(len2 > 1e-24f)) { for (int k = 0; k < 3; k++) tv[k] = e1[k]; len2 = tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]; }
+                    if (!(len2 > 1e-24f)) { tv[0] = 1.0f; tv[1] = tv[2] = 0.0f; len2 = 1.0f; }
+                    const float il = 1.0f / std::sqrt(len2);
+                    for (size_t k = 0; k < 3; k++) desc.tangents[t3 + k] = rfw_vec4{tv[0] * il, tv[1] * il, tv[2] * il, 1.0f};
+                }
+            }
+        }
         if (!any_normals) desc.normals.assign(desc.vertices.size(), rfw_vec3{0, 0, 0}); // Mesh3D::from generates them (objects_3d/mod.rs:680-711)
         else {
             // a primitive without normals inside a mesh that has some: zero the first normal so the whole mesh is regenerated consistently

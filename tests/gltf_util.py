@@ -179,3 +179,90 @@ def write_duplicates_gltf(directory, copies=3000):
     path = directory / "dups.gltf"
     path.write_text(json.dumps(doc))
     return path
+
+
+def encode_png(rgba, filters=(0, 1, 2, 3, 4)):
+    """Minimal PNG writer (8-bit RGBA, non-interlaced) that cycles through the five scanline filters so that a decoder's
+    un-filtering is exercised.  rgba: (h, w, 4) uint8."""
+    import zlib
+    h, w, _ = rgba.shape
+    bpp, stride = 4, w * 4
+    raw = bytearray()
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        cur = rgba[y].reshape(-1).astype(np.int32)
+        f = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if f == 0:
+            out = cur
+        elif f == 1:
+            out = cur - left
+        elif f == 2:
+            out = cur - prev
+        elif f == 3:
+            out = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out = cur - pred
+        raw.append(f)
+        raw += bytes((out & 0xFF).astype(np.uint8))
+        prev = cur
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+
+
+def write_textured_gltf(directory, glb=False):
+    """A lit floor with a base-colour PNG (8 x 8, every texel different) and a lamp above it.  Returns (path, texels (8, 8, 4) RGBA)."""
+    rng = np.random.default_rng(9)
+    tex = rng.integers(30, 255, size=(8, 8, 4), dtype=np.uint8)
+    tex[..., 3] = 255
+    png = encode_png(tex)
+    floor = np.array([[-2, 0, -2], [-2, 0, 2], [2, 0, 2], [2, 0, -2]], np.float32)
+    uv = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float32)
+    fidx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    lamp = np.array([[-0.5, 3, -0.5], [0.5, 3, -0.5], [0.5, 3, 0.5], [-0.5, 3, 0.5]], np.float32)
+    lidx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    parts = [floor.tobytes(), uv.tobytes(), fidx.tobytes(), lamp.tobytes(), lidx.tobytes()]
+    if glb:
+        parts.append(png)
+    views, offset, blob = [], 0, b""
+    for raw in parts:
+        views.append({"buffer": 0, "byteOffset": offset, "byteLength": len(raw)})
+        pad = (-len(raw)) % 4
+        blob += raw + b"\0" * pad
+        offset += len(raw) + pad
+    doc = {
+        "asset": {"version": "2.0"}, "scenes": [{"nodes": [0, 1, 2]}],
+        "nodes": [{"mesh": 0}, {"mesh": 1}, {"camera": 0, "translation": [0, 1.5, 5]}],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8, "znear": 0.01}}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]},
+                   {"primitives": [{"attributes": {"POSITION": 3}, "indices": 4, "material": 1}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicFactor": 0.0, "roughnessFactor": 0.8}},
+                      {"emissiveFactor": [1, 1, 1], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 15.0}}}],
+        "textures": [{"source": 0}],
+        "images": [{"bufferView": 5, "mimeType": "image/png"} if glb else {"uri": "floor.png"}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC2"},
+                      {"bufferView": 2, "componentType": 5123, "count": 6, "type": "SCALAR"}, {"bufferView": 3, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 4, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+        "bufferViews": views, "buffers": [{"byteLength": len(blob)}],
+    }
+    if glb:
+        js = json.dumps(doc).encode()
+        js += b" " * ((-len(js)) % 4)
+        path = directory / "textured.glb"
+        with open(path, "wb") as f:
+            f.write(b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(blob)))
+            f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+            f.write(struct.pack("<II", len(blob), 0x004E4942) + blob)
+        return path, tex
+    doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    (directory / "floor.png").write_bytes(png)
+    path = directory / "textured.gltf"
+    path.write_text(json.dumps(doc))
+    return path, tex

@@ -40,6 +40,9 @@ def test_node_hierarchy_places_the_instances(tmp_path):
     assert list(hit["inst"]) == [0, 1, 2, 3]
     v = scene.view(48, 32)
     assert np.allclose([v.pos.x, v.pos.y, v.pos.z], [0, 1.5, 6])          # the document's camera
+    orc.render(v)
+    st = orc.stats()
+    assert st["shadow"] > 100 and st["extension"] > 100               # the surfaces shade: generated tangents give a valid frame
 
 
 @pytest.mark.parametrize("embed", ["base64", "glb"])
@@ -99,3 +102,20 @@ def test_skinned_document(tmp_path):
     tip = want[-1].mean(axis=0)
     hit = orc.intersect(np.array([[tip[0], tip[1], 4.0]], np.float32), np.array([[0, 0, -1]], np.float32), brute=True)
     assert hit["inst"][0] == 0 and abs(hit["t"][0] - 4.0) < 1e-4
+
+
+@pytest.mark.parametrize("glb", [False, True])
+def test_png_textures_reach_the_sampler(tmp_path, glb):
+    """images (PNG: all five scanline filters) -> BGRA8 textures with mips -> material.diffuse_map; the sampler returns the texels."""
+    from gltf_util import write_textured_gltf
+    path, tex = write_textured_gltf(tmp_path, glb)
+    scene, orc = load(path)
+    for (x, y) in [(0, 0), (3, 5), (7, 7), (6, 1)]:
+        got = orc.sample_texture(0, (x + 0.5) / 8, (y + 0.5) / 8, 0.0)
+        assert np.array_equal(got, tex[y, x].astype(np.float32) * np.float32(1.0 / 255.0)), (x, y)
+    assert np.allclose(orc.sample_texture(0, 0.3, 0.3, 3.0)[:3], tex[..., :3].reshape(-1, 3).mean(axis=0) / 255.0, atol=0.02)   # 1x1 mip = the mean
+    # the floor is lit and textured: a render is not uniform grey
+    v = scene.view(48, 32)
+    orc.render(v)
+    acc = orc.accumulator()[..., :3]
+    assert acc.max() > 0 and acc[20:, :, :].std() > 1e-3

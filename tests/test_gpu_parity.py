@@ -365,14 +365,15 @@ def test_skin_set_change_relayouts_the_scene():
     assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
 
 
-@pytest.mark.parametrize("which", ["room", "skinned"])
+@pytest.mark.parametrize("which", ["room", "skinned", "textured"])
 def test_gltf_scenes_match_oracle(tmp_path, which):
     """a glTF document through the C++ host's importer, then the same boundary calls into both backends."""
-    from gltf_util import write_gltf, write_skinned_gltf
+    from gltf_util import write_gltf, write_skinned_gltf, write_textured_gltf
     from oracle.bindings import Oracle
     from rfw_rs_amd import HipBackend, Scene
     w, h = 96, 64
-    path = write_gltf(tmp_path, "glb") if which == "room" else write_skinned_gltf(tmp_path)[0]
+    path = {"room": lambda: write_gltf(tmp_path, "glb"), "skinned": lambda: write_skinned_gltf(tmp_path)[0],
+            "textured": lambda: write_textured_gltf(tmp_path, True)[0]}[which]()
     scene = Scene().load_gltf(str(path))
     if which == "skinned":
         scene.build("cornell")                                  # something to light the strip
@@ -386,7 +387,7 @@ def test_gltf_scenes_match_oracle(tmp_path, which):
     for _ in range(2):
         be.render(view); orc.render(view)
     ga, ra = be.accumulator(), orc.accumulator()
-    assert ra[..., :3].max() > 0
+    assert ra[..., :3].max() > 0 and orc.stats()["shadow"] > 0
     assert rel_l2(ga, ra) <= TOL
     assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
 
