@@ -15,6 +15,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Every renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by default): two
+# instances whose streams land on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -29,10 +33,13 @@ def main():
     ap.add_argument("--max-path-length", type=int, default=1, help="1 = primary+shadow (the metric); 3 = the reference's path tracer (C4)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="renderer instances used round-robin, each on its own stream: frame k+1 is traced while frame k's tail, "
                          "all-gather and assemble finish (1 = strictly one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
+                         "gathered buffer), without any collective; the value then counts this shard's rays only")
     ap.add_argument("--readback", action="store_true", help="copy every finished frame to host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline value)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -67,11 +74,15 @@ def main():
         scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
-    F = max(1, args.frames_in_flight)
+    # default: 8 frames in flight on one or two GPUs; with the frame sharded over more GPUs each rank's kernels are short (their time is
+    # the slowest wavefront's, plus one all-gather per frame), so more frames have to overlap to keep the chip full (measured with
+    # --emulate-shard 8: 0.42 ms per frame one at a time, 0.127 with 8 in flight, 0.119 with 12)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (8 if world <= 2 else 12)
     bes, streams, gathers = [], [], []
     t0 = time.time()
     for f in range(F):
-        be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank, world=world,
+        be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
+                             world=world if not args.emulate_shard else args.emulate_shard,
                              streams=int(os.environ.get("RFW_STREAMS", "0")))
         # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created: HIP deals streams to
         # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
@@ -83,10 +94,11 @@ def main():
         scene.mark_all_changed()
         scene.sync(be)
         g = None
-        if world > 1:
+        if world > 1 or args.emulate_shard:
             nslab = be.shard_info()["slab_floats"]
+            wn = world if not args.emulate_shard else args.emulate_shard
             send = torch.zeros(nslab, dtype=torch.float32, device="cuda")          # this rank's tiles (written by render())
-            g = (send, torch.zeros(world, nslab, dtype=torch.float32, device="cuda"))  # (send buffer, all ranks' slabs)
+            g = (send, torch.zeros(wn, nslab, dtype=torch.float32, device="cuda"))  # (send buffer, all ranks' slabs)
             be.set_slab_output(send.data_ptr())
         bes.append(be); streams.append(st); gathers.append(g)
     sync_s = (time.time() - t0) / F
@@ -120,6 +132,8 @@ def main():
                     dist.all_gather_into_tensor(host.view(-1), send.cpu())
                     recv.copy_(host)
                 b.assemble_frame(recv.data_ptr())
+            elif args.emulate_shard:
+                b.assemble_frame(g[1].data_ptr())  # the de-tiling a rank would do after the all-gather
             if args.readback:
                 b.framebuffer()  # blocking device-to-host copy of the w x h RGBA32F frame
 

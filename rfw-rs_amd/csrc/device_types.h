@@ -161,6 +161,7 @@ struct QueueCounters {
     unsigned long long overflow, pad;
     unsigned long long wave_max_nodes[3]; // COUNT mode: sum over wavefronts of the largest per-lane node count (lane utilisation = nodes / (64 * this))
     unsigned long long wave_exec[3][2];   // COUNT mode: wavefront-level executions of the node test / of the triangle test
+    unsigned long long max_nodes[3];      // COUNT mode: the largest per-ray node count
     unsigned long long pad2;
 };
 

@@ -82,6 +82,7 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
         atomicAdd(&qc->trav[kind][1], t);
         atomicAdd(&qc->trav[kind][2], i);
         atomicAdd(&qc->wave_max_nodes[kind], (unsigned long long)mx);
+        atomicMax(&qc->max_nodes[kind], (unsigned long long)mx);
         atomicAdd(&qc->wave_exec[kind][0], wn);
         atomicAdd(&qc->wave_exec[kind][1], wt);
     }
