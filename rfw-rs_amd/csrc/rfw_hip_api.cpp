@@ -460,8 +460,14 @@ int build_blas_device(Instance* I)
         launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
         if (I->blas_sah_on_device) {
             HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
-            HIP_TRY(I, sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
-                                 I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost));
+            const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                            I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
+            if (se == hipErrorInvalidValue) { // a tree deeper than the SAH builder's level budget above its LDS phase: LBVH always terminates
+                HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                      I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+            } else {
+                HIP_TRY(I, se);
+            }
         } else {
             HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
                                   I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
