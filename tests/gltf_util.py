@@ -181,12 +181,13 @@ def write_duplicates_gltf(directory, copies=3000):
     return path
 
 
-def encode_png(rgba, filters=(0, 1, 2, 3, 4)):
-    """Minimal PNG writer (8-bit RGBA, non-interlaced) that cycles through the five scanline filters so that a decoder's
-    un-filtering is exercised.  rgba: (h, w, 4) uint8."""
+def encode_png(rgba, filters=(0, 1, 2, 3, 4), colour=6, palette=None, trns=None):
+    """Minimal PNG writer (8-bit, non-interlaced) that cycles through the five scanline filters so that a decoder's
+    un-filtering is exercised.  rgba: (h, w, c) uint8 with c = 4 (colour 6, RGBA), 3 (colour 2, RGB), 2 (colour 4, grey + alpha) or
+    1 (colour 0, grey; colour 3, palette indices with `palette` (n, 3) and optional `trns` (m,))."""
     import zlib
-    h, w, _ = rgba.shape
-    bpp, stride = 4, w * 4
+    h, w, c = rgba.shape
+    bpp, stride = c, w * c
     raw = bytearray()
     prev = np.zeros(stride, np.int32)
     for y in range(h):
@@ -213,16 +214,23 @@ def encode_png(rgba, filters=(0, 1, 2, 3, 4)):
 
     def chunk(tag, body):
         return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
-    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0))
-            + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+    extra = b""
+    if palette is not None:
+        extra += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        extra += chunk(b"tRNS", np.asarray(trns, np.uint8).tobytes())
+    data = zlib.compress(bytes(raw), 6)
+    half = len(data) // 2                                   # two IDAT chunks: a decoder has to concatenate them
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, colour, 0, 0, 0)) + extra
+            + chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:]) + chunk(b"IEND", b""))
 
 
-def write_textured_gltf(directory, glb=False):
+def write_textured_gltf(directory, glb=False, png=None):
     """A lit floor with a base-colour PNG (8 x 8, every texel different) and a lamp above it.  Returns (path, texels (8, 8, 4) RGBA)."""
     rng = np.random.default_rng(9)
     tex = rng.integers(30, 255, size=(8, 8, 4), dtype=np.uint8)
     tex[..., 3] = 255
-    png = encode_png(tex)
+    png = encode_png(tex) if png is None else png
     floor = np.array([[-2, 0, -2], [-2, 0, 2], [2, 0, 2], [2, 0, -2]], np.float32)
     uv = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float32)
     fidx = np.array([0, 1, 2, 0, 2, 3], np.uint16)

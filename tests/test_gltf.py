@@ -119,3 +119,38 @@ def test_png_textures_reach_the_sampler(tmp_path, glb):
     orc.render(v)
     acc = orc.accumulator()[..., :3]
     assert acc.max() > 0 and acc[20:, :, :].std() > 1e-3
+
+
+def test_png_colour_types_and_broken_images(tmp_path):
+    """Grey, grey + alpha, RGB and palette (+ tRNS) PNGs expand to the same RGBA; an image that cannot be decoded leaves the material
+    untextured instead of failing the import."""
+    from gltf_util import encode_png, write_textured_gltf
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 5, size=(8, 8, 1), dtype=np.uint8)
+    pal = rng.integers(0, 255, size=(5, 3), dtype=np.uint8)
+    trns = np.array([255, 10, 200], np.uint8)
+    grey = rng.integers(0, 255, size=(8, 8, 1), dtype=np.uint8)
+    ga = rng.integers(0, 255, size=(8, 8, 2), dtype=np.uint8)
+    rgb = rng.integers(0, 255, size=(8, 8, 3), dtype=np.uint8)
+    cases = {
+        "palette": (encode_png(idx, colour=3, palette=pal, trns=trns),
+                    lambda x, y: np.append(pal[idx[y, x, 0]], trns[idx[y, x, 0]] if idx[y, x, 0] < 3 else 255)),
+        "grey": (encode_png(grey, colour=0), lambda x, y: np.array([grey[y, x, 0]] * 3 + [255])),
+        "grey_alpha": (encode_png(ga, colour=4), lambda x, y: np.array([ga[y, x, 0]] * 3 + [ga[y, x, 1]])),
+        "rgb": (encode_png(rgb, colour=2), lambda x, y: np.append(rgb[y, x], 255)),
+    }
+    for name, (png, want) in cases.items():
+        d = tmp_path / name
+        d.mkdir()
+        _, orc = load(write_textured_gltf(d, png=png)[0])
+        for (x, y) in [(0, 0), (5, 2), (7, 7)]:
+            got = orc.sample_texture(0, (x + 0.5) / 8, (y + 0.5) / 8, 0.0)
+            assert np.array_equal(got, want(x, y).astype(np.float32) * np.float32(1.0 / 255.0)), (name, x, y)
+    good = encode_png(rgb, colour=2)
+    for name, png in {"truncated": good[: len(good) // 2], "not_png": b"JFIF" + good[4:], "interlaced": good[:28] + b"\x01" + good[29:]}.items():
+        d = tmp_path / name
+        d.mkdir()
+        scene, orc = load(write_textured_gltf(d, png=png)[0])        # imports; the floor is simply untextured
+        assert scene.counts()["meshes"] == 2
+        orc.render(scene.view(32, 24))
+        assert orc.stats()["shadow"] > 0
