@@ -193,6 +193,10 @@ RFW_HIP_API int rfw_hip_intersect(void* instance, const float* origins, const fl
                                   float t_min, float t_max, uint64_t n, rfw_hip_hit* hits);
 RFW_HIP_API int rfw_hip_occludes(void* instance, const float* origins, const float* directions,
                                  float t_min, const float* t_max, uint64_t n, uint8_t* occluded);
+/* TIntersector::depth_test (intersector.rs:103-127): the closest hit and, per ray, how many BVH nodes the query visited
+ * (4-wide nodes of THIS backend's trees, top level and meshes; like the reference's number it depends on the builder). */
+RFW_HIP_API int rfw_hip_depth_test(void* instance, const float* origins, const float* directions,
+                                   float t_min, float t_max, uint64_t n, rfw_hip_hit* hits, uint32_t* depth);
 
 /* Debug read-back of the wavefront queues after the last render() bounce `bounce`
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */

@@ -23,7 +23,7 @@ EXPORTS = [
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
     "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
-    "rfw_hip_debug_read", "rfw_hip_bandwidth_probe",
+    "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def hip_lib():
         l.rfw_hip_set_slab_output.argtypes = [vp, vp]
         l.rfw_hip_assemble_frame.argtypes = [vp, vp]
         l.rfw_hip_intersect.argtypes = [vp, vp, vp, f32, f32, u64, vp]
+        l.rfw_hip_depth_test.argtypes = [vp, vp, vp, f32, f32, u64, vp, vp]
         l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
         l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
@@ -259,6 +260,15 @@ class HipBackend:
         hits = np.empty(len(o), dtype=HIT_DTYPE)
         self._check(self._l.rfw_hip_intersect(self._h, o.ctypes.data, d.ctypes.data, t_min, t_max, len(o), hits.ctypes.data))
         return hits
+
+    def depth_test(self, origins, directions, t_min=1e-4, t_max=1e26):
+        """TIntersector::depth_test (crates/rfw-scene/src/intersector.rs:103-127): hits and BVH nodes visited per ray."""
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32)
+        hits = np.empty(len(o), dtype=HIT_DTYPE)
+        depth = np.empty(len(o), dtype=np.uint32)
+        self._check(self._l.rfw_hip_depth_test(self._h, o.ctypes.data, d.ctypes.data, t_min, t_max, len(o), hits.ctypes.data, depth.ctypes.data))
+        return hits, depth
 
     def occludes(self, origins, directions, t_max, t_min=1e-3):
         """TIntersector::occludes (crates/rfw-scene/src/intersector.rs:21-43) for a batch of rays."""

@@ -57,7 +57,7 @@ void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab,
 void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
-                          rfw_hip_hit* hits);
+                          rfw_hip_hit* hits, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
                       uint8_t* occluded);
 

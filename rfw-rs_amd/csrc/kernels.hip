@@ -542,8 +542,10 @@ __global__ void k_assemble(const CameraParams cam, const float4* __restrict__ ga
 }
 
 // ---------------------------------------------------------------- ray queries (TIntersector::intersect / occludes)
+template <bool DEPTH>
 __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                                const float t_min, const float t_max, const uint64_t n, rfw_hip_hit* __restrict__ hits)
+                                                                const float t_min, const float t_max, const uint64_t n, rfw_hip_hit* __restrict__ hits,
+                                                                uint32_t* __restrict__ depth)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
@@ -554,10 +556,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
     int32_t hi = -1, ht = -1;
     TravCounters tc{0, 0, 0};
     const SceneView sv = scene_view(sc);
-    traverse<false, false>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    traverse<false, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
     rfw_hip_hit h;
     h.inst = hi; h.tri = ht; h.t = t; h.u = hu; h.v = hv;
     hits[idx] = h;
+    if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes this ray visited, TLAS and BLAS
 }
 __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, const float* __restrict__ origins, const float* __restrict__ directions,
                                                             const float t_min, const float* __restrict__ t_max, const uint64_t n,
@@ -638,10 +641,12 @@ void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathe
     hipLaunchKernelGGL(k_assemble, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
 }
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
-                          rfw_hip_hit* hits)
+                          rfw_hip_hit* hits, uint32_t* depth)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_query_closest, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, hits);
+    const dim3 grid(ceil_div(n, kTraceBlock)), block(kTraceBlock);
+    if (depth) hipLaunchKernelGGL(k_query_closest<true>, grid, block, 0, s, sc, origins, directions, t_min, t_max, n, hits, depth);
+    else hipLaunchKernelGGL(k_query_closest<false>, grid, block, 0, s, sc, origins, directions, t_min, t_max, n, hits, depth);
 }
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
                       uint8_t* occluded)

@@ -1419,7 +1419,7 @@ int rfw_hip_assemble_frame(void* inst, const void* gathered)
     return RFW_HIP_OK;
 }
 
-int rfw_hip_intersect(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits)
+static int intersect_impl(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits, uint32_t* depth)
 {
     LOCK(inst);
     if (n && (!origins || !directions || !hits)) return fail(I, RFW_HIP_E_INVALID, "intersect: null pointer");
@@ -1428,6 +1428,8 @@ int rfw_hip_intersect(void* inst, const float* origins, const float* directions,
     const uint64_t chunk = spill_stride(I);
     DevBuf<float> d_o, d_d;
     DevBuf<rfw_hip_hit> d_h;
+    DevBuf<uint32_t> d_depth;
+    if (depth) HIP_TRY(I, d_depth.ensure(std::min(n, chunk)));
     HIP_TRY(I, d_o.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_h.ensure(std::min(n, chunk)));
@@ -1438,15 +1440,27 @@ int rfw_hip_intersect(void* inst, const float* origins, const float* directions,
         hipError_t e = hipMemcpyAsync(d_o.ptr, origins + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_d.ptr, directions + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
         if (e == hipSuccess) {
-            launch_query_closest(I->stream, sc, d_o.ptr, d_d.ptr, t_min, t_max, m, d_h.ptr);
+            launch_query_closest(I->stream, sc, d_o.ptr, d_d.ptr, t_min, t_max, m, d_h.ptr, depth ? d_depth.ptr : nullptr);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(hits + off, d_h.ptr, m * sizeof(rfw_hip_hit), hipMemcpyDeviceToHost, I->stream);
+        if (e == hipSuccess && depth) e = hipMemcpyAsync(depth + off, d_depth.ptr, m * sizeof(uint32_t), hipMemcpyDeviceToHost, I->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
         if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("intersect: ") + hipGetErrorString(e));
     }
-    d_o.release(); d_d.release(); d_h.release();
+    d_o.release(); d_d.release(); d_h.release(); d_depth.release();
     return rc;
+}
+
+int rfw_hip_intersect(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits)
+{
+    return intersect_impl(inst, origins, directions, t_min, t_max, n, hits, nullptr);
+}
+
+int rfw_hip_depth_test(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits, uint32_t* depth)
+{
+    if (inst && n && !depth) { LOCK(inst); return fail(I, RFW_HIP_E_INVALID, "depth_test: null pointer"); }
+    return intersect_impl(inst, origins, directions, t_min, t_max, n, hits, depth);
 }
 
 int rfw_hip_occludes(void* inst, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded)

@@ -175,3 +175,23 @@ def test_device_built_trees_are_structurally_valid(builder):
     assert np.all(seen == 1)
     assert visited <= be.scene_stats()["blas_nodes"]
     be.close()
+
+
+def test_depth_test_returns_the_closest_hit_and_a_node_count():
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("soup", 4000, 3, 0.0, 9)
+    be = HipBackend.init(32, 32, 1.0)
+    orc = Oracle(32, 32, threads=2)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    rng = np.random.default_rng(4)
+    o = rng.uniform(-4, 4, (3000, 3)).astype(np.float32)
+    d = rng.normal(size=(3000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hits, depth = be.depth_test(o, d)
+    ref = orc.intersect(o, d, brute=True)
+    assert np.array_equal(hits["tri"], ref["tri"]) and np.array_equal(hits["t"][ref["inst"] >= 0].view(np.uint32), ref["t"][ref["inst"] >= 0].view(np.uint32))
+    assert np.all(depth >= 1) and depth.max() < 2000              # every ray visits at least the TLAS root
+    assert depth[hits["inst"] >= 0].mean() > depth[hits["inst"] < 0].mean() * 0.5
+    assert np.array_equal(be.intersect(o, d)["tri"], hits["tri"])  # the same query without the counter
+    be.close()
