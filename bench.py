@@ -287,6 +287,12 @@ def main():
                                               for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if cs["node_test_executions"][k]},
                          "frame_ms_events": round((iso_ms["ms_total"] / iso_frames) if (iso_ms is not None and iso_frames > 0) else kernel_ms["ms_total"] / nf, 4),
                          "measured": measured,
+                         # what actually bounds the path: vector-instruction issue.  1024 SIMD16s x 2.4 GHz / 4 cycles per
+                         # wave64 instruction = 614.4 G wave-instructions/s; instructions per frame from the committed PMC profile of
+                         # THIS workload at max path length 1 (null otherwise)
+                         "valu_issue": (lambda v: {"wave_instructions_per_frame": v, "peak_per_s": 614.4e9,
+                                                   "frac": round(v / (ms_step * 1e-3) / 614.4e9, 4)} if v else None)(
+                             pmc_valu_per_frame() if (args.workload == "atrium1m" and args.max_path_length == 1 and world == 1 and not args.emulate_shard) else None),
                          # the timed region as a whole: every kernel's algorithmic bytes of one frame over the wall time per frame
                          "timed_region": {"frames_in_flight": F, "algorithmic_bytes_per_frame": int(sum(alg.values())),
                                           "achieved": round(sum(alg.values()) / (ms_step * 1e-3) / 1e9, 1),
@@ -301,6 +307,23 @@ def main():
         dist.destroy_process_group()
     for b in bes:
         b.close()
+
+
+def pmc_valu_per_frame():
+    """Wave64 VALU instructions one frame of the headline workload issues, from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_valu.json: SQ_INSTS_VALU per launch of k_primary, k_shade, k_shadow, k_assemble), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        total = 0
+        for name in ("k_primary<false>", "k_shade", "k_shadow<false>", "k_assemble"):
+            total += k[name]["SQ_INSTS_VALU"]
+        return int(total)
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel):
