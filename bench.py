@@ -78,12 +78,17 @@ def main():
     # the slowest wavefront's, plus one all-gather per frame), so more frames have to overlap to keep the chip full (measured with
     # --emulate-shard 8: 0.42 ms per frame one at a time, 0.127 with 8 in flight, 0.119 with 12)
     F = args.frames_in_flight if args.frames_in_flight > 0 else (8 if world <= 2 else 12)
+    # HOW the frames in flight are held.  One GPU, static scene: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight:
+    # one scene in HBM, per-slot path state and stream).  Sharded frame (N > 1) or a scene that changes every frame (C3): F instances
+    # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers / its own TLAS.
+    use_slots = world == 1 and not animated and not args.emulate_shard and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
+    n_inst = 1 if use_slots else F
     bes, streams, gathers = [], [], []
     t0 = time.time()
-    for f in range(F):
+    for f in range(n_inst):
         be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
                              world=world if not args.emulate_shard else args.emulate_shard,
-                             streams=int(os.environ.get("RFW_STREAMS", "0")))
+                             streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=F if use_slots else 0)
         # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created: HIP deals streams to
         # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
         # all-gather is ordered against the kernels and the HIP events that time them are recorded on the launch stream
@@ -101,7 +106,7 @@ def main():
             g = (send, torch.zeros(wn, nslab, dtype=torch.float32, device="cuda"))  # (send buffer, all ranks' slabs)
             be.set_slab_output(send.data_ptr())
         bes.append(be); streams.append(st); gathers.append(g)
-    sync_s = (time.time() - t0) / F
+    sync_s = (time.time() - t0) / n_inst
     be = bes[0]
     sstats = be.scene_stats()
     torch.cuda.synchronize()
@@ -111,7 +116,7 @@ def main():
     step_no = [0]
 
     def step():
-        k = step_no[0] % F
+        k = step_no[0] % n_inst
         step_no[0] += 1
         b, g = bes[k], gathers[k]
         with (torch.cuda.stream(streams[k]) if world > 1 else contextlib.nullcontext()):  # the library already launches on streams[k]
@@ -188,6 +193,8 @@ def main():
         for i in range(min(48, max(args.steps, 1))):
             bes[0].reset_accumulation()
             bes[0].render(view)
+            if use_slots:
+                bes[0].device_synchronize()  # one frame at a time although the instance would pipeline them over its slots
             if (i + 1) % 24 == 0:
                 ms_, n_ = bes[0].drain_timing()
                 iso_frames += n_
@@ -265,7 +272,7 @@ def main():
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "readback_every_frame": bool(args.readback), "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": bool(args.readback), "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],

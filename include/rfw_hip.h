@@ -61,6 +61,11 @@ typedef struct {
                                   levels by binned SAH on the host cores; DEVICE_LBVH = both levels by LBVH; DEVICE_SAH = as AUTO */
     uint32_t flags;            /* RFW_HIP_FLAG_* */
     uint32_t streams;          /* sub-shards (HIP streams) one frame is split into on this GPU; 0 = default 1, max 8 */
+    uint32_t frames_in_flight; /* 0/1 = one frame at a time.  N > 1: N frame slots inside this instance (own path state, queues,
+                                  accumulator and HIP stream each, ONE scene): a render() that starts a new image (new view, changed
+                                  scene, reset) is queued on the next slot while earlier frames still trace; a render() that adds a
+                                  sample to the current image stays on its slot.  Reads return the latest frame.  world must be 1.
+                                  Export GPU_MAX_HW_QUEUES >= N before the HIP runtime starts. */
 } rfw_hip_options;
 
 enum {

@@ -106,9 +106,9 @@ class HipBackend:
         return cls(width, height, scale, **options)
 
     def __init__(self, width, height, scale=1.0, device=-1, max_path_length=0, clamp_value=0.0, rank=0, world=1,
-                 tile_size=0, builder=pod.RFW_HIP_BUILDER_AUTO, flags=0, streams=0):
+                 tile_size=0, builder=pod.RFW_HIP_BUILDER_AUTO, flags=0, streams=0, frames_in_flight=0):
         self._l = hip_lib()
-        o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags, streams)
+        o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags, streams, frames_in_flight)
         h = self._l.rfw_hip_create(width, height, scale, C.byref(o))
         if not h:
             raise BackendError("rfw_hip_create failed: " + self._l.rfw_hip_last_error(None).decode())

@@ -185,7 +185,23 @@ struct Instance {
     uint32_t last_bounces = 0;
     bool frame_recorded = false;
     bool last_count_flag = false;
+
+    // frames in flight inside ONE instance (options.frames_in_flight > 1): the instance itself is slot 0, `slots` are internal
+    // instances that own only per-frame state (path buffers, queues, accumulator, stream) and render the owner's scene.  A render()
+    // that starts a new image (new view, changed scene, reset) goes to the next slot; one that adds a sample stays on its slot.
+    Instance* scene = nullptr;            // in a slot: the owner whose scene it renders
+    std::vector<Instance*> slots;         // in the owner: slots 1 .. frames_in_flight - 1
+    uint32_t cur_slot = 0;                // slot of the latest render
+    uint64_t scene_version = 1;           // owner: bumped by every synchronize() that changed the scene
+    uint64_t rendered_version = 0;        // per slot: scene version of the image it accumulates
+    bool restart = false;                 // owner: reset_accumulation() -> the next render starts a new image
+    hipEvent_t scene_ready = nullptr;     // owner: recorded after synchronize(); slots wait for it before they read the scene
+    hipEvent_t frame_done = nullptr;      // per slot: recorded after its latest render; the owner waits for it before it edits the scene
 };
+
+inline Instance* scene_of(Instance* I) { return I->scene ? I->scene : I; }
+inline const Instance* scene_of(const Instance* I) { return I->scene ? I->scene : I; }
+inline Instance* slot_ptr(Instance* I, uint32_t k) { return k == 0 ? I : I->slots[k - 1]; }
 
 #define HIP_TRY(inst, expr)                                                                     \
     do {                                                                                        \
@@ -270,22 +286,23 @@ uint32_t spill_stride(const Instance* I) { return (uint32_t)(I->d_spill.cap / kS
 SceneDev scene_dev(Instance* I)
 {
     SceneDev s;
-    s.tlas_nodes = I->d_tlas_nodes.ptr;
-    s.tlas_prims = I->d_tlas_prims.ptr;
-    s.instances = I->d_xforms.ptr;
-    s.instance_normals = I->d_normals.ptr;
-    s.blas_nodes = I->d_blas_nodes.ptr;
-    s.tri_packets = I->d_packets.ptr;
-    s.triangles = I->d_triangles.ptr;
-    s.materials = I->d_materials.ptr;
-    s.area_lights = I->d_area.ptr;
-    s.point_lights = I->d_point.ptr;
-    s.spot_lights = I->d_spot.ptr;
-    s.directional_lights = I->d_dir.ptr;
-    s.tex_data = I->d_tex_data.ptr;
-    s.tex_desc = I->d_tex_desc.ptr;
-    s.n_textures = I->n_textures;
-    s.skybox = I->skybox_desc;
+    const Instance* S = scene_of(I); // a frame slot reads its owner's scene
+    s.tlas_nodes = S->d_tlas_nodes.ptr;
+    s.tlas_prims = S->d_tlas_prims.ptr;
+    s.instances = S->d_xforms.ptr;
+    s.instance_normals = S->d_normals.ptr;
+    s.blas_nodes = S->d_blas_nodes.ptr;
+    s.tri_packets = S->d_packets.ptr;
+    s.triangles = S->d_triangles.ptr;
+    s.materials = S->d_materials.ptr;
+    s.area_lights = S->d_area.ptr;
+    s.point_lights = S->d_point.ptr;
+    s.spot_lights = S->d_spot.ptr;
+    s.directional_lights = S->d_dir.ptr;
+    s.tex_data = S->d_tex_data.ptr;
+    s.tex_desc = S->d_tex_desc.ptr;
+    s.n_textures = S->n_textures;
+    s.skybox = S->skybox_desc;
     s.spill = I->d_spill.ptr;
     s.spill_stride = spill_stride(I);
     s.counters = I->d_counters.ptr;
@@ -716,6 +733,11 @@ int do_synchronize(Instance* I)
     HIP_TRY(I, hipSetDevice(I->device));
     bool any_change = false;
     int rc;
+    if (!I->slots.empty() && (I->meshes_dirty || I->instances_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty)) {
+        // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
+        for (Instance* c : I->slots)
+            if (c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->stream, c->frame_done, 0));
+    }
     if (!I->meshes_dirty && I->instances_dirty) { // a new (mesh, skin) pair needs its region of the mega-buffers
         const auto want = wanted_derived(I);
         bool same = want.size() == I->derived.size();
@@ -775,7 +797,11 @@ int do_synchronize(Instance* I)
         I->lights_dirty = false;
         any_change = true;
     }
-    if (any_change) I->sample_count = 0; // the accumulated image no longer matches the scene
+    if (any_change) {
+        I->sample_count = 0; // the accumulated image no longer matches the scene
+        I->scene_version++;
+        if (I->scene_ready) HIP_TRY(I, hipEventRecord(I->scene_ready, I->stream));
+    }
     I->synchronized = true;
     return RFW_HIP_OK;
 }
@@ -793,10 +819,11 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.p1[0] = v.p1.x; c.p1[1] = v.p1.y; c.p1[2] = v.p1.z;
     c.width = I->width; c.height = I->height;
     c.sample_count = I->sample_count;
-    c.point_light_count = (uint32_t)I->point_lights.size();
-    c.area_light_count = (uint32_t)I->area_lights.size();
-    c.spot_light_count = (uint32_t)I->spot_lights.size();
-    c.directional_light_count = (uint32_t)I->directional_lights.size();
+    const Instance* S = scene_of(I);
+    c.point_light_count = (uint32_t)S->point_lights.size();
+    c.area_light_count = (uint32_t)S->area_lights.size();
+    c.spot_light_count = (uint32_t)S->spot_lights.size();
+    c.directional_light_count = (uint32_t)S->directional_lights.size();
     c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
     c.rank = I->rank * I->substreams + sub; c.world = I->world * I->substreams; c.local_tiles = I->local_tiles_v;
     c.flags = I->flags;
@@ -831,7 +858,8 @@ hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.da
 int do_render(Instance* I, const rfw_camera_view_3d& view)
 {
     HIP_TRY(I, hipSetDevice(I->device));
-    if (!I->synchronized || I->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
+    if (!scene_of(I)->synchronized || scene_of(I)->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
+    if (I->scene && I->scene->scene_ready) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0)); // a slot must not read a scene still being written
     if (I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) I->sample_count = 0;
     I->last_view = view;
     I->have_last_view = true;
@@ -907,6 +935,7 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
     if (I->frame_index - I->drained_index > kTimingRing) I->drained_index = I->frame_index - kTimingRing;
     I->frame_recorded = tm;
     I->last_count_flag = count;
+    if (I->frame_done) HIP_TRY(I, hipEventRecord(I->frame_done, main));
     return RFW_HIP_OK;
 }
 
@@ -971,6 +1000,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     I->width = width;
     I->height = height;
     int dev = -1;
+    uint32_t n_slots = 1;
     if (o) {
         dev = o->device;
         if (o->max_path_length) I->max_path_length = std::min<uint32_t>(o->max_path_length, kMaxBounces);
@@ -981,6 +1011,12 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->builder) I->builder = o->builder;
         I->flags = o->flags;
         if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
+        if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 16u);
+    }
+    if (n_slots > 1 && I->world > 1) {
+        g_create_error = "frames_in_flight > 1 needs world == 1 (a sharded frame is pipelined with one instance per frame in flight)";
+        delete I;
+        return nullptr;
     }
     if (I->rank >= I->world || (I->tile_size % 8) != 0) {
         g_create_error = "invalid shard options (rank >= world, or tile_size not a multiple of 8)";
@@ -1024,6 +1060,27 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         return nullptr;
     }
     (void)hipStreamSynchronize(I->stream);
+    if ((e = hipEventCreateWithFlags(&I->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (n_slots > 1) {
+        if ((e = hipEventCreateWithFlags(&I->scene_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        rfw_hip_options so;
+        std::memset(&so, 0, sizeof(so));
+        if (o) std::memcpy(&so, o, std::min<size_t>(o->struct_size ? o->struct_size : sizeof(so), sizeof(so)));
+        so.struct_size = sizeof(so);
+        so.device = I->device;
+        so.frames_in_flight = 1;
+        for (uint32_t k = 1; k < n_slots; k++) {
+            Instance* c = static_cast<Instance*>(rfw_hip_create(width, height, 1.0, &so));
+            if (!c) { // g_create_error is set
+                for (Instance* d : I->slots) rfw_hip_destroy(d);
+                I->slots.clear();
+                rfw_hip_destroy(I);
+                return nullptr;
+            }
+            c->scene = I;
+            I->slots.push_back(c);
+        }
+    }
     return I;
 }
 
@@ -1031,10 +1088,14 @@ void rfw_hip_destroy(void* inst)
 {
     if (!inst) return;
     Instance* I = static_cast<Instance*>(inst);
+    for (Instance* c : I->slots) rfw_hip_destroy(c); // frame slots first: they read this instance's scene
+    I->slots.clear();
     {
         std::lock_guard<std::mutex> g(I->mu);
         (void)hipSetDevice(I->device);
         (void)hipDeviceSynchronize();
+        if (I->scene_ready) (void)hipEventDestroy(I->scene_ready);
+        if (I->frame_done) (void)hipEventDestroy(I->frame_done);
         I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
@@ -1160,7 +1221,25 @@ int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_vie
 {
     LOCK(inst);
     if (!view) return fail(I, RFW_HIP_E_INVALID, "render: null view");
-    return do_render(I, *view);
+    if (I->slots.empty()) return do_render(I, *view);
+    // frames in flight: does this call add a sample to the image of the current slot, or start a new image on the next slot?
+    Instance* cur = slot_ptr(I, I->cur_slot);
+    const bool same_image = !I->restart && cur->sample_count > 0 && cur->have_last_view && std::memcmp(&cur->last_view, view, sizeof(*view)) == 0 &&
+                            cur->rendered_version == I->scene_version;
+    if (!same_image) {
+        I->cur_slot = (I->cur_slot + 1) % (uint32_t)(I->slots.size() + 1);
+        cur = slot_ptr(I, I->cur_slot);
+        cur->sample_count = 0;
+    }
+    I->restart = false;
+    cur->rendered_version = I->scene_version;
+    if (cur != I) { // the owner's options apply to every slot
+        cur->max_path_length = I->max_path_length; cur->clamp_value = I->clamp_value; cur->flags = I->flags; cur->timing = I->timing;
+        for (int k = 0; k < 3; k++) cur->sky[k] = I->sky[k];
+    }
+    const int rc = do_render(cur, *view);
+    if (rc != RFW_HIP_OK && cur != I) I->err = cur->err;
+    return rc;
 }
 
 int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
@@ -1169,6 +1248,11 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     if (w == 0 || h == 0) return fail(I, RFW_HIP_E_INVALID, "resize: zero size");
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) {
+        const int rc = rfw_hip_resize(c, w, h, 1.0);
+        if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
+    }
+    I->restart = true;
     I->width = w;
     I->height = h;
     return alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
@@ -1231,6 +1315,7 @@ int rfw_hip_reset_accumulation(void* inst)
 {
     LOCK(inst);
     I->sample_count = 0;
+    I->restart = true; // with frame slots: the next render starts a new image (on the next slot)
     return RFW_HIP_OK;
 }
 
@@ -1259,6 +1344,12 @@ int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n)
 {
     LOCK(inst);
     if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_framebuffer: size mismatch");
+    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest frame lives in a slot
+        Instance* c = slot_ptr(I, I->cur_slot);
+        const int rc = rfw_hip_read_framebuffer(c, rgba, n);
+        if (rc != RFW_HIP_OK) I->err = c->err;
+        return rc;
+    }
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_out.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -1268,6 +1359,12 @@ int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
 {
     LOCK(inst);
     if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_accumulator: size mismatch");
+    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest frame lives in a slot
+        Instance* c = slot_ptr(I, I->cur_slot);
+        const int rc = rfw_hip_read_accumulator(c, rgba, n);
+        if (rc != RFW_HIP_OK) I->err = c->err;
+        return rc;
+    }
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_acc.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -1296,6 +1393,12 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
 {
     LOCK(inst);
     if (!out) return fail(I, RFW_HIP_E_INVALID, "get_frame_stats: null out");
+    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest frame lives in a slot
+        Instance* c = slot_ptr(I, I->cur_slot);
+        const int rc = rfw_hip_get_frame_stats(c, out);
+        if (rc != RFW_HIP_OK) I->err = c->err;
+        return rc;
+    }
     HIP_TRY(I, hipSetDevice(I->device));
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -1342,6 +1445,15 @@ int rfw_hip_drain_timing(void* inst, rfw_hip_frame_stats* sum, uint32_t* frames)
     }
     sum->substreams = I->substreams;
     I->drained_index = I->frame_index;
+    for (Instance* c : I->slots) { // frames in flight: the timings of every slot's frames
+        rfw_hip_frame_stats cs;
+        uint32_t cn = 0;
+        const int rc = rfw_hip_drain_timing(c, &cs, &cn);
+        if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
+        sum->ms_total += cs.ms_total; sum->ms_trace_primary += cs.ms_trace_primary; sum->ms_trace_extend += cs.ms_trace_extend;
+        sum->ms_trace_shadow += cs.ms_trace_shadow; sum->ms_shade += cs.ms_shade; sum->ms_other += cs.ms_other;
+        n += cn;
+    }
     *frames = n;
     return RFW_HIP_OK;
 }
@@ -1370,6 +1482,7 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
 int rfw_hip_set_stream(void* inst, void* stream)
 {
     LOCK(inst);
+    if (!I->slots.empty()) return fail(I, RFW_HIP_E_STATE, "set_stream: an instance with frames in flight launches on its slots' own streams");
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     I->stream = stream ? (hipStream_t)stream : I->own_stream;
@@ -1389,6 +1502,7 @@ int rfw_hip_device_synchronize(void* inst)
     LOCK(inst);
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream)); // every frame in flight
     return RFW_HIP_OK;
 }
 
@@ -1503,6 +1617,12 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     if (!what || !dst) return fail(I, RFW_HIP_E_INVALID, "debug_read: null pointer");
     HIP_TRY(I, hipSetDevice(I->device));
     const std::string w(what);
+    if (!I->slots.empty() && I->cur_slot != 0 && w != "xforms" && w != "normals" && w != "triangles" && w != "blas_raw" && w != "blas_order") {
+        Instance* c = slot_ptr(I, I->cur_slot); // per-frame buffers of the latest frame
+        const int rc = rfw_hip_debug_read(c, what, dst, bytes, written);
+        if (rc != RFW_HIP_OK) I->err = c->err;
+        return rc;
+    }
     const void* src = nullptr;
     uint64_t avail = 0;
     const uint64_t q = (uint64_t)I->capacity * 16;
