@@ -78,10 +78,10 @@ def main():
     # the slowest wavefront's, plus one all-gather per frame), so more frames have to overlap to keep the chip full (measured with
     # --emulate-shard 8: 0.42 ms per frame one at a time, 0.127 with 8 in flight, 0.119 with 12)
     F = args.frames_in_flight if args.frames_in_flight > 0 else (8 if world <= 2 else 12)
-    # HOW the frames in flight are held.  One GPU, static scene: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight:
-    # one scene in HBM, per-slot path state and stream).  Sharded frame (N > 1) or a scene that changes every frame (C3): F instances
-    # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers / its own TLAS.
-    use_slots = world == 1 and not animated and not args.emulate_shard and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
+    # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
+    # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
+    # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.
+    use_slots = world == 1 and not args.emulate_shard and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
     n_inst = 1 if use_slots else F
     bes, streams, gathers = [], [], []
     t0 = time.time()

@@ -194,6 +194,8 @@ struct Instance {
     uint32_t cur_slot = 0;                // slot of the latest render
     uint64_t scene_version = 1;           // owner: bumped by every synchronize() that changed the scene
     uint64_t rendered_version = 0;        // per slot: scene version of the image it accumulates
+    uint64_t instances_version = 1;       // owner: bumped whenever the instance lists (or what they refer to) changed
+    uint64_t tlas_version = 0;            // per slot: instances_version its own TLAS / instance descriptors were built from
     bool restart = false;                 // owner: reset_accumulation() -> the next render starts a new image
     hipEvent_t scene_ready = nullptr;     // owner: recorded after synchronize(); slots wait for it before they read the scene
     hipEvent_t frame_done = nullptr;      // per slot: recorded after its latest render; the owner waits for it before it edits the scene
@@ -202,6 +204,11 @@ struct Instance {
 inline Instance* scene_of(Instance* I) { return I->scene ? I->scene : I; }
 inline const Instance* scene_of(const Instance* I) { return I->scene ? I->scene : I; }
 inline Instance* slot_ptr(Instance* I, uint32_t k) { return k == 0 ? I : I->slots[k - 1]; }
+// Whose TLAS and instance descriptors a frame reads.  With frame slots every slot keeps its OWN (rebuilt lazily from the owner's
+// instance lists when stale), so a scene whose instances move every frame still pipelines; skinned copies live in the owner's
+// shared mesh buffers and are rebuilt by synchronize(), so with them all slots share the owner's TLAS and synchronize() drains.
+inline bool per_slot_tlas(const Instance* S) { return !S->slots.empty() && S->derived.empty(); }
+inline Instance* tlas_of(Instance* I) { Instance* S = scene_of(I); return per_slot_tlas(S) ? I : S; }
 
 #define HIP_TRY(inst, expr)                                                                     \
     do {                                                                                        \
@@ -287,10 +294,11 @@ SceneDev scene_dev(Instance* I)
 {
     SceneDev s;
     const Instance* S = scene_of(I); // a frame slot reads its owner's scene
-    s.tlas_nodes = S->d_tlas_nodes.ptr;
-    s.tlas_prims = S->d_tlas_prims.ptr;
-    s.instances = S->d_xforms.ptr;
-    s.instance_normals = S->d_normals.ptr;
+    const Instance* TL = tlas_of(I);
+    s.tlas_nodes = TL->d_tlas_nodes.ptr;
+    s.tlas_prims = TL->d_tlas_prims.ptr;
+    s.instances = TL->d_xforms.ptr;
+    s.instance_normals = TL->d_normals.ptr;
     s.blas_nodes = S->d_blas_nodes.ptr;
     s.tri_packets = S->d_packets.ptr;
     s.triangles = S->d_triangles.ptr;
@@ -550,8 +558,10 @@ int build_blas_host(Instance* I)
 }
 
 // instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
-int build_instances(Instance* I)
+int build_instances(Instance* I, Instance* T)
 {
+    // I: the scene (instance lists, mesh records, skins); T: whose instance-level device buffers, staging blocks and stream are used —
+    // I itself, or one of its frame slots (each slot keeps its own TLAS so that a scene whose instances move every frame still pipelines)
     const auto wait0 = std::chrono::steady_clock::now();
     // sizes first, then ONE pinned staging block: [matrices | mesh_of | valid_gids | mesh_local]
     size_t n_all = 0;
@@ -564,15 +574,15 @@ int build_instances(Instance* I)
     if (!I->derived.empty())
         for (size_t k = 0; k < I->skins.size(); k++) { joint_off[k] = n_joints; n_joints += I->skins[k].size(); }
     const size_t total = off_joints + n_joints * sizeof(rfw_mat4);
-    if (I->stage_pending[I->stage_next]) { // the upload that last used this block (two synchronizes ago) must have left it
-        HIP_TRY(I, hipEventSynchronize(I->stage_event[I->stage_next]));
-        I->stage_pending[I->stage_next] = false;
+    if (T->stage_pending[T->stage_next]) { // the upload that last used this block (two synchronizes ago) must have left it
+        HIP_TRY(I, hipEventSynchronize(T->stage_event[T->stage_next]));
+        T->stage_pending[T->stage_next] = false;
     }
     // back-pressure, not work: a host that runs ahead of the GPU waits here for the copy of two synchronizes ago
-    I->ms_stage_wait = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wait0).count();
+    T->ms_stage_wait = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wait0).count();
     int rc;
-    if ((rc = ensure_stage(I, total))) return rc;
-    char* st = static_cast<char*>(I->stage);
+    if ((rc = ensure_stage(T, total))) return rc;
+    char* st = static_cast<char*>(T->stage);
     rfw_mat4* mats = reinterpret_cast<rfw_mat4*>(st + off_mats);
     uint32_t* mesh_of = reinterpret_cast<uint32_t*>(st + off_meshof);
     uint32_t* valid = reinterpret_cast<uint32_t*>(st + off_valid);
@@ -602,31 +612,31 @@ int build_instances(Instance* I)
             if (mesh_ok && !is_zero_matrix(kv.second.matrices[s])) valid[n_valid++] = gid; // zero matrix = removed slot (instances_3d.rs:79-86)
         }
     }
-    I->n_instances = n_all;
-    I->n_valid_instances = n_valid;
-    HIP_TRY(I, I->d_matrices.ensure(n_all));
-    HIP_TRY(I, I->d_mesh_of_instance.ensure(n_all));
-    HIP_TRY(I, I->d_valid_gids.ensure(n_all));
-    HIP_TRY(I, I->d_mesh_local.ensure(std::max<size_t>(n_mesh, 1)));
-    HIP_TRY(I, I->d_xforms.ensure(n_all));
-    HIP_TRY(I, I->d_normals.ensure(n_all));
-    HIP_TRY(I, I->d_tlas_prims.ensure(n_all));
-    HIP_TRY(I, I->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(I, I->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(I, I->d_node_count.ensure(1));
-    hipStream_t s = I->stream;
+    T->n_instances = n_all;
+    T->n_valid_instances = n_valid;
+    HIP_TRY(I, T->d_matrices.ensure(n_all));
+    HIP_TRY(I, T->d_mesh_of_instance.ensure(n_all));
+    HIP_TRY(I, T->d_valid_gids.ensure(n_all));
+    HIP_TRY(I, T->d_mesh_local.ensure(std::max<size_t>(n_mesh, 1)));
+    HIP_TRY(I, T->d_xforms.ensure(n_all));
+    HIP_TRY(I, T->d_normals.ensure(n_all));
+    HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
+    HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, T->d_node_count.ensure(1));
+    hipStream_t s = T->stream;
     if (n_all) {
-        HIP_TRY(I, hipMemcpyAsync(I->d_matrices.ptr, mats, n_all * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
-        HIP_TRY(I, hipMemcpyAsync(I->d_mesh_of_instance.ptr, mesh_of, n_all * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(I, hipMemcpyAsync(I->d_valid_gids.ptr, valid, n_all * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(T->d_matrices.ptr, mats, n_all * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(T->d_mesh_of_instance.ptr, mesh_of, n_all * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(T->d_valid_gids.ptr, valid, n_all * 4, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(I, hipMemcpyAsync(I->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
+    HIP_TRY(I, hipMemcpyAsync(T->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
     if (!I->derived.empty()) {
         // skinned copies (structs.rs:820-877) and their BLAS, every synchronize, all on-stream: skin -> refit of the tree built over the
         // first pose (gpu-rt: refit_bvh, lib.rs:1350-1352) -> packets -> bounds; with builder = DEVICE_LBVH: skin -> boxes -> LBVH rebuild
         HIP_TRY(I, I->d_joints.ensure(n_joints));
         HIP_TRY(I, hipMemcpyAsync(I->d_joints.ptr, joints, n_joints * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
-        if ((rc = ensure_lbvh_ws(I, std::max<uint32_t>(I->max_derived_tris, n_valid)))) return rc;
+        if ((rc = ensure_lbvh_ws(T, std::max<uint32_t>(I->max_derived_tris, n_valid)))) return rc;
         const bool refit = I->builder != RFW_HIP_BUILDER_DEVICE_LBVH; // DEVICE_LBVH keeps the rebuild-every-frame path
         if (refit) {
             const size_t raw_nodes = I->d_blas_raw.cap;
@@ -647,15 +657,15 @@ int build_instances(Instance* I)
             uint32_t quantise_count = r.node_count;
             if (!refit) {
                 launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
-                HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, raw, order, nullptr));
+                HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, raw, order, nullptr));
             } else if (!d.topology_built) {
                 // first pose of this (mesh, skin) pair: the tree, by binned SAH (blocking, once), and what a refit needs to climb it
                 launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
                 HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
-                HIP_TRY(I, I->d_node_count.ensure(1));
-                HIP_TRY(I, sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, I->d_node_count.ptr, I->sah_max_leaf,
+                HIP_TRY(I, T->d_node_count.ensure(1));
+                HIP_TRY(I, sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, T->d_node_count.ptr, I->sah_max_leaf,
                                      I->sah_trav_cost));
-                HIP_TRY(I, hipMemcpyAsync(&d.node_count, I->d_node_count.ptr, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(I, hipMemcpyAsync(&d.node_count, T->d_node_count.ptr, 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(I, hipStreamSynchronize(s));
                 if (d.node_count == 0 || d.node_count > r.node_count) return fail(I, RFW_HIP_E_STATE, "skinned BLAS: node count out of range");
                 launch_refit_setup(s, raw, d.node_count, I->d_refit_parent.ptr + raw_off, I->d_refit_nint.ptr + raw_off);
@@ -667,30 +677,30 @@ int build_instances(Instance* I)
             }
             launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
             launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, quantise_count);
-            launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, I->d_mesh_local.ptr + d.record);
+            launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, T->d_mesh_local.ptr + d.record);
         }
         HIP_TRY(I, hipGetLastError());
         if (!I->tlas_on_device) { // the host TLAS needs the deformed bounds
             HIP_TRY(I, hipStreamSynchronize(s));
             for (const auto& kv : I->derived)
-                HIP_TRY(I, hipMemcpy(local + kv.second.record, I->d_mesh_local.ptr + kv.second.record, sizeof(DevBox), hipMemcpyDeviceToHost));
+                HIP_TRY(I, hipMemcpy(local + kv.second.record, T->d_mesh_local.ptr + kv.second.record, sizeof(DevBox), hipMemcpyDeviceToHost));
         }
     }
-    launch_prepare_instances(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)n_all, I->d_xforms.ptr, I->d_normals.ptr);
+    launch_prepare_instances(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)n_all, T->d_xforms.ptr, T->d_normals.ptr);
     if (I->tlas_on_device) {
-        HIP_TRY(I, I->d_inst_boxes.ensure(std::max<size_t>(n_valid, 1)));
-        HIP_TRY(I, I->d_tlas_order.ensure(std::max<size_t>(n_valid, 1)));
-        if ((rc = ensure_lbvh_ws(I, n_valid))) return rc;
-        launch_instance_boxes(s, I->d_matrices.ptr, I->d_mesh_of_instance.ptr, I->d_mesh_local.ptr, I->d_valid_gids.ptr, n_valid, I->d_inst_boxes.ptr);
-        HIP_TRY(I, lbvh_build(s, I->d_inst_boxes.ptr, n_valid, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_tlas_raw.ptr, I->d_tlas_order.ptr,
-                              I->d_node_count.ptr));
-        launch_quantize_nodes(s, I->d_tlas_raw.ptr, I->d_tlas_nodes.ptr, std::max<uint32_t>(n_valid, 1u));
-        launch_gather_u32(s, I->d_valid_gids.ptr, I->d_tlas_order.ptr, n_valid, I->d_tlas_prims.ptr);
+        HIP_TRY(I, T->d_inst_boxes.ensure(std::max<size_t>(n_valid, 1)));
+        HIP_TRY(I, T->d_tlas_order.ensure(std::max<size_t>(n_valid, 1)));
+        if ((rc = ensure_lbvh_ws(T, n_valid))) return rc;
+        launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
+        HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
+                              T->d_node_count.ptr));
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, std::max<uint32_t>(n_valid, 1u));
+        launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
-        I->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
-        HIP_TRY(I, hipEventRecord(I->stage_event[I->stage_next], s));
-        I->stage_pending[I->stage_next] = true;
-        I->stage_next = (I->stage_next + 1) % Instance::kStages;
+        T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
+        HIP_TRY(I, hipEventRecord(T->stage_event[T->stage_next], s));
+        T->stage_pending[T->stage_next] = true;
+        T->stage_next = (T->stage_next + 1) % Instance::kStages;
     } else {
         // host TLAS (builder = HOST_SAH): boxes on the host, binned SAH, upload
         std::vector<PrimBox> boxes(n_valid);
@@ -717,11 +727,11 @@ int build_instances(Instance* I)
         build_bvh4_host(boxes, 1, I->build_threads, tlas);
         std::vector<uint32_t> prims(tlas.prim_order.size());
         for (size_t k = 0; k < prims.size(); k++) prims[k] = valid[tlas.prim_order[k]];
-        I->n_tlas_nodes = tlas.nodes.size();
+        T->n_tlas_nodes = tlas.nodes.size();
         std::vector<Node4Q> qn(tlas.nodes.size());
         for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
-        if ((rc = upload(I, I->d_tlas_nodes, qn.data(), qn.size()))) return rc;
-        if ((rc = upload(I, I->d_tlas_prims, prims.data(), prims.size()))) return rc;
+        if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
+        if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));
     }
@@ -732,8 +742,10 @@ int do_synchronize(Instance* I)
 {
     HIP_TRY(I, hipSetDevice(I->device));
     bool any_change = false;
+    // did this call queue work on the owner's stream that the frame slots have to wait for (anything but a per-slot TLAS update)?
+    const bool shared_work = I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
     int rc;
-    if (!I->slots.empty() && (I->meshes_dirty || I->instances_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty)) {
+    if (!I->slots.empty() && (I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I)))) {
         // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
         for (Instance* c : I->slots)
             if (c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->stream, c->frame_done, 0));
@@ -756,7 +768,11 @@ int do_synchronize(Instance* I)
     }
     if (I->instances_dirty) {
         const auto t0 = std::chrono::steady_clock::now();
-        if ((rc = build_instances(I))) return rc;
+        I->instances_version++;
+        if (!per_slot_tlas(I)) { // else: every frame slot rebuilds its own TLAS from the new lists when it renders next
+            if ((rc = build_instances(I, I))) return rc;
+            I->tlas_version = I->instances_version;
+        }
         // host-side work (the device part is asynchronous), without the time spent waiting for the GPU to release a staging block
         I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() - I->ms_stage_wait;
         I->instances_dirty = false;
@@ -800,10 +816,22 @@ int do_synchronize(Instance* I)
     if (any_change) {
         I->sample_count = 0; // the accumulated image no longer matches the scene
         I->scene_version++;
-        if (I->scene_ready) HIP_TRY(I, hipEventRecord(I->scene_ready, I->stream));
+        // recorded only when something was queued here: the owner's stream also carries slot 0's frames, and an event behind them
+        // would make every slot wait for slot 0
+        if (I->scene_ready && shared_work) HIP_TRY(I, hipEventRecord(I->scene_ready, I->stream));
     }
     I->synchronized = true;
     return RFW_HIP_OK;
+}
+
+// frame slots with their own TLAS: (re)build the TLAS and instance descriptors of slot T from the owner's current instance lists
+int ensure_slot_tlas(Instance* S, Instance* T)
+{
+    if (!per_slot_tlas(S) || !S->synchronized || T->tlas_version == S->instances_version) return RFW_HIP_OK;
+    if (T != S && S->scene_ready) HIP_TRY(S, hipStreamWaitEvent(T->stream, S->scene_ready, 0)); // the mesh records it reads may still be uploading
+    const int rc = build_instances(S, T);
+    if (rc == RFW_HIP_OK) T->tlas_version = S->instances_version;
+    return rc;
 }
 
 CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint32_t sub = 0)
@@ -858,7 +886,7 @@ hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.da
 int do_render(Instance* I, const rfw_camera_view_3d& view)
 {
     HIP_TRY(I, hipSetDevice(I->device));
-    if (!scene_of(I)->synchronized || scene_of(I)->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
+    if (!scene_of(I)->synchronized || tlas_of(I)->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
     if (I->scene && I->scene->scene_ready) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0)); // a slot must not read a scene still being written
     if (I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) I->sample_count = 0;
     I->last_view = view;
@@ -1237,8 +1265,9 @@ int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_vie
         cur->max_path_length = I->max_path_length; cur->clamp_value = I->clamp_value; cur->flags = I->flags; cur->timing = I->timing;
         for (int k = 0; k < 3; k++) cur->sky[k] = I->sky[k];
     }
-    const int rc = do_render(cur, *view);
-    if (rc != RFW_HIP_OK && cur != I) I->err = cur->err;
+    int rc = ensure_slot_tlas(I, cur);
+    if (rc == RFW_HIP_OK) rc = do_render(cur, *view);
+    if (rc != RFW_HIP_OK && cur != I && !cur->err.empty()) I->err = cur->err;
     return rc;
 }
 
@@ -1462,6 +1491,11 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
 {
     LOCK(inst);
     if (!out) return fail(I, RFW_HIP_E_INVALID, "get_scene_stats: null out");
+    if (per_slot_tlas(I) && I->synchronized) {
+        (void)hipSetDevice(I->device);
+        const int trc = ensure_slot_tlas(I, I); // the owner's own TLAS may be stale: its slots rebuild theirs independently
+        if (trc != RFW_HIP_OK) return trc;
+    }
     out->triangles = I->n_tris;
     out->instances = I->n_valid_instances;
     out->blas_nodes = I->n_blas_nodes;
@@ -1539,6 +1573,7 @@ static int intersect_impl(void* inst, const float* origins, const float* directi
     if (n && (!origins || !directions || !hits)) return fail(I, RFW_HIP_E_INVALID, "intersect: null pointer");
     if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "intersect: scene not synchronized");
     HIP_TRY(I, hipSetDevice(I->device));
+    { const int trc = ensure_slot_tlas(I, I); if (trc != RFW_HIP_OK) return trc; }
     const uint64_t chunk = spill_stride(I);
     DevBuf<float> d_o, d_d;
     DevBuf<rfw_hip_hit> d_h;
@@ -1583,6 +1618,7 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
     if (n && (!origins || !directions || !t_max || !occluded)) return fail(I, RFW_HIP_E_INVALID, "occludes: null pointer");
     if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "occludes: scene not synchronized");
     HIP_TRY(I, hipSetDevice(I->device));
+    { const int trc = ensure_slot_tlas(I, I); if (trc != RFW_HIP_OK) return trc; }
     const uint64_t chunk = spill_stride(I);
     DevBuf<float> d_o, d_d, d_t;
     DevBuf<uint8_t> d_r;

@@ -453,3 +453,32 @@ def test_frame_slots_pipeline_new_images_and_keep_accumulation_exact():
     o, d = random_rays(2000, 4)
     assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
     be.close()
+
+
+def test_frame_slots_with_instances_that_move_every_frame():
+    """C3 in miniature through ONE instance with frame slots: set_3d_instances + synchronize + render every frame, each frame on the next
+    slot with its own TLAS built from the lists of that moment; every frame must equal the oracle's for the same pose."""
+    w, h = 96, 64
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("cornell").build("spheres", 6, 5, 0.3)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=2, frames_in_flight=4)
+    orc = Oracle(w, h, threads=4, max_path_length=2)
+    wanted = []
+    for frame in range(9):                      # nine frames queued without ever reading back
+        scene.animate(frame / 3.0)
+        scene.sync(be)
+        be.render(view)
+    scene.mark_all_changed(); scene.sync(orc); orc.reset(); orc.render(view)
+    assert be.frame_stats()["sample_count"] == 1
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    for frame in (2, 5):                        # and frame by frame
+        scene.animate(frame / 3.0)
+        scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+        orc.reset(); be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), frame
+        o, d = random_rays(3000, frame)
+        assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
+    assert be.scene_stats()["instances"] == 31
+    be.close()
