@@ -482,3 +482,38 @@ def test_frame_slots_with_instances_that_move_every_frame():
         assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
     assert be.scene_stats()["instances"] == 31
     be.close()
+
+
+def test_frame_slots_with_skinned_meshes_and_resize():
+    """Skinned copies live in the owner's shared mesh buffers: with them the slots share one TLAS and synchronize() waits for the frames in
+    flight before it re-skins.  Every pose must still match the oracle; resize keeps working with slots."""
+    w, h = 96, 64
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("skinned", 0, 0, 0.0, 3)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=3)
+    orc = Oracle(w, h, threads=4, max_path_length=3)
+    for frame, t in enumerate((0.7, 0.2, 1.1, 1.9, 0.0)):   # pose, synchronize, render back to back: frames queue behind each other
+        scene.pose(t)
+        scene.sync(be)
+        be.render(view)
+    scene.mark_all_changed(); scene.sync(orc); orc.reset(); orc.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    be.render(view); orc.render(view)                          # a second sample of the last pose
+    assert be.frame_stats()["sample_count"] == 2
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    # resize: every slot gets new buffers, accumulation restarts
+    w2, h2 = 64, 48
+    be.resize((w2, h2))
+    scene.set_aspect(w2 / h2)
+    v2 = scene.view(w2, h2)
+    orc2 = Oracle(w2, h2, threads=4, max_path_length=3)
+    scene.mark_all_changed(); scene.sync(orc2)
+    for _ in range(2):
+        be.render(v2); orc2.render(v2)
+    assert be.frame_stats()["sample_count"] == 2
+    assert be.accumulator().shape == (h2, w2, 4)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc2.accumulator().view(np.uint32))
+    be.close()
