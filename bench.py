@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 # Every renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by default): two
 # instances whose streams land on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 2 else "16")  # N > 2: 12 instance streams + RCCL's
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
