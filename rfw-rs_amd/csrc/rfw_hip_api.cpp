@@ -511,6 +511,7 @@ int build_blas_device(Instance* I)
     if (n_static) HIP_TRY(I, hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
     I->n_blas_nodes = node_total - static_nodes;
     for (uint32_t c : counts) I->n_blas_nodes += c;
+    I->d_sah_ws.release(); // ~350 B per triangle of build scratch: not kept between scene changes
     return RFW_HIP_OK;
 }
 
