@@ -1552,6 +1552,7 @@ int rfw_hip_shard_info(void* inst, uint64_t* slab_floats, uint32_t* local, uint3
 int rfw_hip_set_slab_output(void* inst, void* ptr)
 {
     LOCK(inst);
+    if (!I->slots.empty()) return fail(I, RFW_HIP_E_STATE, "set_slab_output: not available with frames_in_flight > 1 (one instance per frame in flight instead)");
     I->external_slab = ptr;
     I->sample_count = 0;
     return RFW_HIP_OK;
