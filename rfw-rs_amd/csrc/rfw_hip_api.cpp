@@ -194,6 +194,7 @@ struct Instance {
     uint32_t cur_slot = 0;                // slot of the latest render
     uint64_t scene_version = 1;           // owner: bumped by every synchronize() that changed the scene
     uint64_t rendered_version = 0;        // per slot: scene version of the image it accumulates
+    uint64_t waited_version = 0;          // per slot: scene version whose scene_ready event its stream has already waited for
     uint64_t instances_version = 1;       // owner: bumped whenever the instance lists (or what they refer to) changed
     uint64_t tlas_version = 0;            // per slot: instances_version its own TLAS / instance descriptors were built from
     bool restart = false;                 // owner: reset_accumulation() -> the next render starts a new image
@@ -888,7 +889,10 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
 {
     HIP_TRY(I, hipSetDevice(I->device));
     if (!scene_of(I)->synchronized || tlas_of(I)->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
-    if (I->scene && I->scene->scene_ready) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0)); // a slot must not read a scene still being written
+    if (I->scene && I->scene->scene_ready && I->waited_version != I->scene->scene_version) { // a slot must not read a scene still being written
+        HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0));
+        I->waited_version = I->scene->scene_version;
+    }
     if (I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) I->sample_count = 0;
     I->last_view = view;
     I->have_last_view = true;
@@ -1089,8 +1093,8 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         return nullptr;
     }
     (void)hipStreamSynchronize(I->stream);
-    if ((e = hipEventCreateWithFlags(&I->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (n_slots > 1) {
+        if ((e = hipEventCreateWithFlags(&I->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&I->scene_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         rfw_hip_options so;
         std::memset(&so, 0, sizeof(so));
@@ -1107,6 +1111,14 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
                 return nullptr;
             }
             c->scene = I;
+            if (hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming) != hipSuccess) {
+                g_create_error = "hipEventCreate (frame slot)";
+                rfw_hip_destroy(c);
+                for (Instance* d : I->slots) rfw_hip_destroy(d);
+                I->slots.clear();
+                rfw_hip_destroy(I);
+                return nullptr;
+            }
             I->slots.push_back(c);
         }
     }
