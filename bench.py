@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="renderer instances used round-robin, each on its own stream: frame k+1 is traced while frame k's tail, "
                          "all-gather and assemble finish (1 = strictly one frame at a time)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames traced per rfw_hip_render_batch call (one launch per stage and, with a sharded frame, ONE all-gather for the "
+                         "whole batch); 1 = one render() per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
@@ -74,10 +77,15 @@ def main():
         scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
-    # default: 8 frames in flight on one or two GPUs; with the frame sharded over more GPUs each rank's kernels are short (their time is
-    # the slowest wavefront's, plus one all-gather per frame), so more frames have to overlap to keep the chip full (measured with
-    # --emulate-shard 8: 0.42 ms per frame one at a time, 0.127 with 8 in flight, 0.119 with 12)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (8 if world <= 2 else 12)
+    # Frames per launch and frames in flight.  One GPU: 8 frames in flight, one render() each (render_batch gains 3 % here: 2 x 8 -> 5010
+    # Mrays/s against 4855).  Sharded frame: a rank's kernels cover 1/N of a frame (their time is the slowest wavefront's), so B = 8 frames
+    # are traced per launch (rfw_hip_render_batch: B/N of a frame's paths per kernel, ONE all-gather per batch) and 3 such batches are in
+    # flight.  Measured with --emulate-shard 8, ms per frame on rank 0's shard: one frame at a time 0.42, 12 in flight 0.117, 3 batches
+    # of 8 in flight 0.100; --emulate-shard 4: 0.204 -> 0.184; --emulate-shard 2: 0.364 -> 0.338.
+    B = args.batch if args.batch > 0 else (1 if world == 1 and not args.emulate_shard else 8)
+    if animated:
+        B = 1  # C3 changes the scene every frame: a batch shares one scene
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 8 if world <= 2 else 12)
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.
@@ -88,7 +96,7 @@ def main():
     for f in range(n_inst):
         be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
                              world=world if not args.emulate_shard else args.emulate_shard,
-                             streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=F if use_slots else 0)
+                             streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=F if use_slots else 0, max_batch=B)
         # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created: HIP deals streams to
         # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
         # all-gather is ordered against the kernels and the HIP events that time them are recorded on the launch stream
@@ -102,8 +110,8 @@ def main():
         if world > 1 or args.emulate_shard:
             nslab = be.shard_info()["slab_floats"]
             wn = world if not args.emulate_shard else args.emulate_shard
-            send = torch.zeros(nslab, dtype=torch.float32, device="cuda")          # this rank's tiles (written by render())
-            g = (send, torch.zeros(wn, nslab, dtype=torch.float32, device="cuda"))  # (send buffer, all ranks' slabs)
+            send = torch.zeros(B * nslab, dtype=torch.float32, device="cuda")           # this rank's tiles of B frames (written by render())
+            g = (send, torch.zeros(wn * B * nslab, dtype=torch.float32, device="cuda"), nslab, wn)  # (send buffer, all ranks' slabs)
             be.set_slab_output(send.data_ptr())
         bes.append(be); streams.append(st); gathers.append(g)
     sync_s = (time.time() - t0) / n_inst
@@ -115,10 +123,28 @@ def main():
     sync_ms = [0.0]
     step_no = [0]
 
+    pending = [0]
+    last_issue = [None]
+
     def step():
+        """One frame.  With --batch B the frame is queued and every B-th call traces the B queued frames in one render_batch()."""
+        if B > 1:
+            pending[0] += 1
+            if pending[0] == B:
+                flush()
+            return
+        issue(1)
+
+    def flush():
+        if pending[0]:
+            issue(pending[0])
+            pending[0] = 0
+
+    def issue(nf):
         k = step_no[0] % n_inst
         step_no[0] += 1
         b, g = bes[k], gathers[k]
+        last_issue[0] = (b, nf)
         with (torch.cuda.stream(streams[k]) if world > 1 else contextlib.nullcontext()):  # the library already launches on streams[k]
             if animated:  # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
                 t_s = time.perf_counter()
@@ -126,31 +152,36 @@ def main():
                 frame_no[0] += 1
                 scene.sync(b)
                 sync_ms[0] += (time.perf_counter() - t_s) * 1e3
-            b.reset_accumulation()
-            b.render(view)
+            if B > 1:
+                b.render_batch([view] * nf)  # nf independent new images (here of the same view, like the reset + render below)
+            else:
+                b.reset_accumulation()
+                b.render(view)
             if world > 1:
-                send, recv = g
+                send, recv, nslab, wn = g
+                send, recv = send[:nf * nslab], recv[:wn * nf * nslab]  # slab = [frame][tile pixels]; gathered = [rank][frame][tile pixels]
                 if dist_backend == "nccl":
-                    dist.all_gather_into_tensor(recv.view(-1), send)  # the ONE collective per frame (RCCL over xGMI)
+                    dist.all_gather_into_tensor(recv, send)  # the ONE collective per frame / per batch (RCCL over xGMI)
                 else:
                     host = torch.empty(recv.shape, dtype=recv.dtype)
-                    dist.all_gather_into_tensor(host.view(-1), send.cpu())
+                    dist.all_gather_into_tensor(host, send.cpu())
                     recv.copy_(host)
-                b.assemble_frame(recv.data_ptr())
+                b.assemble_batch(recv.data_ptr(), nf)
             elif args.emulate_shard:
-                b.assemble_frame(g[1].data_ptr())  # the de-tiling a rank would do after the all-gather
+                b.assemble_batch(g[1].data_ptr(), nf)  # the de-tiling a rank would do after the all-gather
             if args.readback:
                 b.framebuffer()  # blocking device-to-host copy of the w x h RGBA32F frame
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
     be.set_option("count_traversal", 1)
-    step()
+    issue(1)
     cs = be.frame_stats()
     be.set_option("count_traversal", 0)
     rays_local = cs["primary_rays"] + cs["shadow_rays"] + cs["extension_rays"]
 
     for _ in range(args.warmup):
         step()
+    flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,11 +207,24 @@ def main():
                 timed_frames += n
                 for k in kernel_ms:
                     kernel_ms[k] += ms[k]
+    flush()  # a last, shorter batch when --steps is not a multiple of --batch: exactly K frames are timed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # Sharded frame: is what the all-gather + assemble left on this rank the frame one GPU renders alone?  (after the timed region;
+    # static scenes only: C3's last frame depends on the animation clock)
+    shard_check = None
+    if world > 1 and rank == 0 and not animated and last_issue[0] is not None:
+        lb, lnf = last_issue[0]
+        whole = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length)
+        scene.mark_all_changed()
+        scene.sync(whole)
+        whole.render(view)
+        ref = whole.accumulator().view(np.uint32)
+        shard_check = all(np.array_equal(lb.accumulator_at(f).view(np.uint32), ref) for f in range(lnf))
+        whole.close()
     # With several frames in flight the kernels of different frames share the machine, so their HIP-event spans in the timed
     # region are not launch durations.  The per-kernel roofline therefore comes from a short pass AFTER the timed region that
     # renders one frame at a time on instance 0 (the same thing `--frames-in-flight 1` times, and what a rocprofv3 kernel trace
@@ -272,7 +316,7 @@ def main():
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": bool(args.readback), "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": bool(args.readback), "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],

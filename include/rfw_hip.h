@@ -66,6 +66,8 @@ typedef struct {
                                   scene, reset) is queued on the next slot while earlier frames still trace; a render() that adds a
                                   sample to the current image stays on its slot.  Reads return the latest frame.  world must be 1.
                                   Export GPU_MAX_HW_QUEUES >= N before the HIP runtime starts. */
+    uint32_t max_batch;        /* 0/1 = none.  B > 1 (<= 16): rfw_hip_render_batch may trace up to B independent frames in ONE launch per
+                                  stage (buffers are sized for B frames).  Sub-streams must be 1. */
 } rfw_hip_options;
 
 enum {
@@ -206,6 +208,16 @@ RFW_HIP_API int rfw_hip_depth_test(void* instance, const float* origins, const f
 /* Debug read-back of the wavefront queues after the last render() bounce `bounce`
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
 RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);
+
+/* A batch of `count` independent NEW images, one per view, traced as one tall virtual frame: every stage of the wavefront loop is ONE
+ * launch over the paths of all frames (bigger launches, fewer of them; with a sharded frame also ONE all-gather per batch).  Each
+ * frame is exactly what rfw_hip_render of that view on a freshly reset instance produces.  count <= options.max_batch; the views must
+ * share one spread angle (same field of view and height).  Afterwards frame f is read with the _at functions; with world > 1 the slab
+ * written is [frame][slab], the gathered buffer handed to rfw_hip_assemble_batch is [rank][frame][slab]. */
+RFW_HIP_API int rfw_hip_render_batch(void* instance, const rfw_camera_view_3d* views, uint32_t count);
+RFW_HIP_API int rfw_hip_assemble_batch(void* instance, const void* gathered_device_ptr, uint32_t count);
+RFW_HIP_API int rfw_hip_read_framebuffer_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
+RFW_HIP_API int rfw_hip_read_accumulator_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
 
 /* Measured HBM roofline for this device in this job: a float4 device-to-device copy of `bytes` bytes
  * (rounded down to 16), repeated `iterations` times on the instance's stream and timed with HIP events.

@@ -23,7 +23,8 @@ EXPORTS = [
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
     "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
-    "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test",
+    "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
+    "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at",
 ]
 
 _lib = None
@@ -83,6 +84,10 @@ def hip_lib():
         l.rfw_hip_assemble_frame.argtypes = [vp, vp]
         l.rfw_hip_intersect.argtypes = [vp, vp, vp, f32, f32, u64, vp]
         l.rfw_hip_depth_test.argtypes = [vp, vp, vp, f32, f32, u64, vp, vp]
+        l.rfw_hip_render_batch.argtypes = [vp, vp, C.c_uint32]
+        l.rfw_hip_assemble_batch.argtypes = [vp, vp, C.c_uint32]
+        l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
+        l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
         l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
@@ -106,9 +111,9 @@ class HipBackend:
         return cls(width, height, scale, **options)
 
     def __init__(self, width, height, scale=1.0, device=-1, max_path_length=0, clamp_value=0.0, rank=0, world=1,
-                 tile_size=0, builder=pod.RFW_HIP_BUILDER_AUTO, flags=0, streams=0, frames_in_flight=0):
+                 tile_size=0, builder=pod.RFW_HIP_BUILDER_AUTO, flags=0, streams=0, frames_in_flight=0, max_batch=0):
         self._l = hip_lib()
-        o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags, streams, frames_in_flight)
+        o = pod.HipOptions(C.sizeof(pod.HipOptions), device, max_path_length, clamp_value, rank, world, tile_size, builder, flags, streams, frames_in_flight, max_batch)
         h = self._l.rfw_hip_create(width, height, scale, C.byref(o))
         if not h:
             raise BackendError("rfw_hip_create failed: " + self._l.rfw_hip_last_error(None).decode())
@@ -205,6 +210,24 @@ class HipBackend:
 
     def set_option(self, key, value):
         self._check(self._l.rfw_hip_set_option(self._h, key.encode(), float(value)))
+
+    def render_batch(self, views):
+        """k independent new images, one per view, in one launch per stage (options.max_batch >= k)."""
+        arr = (pod.CameraView3D * len(views))(*views)
+        self._check(self._l.rfw_hip_render_batch(self._h, arr, len(views)))
+
+    def assemble_batch(self, gathered_ptr, count):
+        self._check(self._l.rfw_hip_assemble_batch(self._h, C.c_void_p(gathered_ptr), count))
+
+    def accumulator_at(self, frame):
+        a = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._l.rfw_hip_read_accumulator_at(self._h, frame, a.ctypes.data, a.size))
+        return a
+
+    def framebuffer_at(self, frame):
+        a = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._l.rfw_hip_read_framebuffer_at(self._h, frame, a.ctypes.data, a.size))
+        return a
 
     def framebuffer(self):
         a = np.empty((self.height, self.width, 4), dtype=np.float32)

@@ -149,6 +149,20 @@ struct CameraParams {
     uint32_t tile_size, tiles_x, tiles_y, rank;
     uint32_t world, local_tiles, flags, max_path_length;
     float sky[3]; float pad2;
+    // a batch of independent frames traced as ONE tall virtual frame (rfw_hip_render_batch): frame f owns paths
+    // [f * frame_capacity, (f + 1) * frame_capacity); a path carries f in the top byte of its path-id word
+    uint32_t batch, frame_capacity, pad3, pad4;
+};
+
+constexpr int kMaxBatch = 16;
+struct FrameView { // the view-dependent part of CameraParams, one per frame of a batch
+    float pos[3]; float lens_size;
+    float right[3]; float pad0;
+    float up[3]; float pad1;
+    float p1[3]; float pad2;
+};
+struct BatchViews {
+    FrameView v[kMaxBatch];
 };
 
 // Device-side queue counters; one slot per bounce so nothing has to be reset or read back between bounces

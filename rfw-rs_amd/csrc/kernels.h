@@ -48,6 +48,7 @@ struct PathDev {
 void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n,
                               InstanceXform* xf, InstanceNormal* nm);
 void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count);
+void launch_primary_batch(hipStream_t s, const CameraParams& cam, const BatchViews& views, const SceneDev& sc, const PathDev& p, bool count);
 void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);

@@ -213,6 +213,39 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
     flush_counters<COUNT>(sc.counters, tc, 0);
 }
 
+// the same for a batch of independent frames (rfw_hip_render_batch): one launch covers the tiles of every frame of the batch
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
+{
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    const uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
+    const uint32_t f = (block * kTraceBlock) / cam.frame_capacity; // uniform: a frame's range is a multiple of the workgroup size
+    TravCounters tc{0, 0, 0};
+    uint32_t px = 0, py = 0;
+    const bool valid = f < cam.batch && slab_to_pixel(cam, idx - f * cam.frame_capacity, px, py);
+    if (valid) {
+        p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // every frame of a batch is a new image
+        CameraParams c = cam;
+        const FrameView& v = views.v[f];
+        for (int k = 0; k < 3; k++) { c.pos[k] = v.pos[k]; c.right[k] = v.right[k]; c.up[k] = v.up[k]; c.p1[k] = v.p1[k]; }
+        c.lens_size = v.lens_size;
+        const uint32_t path_id = px + py * cam.width;
+        uint32_t seed = wang_hash(path_id * 16789u + 0u * 1791u + 0u * 720898027u);
+        f3 O, D;
+        generate_eye_ray(c, O, D, px, py, seed);
+        float t = 1e26f, hu = 0.0f, hv = 0.0f;
+        int32_t hi = -1, ht = -1;
+        const SceneView sv = scene_view(sc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id | (f << 24)));
+        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
+        p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    }
+    flush_counters<COUNT>(sc.counters, tc, 0);
+}
+
 // ---------------------------------------------------------------- ray_extend.comp:245-268
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 }
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
-template <bool COUNT>
+template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
@@ -271,9 +304,9 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const C
         const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {
             const float4 e = p.sh_e[idx];
-            const uint32_t pixel = fbits(o4.w);
+            const uint32_t word = fbits(o4.w), pixel = BATCH ? (word & 0xffffffu) : word;
             uint32_t owner;
-            const uint32_t slot = pixel_to_slab(cam, pixel % cam.width, pixel / cam.width, owner);
+            const uint32_t slot = pixel_to_slab(cam, pixel % cam.width, pixel / cam.width, owner) + (BATCH ? (word >> 24) * cam.frame_capacity : 0u);
             // single writer per pixel per pass (one shadow ray per path per bounce), as ray_shadow.comp:268
             float4 a = p.acc[slot];
             a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
@@ -285,6 +318,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const C
 
 // ---------------------------------------------------------------- shade.comp:70-266
 constexpr int kShadeBlock = 512; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
+template <bool BATCH>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
 
     bool live = idx < count;
     uint32_t px = 0, py = 0;
-    if (live && bounce == 0) live = slab_to_pixel(cam, idx, px, py);
+    if (live && bounce == 0) live = slab_to_pixel(cam, BATCH ? idx % cam.frame_capacity : idx, px, py);
 
     bool push_ext = false, push_shadow = false;
     int light_bucket = 0;
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     uint32_t ext_normal = 0;
     f3 sh_o = mk3(0.0f), sh_d = mk3(0.0f), sh_e = mk3(0.0f);
     float sh_dist = 0.0f;
-    uint32_t PATH_ID = 0;
+    uint32_t PATH_ID = 0, PATH_WORD = 0;
 
     if (live) {
         const uint4 S = p.hit[half][idx];
@@ -317,9 +351,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
             throughput = mk3(T4.x, T4.y, T4.z);
             bsdfPdf = T4.w;
         }
-        PATH_ID = fbits(O4.w);
+        const uint32_t path_word = fbits(O4.w); // batch: frame index in the top byte
+        PATH_ID = BATCH ? (path_word & 0xffffffu) : path_word;
+        PATH_WORD = path_word;
         uint32_t owner;
-        const uint32_t slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner);
+        const uint32_t slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner) + (BATCH ? (path_word >> 24) * cam.frame_capacity : 0u);
         const int32_t INST_ID = (int32_t)S.x;
         const uint32_t TRI_ID = S.y;
         const float T_VAL = bitsf(S.z);
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         uint32_t off = s_base[light_bucket];
         for (uint32_t k = 0; k < wave; k++) off += s_cnt[light_bucket][k];
         const size_t j = (size_t)light_bucket * p.capacity + off + my_rank;
-        p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_ID));
+        p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_WORD));
         p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
         p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
     }
@@ -505,7 +541,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         uint32_t off = s_base[kShadowBuckets];
         for (uint32_t k = 0; k < wave; k++) off += s_cnt[kShadowBuckets][k];
         const uint32_t j = off + r_ex;
-        p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_ID));
+        p.ray_o[next_half][j] = make_float4(ext_o.x, ext_o.y, ext_o.z, bitsf(PATH_WORD));
         p.ray_d[next_half][j] = make_float4(ext_d.x, ext_d.y, ext_d.z, bitsf(ext_normal));
         p.thr[next_half][j] = make_float4(ext_thr.x, ext_thr.y, ext_thr.z, ext_pdf);
     }
@@ -534,8 +570,11 @@ __global__ void k_assemble(const CameraParams cam, const float4* __restrict__ ga
     if (px >= cam.width || py >= cam.height) return;
     uint32_t owner;
     const uint32_t slot = pixel_to_slab(cam, px, py, owner);
-    const float4 a = gathered[(uint64_t)owner * slab_elems + slot];
+    const uint32_t f = blockIdx.z; // frame of a batch; gathered = [rank][frame][slot]
+    const float4 a = gathered[((uint64_t)owner * cam.batch + f) * slab_elems + slot];
     const float n = (float)(int)samples;
+    frame_acc += (size_t)f * cam.width * cam.height;
+    frame_out += (size_t)f * cam.width * cam.height;
     frame_acc[px + py * cam.width] = a;
     frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
                                                  __builtin_sqrtf(a.w * 1.0f / n));
@@ -600,6 +639,12 @@ void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, 
     if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, s, cam, sc, p);
     else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, s, cam, sc, p);
 }
+void launch_primary_batch(hipStream_t s, const CameraParams& cam, const BatchViews& views, const SceneDev& sc, const PathDev& p, bool count)
+{
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
+    if (count) hipLaunchKernelGGL(k_primary_batch<true>, grid, block, 0, s, cam, views, sc, p);
+    else hipLaunchKernelGGL(k_primary_batch<false>, grid, block, 0, s, cam, views, sc, p);
+}
 void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
     const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
@@ -608,13 +653,17 @@ void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
 }
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce)
 {
-    hipLaunchKernelGGL(k_shade, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
+    if (cam.batch > 1) hipLaunchKernelGGL(k_shade<true>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
     const dim3 grid((ceil_div(p.capacity, kTraceBlock) + kShadowBuckets + 511u) & ~511u), block(kTraceBlock);
-    if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, s, cam, sc, p, bounce);
-    else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, s, cam, sc, p, bounce);
+    if (cam.batch > 1) {
+        if (count) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, s, cam, sc, p, bounce);
+        else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, s, cam, sc, p, bounce);
+    } else if (count) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, s, cam, sc, p, bounce);
+    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, s, cam, sc, p, bounce);
 }
 // bandwidth probe: 16 B per lane per access, grid-stride, enough workgroups to cover the 256 CUs several times
 __global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, const uint64_t n)
@@ -637,7 +686,7 @@ void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab,
 void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples)
 {
-    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4));
+    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4), cam.batch > 1 ? cam.batch : 1u);
     hipLaunchKernelGGL(k_assemble, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
 }
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,

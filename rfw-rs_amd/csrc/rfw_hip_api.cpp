@@ -93,6 +93,8 @@ struct Instance {
     uint32_t max_path_length = 3;
     float clamp_value = 10.0f;
     uint32_t rank = 0, world = 1, tile_size = 64;
+    bool after_batch = false;
+    uint32_t max_batch = 1; // frames one render_batch() call may trace together (buffers are sized for it)
     uint32_t builder = RFW_HIP_BUILDER_AUTO;
     uint32_t flags = 0;
     float sky[3] = {0, 0, 0};
@@ -264,7 +266,7 @@ void compute_shard(Instance* I)
 int alloc_paths(Instance* I)
 {
     compute_shard(I);
-    const size_t n = I->capacity;
+    const size_t n = (size_t)I->capacity * I->max_batch; // a batch of frames is one tall virtual frame
     for (int h = 0; h < 2; h++) {
         HIP_TRY(I, I->d_ray_o[h].ensure(n));
         HIP_TRY(I, I->d_ray_d[h].ensure(n));
@@ -276,13 +278,13 @@ int alloc_paths(Instance* I)
     HIP_TRY(I, I->d_sh_e.ensure(n * kShadowBuckets));
     HIP_TRY(I, I->d_acc_slab.ensure(n));
     HIP_TRY(I, hipMemsetAsync(I->d_acc_slab.ptr, 0, n * sizeof(float4), I->stream));
-    const size_t px = (size_t)I->width * I->height;
+    const size_t px = (size_t)I->width * I->height * I->max_batch;
     HIP_TRY(I, I->d_frame_acc.ensure(px));
     HIP_TRY(I, I->d_frame_out.ensure(px));
     HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
     HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
     // per-thread overflow slots: launch grids are padded (XCD tiling, shadow buckets), so leave a margin per sub-shard
-    HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * I->substreams * ((size_t)I->cap_v + kSpillMargin)));
+    HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * I->substreams * ((size_t)I->cap_v * I->max_batch + kSpillMargin)));
     HIP_TRY(I, I->d_counters.ensure(kMaxSub));
     HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, kMaxSub * sizeof(QueueCounters), I->stream));
     I->sample_count = 0;
@@ -859,6 +861,8 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.flags = I->flags;
     c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
+    c.batch = 1;
+    c.frame_capacity = I->cap_v;
     return c;
 }
 
@@ -885,17 +889,29 @@ constexpr int kEvBlit = EV_KERNEL_BASE + 2 * (kMaxBounces * kKernelsPerBounce);
 
 hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.data() + ((size_t)slot * I->substreams + sub) * kNumEvents; }
 
-int do_render(Instance* I, const rfw_camera_view_3d& view)
+// k == 1: one sample of the image for views[0].  k > 1 (rfw_hip_render_batch): k independent NEW images, one per view, traced as one
+// tall virtual frame — every stage is ONE launch over the paths of all k frames.
+int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
 {
+    const rfw_camera_view_3d& view = views[0];
     HIP_TRY(I, hipSetDevice(I->device));
     if (!scene_of(I)->synchronized || tlas_of(I)->d_tlas_nodes.ptr == nullptr) return RFW_HIP_OK; // render before any mesh exists (gpu-rt/src/lib.rs:1686-1688)
     if (I->scene && I->scene->scene_ready && I->waited_version != I->scene->scene_version) { // a slot must not read a scene still being written
         HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0));
         I->waited_version = I->scene->scene_version;
     }
-    if (I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) I->sample_count = 0;
+    if ((I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) || I->after_batch) I->sample_count = 0;
+    I->after_batch = k > 1; // the frames of a batch are complete images: whatever follows starts a new one
     I->last_view = view;
     I->have_last_view = true;
+    if (k > 1) {
+        if (k > I->max_batch || k > (uint32_t)kMaxBatch) return fail(I, RFW_HIP_E_INVALID, "render_batch: more frames than options.max_batch");
+        if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "render_batch: not available with sub-streams");
+        if (I->cap_v >= (1u << 24)) return fail(I, RFW_HIP_E_INVALID, "render_batch: more than 2^24 paths per frame");
+        for (uint32_t f = 1; f < k; f++)
+            if (views[f].spread_angle != view.spread_angle) return fail(I, RFW_HIP_E_INVALID, "render_batch: the views of a batch must share one spread angle (field of view and height)");
+        I->sample_count = 0;         // every frame of a batch is a new image
+    }
 
     const uint32_t S = I->substreams;
     const bool count = (I->flags & RFW_HIP_FLAG_COUNT_TRAVERSAL) != 0;
@@ -925,12 +941,25 @@ int do_render(Instance* I, const rfw_camera_view_3d& view)
         p[s] = path_dev(I, s);
         cam[s] = camera_params(I, view, s);
     }
+    BatchViews bv;
+    if (k > 1) {
+        cam[0].batch = k;
+        p[0].capacity = I->cap_v * k;
+        for (uint32_t f = 0; f < k; f++) {
+            FrameView& v = bv.v[f];
+            v.pos[0] = views[f].pos.x; v.pos[1] = views[f].pos.y; v.pos[2] = views[f].pos.z; v.lens_size = views[f].lens_size;
+            v.right[0] = views[f].right.x; v.right[1] = views[f].right.y; v.right[2] = views[f].right.z; v.pad0 = 0.0f;
+            v.up[0] = views[f].up.x; v.up[1] = views[f].up.y; v.up[2] = views[f].up.z; v.pad1 = 0.0f;
+            v.p1[0] = views[f].p1.x; v.p1[1] = views[f].p1.y; v.p1[2] = views[f].p1.z; v.pad2 = 0.0f;
+        }
+    }
     for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back; stage by stage across the sub-shards
         for (uint32_t s = 0; s < S; s++) {
             hipEvent_t* ev = ring_events(I, slot, s);
             cam[s].path_length = b;
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
-            if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
+            if (b == 0 && k > 1) launch_primary_batch(st[s], cam[s], bv, sc[s], p[s], count);
+            else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
             else launch_extend(st[s], cam[s], sc[s], p[s], b, count);
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 1)], st[s]);
         }
@@ -1045,9 +1074,15 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         I->flags = o->flags;
         if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
         if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 16u);
+        if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
     }
     if (n_slots > 1 && I->world > 1) {
         g_create_error = "frames_in_flight > 1 needs world == 1 (a sharded frame is pipelined with one instance per frame in flight)";
+        delete I;
+        return nullptr;
+    }
+    if (I->max_batch > 1 && I->substreams > 1) {
+        g_create_error = "max_batch > 1 needs streams <= 1 (a batch already fills the device with one launch per stage)";
         delete I;
         return nullptr;
     }
@@ -1102,6 +1137,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         so.struct_size = sizeof(so);
         so.device = I->device;
         so.frames_in_flight = 1;
+        so.max_batch = I->max_batch;
         for (uint32_t k = 1; k < n_slots; k++) {
             Instance* c = static_cast<Instance*>(rfw_hip_create(width, height, 1.0, &so));
             if (!c) { // g_create_error is set
@@ -1258,15 +1294,13 @@ int rfw_hip_synchronize(void* inst)
     return do_synchronize(I);
 }
 
-int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_view_3d* view, uint32_t /*mode*/)
+static int render_impl(Instance* I, const rfw_camera_view_3d* views, uint32_t k)
 {
-    LOCK(inst);
-    if (!view) return fail(I, RFW_HIP_E_INVALID, "render: null view");
-    if (I->slots.empty()) return do_render(I, *view);
+    if (I->slots.empty()) return do_render(I, views, k);
     // frames in flight: does this call add a sample to the image of the current slot, or start a new image on the next slot?
     Instance* cur = slot_ptr(I, I->cur_slot);
-    const bool same_image = !I->restart && cur->sample_count > 0 && cur->have_last_view && std::memcmp(&cur->last_view, view, sizeof(*view)) == 0 &&
-                            cur->rendered_version == I->scene_version;
+    const bool same_image = k == 1 && !I->restart && cur->sample_count > 0 && cur->have_last_view &&
+                            std::memcmp(&cur->last_view, views, sizeof(*views)) == 0 && cur->rendered_version == I->scene_version;
     if (!same_image) {
         I->cur_slot = (I->cur_slot + 1) % (uint32_t)(I->slots.size() + 1);
         cur = slot_ptr(I, I->cur_slot);
@@ -1276,11 +1310,31 @@ int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_vie
     cur->rendered_version = I->scene_version;
     if (cur != I) { // the owner's options apply to every slot
         cur->max_path_length = I->max_path_length; cur->clamp_value = I->clamp_value; cur->flags = I->flags; cur->timing = I->timing;
-        for (int k = 0; k < 3; k++) cur->sky[k] = I->sky[k];
+        for (int c = 0; c < 3; c++) cur->sky[c] = I->sky[c];
     }
     int rc = ensure_slot_tlas(I, cur);
-    if (rc == RFW_HIP_OK) rc = do_render(cur, *view);
+    if (rc == RFW_HIP_OK) rc = do_render(cur, views, k);
     if (rc != RFW_HIP_OK && cur != I && !cur->err.empty()) I->err = cur->err;
+    return rc;
+}
+
+int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_view_3d* view, uint32_t /*mode*/)
+{
+    LOCK(inst);
+    if (!view) return fail(I, RFW_HIP_E_INVALID, "render: null view");
+    return render_impl(I, view, 1);
+}
+
+int rfw_hip_render_batch(void* inst, const rfw_camera_view_3d* views, uint32_t count)
+{
+    LOCK(inst);
+    if (!views || count == 0) return fail(I, RFW_HIP_E_INVALID, "render_batch: no views");
+    if (count == 1) { // a batch of one is still a NEW image
+        I->sample_count = 0;
+        I->restart = true;
+    }
+    const int rc = render_impl(I, views, count);
+    if (rc == RFW_HIP_OK && count == 1) (I->slots.empty() ? I : slot_ptr(I, I->cur_slot))->after_batch = true;
     return rc;
 }
 
@@ -1379,6 +1433,27 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "sah_trav_cost") I->sah_trav_cost = (float)value;
     else if (k == "build_threads") I->build_threads = std::max(1, (int)value);
     else return fail(I, RFW_HIP_E_INVALID, "set_option: unknown key " + k);
+    return RFW_HIP_OK;
+}
+
+static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* rgba, uint64_t n);
+int rfw_hip_read_framebuffer_at(void* inst, uint32_t frame, float* rgba, uint64_t n) { return read_frame_impl(inst, frame, false, rgba, n); }
+int rfw_hip_read_accumulator_at(void* inst, uint32_t frame, float* rgba, uint64_t n) { return read_frame_impl(inst, frame, true, rgba, n); }
+static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* rgba, uint64_t n)
+{
+    LOCK(inst);
+    if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_*_at: size mismatch");
+    if (frame >= I->max_batch) return fail(I, RFW_HIP_E_INVALID, "read_*_at: frame index beyond options.max_batch");
+    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest batch lives in a slot
+        Instance* c = slot_ptr(I, I->cur_slot);
+        const int rc = read_frame_impl(c, frame, accumulator, rgba, n);
+        if (rc != RFW_HIP_OK) I->err = c->err;
+        return rc;
+    }
+    HIP_TRY(I, hipSetDevice(I->device));
+    const float4* src = (accumulator ? I->d_frame_acc.ptr : I->d_frame_out.ptr) + (size_t)frame * I->width * I->height;
+    HIP_TRY(I, hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
     return RFW_HIP_OK;
 }
 
@@ -1569,17 +1644,21 @@ int rfw_hip_set_slab_output(void* inst, void* ptr)
     I->sample_count = 0;
     return RFW_HIP_OK;
 }
-int rfw_hip_assemble_frame(void* inst, const void* gathered)
+static int assemble_impl(void* inst, const void* gathered, uint32_t k)
 {
     LOCK(inst);
     if (!gathered) return fail(I, RFW_HIP_E_INVALID, "assemble_frame: null buffer");
+    if (k == 0 || k > I->max_batch || (k > 1 && I->substreams > 1)) return fail(I, RFW_HIP_E_INVALID, "assemble_batch: bad frame count");
     HIP_TRY(I, hipSetDevice(I->device));
-    const CameraParams cam = camera_params(I, I->last_view);
-    // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]
+    CameraParams cam = camera_params(I, I->last_view);
+    cam.batch = k;
+    // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]; for a batch (one sub-stream): [rank][frame][cap_v]
     launch_assemble(I->stream, cam, (const float4*)gathered, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
     HIP_TRY(I, hipGetLastError());
     return RFW_HIP_OK;
 }
+int rfw_hip_assemble_frame(void* inst, const void* gathered) { return assemble_impl(inst, gathered, 1); }
+int rfw_hip_assemble_batch(void* inst, const void* gathered, uint32_t count) { return assemble_impl(inst, gathered, count); }
 
 static int intersect_impl(void* inst, const float* origins, const float* directions, float t_min, float t_max, uint64_t n, rfw_hip_hit* hits, uint32_t* depth)
 {

@@ -109,7 +109,7 @@ class SkinData(C.Structure):
 class HipOptions(C.Structure):
     _fields_ = [
         ("struct_size", u32), ("device", i32), ("max_path_length", u32), ("clamp_value", f32), ("rank", u32), ("world", u32),
-        ("tile_size", u32), ("builder", u32), ("flags", u32), ("streams", u32), ("frames_in_flight", u32),
+        ("tile_size", u32), ("builder", u32), ("flags", u32), ("streams", u32), ("frames_in_flight", u32), ("max_batch", u32),
     ]
 
 

@@ -28,6 +28,14 @@ owner, slot = rd.slab_index_map(w, h, world, ts, streams)
 assert set(np.unique(owner)) == set(range(world))
 # every (owner, slot) pair addresses a distinct slab element: no two pixels collide
 assert len(np.unique(owner * gathered.shape[1] + slot)) == w * h
+# a batch of frames (rfw_hip_render_batch on a sharded frame): slab = [frame][tile pixels], ONE all-gather for the batch,
+# gathered = [rank][frame][tile pixels]; frame f is assembled from gathered[:, f]
+k = 3
+frames = rng.random((k, h, w, 4), dtype=np.float32)
+bslab = torch.from_numpy(np.stack([rd.extract_slab(frames[f], rank, world, ts, 1) for f in range(k)]))
+bg = rd.all_gather_slabs(bslab)  # (world, k, slab_elems, 4)
+for f in range(k):
+    assert np.array_equal(rd.assemble(bg[:, f].numpy(), w, h, ts, 1), frames[f]), "batched frame differs"
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -16,7 +16,7 @@ def make(kind, w, h, a=0, b=0, c=0.0, seed=1, **opts):
     from rfw_rs_amd import HipBackend, Scene
     scene = Scene().build(kind, a, b, c, seed)
     scene.set_aspect(w / h)
-    be = HipBackend.init(w, h, 1.0, **{k: v for k, v in opts.items() if k in ("max_path_length", "flags", "builder", "streams", "frames_in_flight")})
+    be = HipBackend.init(w, h, 1.0, **{k: v for k, v in opts.items() if k in ("max_path_length", "flags", "builder", "streams", "frames_in_flight", "max_batch")})
     scene.sync(be)
     orc = Oracle(w, h, threads=8)
     if "max_path_length" in opts:
@@ -223,6 +223,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rays_per_frame"] >= 320 * 200
     assert out["roofline"]["kernel"] in ("k_primary", "k_shadow", "k_shade")
+    assert out["config"]["frames_per_batch"] == 8 and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
 
 
 def test_animated_instances_match_oracle():
@@ -517,3 +518,79 @@ def test_frame_slots_with_skinned_meshes_and_resize():
     assert be.accumulator().shape == (h2, w2, 4)
     assert np.array_equal(be.accumulator().view(np.uint32), orc2.accumulator().view(np.uint32))
     be.close()
+
+
+def batch_views(scene, w, h, k):
+    views = []
+    for i in range(k):
+        scene.set_camera([0.35 * i - 0.7, 0.3 + 0.1 * i, -4.0 + 0.15 * i], [0.05 * i, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    return views
+
+
+@pytest.mark.parametrize("kind,a,b,mpl,k", [("soup", 1500, 4, 3, 4), ("cornell", 0, 0, 2, 7), ("gallery", 0, 0, 4, 16)])
+def test_render_batch_equals_single_renders(kind, a, b, mpl, k):
+    """rfw_hip_render_batch: k independent new images in one launch per stage.  Frame f must be exactly what render(view f) on a reset
+    instance produces — and so exactly the oracle's image of that view."""
+    w, h = 104, 72  # ragged edge tiles
+    scene, be, orc = make(kind, w, h, a, b, seed=31, max_path_length=mpl, max_batch=16)
+    views = batch_views(scene, w, h, k)
+    be.render_batch(views)
+    assert be.frame_stats()["sample_count"] == 1
+    for f, v in enumerate(views):
+        orc.reset(); orc.render(v)
+        assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+        assert np.array_equal(be.framebuffer_at(f).view(np.uint32), orc.framebuffer().view(np.uint32)), f
+    # a plain render afterwards starts a new image (and accumulates from there), even for a view of the batch
+    be.render(views[0]); be.render(views[0])
+    orc.reset(); orc.render(views[0]); orc.render(views[0])
+    assert be.frame_stats()["sample_count"] == 2
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    # a shorter batch after a longer one; more frames than max_batch is an error, not a truncation
+    be.render_batch(views[1:3])
+    orc.reset(); orc.render(views[2])
+    assert np.array_equal(be.accumulator_at(1).view(np.uint32), orc.accumulator().view(np.uint32))
+    be.render_batch(views[3:4]); be.render_batch(views[3:4])   # a batch of one is still a new image each time
+    orc.reset(); orc.render(views[3])
+    assert be.frame_stats()["sample_count"] == 1 and np.array_equal(be.accumulator_at(0).view(np.uint32), orc.accumulator().view(np.uint32))
+    from rfw_rs_amd import BackendError
+    with pytest.raises(BackendError):
+        be.render_batch((views * 17)[:17])
+    with pytest.raises(BackendError):
+        be.accumulator_at(16)
+    be.close()
+
+
+def test_render_batch_through_frame_slots_and_shards():
+    """A batch per frame slot (consecutive batches overlap), and a batch on a tile-sharded frame: the slab is [frame][slab], the gathered
+    buffer [rank][frame][slab], one assemble for all frames."""
+    import torch
+    from rfw_rs_amd import HipBackend
+    w, h = 120, 88
+    scene, be, orc = make("soup", w, h, 900, 6, seed=12, max_path_length=3, max_batch=4, frames_in_flight=3)
+    views = batch_views(scene, w, h, 8)
+    be.render_batch(views[:4])
+    be.render_batch(views[4:])
+    for f in range(4):
+        orc.reset(); orc.render(views[4 + f])
+        assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+    be.close()
+    world, k = 3, 3
+    ranks = []
+    for r in range(world):
+        b = HipBackend.init(w, h, 1.0, rank=r, world=world, tile_size=32, max_path_length=3, max_batch=4)
+        scene.mark_all_changed()
+        scene.sync(b)
+        ranks.append(b)
+    slab = ranks[0].shard_info()["slab_floats"]
+    gathered = torch.zeros(world, 4, slab, dtype=torch.float32, device="cuda")[:, :k].contiguous()
+    for r, b in enumerate(ranks):
+        b.set_slab_output(gathered[r].data_ptr())
+        b.render_batch(views[:k])
+        b.device_synchronize()
+    ranks[1].assemble_batch(gathered.data_ptr(), k)
+    for f in range(k):
+        orc.reset(); orc.render(views[f])
+        assert np.array_equal(ranks[1].accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+    for b in ranks:
+        b.close()
