@@ -184,12 +184,14 @@ RFW_HIP_API int rfw_hip_set_stream(void* instance, void* hip_stream);
 RFW_HIP_API void* rfw_hip_get_stream(void* instance);
 RFW_HIP_API int rfw_hip_device_synchronize(void* instance);
 
-/* Multi-GPU tile sharding.  With world > 1 an instance renders only the
- * tiles dealt to `rank` into a compact slab of `slab_floats` floats (RGBA32F accumulator
- * values).  The caller all-gathers the slabs (RCCL) into a buffer of world*slab_floats and
- * hands it back to rfw_hip_assemble_frame, which de-tiles into the full accumulator/frame. */
+/* Multi-GPU tile sharding.  With world > 1 an instance renders only the tiles dealt to `rank`.  Its contribution to
+ * the frame is a compact slab of `slab_floats` floats: the RGB of the accumulator for each of its slab elements (alpha is never
+ * written by the path tracer, so 12 B per pixel travel instead of 16).  After tracing, render() packs that slab into the device
+ * buffer given to rfw_hip_set_slab_output (typically this rank's slice of the all-gather buffer); the caller all-gathers the
+ * slabs (RCCL) into a buffer of world * slab_floats and hands it to rfw_hip_assemble_frame, which de-tiles it into the full
+ * accumulator and frame.  Accumulation over samples happens in the instance's own slab, not in the caller's buffer. */
 RFW_HIP_API int rfw_hip_shard_info(void* instance, uint64_t* slab_floats, uint32_t* num_tiles_local, uint32_t* num_tiles_total);
-/* device pointer the slab is written to by render(); NULL restores the internal slab */
+/* device buffer (slab_floats floats; count * slab_floats for render_batch) render() leaves this rank's slab in; NULL = none */
 RFW_HIP_API int rfw_hip_set_slab_output(void* instance, void* device_ptr);
 RFW_HIP_API int rfw_hip_assemble_frame(void* instance, const void* gathered_device_ptr);
 

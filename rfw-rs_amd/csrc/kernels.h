@@ -55,8 +55,9 @@ void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n);
 void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples);
-void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples);
+void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,

@@ -562,8 +562,20 @@ __global__ void k_blit(const CameraParams cam, const float4* __restrict__ acc_sl
     frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
                                                  __builtin_sqrtf(a.w * 1.0f / n));
 }
-// all-gathered slabs [world][slab_elems] -> full frame
-__global__ void k_assemble(const CameraParams cam, const float4* __restrict__ gathered, const uint64_t slab_elems, float4* __restrict__ frame_acc,
+// what a rank contributes to the all-gather: the RGB of its slab (alpha is never written: 12 B per pixel on the links instead of 16)
+__global__ __launch_bounds__(256) void k_pack_rgb(const float4* __restrict__ acc_slab, float* __restrict__ out, const uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = acc_slab[i];
+    out[3 * i] = a.x;
+    out[3 * i + 1] = a.y;
+    out[3 * i + 2] = a.z;
+}
+// all-gathered slabs [world][slab_elems] -> full frame.  RGB: the gathered buffer holds 3 floats per element (k_pack_rgb), else the
+// instance's own float4 slab (world == 1)
+template <bool RGB>
+__global__ void k_assemble(const CameraParams cam, const void* __restrict__ gathered_v, const uint64_t slab_elems, float4* __restrict__ frame_acc,
                            float4* __restrict__ frame_out, const uint32_t samples)
 {
     const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
@@ -571,7 +583,14 @@ __global__ void k_assemble(const CameraParams cam, const float4* __restrict__ ga
     uint32_t owner;
     const uint32_t slot = pixel_to_slab(cam, px, py, owner);
     const uint32_t f = blockIdx.z; // frame of a batch; gathered = [rank][frame][slot]
-    const float4 a = gathered[((uint64_t)owner * cam.batch + f) * slab_elems + slot];
+    const uint64_t e = ((uint64_t)owner * cam.batch + f) * slab_elems + slot;
+    float4 a;
+    if (RGB) {
+        const float* g = static_cast<const float*>(gathered_v) + 3 * e;
+        a = make_float4(g[0], g[1], g[2], 0.0f);
+    } else {
+        a = static_cast<const float4*>(gathered_v)[e];
+    }
     const float n = (float)(int)samples;
     frame_acc += (size_t)f * cam.width * cam.height;
     frame_out += (size_t)f * cam.width * cam.height;
@@ -683,11 +702,16 @@ void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab,
     const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4));
     hipLaunchKernelGGL(k_blit, grid, block, 0, s, cam, acc_slab, frame_acc, frame_out, samples);
 }
-void launch_assemble(hipStream_t s, const CameraParams& cam, const float4* gathered, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples)
 {
     const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4), cam.batch > 1 ? cam.batch : 1u);
-    hipLaunchKernelGGL(k_assemble, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+    if (rgb) hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+    else hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+}
+void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n)
+{
+    if (n) hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, acc_slab, out, n);
 }
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth)

@@ -879,7 +879,7 @@ PathDev path_dev(Instance* I, uint32_t sub = 0)
     p.sh_o = I->d_sh_o.ptr + off * kShadowBuckets;
     p.sh_d = I->d_sh_d.ptr + off * kShadowBuckets;
     p.sh_e = I->d_sh_e.ptr + off * kShadowBuckets;
-    p.acc = (I->external_slab ? (float4*)I->external_slab : I->d_acc_slab.ptr) + off;
+    p.acc = I->d_acc_slab.ptr + off;
     p.capacity = I->cap_v;
     return p;
 }
@@ -985,8 +985,9 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
     I->sample_count += 1;
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
     if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
-        launch_assemble(main, cam[0], I->external_slab ? (const float4*)I->external_slab : I->d_acc_slab.ptr, I->cap_v, I->d_frame_acc.ptr,
-                        I->d_frame_out.ptr, I->sample_count);
+        launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, I->sample_count);
+    if (I->external_slab) // this rank's contribution to the all-gather: RGB of the slab(s), [frame][sub-shard][slot]
+        launch_pack_rgb(main, I->d_acc_slab.ptr, (float*)I->external_slab, (uint64_t)I->capacity * k);
     if (tm) (void)hipEventRecord(I->events[kEvBlit + 1], main);
     if (tm) (void)hipEventRecord(I->events[EV_FRAME1], main);
     HIP_TRY(I, hipGetLastError());
@@ -1631,7 +1632,7 @@ int rfw_hip_device_synchronize(void* inst)
 int rfw_hip_shard_info(void* inst, uint64_t* slab_floats, uint32_t* local, uint32_t* total)
 {
     LOCK(inst);
-    if (slab_floats) *slab_floats = (uint64_t)I->capacity * 4;
+    if (slab_floats) *slab_floats = (uint64_t)I->capacity * 3; // RGB of the accumulator per slab element
     if (local) *local = I->local_tiles;
     if (total) *total = I->tiles_x * I->tiles_y;
     return RFW_HIP_OK;
@@ -1653,7 +1654,7 @@ static int assemble_impl(void* inst, const void* gathered, uint32_t k)
     CameraParams cam = camera_params(I, I->last_view);
     cam.batch = k;
     // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]; for a batch (one sub-stream): [rank][frame][cap_v]
-    launch_assemble(I->stream, cam, (const float4*)gathered, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
+    launch_assemble(I->stream, cam, gathered, true, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
     HIP_TRY(I, hipGetLastError());
     return RFW_HIP_OK;
 }
