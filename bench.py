@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
                          "gathered buffer), without any collective; the value then counts this shard's rays only")
-    ap.add_argument("--readback", action="store_true", help="copy every finished frame to host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline value)")
+    ap.add_argument("--readback", nargs="?", const="float", default=None, choices=["float", "presented"],
+                    help="copy every finished frame to (pinned) host memory inside the timed region, queued behind its kernels (the PCIe-inclusive "
+                         "rate of DESIGN.md; never the headline value): the RGBA32F frame, or the presented BGRA8 sRGB frame of the reference's swap chain")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -123,6 +125,7 @@ def main():
     sync_ms = [0.0]
     step_no = [0]
 
+    host_ring = {b_: [[b_.host_frame(presented=args.readback == "presented") for _ in range(2 * max(F if use_slots else 1, B))], 0] for b_ in bes} if args.readback else {}
     pending = [0]
     last_issue = [None]
 
@@ -169,8 +172,14 @@ def main():
                 b.assemble_batch(recv.data_ptr(), nf)
             elif args.emulate_shard:
                 b.assemble_batch(g[1].data_ptr(), nf)  # the de-tiling a rank would do after the all-gather
-            if args.readback:
-                b.framebuffer()  # blocking device-to-host copy of the w x h RGBA32F frame
+            if args.readback:  # every finished frame to (pinned) host memory, queued behind its kernels: the DMA overlaps the next frames' tracing
+                for f_ in range(nf):
+                    ring = host_ring[b]
+                    dst = ring[0][ring[1] % len(ring[0])]
+                    if ring[1] >= len(ring[0]):  # the ring hands this buffer out again: its copy (2 F frames ago) must have landed
+                        b.wait_downloads(dst)
+                    b.download_frame(dst, frame=f_)
+                    ring[1] += 1
 
     # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
     be.set_option("count_traversal", 1)
@@ -208,6 +217,9 @@ def main():
                 for k in kernel_ms:
                     kernel_ms[k] += ms[k]
     flush()  # a last, shorter batch when --steps is not a multiple of --batch: exactly K frames are timed
+    if args.readback:
+        for b in bes:
+            b.wait_downloads()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -316,7 +328,7 @@ def main():
             "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": bool(args.readback), "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],

@@ -221,6 +221,23 @@ RFW_HIP_API int rfw_hip_assemble_batch(void* instance, const void* gathered_devi
 RFW_HIP_API int rfw_hip_read_framebuffer_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
 RFW_HIP_API int rfw_hip_read_accumulator_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
 
+/* Frames to host memory without stalling the pipeline.  rfw_hip_download_frame queues the copy of the latest frame (what = 0: the
+ * finalised frame, 1: the accumulator; `frame` = index inside the last batch, 0 otherwise) behind the kernels that produce it, on
+ * that frame's stream, and returns at once; with frames in flight the DMA of frame k overlaps the tracing of the following frames.
+ * what = 2 is the PRESENTED frame: what gpu-rt's final pass leaves on its Bgra8UnormSrgb swap chain (gpu-rt/src/lib.rs:373,560-585,
+ * shaders/quad.frag) — the finalised frame clamped, sRGB-encoded and quantised, one B,G,R,A byte quadruple per pixel (alpha 255),
+ * n_floats = width * height 32-bit words; a quarter of the bytes of the float frame on the PCIe link.  rfw_hip_srgb_steps returns
+ * the 255 linear values at which the encoded byte steps (the encoder compares against them, so it is exact everywhere).
+ * The destination should come from rfw_hip_host_alloc (pinned; a pageable buffer makes the copy synchronous).  The bytes are valid
+ * after rfw_hip_wait_downloads, which waits for every copy queued so far (and for nothing else). */
+RFW_HIP_API void rfw_hip_srgb_steps(float* out255);
+RFW_HIP_API void* rfw_hip_host_alloc(uint64_t bytes);
+RFW_HIP_API void rfw_hip_host_free(void* ptr);
+RFW_HIP_API int rfw_hip_download_frame(void* instance, uint32_t what, uint32_t frame, float* host_rgba, uint64_t n_floats);
+RFW_HIP_API int rfw_hip_wait_downloads(void* instance);
+/* waits only for the copy into host_ptr (e.g. before a ring of host buffers hands that buffer out again) */
+RFW_HIP_API int rfw_hip_wait_download(void* instance, const void* host_ptr);
+
 /* Measured HBM roofline for this device in this job: a float4 device-to-device copy of `bytes` bytes
  * (rounded down to 16), repeated `iterations` times on the instance's stream and timed with HIP events.
  * *gb_per_s = 2 * bytes * iterations / time (bytes read + bytes written).  Allocates and frees 2 * bytes of HBM. */

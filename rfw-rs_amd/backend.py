@@ -24,7 +24,8 @@ EXPORTS = [
     "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
-    "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at",
+    "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps",
 ]
 
 _lib = None
@@ -88,6 +89,15 @@ def hip_lib():
         l.rfw_hip_assemble_batch.argtypes = [vp, vp, C.c_uint32]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
+        l.rfw_hip_host_alloc.restype = vp
+        l.rfw_hip_host_alloc.argtypes = [u64]
+        l.rfw_hip_host_free.restype = None
+        l.rfw_hip_host_free.argtypes = [vp]
+        l.rfw_hip_download_frame.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u64]
+        l.rfw_hip_wait_downloads.argtypes = [vp]
+        l.rfw_hip_wait_download.argtypes = [vp, vp]
+        l.rfw_hip_srgb_steps.restype = None
+        l.rfw_hip_srgb_steps.argtypes = [vp]
         l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
         l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
@@ -118,12 +128,16 @@ class HipBackend:
         if not h:
             raise BackendError("rfw_hip_create failed: " + self._l.rfw_hip_last_error(None).decode())
         self._h = C.c_void_p(h)
+        self._pinned = {}
         self.width, self.height = width, height
         self.rank, self.world = rank, max(world, 1)
 
     def close(self):
         if getattr(self, "_h", None):
-            self._l.rfw_hip_destroy(self._h)
+            self._l.rfw_hip_destroy(self._h)  # waits for queued work (incl. downloads) first
+            for p in self._pinned.values():
+                self._l.rfw_hip_host_free(p)
+            self._pinned = {}
             self._h = None
 
     def __del__(self):
@@ -228,6 +242,41 @@ class HipBackend:
         a = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self._l.rfw_hip_read_framebuffer_at(self._h, frame, a.ctypes.data, a.size))
         return a
+
+    def host_frame(self, presented=False):
+        """A pinned (h, w, 4) array for download_frame: float32, or uint8 B,G,R,A for the presented frame; freed with free_host_frame."""
+        n = self.height * self.width * (1 if presented else 4)
+        p = self._l.rfw_hip_host_alloc(n * 4)
+        if not p:
+            raise BackendError("rfw_hip_host_alloc failed")
+        if presented:
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.height, self.width, 4))
+        else:
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.height, self.width, 4))
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def free_host_frame(self, a):
+        self._l.rfw_hip_host_free(self._pinned.pop(a.ctypes.data))
+
+    def download_frame(self, dst, accumulator=False, frame=0):
+        """Queue the copy of the latest frame into `dst` (from host_frame) behind its kernels; valid after wait_downloads()."""
+        if dst.dtype == np.uint8:  # the presented (swap-chain) frame
+            self._check(self._l.rfw_hip_download_frame(self._h, 2, frame, dst.ctypes.data, dst.size // 4))
+        else:
+            self._check(self._l.rfw_hip_download_frame(self._h, 1 if accumulator else 0, frame, dst.ctypes.data, dst.size))
+
+    def srgb_steps(self):
+        t = np.empty(255, np.float32)
+        self._l.rfw_hip_srgb_steps(t.ctypes.data)
+        return t
+
+    def wait_downloads(self, dst=None):
+        """Wait for every queued download, or only for the one into `dst`."""
+        if dst is None:
+            self._check(self._l.rfw_hip_wait_downloads(self._h))
+        else:
+            self._check(self._l.rfw_hip_wait_download(self._h, dst.ctypes.data))
 
     def framebuffer(self):
         a = np.empty((self.height, self.width, 4), dtype=np.float32)

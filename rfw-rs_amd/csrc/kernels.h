@@ -58,6 +58,7 @@ void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab,
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
                      uint32_t samples);
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
+void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,

@@ -572,6 +572,26 @@ __global__ __launch_bounds__(256) void k_pack_rgb(const float4* __restrict__ acc
     out[3 * i + 1] = a.y;
     out[3 * i + 2] = a.z;
 }
+// Presentation (gpu-rt/src/lib.rs:373,560-585 + shaders/quad.frag): the RGBA32F output is drawn onto a Bgra8UnormSrgb swap chain, i.e.
+// clamped, sRGB-encoded and quantised to 8 bits per channel by the attachment write.  Encoding by comparison against the 255 linear
+// values at which the encoded byte steps (binary search, 8 compares per channel): exact and identical on every machine.
+struct SrgbSteps { float t[256]; };
+__global__ __launch_bounds__(256) void k_present(const float4* __restrict__ frame, uint32_t* __restrict__ bgra, const uint64_t n, const SrgbSteps steps)
+{
+    __shared__ float s_t[256];
+    s_t[threadIdx.x] = steps.t[threadIdx.x];
+    __syncthreads();
+    auto enc = [&](float x) -> uint32_t { // number of steps <= x (a NaN encodes as 0, like a clamped attachment write)
+        uint32_t lo = 0;
+        for (uint32_t bit = 128; bit != 0; bit >>= 1)
+            if (x >= s_t[lo + bit - 1]) lo += bit;
+        return lo;
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const float4 c = frame[i];
+        bgra[i] = enc(c.z) | (enc(c.y) << 8) | (enc(c.x) << 16) | 0xff000000u; // B, G, R, A in memory order; the surface is opaque
+    }
+}
 // all-gathered slabs [world][slab_elems] -> full frame.  RGB: the gathered buffer holds 3 floats per element (k_pack_rgb), else the
 // instance's own float4 slab (world == 1)
 template <bool RGB>
@@ -708,6 +728,15 @@ void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathere
     const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4), cam.batch > 1 ? cam.batch : 1u);
     if (rgb) hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
     else hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+}
+// `narrow`: the destination is host memory written over the PCIe link: a few workgroups saturate the link, and more would only hold
+// wave slots the trace kernels of the other frames in flight want
+void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow)
+{
+    SrgbSteps st;
+    for (int k = 0; k < 255; k++) st.t[k] = steps255[k];
+    st.t[255] = __builtin_inff(); // never reached: lo + bit - 1 <= 254
+    if (n) hipLaunchKernelGGL(k_present, dim3(narrow ? 64u : (unsigned)std::min<uint64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, s, frame, bgra, n, st);
 }
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n)
 {

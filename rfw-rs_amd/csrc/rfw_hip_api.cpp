@@ -94,6 +94,8 @@ struct Instance {
     float clamp_value = 10.0f;
     uint32_t rank = 0, world = 1, tile_size = 64;
     bool after_batch = false;
+    hipEvent_t download_done = nullptr; // recorded behind the last rfw_hip_download_frame copy on this slot's stream
+    std::vector<const void*> download_dst; // destinations of the copies queued since the last wait on this slot
     uint32_t max_batch = 1; // frames one render_batch() call may trace together (buffers are sized for it)
     uint32_t builder = RFW_HIP_BUILDER_AUTO;
     uint32_t flags = 0;
@@ -168,6 +170,7 @@ struct Instance {
 
     // device path state
     DevBuf<float4> d_ray_o[2], d_ray_d[2], d_thr[2], d_sh_o, d_sh_d, d_sh_e, d_acc_slab, d_frame_acc, d_frame_out;
+    DevBuf<uint32_t> d_present; // BGRA8 sRGB frame, made on demand by rfw_hip_download_frame(what = 2)
     DevBuf<uint4> d_hit[2];
     void* external_slab = nullptr;
     uint32_t tiles_x = 0, tiles_y = 0, local_tiles = 0, capacity = 0;
@@ -1174,6 +1177,7 @@ void rfw_hip_destroy(void* inst)
         (void)hipDeviceSynchronize();
         if (I->scene_ready) (void)hipEventDestroy(I->scene_ready);
         if (I->frame_done) (void)hipEventDestroy(I->frame_done);
+        if (I->download_done) (void)hipEventDestroy(I->download_done);
         I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
@@ -1186,7 +1190,7 @@ void rfw_hip_destroy(void* inst)
             if (I->stage_event[k]) (void)hipEventDestroy(I->stage_event[k]);
         }
         for (int h = 0; h < 2; h++) { I->d_ray_o[h].release(); I->d_ray_d[h].release(); I->d_thr[h].release(); I->d_hit[h].release(); }
-        I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release();
+        I->d_sh_o.release(); I->d_sh_d.release(); I->d_sh_e.release(); I->d_acc_slab.release(); I->d_frame_acc.release(); I->d_frame_out.release(); I->d_present.release();
         for (auto& ev : I->ring)
             if (ev) (void)hipEventDestroy(ev);
         if (I->ev_fork) (void)hipEventDestroy(I->ev_fork);
@@ -1457,6 +1461,89 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     return RFW_HIP_OK;
 }
+
+// step k = the smallest linear value whose sRGB encoding rounds to byte k + 1: srgb_to_linear((k + 0.5) / 255), IEC 61966-2-1
+static const float* srgb_steps()
+{
+    static float t[255];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int k = 0; k < 255; k++) {
+            const double e = (k + 0.5) / 255.0;
+            const double lin = e <= 0.04045 ? e / 12.92 : std::pow((e + 0.055) / 1.055, 2.4);
+            float f = (float)lin;
+            if ((double)f < lin) f = std::nextafter(f, 2.0f); // smallest float NOT below the exact step
+            t[k] = f;
+        }
+    });
+    return t;
+}
+void rfw_hip_srgb_steps(float* out255)
+{
+    if (out255) std::memcpy(out255, srgb_steps(), 255 * sizeof(float));
+}
+// Pinned host memory for rfw_hip_download_frame (a pageable destination would make the copy synchronous and staged)
+void* rfw_hip_host_alloc(uint64_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void rfw_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+// Queue the copy of the latest frame (what = 0: finalised frame, 1: accumulator; batch frame `frame`) to host memory behind the
+// kernels that produce it, on that frame's stream, and return: with frames in flight the copy of frame k runs on the DMA engines
+// while the slots of frames k+1... trace.  The bytes are valid after rfw_hip_wait_downloads.
+int rfw_hip_download_frame(void* inst, uint32_t what, uint32_t frame, float* host_rgba, uint64_t n)
+{
+    LOCK(inst);
+    const uint64_t px = (uint64_t)I->width * I->height;
+    if (!host_rgba || n != (what == 2 ? px : px * 4)) return fail(I, RFW_HIP_E_INVALID, "download_frame: size mismatch");
+    if (what > 2 || frame >= I->max_batch) return fail(I, RFW_HIP_E_INVALID, "download_frame: bad selector");
+    Instance* c = I->slots.empty() ? I : slot_ptr(I, I->cur_slot);
+    HIP_TRY(I, hipSetDevice(I->device));
+    if (!c->download_done) HIP_TRY(I, hipEventCreateWithFlags(&c->download_done, hipEventDisableTiming));
+    const float4* src = (what == 1 ? c->d_frame_acc.ptr : c->d_frame_out.ptr) + (size_t)frame * px;
+    // Presented frame into a pinned destination (rfw_hip_host_alloc, or registered by the caller): the encoding kernel stores straight
+    // into host memory over the link, no copy command (measured: 0.731 ms per frame against 0.762 with encode + copy, 8 frames in flight).
+    // Float frames, and pageable destinations, go through the runtime's copy.
+    void* mapped = nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host_rgba) == hipSuccess && attr.type == hipMemoryTypeHost) mapped = attr.devicePointer;
+    else (void)hipGetLastError();
+    if (what == 2) { // the swap-chain image: encode on the device, a quarter of the bytes travel
+        uint32_t* out = (uint32_t*)mapped;
+        if (!out) {
+            HIP_TRY(I, c->d_present.ensure(px));
+            out = c->d_present.ptr;
+        }
+        launch_present(c->stream, src, out, px, srgb_steps(), mapped != nullptr);
+        HIP_TRY(I, hipGetLastError());
+        if (!mapped) HIP_TRY(I, hipMemcpyAsync(host_rgba, c->d_present.ptr, px * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    } else { // 33 MB per 1080p frame: the DMA engine moves it at ~40 GB/s; stores from a kernel reach ~28 GB/s (measured)
+        HIP_TRY(I, hipMemcpyAsync(host_rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(I, hipEventRecord(c->download_done, c->stream));
+    c->download_dst.push_back(host_rgba);
+    return RFW_HIP_OK;
+}
+// host_ptr == NULL: every copy queued so far; else the copy into host_ptr (and, being on the same stream, those queued before it on its slot)
+int rfw_hip_wait_download(void* inst, const void* host_ptr)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    for (size_t k = 0; k <= I->slots.size(); k++) {
+        Instance* c = slot_ptr(I, (uint32_t)k);
+        if (c->download_dst.empty()) continue;
+        if (host_ptr && std::find(c->download_dst.begin(), c->download_dst.end(), host_ptr) == c->download_dst.end()) continue;
+        HIP_TRY(I, hipEventSynchronize(c->download_done)); // the event is behind the LAST copy of this slot
+        c->download_dst.clear();
+    }
+    return RFW_HIP_OK;
+}
+int rfw_hip_wait_downloads(void* inst) { return rfw_hip_wait_download(inst, nullptr); }
 
 int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n)
 {

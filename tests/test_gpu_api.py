@@ -195,3 +195,47 @@ def test_depth_test_returns_the_closest_hit_and_a_node_count():
     assert depth[hits["inst"] >= 0].mean() > depth[hits["inst"] < 0].mean() * 0.5
     assert np.array_equal(be.intersect(o, d)["tri"], hits["tri"])  # the same query without the counter
     be.close()
+
+
+def test_download_frame_is_the_frame_and_does_not_stall_the_slots():
+    """rfw_hip_download_frame queues a copy of the latest frame into pinned host memory behind its kernels; several can be outstanding
+    (one per frame slot); after wait_downloads each buffer holds exactly what read_framebuffer / read_accumulator return."""
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 96, 64
+    scene = Scene().build("soup", 1500, 3, 0.0, 2)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=2, frames_in_flight=3)
+    scene.sync(be)
+    views, bufs, want = [], [], []
+    for k in range(5):
+        scene.set_camera([0.2 * k - 0.4, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+        bufs.append((be.host_frame(), be.host_frame()))
+    for v, (fb, acc) in zip(views, bufs):
+        be.render(v)
+        be.download_frame(fb)
+        be.download_frame(acc, accumulator=True)
+    be.wait_downloads()
+    ref = HipBackend.init(w, h, 1.0, max_path_length=2)
+    scene.mark_all_changed(); scene.sync(ref)
+    for v, (fb, acc) in zip(views, bufs):
+        ref.reset_accumulation(); ref.render(v)
+        assert np.array_equal(fb.view(np.uint32), ref.framebuffer().view(np.uint32))
+        assert np.array_equal(acc.view(np.uint32), ref.accumulator().view(np.uint32))
+    with pytest.raises(Exception):
+        be.download_frame(np.zeros((4, 4, 4), np.float32))
+    # the presented frame: gpu-rt's Bgra8UnormSrgb swap chain image of the same frame (B, G, R, A bytes)
+    steps = be.srgb_steps()
+    e = (np.arange(255) + 0.5) / 255.0
+    exact = np.where(e <= 0.04045, e / 12.92, ((e + 0.055) / 1.055) ** 2.4)
+    assert np.all(np.diff(steps) > 0) and np.all(np.abs(steps.astype(np.float64) - exact) <= np.spacing(steps).astype(np.float64))
+    for lin, byte in ((0.0, 0), (1.0, 255), (7.0, 255), (0.5, 188), (0.18, 118), (0.0031308 / 2, 5), (-1.0, 0)):
+        assert np.searchsorted(steps, np.float32(lin), side="right") == byte, lin
+    pres = be.host_frame(presented=True)
+    be.render(views[2]); be.download_frame(pres); be.wait_downloads()
+    ref.reset_accumulation(); ref.render(views[2])
+    fb = ref.framebuffer()
+    want = np.searchsorted(steps, fb[..., :3], side="right").astype(np.uint8)
+    assert np.array_equal(pres[..., 0], want[..., 2]) and np.array_equal(pres[..., 1], want[..., 1]) and np.array_equal(pres[..., 2], want[..., 0])
+    assert np.all(pres[..., 3] == 255) and pres[..., :3].max() > 40
+    be.close(); ref.close()
