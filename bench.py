@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="frames traced per rfw_hip_render_batch call (one launch per stage and, with a sharded frame, ONE all-gather for the "
                          "whole batch); 1 = one render() per frame")
+    ap.add_argument("--procedural", action="store_true",
+                    help="hand the generated scene to the backend directly; default: write it as a binary glTF 2.0 file (host/gltf_export.cpp) and "
+                         "run on what the glTF importer (host/gltf.cpp) reads back — the configurations of BASELINE.json are glTF scenes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
@@ -74,6 +77,16 @@ def main():
     w, h = args.width, args.height
     tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267}[args.workload]
     scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 0, 0.0, 0xC0FFEE)
+    scene_source = "procedural"
+    if not args.procedural:
+        # the synthetic scene as a real glTF file, read back through the importer (a lossless round trip: tests/test_gltf.py)
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="rfw_bench_") as tmp:
+            t_io = time.time()
+            glb = scene.save_glb(os.path.join(tmp, f"{args.workload}_rank{rank}.glb"))
+            glb_mb = os.path.getsize(glb) / 1e6
+            scene = Scene().load_gltf(glb)
+            scene_source = f"binary glTF 2.0, {glb_mb:.0f} MB, written by host/gltf_export.cpp and imported by host/gltf.cpp ({time.time() - t_io:.1f} s)"
     animated = args.workload == "spheres10k"
     if animated:
         scene.build("spheres", 100, 100, 0.28)
@@ -325,10 +338,10 @@ def main():
             "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: procedural atrium, {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
+            "config": {"workload": f"{args.workload}: synthetic atrium ({'glTF scene' if not args.procedural else 'procedural'}), {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "scene_source": scene_source, "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],

@@ -6,6 +6,7 @@
 //   * every glTF mesh -> one MeshDescriptor, all TRIANGLES primitives concatenated and de-indexed (3 vertices per triangle),
 //     per-vertex material id (gltf.rs:77-83 remaps them into the scene's material list), then Mesh3D::from
 //     (crates/rfw-scene/src/objects_3d/mod.rs:673-895: normals generated when absent, RTTriangle lod/area, ranges);
+//   * KHR_lights_punctual -> directional / point / spot lights (direction = the node's -Z axis);
 //   * pbrMetallicRoughness -> Material {color, metallic, roughness}; emissiveFactor (x KHR_materials_emissive_strength)
 //     replaces the colour when it is non-zero, which is how the scene recognises lights (material/list.rs:492-515: rgb > 1);
 //   * the node hierarchy is flattened: every node with a mesh becomes one instance with the node's world matrix
@@ -585,6 +586,20 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             if (const Json* ior = ext->get("KHR_materials_ior")) mat.eta = (float)ior->number("ior", 1.5);
             if (const Json* tr = ext->get("KHR_materials_transmission")) mat.transmission = (float)tr->number("transmissionFactor", 0.0);
         }
+        // a file written by save_glb (gltf_export.cpp) carries the Disney parameters glTF has no slot for, and exact emitter colours
+        if (const Json* ex = m.get("extras"))
+            if (const Json* d = ex->get("rfw_disney")) {
+                auto vec4 = [&](const char* k, float* dst) {
+                    if (const Json* a = d->get(k))
+                        for (size_t i = 0; i < 4 && i < a->size(); i++) dst[i] = (float)a->arr[i].num;
+                };
+                vec4("color", mat.color); vec4("absorption", mat.absorption); vec4("specular", mat.specular);
+                if (const Json* pa = d->get("params"); pa && pa->size() >= 13) {
+                    float* dst[13] = {&mat.subsurface, &mat.specular_f, &mat.specular_tint, &mat.anisotropic, &mat.sheen, &mat.sheen_tint, &mat.clearcoat,
+                                      &mat.clearcoat_gloss, &mat.eta, &mat.custom0, &mat.custom1, &mat.custom2, &mat.custom3};
+                    for (size_t i = 0; i < 13; i++) *dst[i] = (float)pa->arr[i].num;
+                }
+            }
         mat_ids.push_back(scene.add_material(mat));
     }
     int64_t default_mat = -1;
@@ -761,10 +776,67 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
         scene.skins_changed = true;
     }
 
-    // ---- instances, camera
+    // the node's -Z axis in world space; an axis that is a unit vector to float precision is taken as it is (no second rounding)
+    auto minus_z = [](const M4& w, float out[3]) {
+        const double dz[3] = {-w.m[8], -w.m[9], -w.m[10]};
+        const double len = std::sqrt(dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2]);
+        if (!(len > 0.0)) return;
+        const double scale = std::fabs(len - 1.0) < 1e-6 ? 1.0 : 1.0 / len;
+        for (int k = 0; k < 3; k++) out[k] = (float)(dz[k] * scale + 0.0); // + 0.0: no negative zeros out of the matrix product
+    };
+    // ---- KHR_lights_punctual: directional / point / spot lights on nodes (direction = the node's -Z)
+    const Json* light_defs = nullptr;
+    if (const Json* ext = root.get("extensions"))
+        if (const Json* lp = ext->get("KHR_lights_punctual")) light_defs = lp->get("lights");
+    auto add_light = [&](const Json& nd, const M4& w) {
+        const Json* ext = nd.get("extensions");
+        const Json* lp = ext ? ext->get("KHR_lights_punctual") : nullptr;
+        if (!lp || !light_defs) return;
+        const int64_t li = lp->integer("light", -1);
+        if (li < 0 || (size_t)li >= light_defs->size()) return;
+        const Json& L = light_defs->arr[(size_t)li];
+        const double intensity = L.number("intensity", 1.0);
+        double col[3] = {1, 1, 1};
+        if (const Json* c = L.get("color"))
+            for (size_t k = 0; k < 3 && k < c->size(); k++) col[k] = c->arr[k].num;
+        float rad[3] = {(float)(col[0] * intensity), (float)(col[1] * intensity), (float)(col[2] * intensity)};
+        if (const Json* ex = L.get("extras"))
+            if (const Json* rr = ex->get("rfw_radiance"); rr && rr->size() >= 3)
+                for (int k = 0; k < 3; k++) rad[k] = (float)rr->arr[(size_t)k].num;
+        const float energy = std::sqrt(rad[0] * rad[0] + rad[1] * rad[1] + rad[2] * rad[2]); // lights.rs: energy = |radiance|
+        float dir[3] = {0, 0, -1};
+        minus_z(w, dir);
+        const rfw_vec3 position{(float)w.m[12], (float)w.m[13], (float)w.m[14]}, radiance{rad[0], rad[1], rad[2]}, direction{dir[0], dir[1], dir[2]};
+        const std::string type = L.string("type");
+        if (type == "directional") {
+            rfw_directional_light l;
+            std::memset(&l, 0, sizeof(l));
+            l.direction = direction; l.radiance = radiance; l.energy = energy;
+            scene.directional_lights.push_back(l);
+        } else if (type == "point") {
+            rfw_point_light l;
+            std::memset(&l, 0, sizeof(l));
+            l.position = position; l.radiance = radiance; l.energy = energy;
+            scene.point_lights.push_back(l);
+        } else if (type == "spot") {
+            rfw_spot_light l;
+            std::memset(&l, 0, sizeof(l));
+            double inner = 0.0, outer = 0.7853981633974483;
+            const Json* sp = L.get("spot");
+            if (sp) { inner = sp->number("innerConeAngle", 0.0); outer = sp->number("outerConeAngle", 0.7853981633974483); }
+            l.position = position; l.radiance = radiance; l.direction = direction; l.energy = energy;
+            l.cos_inner = (float)std::cos(inner); l.cos_outer = (float)std::cos(outer);
+            if (sp)
+                if (const Json* ex = sp->get("extras"))
+                    if (const Json* cs = ex->get("rfw_cos"); cs && cs->size() >= 2) { l.cos_inner = (float)cs->arr[0].num; l.cos_outer = (float)cs->arr[1].num; }
+            scene.spot_lights.push_back(l);
+        }
+    };
+    // ---- instances, camera, lights
     bool cam_set = false;
     for (const size_t ni : order) {
         const Json& nd = nodes[ni];
+        add_light(nd, world[ni]);
         const int64_t mi = nd.integer("mesh", -1);
         if (mi >= 0 && (size_t)mi < mesh_ids.size() && mesh_ids[(size_t)mi] >= 0) {
             const uint32_t mesh = (uint32_t)mesh_ids[(size_t)mi];
@@ -783,13 +855,15 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             if (const Json* persp = cj.get("perspective")) {
                 const M4& w = world[ni];
                 cam->pos[0] = (float)w.m[12]; cam->pos[1] = (float)w.m[13]; cam->pos[2] = (float)w.m[14];
-                double dz[3] = {-w.m[8], -w.m[9], -w.m[10]}; // a glTF camera looks down its local -Z
-                const double len = std::sqrt(dz[0] * dz[0] + dz[1] * dz[1] + dz[2] * dz[2]);
-                if (len > 0.0)
-                    for (int k = 0; k < 3; k++) cam->direction[k] = (float)(dz[k] / len);
+                minus_z(w, cam->direction); // a glTF camera looks down its local -Z
                 cam->fov = (float)(persp->number("yfov", 0.6981317) * 180.0 / 3.14159265358979323846);
                 if (persp->has("aspectRatio")) cam->aspect_ratio = (float)persp->number("aspectRatio", 1.0);
                 cam->aperture = 0.0f;
+                if (const Json* ex = cj.get("extras"))
+                    if (const Json* fa = ex->get("rfw_fov_aperture"); fa && fa->size() >= 2) { // written by save_glb: degrees and lens size as floats
+                        cam->fov = (float)fa->arr[0].num;
+                        cam->aperture = (float)fa->arr[1].num;
+                    }
                 cam_set = true;
             }
         }

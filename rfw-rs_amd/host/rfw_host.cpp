@@ -1220,6 +1220,14 @@ HOST_API int rfwhost_load_gltf(void* p, const char* path, int use_camera)
     }
     return 0;
 }
+HOST_API int rfwhost_save_glb(void* p, const char* path)
+{
+    HostScene& h = *(HostScene*)p;
+    if (!path) { h.error = "save_glb: null path"; return -1; }
+    std::string err;
+    if (!rfw::save_glb(path, h.scene, &h.cam, err)) { h.error = err; return -1; }
+    return 0;
+}
 HOST_API const char* rfwhost_last_error(void* p) { return ((HostScene*)p)->error.c_str(); }
 HOST_API int rfwhost_animate(void* p, float time)
 {

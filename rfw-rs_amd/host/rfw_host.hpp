@@ -234,6 +234,8 @@ void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed);
 void build_skinned(Scene& scene, Camera3D& cam, uint32_t seed);
 // glTF 2.0 (.gltf / .glb) -> meshes, materials, instances, skins (gltf.cpp; crates/rfw-scene/src/loaders/gltf.rs:26-90 via l3d)
 bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string& err);
+// gltf_export.cpp: the scene (static meshes, instances, materials, punctual lights, camera) as a binary glTF 2.0 file
+bool save_glb(const std::string& path, const Scene& scene, const Camera3D* cam, std::string& err);
 void pose_skins(Scene& scene, float time); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox
 
 } // namespace rfw

@@ -31,6 +31,7 @@ def host_lib():
         l.rfwhost_build.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
         l.rfwhost_animate.argtypes = [C.c_void_p, C.c_float]
         l.rfwhost_load_gltf.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        l.rfwhost_save_glb.argtypes = [C.c_void_p, C.c_char_p]
         l.rfwhost_last_error.argtypes = [C.c_void_p]
         l.rfwhost_last_error.restype = C.c_char_p
         l.rfwhost_pose.argtypes = [C.c_void_p, C.c_float]
@@ -74,6 +75,12 @@ class Scene:
         if self._l.rfwhost_load_gltf(self._h, os.fsencode(path), 1 if use_camera else 0) != 0:
             raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
         return self
+
+    def save_glb(self, path):
+        """Writes the scene (static meshes, instances, materials, punctual lights, camera) as a binary glTF 2.0 file."""
+        if self._l.rfwhost_save_glb(self._h, os.fsencode(path)) != 0:
+            raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
+        return path
 
     def animate(self, time):
         if self._l.rfwhost_animate(self._h, time) != 0:
