@@ -23,6 +23,7 @@ struct Node4 {
 static_assert(sizeof(Node4) == 128, "Node4 must be one 128-B line");
 constexpr uint32_t kInvalidRef = 0xffffffffu;
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoPath = 0xfffffffeu; // hit.inst of a slab slot that holds no pixel (a miss is -1)
 constexpr uint32_t kLeafFirstMask = 0x07ffffffu;
 constexpr int kMaxLeafTris = 8;
 inline __host__ __device__ uint32_t make_leaf(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 27) | first; }

@@ -152,23 +152,26 @@ RFW_DI void generate_eye_ray(const CameraParams& cam, f3& O, f3& D, uint32_t sx,
     float r1 = randf(seed);
     float r2 = randf(seed);
     float r3 = randf(seed);
-    const float blade = (float)f2i(r0 * 9.0f);
-    r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
-    float x1, y1, x2, y2;
-    const float piOver4point5 = 3.14159265359f / 4.5f;
-    rfw_sincosf(blade * piOver4point5, &y1, &x1);
-    rfw_sincosf((blade + 1.0f) * piOver4point5, &y2, &x2);
-    if ((r2 + r3) > 1.0f) {
-        r2 = 1.0f - r2;
-        r3 = 1.0f - r3;
-    }
-    const float xr = x1 * r2 + x2 * r3;
-    const float yr = y1 * r2 + y2 * r3;
     const f3 pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const f3 right = mk3(cam.right[0], cam.right[1], cam.right[2]);
     const f3 up = mk3(cam.up[0], cam.up[1], cam.up[2]);
     const f3 p1 = mk3(cam.p1[0], cam.p1[1], cam.p1[2]);
-    O = pos + cam.lens_size * (right * xr + up * yr);
+    O = pos;
+    if (cam.lens_size != 0.0f) { // pinhole (uniform branch): pos + 0 * (finite) == pos, so the 9-blade lens sample is only drawn, not evaluated
+        const float blade = (float)f2i(r0 * 9.0f);
+        r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+        float x1, y1, x2, y2;
+        const float piOver4point5 = 3.14159265359f / 4.5f;
+        rfw_sincosf(blade * piOver4point5, &y1, &x1);
+        rfw_sincosf((blade + 1.0f) * piOver4point5, &y2, &x2);
+        if ((r2 + r3) > 1.0f) {
+            r2 = 1.0f - r2;
+            r3 = 1.0f - r3;
+        }
+        const float xr = x1 * r2 + x2 * r3;
+        const float yr = y1 * r2 + y2 * r3;
+        O = pos + cam.lens_size * (right * xr + up * yr);
+    }
     const float u = ((float)(int)sx + r0) * (1.0f / (float)(int)cam.width);
     const float v = ((float)(int)sy + r1) * (1.0f / (float)(int)cam.height);
     const f3 pointOnPixel = p1 + u * right + v * up;
@@ -209,6 +212,8 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
         p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id));
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    } else if (idx < p.capacity) {
+        p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u); // a slab slot without a pixel (ragged edge tile): k_shade skips it without redoing the index arithmetic
     }
     flush_counters<COUNT>(sc.counters, tc, 0);
 }
@@ -242,6 +247,8 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
         p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id | (f << 24)));
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    } else if (f < cam.batch) {
+        p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u);
     }
     flush_counters<COUNT>(sc.counters, tc, 0);
 }
@@ -304,9 +311,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const C
         const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {
             const float4 e = p.sh_e[idx];
-            const uint32_t word = fbits(o4.w), pixel = BATCH ? (word & 0xffffffu) : word;
-            uint32_t owner;
-            const uint32_t slot = pixel_to_slab(cam, pixel % cam.width, pixel / cam.width, owner) + (BATCH ? (word >> 24) * cam.frame_capacity : 0u);
+            const uint32_t slot = fbits(e.w); // the path's accumulator slot rides in the queue entry (k_shade knows it without arithmetic)
             // single writer per pixel per pass (one shadow ray per path per bounce), as ray_shadow.comp:268
             float4 a = p.acc[slot];
             a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
@@ -328,8 +333,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     const uint32_t path_length = bounce;
 
     bool live = idx < count;
-    uint32_t px = 0, py = 0;
-    if (live && bounce == 0) live = slab_to_pixel(cam, BATCH ? idx % cam.frame_capacity : idx, px, py);
 
     bool push_ext = false, push_shadow = false;
     int light_bucket = 0;
@@ -338,10 +341,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     uint32_t ext_normal = 0;
     f3 sh_o = mk3(0.0f), sh_d = mk3(0.0f), sh_e = mk3(0.0f);
     float sh_dist = 0.0f;
-    uint32_t PATH_ID = 0, PATH_WORD = 0;
+    uint32_t PATH_ID = 0, PATH_WORD = 0, sh_slot = 0;
 
+    uint4 S = make_uint4(kNoPath, 0u, 0u, 0u);
     if (live) {
-        const uint4 S = p.hit[half][idx];
+        S = p.hit[half][idx];
+        live = S.x != kNoPath; // bounce 0: a slab slot of a ragged edge tile that holds no pixel (marked by k_primary)
+    }
+    if (live) {
         const float4 O4 = p.ray_o[half][idx], D4 = p.ray_d[half][idx];
         const f3 O = mk3(O4.x, O4.y, O4.z), D = mk3(D4.x, D4.y, D4.z);
         f3 throughput = mk3(1.0f);
@@ -354,8 +361,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         const uint32_t path_word = fbits(O4.w); // batch: frame index in the top byte
         PATH_ID = BATCH ? (path_word & 0xffffffu) : path_word;
         PATH_WORD = path_word;
-        uint32_t owner;
-        const uint32_t slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner) + (BATCH ? (path_word >> 24) * cam.frame_capacity : 0u);
+        // bounce 0: path idx of the (tall) virtual frame IS its accumulator slot; later bounces recompute it from the pixel
+        uint32_t owner, slot = idx;
+        if (bounce != 0) slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner) + (BATCH ? (path_word >> 24) * cam.frame_capacity : 0u);
         const int32_t INST_ID = (int32_t)S.x;
         const uint32_t TRI_ID = S.y;
         const float T_VAL = bitsf(S.z);
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
             const float tri_area = bitsf(q10.w);
             ShadingData sd = extractParameters(sc.materials + mat_id);
 
-            const uint32_t sampleId = PATH_ID / (cam.width * cam.height) + cam.sample_count;
+            const uint32_t sampleId = cam.sample_count; // shade.comp:102: pathId / (w * h) + sample count, and a path id is a pixel index here
             uint32_t seed = wang_hash(PATH_ID * 16789u + sampleId * 1791u + path_length * 720898027u);
 
             const float u = (float)(S.w & 65535u) * (1.0f / 65535.0f);
@@ -482,6 +490,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                                     sh_d = L;
                                     sh_dist = dist - 1e-4f;
                                     sh_e = contribution;
+                                    sh_slot = slot;
                                     push_shadow = true;
                                     light_bucket = picked & (kShadowBuckets - 1);
                                 }
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         const size_t j = (size_t)light_bucket * p.capacity + off + my_rank;
         p.sh_o[j] = make_float4(sh_o.x, sh_o.y, sh_o.z, bitsf(PATH_WORD));
         p.sh_d[j] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_dist);
-        p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, 0.0f);
+        p.sh_e[j] = make_float4(sh_e.x, sh_e.y, sh_e.z, bitsf(sh_slot));
     }
     if (push_ext) {
         uint32_t off = s_base[kShadowBuckets];
