@@ -395,8 +395,10 @@ def pmc_valu_per_frame():
     try:
         k = json.load(open(files[-1]))["kernels"]
         total = 0
-        for name in ("k_primary<false>", "k_shade", "k_shadow<false>", "k_assemble"):
-            total += k[name]["SQ_INSTS_VALU"]
+        # the non-counting, single-frame instantiations of the frame's four kernels (names as the profiler prints them, older sets included)
+        for names in (("k_primary<false>",), ("k_shade<false>", "k_shade"), ("k_shadow<false, false>", "k_shadow<false,false>", "k_shadow<false>"),
+                      ("k_assemble<false>", "k_assemble")):
+            total += k[next(n for n in names if n in k)]["SQ_INSTS_VALU"]
         return int(total)
     except Exception:
         return None
@@ -412,9 +414,9 @@ def pmc_traffic(kernel):
         return None
     try:
         k = json.load(open(files[-1]))["kernels"]
-        for name, v in k.items():
-            if name.startswith(kernel) and "<true>" not in name:
-                return v["hbm_bytes_per_launch_corrected"]
+        for name in (kernel + "<false, false>", kernel + "<false>", kernel):  # the non-counting single-frame instantiation
+            if name in k:
+                return k[name]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
     return None
