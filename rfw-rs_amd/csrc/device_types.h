@@ -31,13 +31,14 @@ inline __host__ __device__ uint32_t make_leaf(uint32_t first, uint32_t count) { 
 // The node the traversal kernels actually read: the same 4 child boxes quantised to 8 bits per plane relative to the
 // node's own origin with power-of-two scales (floor for lo, ceil for hi => conservative), 64 B = 4 dwordx4 per lane
 // instead of 7.  The trace kernels are bound by the L1/TA data-return path (16 cycles per dwordx4 wave-instruction,
-// profiles/), so bytes per node visit are what matters.  plane = origin + q * scale, scale = 2^(exp - 127).
+// profiles/), so bytes per node visit are what matters.  plane = origin + q * scale, scale = a power of two per axis, stored as the
+// float itself (the kernels are instruction-bound: an exponent byte would cost a shift and a mask per axis and visit to unpack).
 struct Node4Q {
     float ox, oy, oz;
-    uint32_t exps;      // byte a = biased exponent of the scale of axis a
+    float sx;           // scale of axis x
     uint32_t qlo[3];    // byte i of qlo[a] = quantised lower plane of child i on axis a
     uint32_t qhi[3];
-    uint32_t pad[2];
+    float sy, sz;       // scales of axes y, z
     uint32_t child[4];  // as Node4::child
 };
 static_assert(sizeof(Node4Q) == 64, "Node4Q must be half a 128-B line");
@@ -58,7 +59,6 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
             hi[a] = nhi[a][i] > hi[a] ? nhi[a][i] : hi[a];
         }
     }
-    uint32_t exps = 0;
     float scale[3];
     for (int a = 0; a < 3; a++) {
         if (!(hi[a] >= lo[a])) { lo[a] = 0.0f; hi[a] = 0.0f; } // node without children
@@ -70,10 +70,9 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
         if (e > 254u) e = 254u;
         scale[a] = rfw_bits2f(e << 23);
         if (255.0f * scale[a] < (hi[a] - lo[a]) && e < 254u) { e += 1u; scale[a] = rfw_bits2f(e << 23); }
-        exps |= e << (8 * a);
     }
     q.ox = lo[0]; q.oy = lo[1]; q.oz = lo[2];
-    q.exps = exps;
+    q.sx = scale[0]; q.sy = scale[1]; q.sz = scale[2];
     for (int a = 0; a < 3; a++) { q.qlo[a] = 0u; q.qhi[a] = 0u; }
     for (int i = 0; i < 4; i++) {
         q.child[i] = n.child[i];
@@ -93,7 +92,6 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
             q.qhi[a] |= qh << (8 * i);
         }
     }
-    q.pad[0] = 0u; q.pad[1] = 0u;
     return q;
 }
 

@@ -1039,7 +1039,7 @@ int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf,
             if (q.child[i] != nd.child[i]) errors++;
             if (nd.child[i] == kInvalidRef) continue;
             for (int a = 0; a < 3; a++) {
-                const float scale = rfw_bits2f(((q.exps >> (8 * a)) & 0xffu) << 23);
+                const float scale = a == 0 ? q.sx : (a == 1 ? q.sy : q.sz);
                 const float dlo = o[a] + (float)((q.qlo[a] >> (8 * i)) & 0xffu) * scale, dhi = o[a] + (float)((q.qhi[a] >> (8 * i)) & 0xffu) * scale;
                 if (dlo > lo[a][i] || dhi < hi[a][i]) errors++;
             }

@@ -87,9 +87,9 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     int sp = 0;
     int blas_sp = -1;          // stack height at BLAS entry; -1 = currently in the TLAS
     int32_t cur_inst = -1;
-    uint32_t node_base = 0, tri_base = 0;
+    uint32_t tri_base = 0;
     uint32_t cur = 0;          // TLAS root (interior ref 0)
-    const Node4Q* nodes = sc.tlas_nodes;
+    const Node4Q* nodes = sc.tlas_nodes; // node array of the current space (TLAS, or the entered instance's BLAS)
 
     auto push = [&](uint32_t v) {
         if (sp < kStackLds) lds_stack[sp * kTraceBlock + lane_slot] = v;
@@ -108,15 +108,14 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         iteration++;
         if (!(cur & kLeafBit)) {
             // ---- interior node: 4-wide slab test on the quantised child boxes (64 B = 4 dwordx4 per lane)
-            const uint4* np = reinterpret_cast<const uint4*>(nodes + node_base + cur);
+            const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
             const uint4 w0 = np[0], w1 = np[1], w2 = np[2], ch = np[3];
             if (COUNT) {
                 tc.nodes++;
                 if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) tc.wave_nodes++;
             }
             // plane = origin + q * scale  =>  t = q * (scale * inv) + (origin - o) * inv : one cvt + one fma per plane
-            const float Ax = bitsf((w0.w & 0xffu) << 23) * inv.x, Ay = bitsf(((w0.w >> 8) & 0xffu) << 23) * inv.y,
-                        Az = bitsf(((w0.w >> 16) & 0xffu) << 23) * inv.z;
+            const float Ax = bitsf(w0.w) * inv.x, Ay = bitsf(w2.z) * inv.y, Az = bitsf(w2.w) * inv.z;
             const float Bx = (bitsf(w0.x) - o.x) * inv.x, By = (bitsf(w0.y) - o.y) * inv.y, Bz = (bitsf(w0.z) - o.z) * inv.z;
             int32_t key[4];
             bool hit[4];
@@ -234,10 +233,9 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             o = xform_rows(r0, r1, r2, O, 1.0f);
             d = xform_rows(r0, r1, r2, D, 0.0f);
             inv = slab_inv(d);
-            node_base = meta.x;
             tri_base = meta.y;
             cur_inst = (int32_t)gid;
-            nodes = sc.blas_nodes;
+            nodes = sc.blas_nodes + meta.x;
             blas_sp = sp;
             cur = 0;
             continue;
@@ -249,7 +247,6 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             d = D;
             inv = slab_inv(d);
             nodes = sc.tlas_nodes;
-            node_base = 0;
         }
         if (sp == 0) break;
         cur = pop();
