@@ -12,8 +12,13 @@
 #include "shade_device.h"
 #include "traverse.h"
 
+// waves per SIMD the trace kernels are compiled for (register budget 512 / waves), chosen by measurement with frames in flight:
+// closest hit (k_primary, k_extend) 6 (5: -6 %, 7: -2 %, 8: -11 %); any hit (k_shadow: fewer live values) 8 (7: -1.4 %, 6: -2.8 %)
 #ifndef RFW_TRACE_WAVES
-#define RFW_TRACE_WAVES 6 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves); 6 measured best with frames in flight (5: -6 %, 8: -2 %)
+#define RFW_TRACE_WAVES 6
+#endif
+#ifndef RFW_TRACE_WAVES_ANY
+#define RFW_TRACE_WAVES_ANY 8
 #endif
 
 namespace rfwhip {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
 template <bool COUNT, bool BATCH = false>
-__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
     // the queue is bucketed by light (shade pushes into region light & 7): walk the buckets, each padded to whole wavefronts, so
