@@ -92,14 +92,15 @@ def main():
         scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
     view = scene.view(w, h)
-    # Frames per launch and frames in flight.  One GPU: 8 frames in flight, one render() each (render_batch gains 3 % here: 2 x 8 -> 5010
-    # Mrays/s against 4855).  Sharded frame: a rank's kernels cover 1/N of a frame (their time is the slowest wavefront's), so B = 8 frames
-    # are traced per launch (rfw_hip_render_batch: B/N of a frame's paths per kernel, ONE all-gather per batch) and 3 such batches are in
-    # flight.  Measured with --emulate-shard 8, ms per frame on rank 0's shard: one frame at a time 0.42, 12 in flight 0.117, 3 batches
-    # of 8 in flight 0.100; --emulate-shard 4: 0.204 -> 0.184; --emulate-shard 2: 0.364 -> 0.338.
-    B = args.batch if args.batch > 0 else (1 if world == 1 and not args.emulate_shard else 8)
+    # Frames per launch and frames in flight.  Default: B = 8 independent frames traced per rfw_hip_render_batch call (one launch per
+    # stage over the paths of all 8; with a sharded frame ONE all-gather per batch), 3 such batches in flight.  Measured on one GPU:
+    # 5350-5400 Mrays/s, against 5160 with `--batch 1 --frames-in-flight 8` (eight frame slots, one render() -- the reference's own call
+    # -- per frame).  A sharded frame needs the batches more: a rank's kernels cover 1/N of a frame and their time is the slowest
+    # wavefront's; --emulate-shard 8, ms per frame on rank 0's shard: one frame at a time 0.42, 12 in flight 0.116, 3 batches of 8 in
+    # flight 0.098.  C3 changes the scene every frame (a batch shares one scene): one render() per frame, 8 (12 for N > 2) in flight.
+    B = args.batch if args.batch > 0 else 8
     if animated:
-        B = 1  # C3 changes the scene every frame: a batch shares one scene
+        B = 1
     F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 8 if world <= 2 else 12)
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
@@ -213,7 +214,7 @@ def main():
         b.drain_timing()
     # per-kernel HIP events inside the timed region only when they mean something: with frames in flight the kernels of different
     # frames overlap and the per-kernel roofline comes from the isolated pass below, so the ~14 event records per frame are skipped
-    events_in_timed_region = F == 1
+    events_in_timed_region = F == 1 and B == 1
     for b in bes:
         b.set_option("timing", 1 if events_in_timed_region else 0)
     timed_frames = 0
@@ -255,7 +256,7 @@ def main():
     # renders one frame at a time on instance 0 (the same thing `--frames-in-flight 1` times, and what a rocprofv3 kernel trace
     # of that command shows); the timed region's own aggregate (all kernels' bytes / ms_per_step) is reported next to it.
     iso_ms, iso_frames = None, 0
-    if F > 1:
+    if F > 1 or B > 1:
         iso_ms = {k: 0.0 for k in kernel_ms}
         bes[0].set_option("timing", 1)
         bes[0].drain_timing()
@@ -325,7 +326,7 @@ def main():
         ms_timed = {"k_primary": kernel_ms["ms_trace_primary"] / nf, "k_shadow": kernel_ms["ms_trace_shadow"] / nf, "k_shade": kernel_ms["ms_shade"] / nf}
         if iso_ms is not None and iso_frames > 0:
             ms = {"k_primary": iso_ms["ms_trace_primary"] / iso_frames, "k_shadow": iso_ms["ms_trace_shadow"] / iso_frames, "k_shade": iso_ms["ms_shade"] / iso_frames}
-            measured = f"{iso_frames} frames rendered one at a time after the timed region (kernels of the {F} frames in flight overlap inside it)"
+            measured = f"{iso_frames} frames rendered one at a time after the timed region (kernels of the {F * B} frames in flight overlap inside it)"
         else:
             ms = ms_timed
             measured = f"all {nf} frames of the timed region"
@@ -341,7 +342,7 @@ def main():
             "config": {"workload": f"{args.workload}: synthetic atrium ({'glTF scene' if not args.procedural else 'procedural'}), {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "scene_source": scene_source, "rays_per_frame": int(rays_total), "frames_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "scene_source": scene_source, "rays_per_frame": int(rays_total), "frames_in_flight": F * B, "batches_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
@@ -370,7 +371,7 @@ def main():
                                                    "frac": round(v / (ms_step * 1e-3) / 614.4e9, 4)} if v else None)(
                              pmc_valu_per_frame() if (args.workload == "atrium1m" and args.max_path_length == 1 and world == 1 and not args.emulate_shard) else None),
                          # the timed region as a whole: every kernel's algorithmic bytes of one frame over the wall time per frame
-                         "timed_region": {"frames_in_flight": F, "algorithmic_bytes_per_frame": int(sum(alg.values())),
+                         "timed_region": {"frames_in_flight": F * B, "algorithmic_bytes_per_frame": int(sum(alg.values())),
                                           "achieved": round(sum(alg.values()) / (ms_step * 1e-3) / 1e9, 1),
                                           "frac": round(sum(alg.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "per_kernel_events": events_in_timed_region}},
