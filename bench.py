@@ -364,11 +364,14 @@ def main():
                                               for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if cs["node_test_executions"][k]},
                          "frame_ms_events": round((iso_ms["ms_total"] / iso_frames) if (iso_ms is not None and iso_frames > 0) else kernel_ms["ms_total"] / nf, 4),
                          "measured": measured,
-                         # what actually bounds the path: vector-instruction issue.  1024 SIMD16s x 2.4 GHz / 4 cycles per
-                         # wave64 instruction = 614.4 G wave-instructions/s; instructions per frame from the committed PMC profile of
-                         # THIS workload at max path length 1 (null otherwise)
-                         "valu_issue": (lambda v: {"wave_instructions_per_frame": v, "peak_per_s": 614.4e9,
-                                                   "frac": round(v / (ms_step * 1e-3) / 614.4e9, 4)} if v else None)(
+                         # what the path is closest to: vector-instruction issue.  gfx950 runs FP32 vector instructions at 32 lanes
+                         # per SIMD and clock, so the peak is 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G wave64 instructions/s (= the 157 TFLOP/s
+                         # FP32 vector peak); tools/probes/valu_issue_probe.hip measures 880-1000 G/s for independent FMAs and 517 G/s when every
+                         # instruction depends on the one before.  Instructions per frame: the committed PMC profile of THIS workload at max path
+                         # length 1 (null otherwise)
+                         "valu_issue": (lambda v: {"wave_instructions_per_frame": v, "peak_per_s": 1228.8e9, "measured_independent_fma_per_s": 1.0e12,
+                                                   "measured_dependent_chain_per_s": 0.517e12,
+                                                   "frac": round(v / (ms_step * 1e-3) / 1228.8e9, 4)} if v else None)(
                              pmc_valu_per_frame() if (args.workload == "atrium1m" and args.max_path_length == 1 and world == 1 and not args.emulate_shard) else None),
                          # the timed region as a whole: every kernel's algorithmic bytes of one frame over the wall time per frame
                          "timed_region": {"frames_in_flight": F * B, "algorithmic_bytes_per_frame": int(sum(alg.values())),

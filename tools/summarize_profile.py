@@ -66,11 +66,12 @@ def main():
             if valu and m.get("SQ_THREAD_CYCLES_VALU"):
                 e["valu_lane_utilisation"] = round(m["SQ_THREAD_CYCLES_VALU"] / (m.get("SQ_ACTIVE_INST_VALU", valu) * 64.0), 3)
             if valu and gui:
-                # GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction occupies its SIMD16 for 4 cycles; 1024 SIMDs
-                e["valu_busy_fraction"] = round(valu * 4.0 / (gui / 8.0 * 1024.0), 3)
+                # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs.  Cycles between two vector instructions of a SIMD (an FP32 instruction
+                # occupies it for 2: tools/probes/valu_issue_probe.hip)
+                e["cycles_per_valu_inst_per_simd"] = round((gui / 8.0 * 1024.0) / max(valu, 1.0), 2)
             res[k] = e
-        json.dump({"note": "means per launch from two rocprofv3 --pmc passes (instruction counts; VALU activity). valu_busy_fraction = "
-                           "SQ_INSTS_VALU * 4 cycles / (kernel cycles * 1024 SIMDs); valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
+        json.dump({"note": "means per launch from two rocprofv3 --pmc passes (instruction counts; VALU activity). cycles_per_valu_inst_per_simd = "
+                           "kernel cycles * 1024 SIMDs / SQ_INSTS_VALU (an FP32 instruction occupies its SIMD for 2 cycles); valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
                    "kernels": res}, open(os.path.join(out, f"{tag}_pmc_valu.json"), "w"), indent=1)
     print("wrote profiles/", tag)
 
