@@ -1,6 +1,6 @@
 """Randomised differential soak, GPU against the oracle (not collected by pytest; run on an MI355X: `ITERS=300 python tests/soak_gpu.py`).
-Random soups x instance counts x builders x frame slots x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
-accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, 0 mismatches."""
+Random soups x instance counts x builders x frame slots x frame batches x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
+accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 more with frame batches and downloads in the mix: 0 mismatches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,8 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     tris = int(rng.integers(200, 6000)); inst = int(rng.integers(1, 24)); seed = int(rng.integers(1, 1 << 30))
     builder = int(rng.integers(0, 4)); fif = int(rng.choice([0, 3])); w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 70]))
     scene = Scene().build("soup", tris, inst, 0.0, seed); scene.set_aspect(w / h)
-    be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif)
+    mb = int(rng.choice([0, 5]))
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif, max_batch=mb)
     orc = Oracle(w, h, threads=8, max_path_length=3)
     scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
     o = rng.uniform(-5, 5, (20000, 3)).astype(np.float32); d = rng.normal(size=(20000, 3)).astype(np.float32)
@@ -27,8 +28,20 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     for _ in range(2):
         be.render(view); orc.render(view)
     ok = ok and np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    if mb:  # a batch of independent views in one launch per stage: every frame == the oracle's render of that view
+        views = []
+        for k in range(int(rng.integers(2, mb + 1))):
+            scene.set_camera(list(rng.uniform(-1.5, 1.5, 3) + np.array([0, 0, -4.0])), [float(rng.uniform(-0.2, 0.2)), 0.0, 1.0], fov=45.0, aspect=w / h)
+            views.append(scene.view(w, h))
+        be.render_batch(views)
+        host = be.host_frame()
+        for k, v in enumerate(views):
+            orc.reset(); orc.render(v)
+            ok = ok and np.array_equal(be.accumulator_at(k).view(np.uint32), orc.accumulator().view(np.uint32))
+            be.download_frame(host, frame=k); be.wait_downloads(host)
+            ok = ok and np.array_equal(host.view(np.uint32), orc.framebuffer().view(np.uint32))
     s, so = be.frame_stats(), orc.stats()
-    print(it, "tris", tris, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "OK" if ok else "MISMATCH", flush=True)
+    print(it, "tris", tris, "batch", mb, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "OK" if ok else "MISMATCH", flush=True)
     bad += 0 if ok else 1
     be.close()
 print("mismatches:", bad, "time", round(time.time() - t0, 1))
