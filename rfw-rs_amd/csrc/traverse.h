@@ -152,7 +152,19 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             } else {
                 // one hit child (the common case near the leaves): it is the next node, no ordering needed
                 cur = hit[0] ? ch.x : (hit[1] ? ch.y : (hit[2] ? ch.z : ch.w));
-                if (nhit > 1) {
+                if (ANY_HIT && nhit > 1 && __ballot(nhit > 2u) == 0ull) {
+                    // any hit only (measured: shadow -3.7 %; the same path costs the closest-hit kernels +6.7 %): every lane of the
+                    // wavefront that has several hits has exactly two, so one compare orders them (the common case below the top of the
+                    // tree); `cur` already holds the hit child of the lower slot
+                    const uint32_t second = hit[3] ? ch.w : (hit[2] ? ch.z : ch.y);
+                    const int32_t k_first = hit[0] ? key[0] : (hit[1] ? key[1] : key[2]);
+                    const int32_t k_second = hit[3] ? key[3] : (hit[2] ? key[2] : key[1]);
+                    const bool swap = bitsf((uint32_t)k_second) < bitsf((uint32_t)k_first); // the float order the any-hit sort uses
+                    const uint32_t far = swap ? cur : second;
+                    cur = swap ? second : cur;
+                    if (sp < kStackLds) { lds_stack[sp * kTraceBlock + lane_slot] = far; sp++; }
+                    else push(far);
+                } else if (nhit > 1) {
                     // sort the 4 keys ascending (misses become FLT_MAX-class keys and sink to the end; +inf | idx would be a NaN); child index rides in the 2 LSBs
                     for (int i = 0; i < 4; i++) key[i] = hit[i] ? key[i] : (int32_t)(0x7f7ffffcu | (uint32_t)i);
                     RFW_CSWAP(key[0], key[1])
