@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock]; // any hit: nothing is parked above the stack
+    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
     // the queue is bucketed by light (shade pushes into region light & 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
     uint32_t block = xcd_block(blockIdx.x);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
                                                             const float t_min, const float* __restrict__ t_max, const uint64_t n,
                                                             uint8_t* __restrict__ occluded)
 {
-    __shared__ uint32_t s_stack[kStackLds * kTraceBlock];
+    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     if (idx >= n) return;
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);

@@ -15,6 +15,9 @@
 #include "device_math.h"
 #include "device_types.h"
 
+#ifndef RFW_ANY_PARK
+#define RFW_ANY_PARK 1 // any hit parks its ray too, over a 12-row stack (measured: no spills at 8 waves per SIMD, +0.6 %)
+#endif
 #ifndef RFW_RAY_IN_LDS
 #define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
 #endif
@@ -22,6 +25,7 @@ namespace rfwhip {
 
 constexpr int kTraceBlock = 64;   // threads per workgroup of the trace kernels (one wavefront)
 constexpr int kStackLds = 16;     // stack entries per lane kept in LDS
+constexpr int kStackLdsAny = 12;  // the same for any hit when its ray is parked in LDS too (RFW_ANY_PARK): 18 rows = 4.5 KB per wavefront
 constexpr int kStackSpill = 48;   // further entries per lane in HBM (rarely touched)
 
 struct SceneView {
@@ -85,23 +89,25 @@ template <bool ANY_HIT, bool COUNT>
 RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_min, float& t, float& hu, float& hv, int32_t& hit_inst,
                      int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
 {
+    constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds; // LDS stack rows of this kernel flavour
+    constexpr bool kPark = RFW_RAY_IN_LDS && (!ANY_HIT || RFW_ANY_PARK);
     f3 o = O, d = D;
 #if RFW_RAY_IN_LDS
     // closest hit: the world-space ray is parked in LDS (6 words above the lane's stack column) and fetched back when an instance is
     // entered or left, so it does not occupy six registers through the whole loop (the closest-hit kernels spill at 6 waves per SIMD)
-    if (!ANY_HIT) {
-        uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+    if (kPark) {
+        uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         park[0] = fbits(O.x); park[kTraceBlock] = fbits(O.y); park[2 * kTraceBlock] = fbits(O.z);
         park[3 * kTraceBlock] = fbits(D.x); park[4 * kTraceBlock] = fbits(D.y); park[5 * kTraceBlock] = fbits(D.z);
     }
     auto world_o = [&]() -> f3 {
-        if (ANY_HIT) return O;
-        const uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+        if (!kPark) return O;
+        const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[0]), bitsf(park[kTraceBlock]), bitsf(park[2 * kTraceBlock]));
     };
     auto world_d = [&]() -> f3 {
-        if (ANY_HIT) return D;
-        const uint32_t* park = lds_stack + kStackLds * kTraceBlock + lane_slot;
+        if (!kPark) return D;
+        const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[3 * kTraceBlock]), bitsf(park[4 * kTraceBlock]), bitsf(park[5 * kTraceBlock]));
     };
 #else
@@ -117,15 +123,15 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     const Node4Q* nodes = sc.tlas_nodes; // node array of the current space (TLAS, or the entered instance's BLAS)
 
     auto push = [&](uint32_t v) {
-        if (sp < kStackLds) lds_stack[sp * kTraceBlock + lane_slot] = v;
-        else if (sp < kStackLds + kStackSpill) sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot] = v;
+        if (sp < kStack) lds_stack[sp * kTraceBlock + lane_slot] = v;
+        else if (sp < kStack + kStackSpill) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
         else sc.counters->overflow = 1ull; // overflow: reported by the host, never silently dropped
         sp++;
     };
     auto pop = [&]() -> uint32_t {
         sp--;
-        if (sp < kStackLds) return lds_stack[sp * kTraceBlock + lane_slot];
-        return sc.spill[(size_t)(sp - kStackLds) * sc.spill_stride + spill_slot];
+        if (sp < kStack) return lds_stack[sp * kTraceBlock + lane_slot];
+        return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
     };
 
     uint32_t iteration = 0;
@@ -187,7 +193,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                     const bool swap = bitsf((uint32_t)k_second) < bitsf((uint32_t)k_first); // the float order the any-hit sort uses
                     const uint32_t far = swap ? cur : second;
                     cur = swap ? second : cur;
-                    if (sp < kStackLds) { lds_stack[sp * kTraceBlock + lane_slot] = far; sp++; }
+                    if (sp < kStack) { lds_stack[sp * kTraceBlock + lane_slot] = far; sp++; }
                     else push(far);
                 } else if (nhit > 1) {
                     // sort the 4 keys ascending (misses become FLT_MAX-class keys and sink to the end; +inf | idx would be a NaN); child index rides in the 2 LSBs
@@ -200,7 +206,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                     cur = sel4(ch, (uint32_t)key[0] & 3u);
                     const uint32_t c1 = sel4(ch, (uint32_t)key[1] & 3u), c2 = sel4(ch, (uint32_t)key[2] & 3u), c3 = sel4(ch, (uint32_t)key[3] & 3u);
                     const int extra = (int)nhit - 1;
-                    if (sp + 3 <= kStackLds) {
+                    if (sp + 3 <= kStack) {
                         // far children go on first: child j (1..3 in sorted order) lands in slot sp + extra - j.  Straight LDS writes,
                         // no per-push capacity branches; with fewer than 4 hits the third write lands above the new top (never read)
                         lds_stack[(sp + extra - 1) * kTraceBlock + lane_slot] = c1;
