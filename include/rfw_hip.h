@@ -189,7 +189,9 @@ RFW_HIP_API int rfw_hip_device_synchronize(void* instance);
  * written by the path tracer, so 12 B per pixel travel instead of 16).  After tracing, render() packs that slab into the device
  * buffer given to rfw_hip_set_slab_output (typically this rank's slice of the all-gather buffer); the caller all-gathers the
  * slabs (RCCL) into a buffer of world * slab_floats and hands it to rfw_hip_assemble_frame, which de-tiles it into the full
- * accumulator and frame.  Accumulation over samples happens in the instance's own slab, not in the caller's buffer. */
+ * frame.  Accumulation over samples happens in the instance's own slab, not in the caller's buffer.  The linear accumulator of the
+ * assembled frame (rfw_hip_read_accumulator*) is de-tiled on demand from the gathered buffer, which therefore has to stay valid
+ * until the next assemble if that call is used. */
 RFW_HIP_API int rfw_hip_shard_info(void* instance, uint64_t* slab_floats, uint32_t* num_tiles_local, uint32_t* num_tiles_total);
 /* device buffer (slab_floats floats; count * slab_floats for render_batch) render() leaves this rank's slab in; NULL = none */
 RFW_HIP_API int rfw_hip_set_slab_output(void* instance, void* device_ptr);

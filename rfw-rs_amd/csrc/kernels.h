@@ -54,8 +54,7 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n);
-void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples);
-void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples);
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);

@@ -561,21 +561,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
     }
 }
 
-// ---------------------------------------------------------------- blit.comp:15-23 (+ slab -> frame de-tiling)
-__global__ void k_blit(const CameraParams cam, const float4* __restrict__ acc_slab, float4* __restrict__ frame_acc, float4* __restrict__ frame_out,
-                       const uint32_t samples)
-{
-    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
-    if (px >= cam.width || py >= cam.height) return;
-    uint32_t owner;
-    const uint32_t slot = pixel_to_slab(cam, px, py, owner);
-    if (owner != cam.rank) return;
-    const float4 a = acc_slab[slot];
-    const float n = (float)(int)samples;
-    frame_acc[px + py * cam.width] = a;
-    frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
-                                                 __builtin_sqrtf(a.w * 1.0f / n));
-}
+// ---------------------------------------------------------------- blit.comp:15-23 (+ slab -> frame de-tiling): k_assemble below
 // what a rank contributes to the all-gather: the RGB of its slab (alpha is never written: 12 B per pixel on the links instead of 16)
 __global__ __launch_bounds__(256) void k_pack_rgb(const float4* __restrict__ acc_slab, float* __restrict__ out, const uint64_t n)
 {
@@ -608,9 +594,11 @@ __global__ __launch_bounds__(256) void k_present(const float4* __restrict__ fram
 }
 // all-gathered slabs [world][slab_elems] -> full frame.  RGB: the gathered buffer holds 3 floats per element (k_pack_rgb), else the
 // instance's own float4 slab (world == 1)
-template <bool RGB>
-__global__ void k_assemble(const CameraParams cam, const void* __restrict__ gathered_v, const uint64_t slab_elems, float4* __restrict__ frame_acc,
-                           float4* __restrict__ frame_out, const uint32_t samples)
+// ACC = false: the finalised frame (blit.comp: sqrt(acc / samples)) — what every frame needs; ACC = true: the linear accumulator itself,
+// produced only when somebody asks for it (rfw_hip_read_accumulator): a third of the de-tiling traffic of every frame otherwise
+template <bool RGB, bool ACC>
+__global__ void k_assemble(const CameraParams cam, const void* __restrict__ gathered_v, const uint64_t slab_elems, float4* __restrict__ frame,
+                           const uint32_t samples)
 {
     const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
     if (px >= cam.width || py >= cam.height) return;
@@ -625,12 +613,14 @@ __global__ void k_assemble(const CameraParams cam, const void* __restrict__ gath
     } else {
         a = static_cast<const float4*>(gathered_v)[e];
     }
-    const float n = (float)(int)samples;
-    frame_acc += (size_t)f * cam.width * cam.height;
-    frame_out += (size_t)f * cam.width * cam.height;
-    frame_acc[px + py * cam.width] = a;
-    frame_out[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
+    frame += (size_t)f * cam.width * cam.height;
+    if (ACC) {
+        frame[px + py * cam.width] = a;
+    } else {
+        const float n = (float)(int)samples;
+        frame[px + py * cam.width] = make_float4(__builtin_sqrtf(a.x * 1.0f / n), __builtin_sqrtf(a.y * 1.0f / n), __builtin_sqrtf(a.z * 1.0f / n),
                                                  __builtin_sqrtf(a.w * 1.0f / n));
+    }
 }
 
 // ---------------------------------------------------------------- ray queries (TIntersector::intersect / occludes)
@@ -731,17 +721,14 @@ void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t
 {
     if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);
 }
-void launch_blit(hipStream_t s, const CameraParams& cam, const float4* acc_slab, float4* frame_acc, float4* frame_out, uint32_t samples)
-{
-    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4));
-    hipLaunchKernelGGL(k_blit, grid, block, 0, s, cam, acc_slab, frame_acc, frame_out, samples);
-}
-void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, uint64_t slab_elems, float4* frame_acc, float4* frame_out,
+void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)
 {
     const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4), cam.batch > 1 ? cam.batch : 1u);
-    if (rgb) hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
-    else hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, cam, gathered, slab_elems, frame_acc, frame_out, samples);
+    if (rgb && accumulator) hipLaunchKernelGGL((k_assemble<true, true>), grid, block, 0, s, cam, gathered, slab_elems, frame, samples);
+    else if (rgb) hipLaunchKernelGGL((k_assemble<true, false>), grid, block, 0, s, cam, gathered, slab_elems, frame, samples);
+    else if (accumulator) hipLaunchKernelGGL((k_assemble<false, true>), grid, block, 0, s, cam, gathered, slab_elems, frame, samples);
+    else hipLaunchKernelGGL((k_assemble<false, false>), grid, block, 0, s, cam, gathered, slab_elems, frame, samples);
 }
 // `narrow`: the destination is host memory written over the PCIe link: a few workgroups saturate the link, and more would only hold
 // wave slots the trace kernels of the other frames in flight want

@@ -95,6 +95,11 @@ struct Instance {
     uint32_t rank = 0, world = 1, tile_size = 64;
     bool after_batch = false;
     hipEvent_t download_done = nullptr; // recorded behind the last rfw_hip_download_frame copy on this slot's stream
+    // The linear accumulator frame is made on demand (rfw_hip_read_accumulator*, download what = 1) from where the samples live: the
+    // instance's own slab (world == 1) or the gathered buffer of the last assemble (world > 1, caller-owned: valid until the next one)
+    const void* acc_source = nullptr;
+    bool acc_source_rgb = false;
+    uint32_t acc_source_batch = 1;
     std::vector<const void*> download_dst; // destinations of the copies queued since the last wait on this slot
     uint32_t max_batch = 1; // frames one render_batch() call may trace together (buffers are sized for it)
     uint32_t builder = RFW_HIP_BUILDER_AUTO;
@@ -282,9 +287,8 @@ int alloc_paths(Instance* I)
     HIP_TRY(I, I->d_acc_slab.ensure(n));
     HIP_TRY(I, hipMemsetAsync(I->d_acc_slab.ptr, 0, n * sizeof(float4), I->stream));
     const size_t px = (size_t)I->width * I->height * I->max_batch;
-    HIP_TRY(I, I->d_frame_acc.ensure(px));
     HIP_TRY(I, I->d_frame_out.ensure(px));
-    HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
+    I->acc_source = nullptr;
     HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
     // per-thread overflow slots: launch grids are padded (XCD tiling, shadow buckets), so leave a margin per sub-shard
     HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * I->substreams * ((size_t)I->cap_v * I->max_batch + kSpillMargin)));
@@ -988,7 +992,10 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
     I->sample_count += 1;
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
     if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
-        launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, I->sample_count);
+    {
+        launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, false, I->cap_v, I->d_frame_out.ptr, I->sample_count);
+        I->acc_source = I->d_acc_slab.ptr; I->acc_source_rgb = false; I->acc_source_batch = k;
+    }
     if (I->external_slab) // this rank's contribution to the all-gather: RGB of the slab(s), [frame][sub-shard][slot]
         launch_pack_rgb(main, I->d_acc_slab.ptr, (float*)I->external_slab, (uint64_t)I->capacity * k);
     if (tm) (void)hipEventRecord(I->events[kEvBlit + 1], main);
@@ -1441,6 +1448,21 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     return RFW_HIP_OK;
 }
 
+// de-tiles the linear accumulator of the latest frame(s) into d_frame_acc, on the instance's stream (zeros before the first frame)
+static int materialize_accumulator(Instance* I)
+{
+    const size_t px = (size_t)I->width * I->height * I->max_batch;
+    HIP_TRY(I, I->d_frame_acc.ensure(px));
+    if (!I->acc_source) {
+        HIP_TRY(I, hipMemsetAsync(I->d_frame_acc.ptr, 0, px * sizeof(float4), I->stream));
+        return RFW_HIP_OK;
+    }
+    CameraParams cam = camera_params(I, I->last_view);
+    cam.batch = I->acc_source_batch;
+    launch_assemble(I->stream, cam, I->acc_source, I->acc_source_rgb, true, I->cap_v, I->d_frame_acc.ptr, 1u);
+    HIP_TRY(I, hipGetLastError());
+    return RFW_HIP_OK;
+}
 static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* rgba, uint64_t n);
 int rfw_hip_read_framebuffer_at(void* inst, uint32_t frame, float* rgba, uint64_t n) { return read_frame_impl(inst, frame, false, rgba, n); }
 int rfw_hip_read_accumulator_at(void* inst, uint32_t frame, float* rgba, uint64_t n) { return read_frame_impl(inst, frame, true, rgba, n); }
@@ -1456,6 +1478,10 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
         return rc;
     }
     HIP_TRY(I, hipSetDevice(I->device));
+    if (accumulator) {
+        const int rc = materialize_accumulator(I);
+        if (rc != RFW_HIP_OK) return rc;
+    }
     const float4* src = (accumulator ? I->d_frame_acc.ptr : I->d_frame_out.ptr) + (size_t)frame * I->width * I->height;
     HIP_TRY(I, hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -1505,6 +1531,10 @@ int rfw_hip_download_frame(void* inst, uint32_t what, uint32_t frame, float* hos
     Instance* c = I->slots.empty() ? I : slot_ptr(I, I->cur_slot);
     HIP_TRY(I, hipSetDevice(I->device));
     if (!c->download_done) HIP_TRY(I, hipEventCreateWithFlags(&c->download_done, hipEventDisableTiming));
+    if (what == 1) {
+        const int rc = materialize_accumulator(c);
+        if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
+    }
     const float4* src = (what == 1 ? c->d_frame_acc.ptr : c->d_frame_out.ptr) + (size_t)frame * px;
     // Presented frame into a pinned destination (rfw_hip_host_alloc, or registered by the caller): the encoding kernel stores straight
     // into host memory over the link, no copy command (measured: 0.731 ms per frame against 0.762 with encode + copy, 8 frames in flight).
@@ -1571,6 +1601,10 @@ int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
         return rc;
     }
     HIP_TRY(I, hipSetDevice(I->device));
+    {
+        const int rc = materialize_accumulator(I);
+        if (rc != RFW_HIP_OK) return rc;
+    }
     HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_acc.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     return RFW_HIP_OK;
@@ -1741,7 +1775,8 @@ static int assemble_impl(void* inst, const void* gathered, uint32_t k)
     CameraParams cam = camera_params(I, I->last_view);
     cam.batch = k;
     // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]; for a batch (one sub-stream): [rank][frame][cap_v]
-    launch_assemble(I->stream, cam, gathered, true, I->cap_v, I->d_frame_acc.ptr, I->d_frame_out.ptr, std::max(1u, I->sample_count));
+    launch_assemble(I->stream, cam, gathered, true, false, I->cap_v, I->d_frame_out.ptr, std::max(1u, I->sample_count));
+    I->acc_source = gathered; I->acc_source_rgb = true; I->acc_source_batch = k;
     HIP_TRY(I, hipGetLastError());
     return RFW_HIP_OK;
 }
