@@ -401,7 +401,7 @@ def pmc_valu_per_frame():
         total = 0
         # the non-counting, single-frame instantiations of the frame's four kernels (names as the profiler prints them, older sets included)
         for names in (("k_primary<false>",), ("k_shade<false>", "k_shade"), ("k_shadow<false, false>", "k_shadow<false,false>", "k_shadow<false>"),
-                      ("k_assemble<false>", "k_assemble")):
+                      ("k_assemble<false, false>", "k_assemble<false>", "k_assemble")):
             total += k[next(n for n in names if n in k)]["SQ_INSTS_VALU"]
         return int(total)
     except Exception:
