@@ -263,3 +263,38 @@ def test_cpp_example_animated_runs_the_reference_frame_loop(tmp_path):
     assert img.mean() > 8 and img.std() > 8          # a lit, structured image
     bad = subprocess.run([exe, "--gltf", str(tmp_path / "missing.glb")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert bad.returncode == 1 and "missing.glb" in bad.stderr
+
+
+def test_batch_and_accumulator_corner_cases():
+    """Error paths of rfw_hip_render_batch, the on-demand accumulator frame before the first frame and after several samples, and a
+    batch on an instance created without max_batch."""
+    from rfw_rs_amd import BackendError, HipBackend
+    scene, be, orc = pair("cornell", 40, 24)
+    assert not be.accumulator().any() and not be.framebuffer().any()        # nothing rendered yet: zeros, not garbage
+    v = scene.view(40, 24)
+    with pytest.raises(BackendError):
+        be.render_batch([v, v])                                              # options.max_batch was not set
+    for _ in range(3):
+        be.render(v); orc.render(v)
+    assert same(be, orc)                                                     # accumulator de-tiled on demand, three samples in it
+    acc = be.host_frame()
+    be.download_frame(acc, accumulator=True); be.wait_downloads()
+    assert np.array_equal(acc.view(np.uint32), orc.accumulator().view(np.uint32))
+    be.close()
+    b2 = HipBackend.init(40, 24, 1.0, max_path_length=2, max_batch=3)
+    scene.mark_all_changed(); scene.sync(b2)
+    scene.set_camera([0, 0, -3.4], [0, 0, 1], fov=60.0, aspect=40 / 24)
+    wide = scene.view(40, 24)
+    with pytest.raises(BackendError):
+        b2.render_batch([v, wide])                                           # the views of a batch must share one spread angle
+    with pytest.raises(BackendError):
+        b2.render_batch([v] * 4)                                             # more than max_batch
+    with pytest.raises(BackendError):
+        HipBackend.init(40, 24, 1.0, streams=2, max_batch=2)                 # sub-streams and batches exclude each other
+    b2.render_batch([v, v, v])
+    orc.reset(); orc.render(v)
+    for f in range(3):
+        assert np.array_equal(b2.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32))
+    b2.resize((24, 16), 1.0)                                                 # resize drops the frames: zeros again
+    assert not b2.accumulator().any()
+    b2.close()
