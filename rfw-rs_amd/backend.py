@@ -12,7 +12,7 @@ from . import pod
 from .scene import BackendTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.environ.get("RFW_HIP_LIB") or os.path.join(_HERE, "csrc", "librfw_hip.so")  # RFW_HIP_LIB: experiment builds (tools/variants.sh)
+HIP_LIB = os.environ.get("RFW_HIP_LIB") or os.path.join(_HERE, "csrc", "librfw_hip.so")  # RFW_HIP_LIB: experiment builds (make -C rfw-rs_amd/csrc variant VARIANT=x VFLAGS=-D...)
 
 EXPORTS = [
     "rfw_hip_create", "rfw_hip_destroy", "rfw_hip_last_error", "rfw_hip_abi_version", "rfw_hip_selftest_bvh",
