@@ -30,7 +30,13 @@ def slab_index_map(width, height, world, tile_size=64, streams=1):
     owner, sub = vowner // streams, vowner % streams
     lt = tile // wv
     ix, iy = xs - tx * tile_size, ys - ty * tile_size
-    block = (iy >> 3) * (tile_size >> 3) + (ix >> 3)
+    bpr = tile_size >> 3
+    if bpr <= 16 and (bpr & (bpr - 1)) == 0:   # the 8x8 blocks of a tile follow a Z curve (kernels.hip: morton_tile)
+        def spread(v):
+            return (v & 1) | ((v & 2) << 1) | ((v & 4) << 2) | ((v & 8) << 3)
+        block = spread(ix >> 3) | (spread(iy >> 3) << 1)
+    else:
+        block = (iy >> 3) * bpr + (ix >> 3)
     slot = sub * g["sub_elems"] + lt * tile_size * tile_size + block * 64 + ((iy & 7) << 3) + (ix & 7)
     return owner.astype(np.int64), slot.astype(np.int64)
 

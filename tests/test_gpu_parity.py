@@ -178,6 +178,11 @@ def test_tile_sharding_is_bit_exact():
     ranks[0].assemble_frame(gathered.data_ptr())
     got = ranks[0].accumulator()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # the numpy twin of the kernels' slab indexing (rfw-rs_amd/dist.py, used by the CPU tests of the N > 1 path) names the same slots
+    from rfw_rs_amd import dist as rd
+    for r in range(world):
+        want = rd.extract_slab(ref[..., :3], r, world, 32)
+        assert np.array_equal(gathered[r].cpu().numpy().reshape(-1, 3).view(np.uint32), want.view(np.uint32)), r
 
 
 def test_full_size_properties():
