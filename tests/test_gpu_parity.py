@@ -148,7 +148,8 @@ def test_accumulation_reset_on_camera_change():
     assert be.frame_stats()["sample_count"] == 1
 
 
-def test_tile_sharding_is_bit_exact():
+@pytest.mark.parametrize("tile_size", [32, 24, 128])   # Z-ordered 4 x 4 blocks, row-major 3 x 3 blocks (not a power of two), Z-ordered 16 x 16
+def test_tile_sharding_is_bit_exact(tile_size):
     """1 GPU == N shards: each rank renders its tiles into a slab; gathered + assembled frame == the unsharded frame."""
     import torch
     from rfw_rs_amd import HipBackend, Scene
@@ -164,7 +165,7 @@ def test_tile_sharding_is_bit_exact():
     world = 3
     ranks = []
     for r in range(world):
-        be = HipBackend.init(w, h, 1.0, rank=r, world=world, tile_size=32)
+        be = HipBackend.init(w, h, 1.0, rank=r, world=world, tile_size=tile_size)
         scene.mark_all_changed()
         scene.sync(be)
         ranks.append(be)
@@ -181,7 +182,7 @@ def test_tile_sharding_is_bit_exact():
     # the numpy twin of the kernels' slab indexing (rfw-rs_amd/dist.py, used by the CPU tests of the N > 1 path) names the same slots
     from rfw_rs_amd import dist as rd
     for r in range(world):
-        want = rd.extract_slab(ref[..., :3], r, world, 32)
+        want = rd.extract_slab(ref[..., :3], r, world, tile_size)
         assert np.array_equal(gathered[r].cpu().numpy().reshape(-1, 3).view(np.uint32), want.view(np.uint32)), r
 
 
