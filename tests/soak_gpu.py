@@ -1,6 +1,6 @@
 """Randomised differential soak, GPU against the oracle (not collected by pytest; run on an MI355X: `ITERS=300 python tests/soak_gpu.py`).
 Random soups x instance counts x builders x frame slots x frame batches x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
-accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 more with frame batches and downloads in the mix: 0 mismatches."""
+accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 and, on the final kernels of the round, 300 + 2 more with frame batches and downloads in the mix: 0 mismatches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
