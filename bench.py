@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s (primary + shadow, 1 spp) of the hot path on N MI355X (contract in the task statement).
 
-A step = one render() of one 1920x1080 frame of the ~1M-triangle synthetic atrium scene (the configuration the
-metric's target is quoted on, BASELINE.json north_star; SURVEY.md §8d C4 geometry, primary + shadow rays), all
-inputs resident in HBM.  For N > 1 the frame is sharded by 64x64 tiles across ranks and the accumulator slabs are
-all-gathered with RCCL once per frame (strong scaling: the frame is fixed)."""
+A step = one frame: one 1920x1080 image of the ~1M-triangle synthetic atrium (the configuration the metric's target is quoted on,
+BASELINE.json north_star; SURVEY.md §8d C4 geometry, primary + shadow rays), every input resident in HBM.
+
+N = 1: `value` is what a client of the reference's plugin trait gets — ONE `Backend::render` call per frame and nothing else
+(rfw_hip_render; 8 frame slots inside the instance keep frames in flight because every frame has its own camera view, a slow dolly,
+so each call starts a new image).  Two further modes are measured after the timed region and reported beside it (`config.modes`):
+strictly one frame at a time, and frames traced 8 per launch through the rfw_hip_render_batch extension.  The first and the last
+frame of the timed region are read back and compared, bit for bit, with the CPU oracle's frames of the same views at the same
+resolution (`config.timed_frame_equals_oracle`); the oracle's time for those frames is the `cpu_baseline`.
+
+N > 1: the frame is sharded by 64x64 tiles across ranks, batches of 8 frames (8 different views) are traced per launch and the ranks'
+slabs are all-gathered once per batch (RCCL over xGMI; strong scaling: the frame is fixed)."""
 import argparse
 import contextlib
+import ctypes
+import glob
 import json
 import os
 import sys
@@ -15,11 +25,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Every renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by default): two
-# instances whose streams land on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 2 else "16")  # N > 2: 12 instance streams + RCCL's
+# Every frame slot / renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by
+# default): two streams on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 2 else "16")
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured for a float4 copy)
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
+L1_PEAK_GBS = 256 * 64 * 2.4  # 64 B per clock and CU out of the vector L1 / TA return path x 256 CUs x 2.4 GHz = 39.3 TB/s
+VALU_PEAK_GIPS = 1228.8      # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 FP32 instruction (= the 157 TFLOP/s vector peak)
+N_VIEWS = 16                 # distinct camera views the frames cycle through
+
+
+def dolly_views(base, n, step):
+    """n camera views: `base` translated k * step along its viewing direction (pos and the virtual screen's corner move together)."""
+    from rfw_rs_amd import pod
+    out = []
+    for k in range(n):
+        v = pod.CameraView3D.from_buffer_copy(base)
+        for a in "xyz":
+            d = getattr(base.direction, a) * step * k
+            setattr(v.pos, a, getattr(base.pos, a) + d)
+            setattr(v.p1, a, getattr(base.p1, a) + d)
+        out.append(v)
+    return out
 
 
 def main():
@@ -33,23 +61,25 @@ def main():
     ap.add_argument("--max-path-length", type=int, default=1, help="1 = primary+shadow (the metric); 3 = the reference's path tracer (C4)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="renderer instances used round-robin, each on its own stream: frame k+1 is traced while frame k's tail, "
-                         "all-gather and assemble finish (1 = strictly one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frame slots (N = 1) / renderer instances (N > 1) used round-robin; 1 = strictly one frame at a time")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames traced per rfw_hip_render_batch call (one launch per stage and, with a sharded frame, ONE all-gather for the "
-                         "whole batch); 1 = one render() per frame")
+                    help="frames traced per rfw_hip_render_batch call.  Default 1 at N = 1 (one trait call per frame: the headline) and 8 at N > 1 "
+                         "(one all-gather per batch)")
     ap.add_argument("--procedural", action="store_true",
                     help="hand the generated scene to the backend directly; default: write it as a binary glTF 2.0 file (host/gltf_export.cpp) and "
                          "run on what the glTF importer (host/gltf.cpp) reads back — the configurations of BASELINE.json are glTF scenes")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (CPU baseline + check of the timed frames)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the secondary modes (one frame at a time / batches) after the timed region")
+    ap.add_argument("--identical-frames", action="store_true", help="every frame the same view (round 1's configuration; frames then share every cache line)")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
                          "gathered buffer), without any collective; the value then counts this shard's rays only")
+    ap.add_argument("--collective", default="torch", choices=["torch", "native"],
+                    help="N > 1: who issues the all-gather — torch.distributed (RCCL through PyTorch) or the library itself (rfw_hip_comm_*: librccl on the instance's stream)")
     ap.add_argument("--readback", nargs="?", const="float", default=None, choices=["float", "presented"],
-                    help="copy every finished frame to (pinned) host memory inside the timed region, queued behind its kernels (the PCIe-inclusive "
-                         "rate of DESIGN.md; never the headline value): the RGBA32F frame, or the presented BGRA8 sRGB frame of the reference's swap chain")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+                    help="copy every finished frame to (pinned) host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mode-frames", type=int, default=48, help="frames per secondary mode")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,94 +121,127 @@ def main():
     if animated:
         scene.build("spheres", 100, 100, 0.28)
     scene.set_aspect(w / h)
-    view = scene.view(w, h)
-    # Frames per launch and frames in flight.  Default: B = 8 independent frames traced per rfw_hip_render_batch call (one launch per
-    # stage over the paths of all 8; with a sharded frame ONE all-gather per batch), 3 such batches in flight.  Measured on one GPU:
-    # 5350-5400 Mrays/s, against 5160 with `--batch 1 --frames-in-flight 8` (eight frame slots, one render() -- the reference's own call
-    # -- per frame).  A sharded frame needs the batches more: a rank's kernels cover 1/N of a frame and their time is the slowest
-    # wavefront's; --emulate-shard 8, ms per frame on rank 0's shard: one frame at a time 0.42, 12 in flight 0.116, 3 batches of 8 in
-    # flight 0.098.  C3 changes the scene every frame (a batch shares one scene): one render() per frame, 8 (12 for N > 2) in flight.
-    B = args.batch if args.batch > 0 else 8
+    base_view = scene.view(w, h)
+    # every frame its own view: a dolly of 5 mm per frame along the viewing direction, 16 views cycled.  Frames in flight then differ in
+    # every ray (round 1 traced 24 bit-identical frames), and one render() per view is a new image each time — which is what lets the
+    # trait's own call pipeline over the frame slots.  C3 keeps one view: there the scene changes every frame.
+    views = [base_view] * N_VIEWS if (args.identical_frames or animated) else dolly_views(base_view, N_VIEWS, 0.005)
+
+    single = world == 1 and not args.emulate_shard
+    B = args.batch if args.batch > 0 else (1 if single else 8)
     if animated:
         B = 1
     F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 8 if world <= 2 else 12)
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.
-    use_slots = world == 1 and not args.emulate_shard and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
-    n_inst = 1 if use_slots else F
-    bes, streams, gathers = [], [], []
+    use_slots = single and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
+    native = args.collective == "native" and world > 1 and dist_backend == "nccl"
+
+    def make_instances(n_slots_or_inst, batch, slots):
+        n_inst = 1 if slots else n_slots_or_inst
+        out = []
+        for f in range(n_inst):
+            be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
+                                 world=world if not args.emulate_shard else args.emulate_shard,
+                                 streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=n_slots_or_inst if slots else 0, max_batch=batch)
+            # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created), so RCCL's
+            # all-gather is ordered against the kernels
+            st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
+            for key in ("sah_max_leaf", "sah_trav_cost"):  # builder experiments
+                if os.environ.get("RFW_" + key.upper()):
+                    be.set_option(key, float(os.environ["RFW_" + key.upper()]))
+            scene.mark_all_changed()
+            scene.sync(be)
+            g = None
+            if world > 1 or args.emulate_shard:
+                nslab = be.shard_info()["slab_floats"]
+                wn = world if not args.emulate_shard else args.emulate_shard
+                send = torch.zeros(batch * nslab, dtype=torch.float32, device="cuda")           # this rank's tiles of `batch` frames (written by render())
+                g = (send, torch.zeros(wn * batch * nslab, dtype=torch.float32, device="cuda"), nslab, wn)  # (send buffer, all ranks' slabs)
+                be.set_slab_output(send.data_ptr())
+            out.append((be, st, g))
+        return out
+
     t0 = time.time()
-    for f in range(n_inst):
-        be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
-                             world=world if not args.emulate_shard else args.emulate_shard,
-                             streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=F if use_slots else 0, max_batch=B)
-        # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created: HIP deals streams to
-        # a few hardware queues in creation order, and two instances whose streams share a queue would serialise), so RCCL's
-        # all-gather is ordered against the kernels and the HIP events that time them are recorded on the launch stream
-        st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
-        for key in ("sah_max_leaf", "sah_trav_cost"):  # builder experiments
-            if os.environ.get("RFW_" + key.upper()):
-                be.set_option(key, float(os.environ["RFW_" + key.upper()]))
-        scene.mark_all_changed()
-        scene.sync(be)
-        g = None
-        if world > 1 or args.emulate_shard:
-            nslab = be.shard_info()["slab_floats"]
-            wn = world if not args.emulate_shard else args.emulate_shard
-            send = torch.zeros(B * nslab, dtype=torch.float32, device="cuda")           # this rank's tiles of B frames (written by render())
-            g = (send, torch.zeros(wn * B * nslab, dtype=torch.float32, device="cuda"), nslab, wn)  # (send buffer, all ranks' slabs)
-            be.set_slab_output(send.data_ptr())
-        bes.append(be); streams.append(st); gathers.append(g)
-    sync_s = (time.time() - t0) / n_inst
+    inst = make_instances(F, B, use_slots)
+    sync_s = (time.time() - t0) / len(inst)
+    if native:
+        # the communicator lives inside the library (librccl): rank 0's unique id travels through torch's store once
+        uid = [inst[0][0].comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        for be, _, _ in inst:
+            be.comm_init(uid[0], rank, world)
+    bes = [i[0] for i in inst]
     be = bes[0]
     sstats = be.scene_stats()
     torch.cuda.synchronize()
 
     frame_no = [0]
     sync_ms = [0.0]
-    step_no = [0]
 
-    host_ring = {b_: [[b_.host_frame(presented=args.readback == "presented") for _ in range(2 * max(F if use_slots else 1, B))], 0] for b_ in bes} if args.readback else {}
-    pending = [0]
-    last_issue = [None]
+    def animate_and_sync(b):
+        # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
+        t_s = time.perf_counter()
+        scene.animate(frame_no[0] / 60.0)
+        frame_no[0] += 1
+        scene.sync(b)
+        sync_ms[0] += (time.perf_counter() - t_s) * 1e3
 
-    def step():
-        """One frame.  With --batch B the frame is queued and every B-th call traces the B queued frames in one render_batch()."""
-        if B > 1:
-            pending[0] += 1
-            if pending[0] == B:
-                flush()
-            return
-        issue(1)
+    # ---- rays per view, counted by the traversal itself (one instrumented frame per view, untimed): exact ray totals for the timed
+    # region and the algorithmic bytes of SURVEY §8(d)
+    be.set_option("count_traversal", 1)
+    per_view = []
+    for k in range(N_VIEWS if not (animated or args.identical_frames) else 1):
+        if animated:
+            animate_and_sync(be)
+        be.reset_accumulation()
+        be.render(views[k])
+        s = be.frame_stats()
+        per_view.append(s)
+    be.set_option("count_traversal", 0)
+    be.reset_accumulation()
+    cs = per_view[0]
+    rays_of_view = [float(s["primary_rays"] + s["shadow_rays"] + s["extension_rays"]) for s in per_view]
+    if world > 1:  # a rank counts its own shard: sum over ranks
+        t = torch.tensor(rays_of_view, dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rays_of_view_total = [float(x) for x in t]
+    else:
+        rays_of_view_total = rays_of_view
 
-    def flush():
-        if pending[0]:
-            issue(pending[0])
-            pending[0] = 0
+    def view_rays(i):
+        return rays_of_view_total[i % len(rays_of_view_total)]
 
-    def issue(nf):
-        k = step_no[0] % n_inst
-        step_no[0] += 1
-        b, g = bes[k], gathers[k]
-        last_issue[0] = (b, nf)
-        with (torch.cuda.stream(streams[k]) if world > 1 else contextlib.nullcontext()):  # the library already launches on streams[k]
-            if animated:  # C3: every instance moves every frame (examples/animated/src/main.rs:197-219) -> set_3d_instances + synchronize
-                t_s = time.perf_counter()
-                scene.animate(frame_no[0] / 60.0)
-                frame_no[0] += 1
-                scene.sync(b)
-                sync_ms[0] += (time.perf_counter() - t_s) * 1e3
-            if B > 1:
-                b.render_batch([view] * nf)  # nf independent new images (here of the same view, like the reset + render below)
-            else:
+    # ---- one frame / one batch of frames
+    host_ring = {id(b_): [[b_.host_frame(presented=args.readback == "presented") for _ in range(2 * max(F if use_slots else 1, B))], 0] for b_ in bes} if args.readback else {}
+    state = {"issued": 0, "pending": [], "k": 0, "last": None}
+
+    def issue(frames):
+        """frames = list of view indices traced by ONE call (len 1: render(); more: render_batch())."""
+        k = state["k"] % len(inst)
+        state["k"] += 1
+        b, st, g = inst[k]
+        state["last"] = (b, list(frames))
+        nf = len(frames)
+        with (torch.cuda.stream(st) if (world > 1 and not native) else contextlib.nullcontext()):  # the library already launches on st
+            if animated:
+                animate_and_sync(b)
+            if nf > 1:
+                b.render_batch([views[i % N_VIEWS] for i in frames])
+            elif args.identical_frames or animated or not use_slots:
+                # (a repeated view would accumulate on its slot instead of starting a new image: reset first; C3's scene changed anyway)
                 b.reset_accumulation()
-                b.render(view)
+                b.render(views[frames[0] % N_VIEWS])
+            else:
+                b.render(views[frames[0] % N_VIEWS])  # THE headline call: Backend::render, nothing else
             if world > 1:
                 send, recv, nslab, wn = g
                 send, recv = send[:nf * nslab], recv[:wn * nf * nslab]  # slab = [frame][tile pixels]; gathered = [rank][frame][tile pixels]
-                if dist_backend == "nccl":
-                    dist.all_gather_into_tensor(recv, send)  # the ONE collective per frame / per batch (RCCL over xGMI)
+                if native:
+                    b.comm_all_gather(send.data_ptr(), recv.data_ptr(), nf * nslab)  # librccl, on the instance's own stream
+                elif dist_backend == "nccl":
+                    dist.all_gather_into_tensor(recv, send)  # the ONE collective per batch (RCCL over xGMI)
                 else:
                     host = torch.empty(recv.shape, dtype=recv.dtype)
                     dist.all_gather_into_tensor(host, send.cpu())
@@ -186,97 +249,87 @@ def main():
                 b.assemble_batch(recv.data_ptr(), nf)
             elif args.emulate_shard:
                 b.assemble_batch(g[1].data_ptr(), nf)  # the de-tiling a rank would do after the all-gather
-            if args.readback:  # every finished frame to (pinned) host memory, queued behind its kernels: the DMA overlaps the next frames' tracing
+            if args.readback:
                 for f_ in range(nf):
-                    ring = host_ring[b]
+                    ring = host_ring[id(b)]
                     dst = ring[0][ring[1] % len(ring[0])]
-                    if ring[1] >= len(ring[0]):  # the ring hands this buffer out again: its copy (2 F frames ago) must have landed
+                    if ring[1] >= len(ring[0]):
                         b.wait_downloads(dst)
                     b.download_frame(dst, frame=f_)
                     ring[1] += 1
 
-    # algorithmic bytes per ray from the traversal's own visit counters (one instrumented frame, untimed)
-    be.set_option("count_traversal", 1)
-    issue(1)
-    cs = be.frame_stats()
-    be.set_option("count_traversal", 0)
-    rays_local = cs["primary_rays"] + cs["shadow_rays"] + cs["extension_rays"]
+    def step(i):
+        if B > 1:
+            state["pending"].append(i)
+            if len(state["pending"]) == B:
+                flush()
+        else:
+            issue([i])
 
-    for _ in range(args.warmup):
-        step()
+    def flush():
+        if state["pending"]:
+            issue(state["pending"])
+            state["pending"] = []
+
+    for i in range(args.warmup):
+        step(i)
     flush()
     torch.cuda.synchronize()
+    for b in bes:
+        b.device_synchronize()
+        b.drain_timing()
+        b.set_option("timing", 1 if (F == 1 and B == 1) else 0)  # per-kernel events only where kernels of different frames cannot overlap
+    # frame 0 of the timed region is copied out (asynchronously, behind its kernels, into pinned memory) for the oracle check
+    check0 = bes[0].host_frame() if (single and rank == 0 and not args.no_cpu_baseline and B == 1) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = {"ms_trace_primary": 0.0, "ms_trace_shadow": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
-    for b in bes:
-        b.drain_timing()
-    # per-kernel HIP events inside the timed region only when they mean something: with frames in flight the kernels of different
-    # frames overlap and the per-kernel roofline comes from the isolated pass below, so the ~14 event records per frame are skipped
-    events_in_timed_region = F == 1 and B == 1
-    for b in bes:
-        b.set_option("timing", 1 if events_in_timed_region else 0)
-    timed_frames = 0
     sync_ms[0] = 0.0
+    frame0_time = frame_no[0]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step()
-        if events_in_timed_region and ((i + 1) % (24 * F) == 0 or i + 1 == args.steps):
-            # per-kernel HIP-event durations, recorded inside render() on the launch stream for EVERY timed frame and
-            # read back in batches (one stream sync per 24 frames per instance instead of one per frame)
-            for b in bes:
-                ms, n = b.drain_timing()
-                timed_frames += n
-                for k in kernel_ms:
-                    kernel_ms[k] += ms[k]
+        step(i)
+        if i == 0 and check0 is not None:
+            bes[0].download_frame(check0, accumulator=True)
     flush()  # a last, shorter batch when --steps is not a multiple of --batch: exactly K frames are timed
     if args.readback:
         for b in bes:
             b.wait_downloads()
+    for b in bes:
+        b.device_synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # Sharded frame: is what the all-gather + assemble left on this rank the frame one GPU renders alone?  (after the timed region;
-    # static scenes only: C3's last frame depends on the animation clock)
+    rays_total = sum(view_rays(i) for i in range(args.steps))
+    last_frame_time = frame_no[0] - 1
+
+    # ---- what the timed region left behind
+    timed_frames_gpu = None
+    if check0 is not None:
+        bes[0].wait_downloads()
+        lb, lframes = state["last"]
+        timed_frames_gpu = [(0, np.array(check0, copy=True)), (lframes[-1], lb.accumulator())]
+    # Sharded frame: is what the all-gather + assemble left on this rank the frame one GPU renders alone?  (static scenes only)
     shard_check = None
-    if world > 1 and rank == 0 and not animated and last_issue[0] is not None:
-        lb, lnf = last_issue[0]
+    if world > 1 and rank == 0 and not animated and state["last"] is not None:
+        lb, lframes = state["last"]
         whole = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length)
         scene.mark_all_changed()
         scene.sync(whole)
-        whole.render(view)
-        ref = whole.accumulator().view(np.uint32)
-        shard_check = all(np.array_equal(lb.accumulator_at(f).view(np.uint32), ref) for f in range(lnf))
+        shard_check = True
+        for f, vi in enumerate(lframes):
+            whole.reset_accumulation()
+            whole.render(views[vi % N_VIEWS])
+            shard_check = shard_check and bool(np.array_equal(lb.accumulator_at(f).view(np.uint32), whole.accumulator().view(np.uint32)))
         whole.close()
-    # With several frames in flight the kernels of different frames share the machine, so their HIP-event spans in the timed
-    # region are not launch durations.  The per-kernel roofline therefore comes from a short pass AFTER the timed region that
-    # renders one frame at a time on instance 0 (the same thing `--frames-in-flight 1` times, and what a rocprofv3 kernel trace
-    # of that command shows); the timed region's own aggregate (all kernels' bytes / ms_per_step) is reported next to it.
-    iso_ms, iso_frames = None, 0
-    if F > 1 or B > 1:
-        iso_ms = {k: 0.0 for k in kernel_ms}
-        bes[0].set_option("timing", 1)
-        bes[0].drain_timing()
-        for i in range(min(48, max(args.steps, 1))):
-            bes[0].reset_accumulation()
-            bes[0].render(view)
-            if use_slots:
-                bes[0].device_synchronize()  # one frame at a time although the instance would pipeline them over its slots
-            if (i + 1) % 24 == 0:
-                ms_, n_ = bes[0].drain_timing()
-                iso_frames += n_
-                for k in iso_ms:
-                    iso_ms[k] += ms_[k]
-        ms_, n_ = bes[0].drain_timing()
-        iso_frames += n_
-        for k in iso_ms:
-            iso_ms[k] += ms_[k]
-        torch.cuda.synchronize()
-    # host cost of the per-frame scene update (animate + set_3d_instances + synchronize) without back-pressure: inside the timed
-    # region a host that runs ahead of the GPU spends most of synchronize() waiting for a staging block, which is idle time
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # host cost of the per-frame scene update (animate + set_3d_instances + synchronize) without back-pressure
     host_sync_ms = None
     if animated:
         acc_t = 0.0
@@ -287,54 +340,112 @@ def main():
             frame_no[0] += 1
             scene.sync(bes[0])
             acc_t += time.perf_counter() - t_s
-            bes[0].render(view)
-        torch.cuda.synchronize()
+            bes[0].render(views[0])
+        bes[0].device_synchronize()
         host_sync_ms = acc_t / 20 * 1e3
-    if world > 1:
-        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
-        elapsed, rays_total = float(tmax[0]), float(t[1])
-    else:
-        rays_total = float(rays_local)
+
+    ms_step = elapsed / args.steps * 1e3
+    value = rays_total / elapsed / 1e6
+    headline_mode = ("render() per frame" if B == 1 else f"render_batch of {B}") + (f", {F} frame slots" if use_slots else (f", {F} instances" if F > 1 else ", one frame at a time"))
+
+    # ---- secondary modes on one GPU (after the timed region; same views, fresh instances so that buffer sizes match the mode)
+    modes = {}
+    iso = None
+    if rank == 0:
+        modes[headline_mode] = {"Mrays_per_s": round(value, 1), "ms_per_frame": round(ms_step, 4), "frames": args.steps, "is_value": True}
+    if single and not args.no_modes and not animated:
+        if F == 1 and B == 1:
+            iso = bes[0].drain_timing()  # the timed region itself was one frame at a time: its own per-kernel events
+        for b_, _, _ in inst:
+            b_.close()
+        inst, bes = [], []
+
+        def run_mode(slots, batch, frames, timing):
+            ins = make_instances(max(slots, 1), batch, slots > 1)
+            mb = ins[0][0]
+            mb.set_option("timing", 1 if timing else 0)
+            seq = list(range(frames))
+
+            def go(ids):
+                if batch > 1:
+                    for j in range(0, len(ids), batch):
+                        mb.render_batch([views[i % N_VIEWS] for i in ids[j:j + batch]])
+                else:
+                    for i in ids:
+                        if slots <= 1 or args.identical_frames:
+                            mb.reset_accumulation()
+                        mb.render(views[i % N_VIEWS])
+            go(seq[:max(batch * max(slots, 1), 8)])  # warm
+            mb.device_synchronize()
+            mb.drain_timing()
+            t_s = time.perf_counter()
+            go(seq)
+            mb.device_synchronize()
+            el = time.perf_counter() - t_s
+            ms, n = mb.drain_timing() if timing else ({}, 0)
+            mb.close()
+            rays = sum(view_rays(i) for i in seq)
+            return {"Mrays_per_s": round(rays / el / 1e6, 1), "ms_per_frame": round(el / frames * 1e3, 4), "frames": frames}, ms, n
+
+        nf_mode = max(args.mode_frames, 16)
+        if not (F == 1 and B == 1):
+            m, iso_ms, iso_n = run_mode(1, 1, nf_mode, True)
+            modes["render() per frame, one frame at a time"] = m
+            iso = (iso_ms, iso_n)
+        if not (B == 1 and use_slots and F == 8):
+            modes["render() per frame, 8 frame slots"] = run_mode(8, 1, nf_mode, False)[0]
+        if not (B == 8 and use_slots and F == 3):
+            modes["render_batch of 8, 3 frame slots (extension call)"] = run_mode(3, 8, nf_mode - nf_mode % 8, False)[0]
+    elif F == 1 and B == 1 and single:
+        ms, n = bes[0].drain_timing()
+        iso = (ms, n)
+    elif single and not animated:
+        # no separate strict mode requested: a short one-frame-at-a-time pass on the instance at hand gives the per-kernel durations
+        bes[0].set_option("timing", 1)
+        bes[0].drain_timing()
+        for i in range(24):
+            bes[0].reset_accumulation()
+            bes[0].render(views[i % N_VIEWS])
+            bes[0].device_synchronize()
+        iso = bes[0].drain_timing()
 
     # this job's own HBM roofline: a float4 device copy, measured after the timed region
-    try:
-        bw_measured = bes[0].bandwidth_probe(1 << 30, 20) if rank == 0 else None
-    except Exception:
-        bw_measured = None
+    bw_measured = None
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = rays_total / (elapsed / args.steps) / 1e6
-        # roofline: ALGORITHMIC bytes each kernel moves per launch (DESIGN.md §"algorithmic bytes") / its mean HIP-event duration
+        try:
+            pb = bes[0] if bes else HipBackend.init(64, 64, 1.0, device=dev)
+            bw_measured = pb.bandwidth_probe(1 << 30, 20)
+            if not bes:
+                pb.close()
+        except Exception:
+            bw_measured = None
+
+    if rank == 0:
         node_b, tri_b = sstats["node_bytes"], sstats["tri_bytes"]
-        nf = max(timed_frames, 1)
-        n_prim, n_shad = cs["primary_rays"], cs["shadow_rays"]
+        nv = len(per_view)
+        mean = lambda key, k=None: sum((s[key][k] if k is not None else s[key]) for s in per_view) / nv
+        n_prim, n_shad = mean("primary_rays"), mean("shadow_rays")
+        # SURVEY §8(d)'s contract figure: ALGORITHMIC bytes per launch (mean over the views)
         alg = {
-            # nodes x 128 B + triangles x 48 B + instance records x 64 B + 48 B written per ray (origin, direction, hit) + 16 B accumulator clear
-            "k_primary": cs["nodes_visited"][0] * node_b + cs["tris_tested"][0] * tri_b + cs["instances_entered"][0] * 64 + n_prim * (48 + 16),
+            # nodes x 64 B + triangles x 48 B + instance records x 64 B + 48 B written per ray (origin, direction, hit) + 16 B accumulator clear
+            "k_primary": mean("nodes_visited", 0) * node_b + mean("tris_tested", 0) * tri_b + mean("instances_entered", 0) * 64 + n_prim * (48 + 16),
             # + 32 B queue entry read per ray, 16 B contribution read and 32 B accumulator read-modify-write per unoccluded ray (counted for all)
-            "k_shadow": cs["nodes_visited"][2] * node_b + cs["tris_tested"][2] * tri_b + cs["instances_entered"][2] * 64 + n_shad * (32 + 16 + 32),
+            "k_shadow": mean("nodes_visited", 2) * node_b + mean("tris_tested", 2) * tri_b + mean("instances_entered", 2) * 64 + n_shad * (32 + 16 + 32),
             # per path: hit 16 + ray 32 read; per hit: RTTriangle 176 + material 96 + normal matrix 48; shadow-queue push 48 per shadow ray
             "k_shade": n_prim * (16 + 32) + n_prim * (176 + 96 + 48) + n_shad * 48,
         }
-        # a frame is split into `sub` sub-shards traced on separate streams: each kernel is launched `sub` times per frame; the
-        # HIP-event durations below are per-frame SUMS over those launches, so bytes-per-frame / sum-of-durations is exactly
-        # (bytes per launch) / (mean launch duration)
-        sub = max(cs.get("substreams", 1), 1)
-        ms_timed = {"k_primary": kernel_ms["ms_trace_primary"] / nf, "k_shadow": kernel_ms["ms_trace_shadow"] / nf, "k_shade": kernel_ms["ms_shade"] / nf}
-        if iso_ms is not None and iso_frames > 0:
-            ms = {"k_primary": iso_ms["ms_trace_primary"] / iso_frames, "k_shadow": iso_ms["ms_trace_shadow"] / iso_frames, "k_shade": iso_ms["ms_shade"] / iso_frames}
-            measured = f"{iso_frames} frames rendered one at a time after the timed region (kernels of the {F * B} frames in flight overlap inside it)"
-        else:
-            ms = ms_timed
-            measured = f"all {nf} frames of the timed region"
-        dom = max(ms, key=lambda k: ms[k])
-        gbs = {k: (alg[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0) for k in alg}
-        achieved = gbs[dom]
-        traffic = pmc_traffic(dom)
-        rays_local_f = max(rays_local, 1)
+        kms = None
+        if iso and iso[1] > 0:
+            kms = {"k_primary": iso[0]["ms_trace_primary"] / iso[1], "k_shadow": iso[0]["ms_trace_shadow"] / iso[1], "k_shade": iso[0]["ms_shade"] / iso[1]}
+        roofline = build_roofline(alg, kms, ms_step, sum(alg.values()), bw_measured, args, single)
+        roofline["nodes_per_ray"] = {"primary": round(mean("nodes_visited", 0) / max(n_prim, 1), 2), "shadow": round(mean("nodes_visited", 2) / max(n_shad, 1), 2)}
+        roofline["tris_per_ray"] = {"primary": round(mean("tris_tested", 0) / max(n_prim, 1), 2), "shadow": round(mean("tris_tested", 2) / max(n_shad, 1), 2)}
+        # SIMD efficiency of the traversal, from the instrumented frames: active lanes / 64 per execution of the node test and of the
+        # triangle test, and what lanes that finished before their wavefront cost (nodes / (64 x max per wave))
+        roofline["lane_utilisation"] = {name: {"node_test": round(mean("nodes_visited", k) / max(64 * mean("node_test_executions", k), 1), 3),
+                                               "triangle_test": round(mean("tris_tested", k) / max(64 * mean("tri_test_executions", k), 1), 3),
+                                               "finished_lanes_bound": round(mean("nodes_visited", k) / max(64 * mean("wave_max_nodes", k), 1), 3)}
+                                        for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if mean("node_test_executions", k)}
         out = {
             "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
@@ -342,45 +453,36 @@ def main():
             "config": {"workload": f"{args.workload}: synthetic atrium ({'glTF scene' if not args.procedural else 'procedural'}), {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
                                    + ("primary+shadow (max path length 1)" if args.max_path_length == 1 else f"path traced, max path length {args.max_path_length}, NEE")
                                    + (", every instance moved and the TLAS rebuilt on the device every frame" if animated else ", static scene") + ", BVH4",
-                       "scene_source": scene_source, "rays_per_frame": int(rays_total), "frames_in_flight": F * B, "batches_in_flight": F, "frames_per_batch": B, "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{n_inst} renderer instances" if n_inst > 1 else "-"), "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check, "tile_shard": "64x64 round-robin" if world > 1 else "none",
+                       "scene_source": scene_source, "mode": headline_mode,
+                       "views": "one view (identical frames)" if args.identical_frames else ("one view, the scene changes every frame" if animated else f"{N_VIEWS} camera views cycled (5 mm dolly per frame): no two frames in flight are the same image"),
+                       "rays_per_frame": int(sum(rays_of_view_total) / len(rays_of_view_total)), "rays_timed": int(rays_total),
+                       "frames_in_flight": F * B, "batches_in_flight": F, "frames_per_batch": B,
+                       "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{F} renderer instances" if F > 1 else "-"),
+                       "modes": modes,
+                       "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check,
+                       "tile_shard": "64x64 round-robin" if world > 1 else "none", "collective": (args.collective if world > 1 else None),
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
                        "per_frame_synchronize_ms": round(host_sync_ms, 3) if animated else None,
                        "per_frame_synchronize_wall_ms_in_timed_region": round(sync_ms[0] / args.steps, 3) if animated else None},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "peak_measured": round(bw_measured, 1) if bw_measured else None,   # device float4 copy in this job, read + write
-                         "frac_of_measured": round(achieved / bw_measured, 4) if bw_measured else None,
-                         "algorithmic_bytes_per_launch": int(alg[dom] / sub), "avg_launch_ms": round(ms[dom] / sub, 4), "launches_per_frame": sub,
-                         "per_kernel": {k: {"ms_sum_per_frame": round(ms[k], 4), "alg_GBps": round(gbs[k], 1), "frac": round(gbs[k] / HBM_PEAK_GBS, 4)} for k in alg},
-                         "nodes_per_ray": {"primary": round(cs["nodes_visited"][0] / max(n_prim, 1), 2), "shadow": round(cs["nodes_visited"][2] / max(n_shad, 1), 2)},
-                         "tris_per_ray": {"primary": round(cs["tris_tested"][0] / max(n_prim, 1), 2), "shadow": round(cs["tris_tested"][2] / max(n_shad, 1), 2)},
-                         # SIMD efficiency of the traversal, from the instrumented frame: active lanes / 64 per execution of the node test
-                         # and of the triangle test, and what lanes that finished before their wavefront cost (nodes / (64 x max per wave))
-                         "lane_utilisation": {name: {"node_test": round(cs["nodes_visited"][k] / max(64 * cs["node_test_executions"][k], 1), 3),
-                                                     "triangle_test": round(cs["tris_tested"][k] / max(64 * cs["tri_test_executions"][k], 1), 3),
-                                                     "finished_lanes_bound": round(cs["nodes_visited"][k] / max(64 * cs["wave_max_nodes"][k], 1), 3)}
-                                              for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if cs["node_test_executions"][k]},
-                         "frame_ms_events": round((iso_ms["ms_total"] / iso_frames) if (iso_ms is not None and iso_frames > 0) else kernel_ms["ms_total"] / nf, 4),
-                         "measured": measured,
-                         # what the path is closest to: vector-instruction issue.  gfx950 runs FP32 vector instructions at 32 lanes
-                         # per SIMD and clock, so the peak is 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G wave64 instructions/s (= the 157 TFLOP/s
-                         # FP32 vector peak); tools/probes/valu_issue_probe.hip measures 880-1000 G/s for independent FMAs and 517 G/s when every
-                         # instruction depends on the one before.  Instructions per frame: the committed PMC profile of THIS workload at max path
-                         # length 1 (null otherwise)
-                         "valu_issue": (lambda v: {"wave_instructions_per_frame": v, "peak_per_s": 1228.8e9, "measured_independent_fma_per_s": 1.0e12,
-                                                   "measured_dependent_chain_per_s": 0.517e12,
-                                                   "frac": round(v / (ms_step * 1e-3) / 1228.8e9, 4)} if v else None)(
-                             pmc_valu_per_frame() if (args.workload == "atrium1m" and args.max_path_length == 1 and world == 1 and not args.emulate_shard) else None),
-                         # the timed region as a whole: every kernel's algorithmic bytes of one frame over the wall time per frame
-                         "timed_region": {"frames_in_flight": F * B, "algorithmic_bytes_per_frame": int(sum(alg.values())),
-                                          "achieved": round(sum(alg.values()) / (ms_step * 1e-3) / 1e9, 1),
-                                          "frac": round(sum(alg.values()) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                          "per_kernel_events": events_in_timed_region}},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, view, w, h, args.cpu_seconds)
+            check = []
+            if timed_frames_gpu is not None:
+                check = [(views[vi % N_VIEWS], (frame0_time + k_ * (args.steps - 1)) if animated else None) for k_, (vi, _) in enumerate(timed_frames_gpu)]
+            cb, frames_cpu = cpu_baseline(scene, check if check else [(views[0], None)], w, h, args.cpu_seconds, args.max_path_length, animated)
+            out["cpu_baseline"] = cb
+            if timed_frames_gpu is not None:
+                names = ("first", "last")
+                res = {}
+                for name, (vi, g_), c_ in zip(names, timed_frames_gpu, frames_cpu):
+                    same = bool(np.array_equal(g_.view(np.uint32), c_.view(np.uint32)))
+                    rel = float(np.linalg.norm(g_.astype(np.float64) - c_.astype(np.float64)) / max(np.linalg.norm(c_.astype(np.float64)), 1e-30))
+                    res[name] = {"frame": int(vi) if name == "first" else args.steps - 1, "bit_identical": same, "rel_l2": rel}
+                res["all"] = all(v["bit_identical"] for v in res.values())
+                out["config"]["timed_frame_equals_oracle"] = res
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -389,69 +491,122 @@ def main():
         b.close()
 
 
-def pmc_valu_per_frame():
-    """Wave64 VALU instructions one frame of the headline workload issues, from the committed rocprofv3 PMC summary
-    (profiles/*_pmc_valu.json: SQ_INSTS_VALU per launch of k_primary, k_shade, k_shadow, k_assemble), or None."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+def latest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"]
-        total = 0
-        # the non-counting, single-frame instantiations of the frame's four kernels (names as the profiler prints them, older sets included)
-        for names in (("k_primary<false>",), ("k_shade<false>", "k_shade"), ("k_shadow<false, false>", "k_shadow<false,false>", "k_shadow<false>"),
-                      ("k_assemble<false, false>", "k_assemble<false>", "k_assemble")):
-            total += k[next(n for n in names if n in k)]["SQ_INSTS_VALU"]
-        return int(total)
+        return json.load(open(files[-1])), os.path.basename(files[-1])
     except Exception:
         return None
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this workload (profiles/*_pmc.json,
-    written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes; gfx950 correction applied).
-    Counters cannot be read from inside this process, so this is the latest committed measurement, or null."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["kernels"]
-        for name in (kernel + "<false, false>", kernel + "<false>", kernel):  # the non-counting single-frame instantiation
-            if name in k:
-                return k[name]["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        return None
+def profile_kernel(kernels, name):
+    """The entry of kernel `name` in a committed PMC summary: the non-counting, single-frame instantiation as the profiler prints it."""
+    for n in (name + "<false, false>", name + "<false,false>", name + "<false>", name):
+        if n in kernels:
+            return kernels[n]
     return None
 
 
-def cpu_baseline(scene, view, w, h, budget_s):
-    """The oracle (CPU restatement of the reference's rtbvh/MBVH path) timed on this host's cores on a bounded
-    sample of the same workload: the same scene and camera at reduced resolution, 1 spp primary + shadow."""
+def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
+    """Which ceiling bounds the dominant kernel: every candidate as a fraction <= 1 of its own peak, the highest one is `bound`.
+
+    Live in this run: the kernels' mean launch durations (HIP events on the launch stream, one frame at a time) and the algorithmic
+    byte counts.  From the committed rocprofv3 PMC summaries of this workload (profiles/*_pmc_valu.json, *_pmc.json, *_pmc_cache.json —
+    counters cannot be read from inside the process): wave64 VALU instructions, vector-memory read instructions, L2 requests and
+    HBM-side bytes per launch.  Instruction counts are properties of (scene, view, kernel code), so dividing them by the live
+    duration is legitimate as long as the profile is of the same code; the profile's tag is named in `counters_from`."""
+    pv, pm, pc = latest_profile("*_pmc_valu.json"), latest_profile("*_pmc.json"), latest_profile("*_pmc_cache.json")
+    usable = args.workload == "atrium1m" and args.max_path_length == 1 and single and args.width == 1920 and args.height == 1080
+    r = {"unit": "GB/s", "counters_from": [p[1] for p in (pv, pm, pc) if p] if usable else None}
+    if not kms or not any(kms.values()):
+        r.update({"bound": None, "kernel": None, "achieved": None, "peak": None, "frac": None, "traffic": None,
+                  "note": "no isolated per-kernel durations in this configuration (kernels of frames in flight overlap)"})
+        return r
+    dom = max(kms, key=lambda k: kms[k])
+    dur = kms[dom] * 1e-3
+    ceilings = {}
+    traffic = None
+    if usable:
+        kv = profile_kernel(pv[0]["kernels"], dom) if pv else None
+        km = profile_kernel(pm[0]["kernels"], dom) if pm else None
+        kc = profile_kernel(pc[0]["kernels"], dom) if pc else None
+        if kv and kv.get("SQ_INSTS_VALU"):
+            a = kv["SQ_INSTS_VALU"] / dur / 1e9
+            ceilings["valu_issue"] = {"achieved": round(a, 1), "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s", "frac": round(a / VALU_PEAK_GIPS, 4),
+                                      "per_launch": int(kv["SQ_INSTS_VALU"])}
+        if kv and kv.get("SQ_INSTS_VMEM_RD"):
+            # every vector-memory read instruction of these kernels is a 16-B-per-lane load: 1 KiB of L1 / TA return path per wave instruction
+            a = kv["SQ_INSTS_VMEM_RD"] * 1024.0 / dur / 1e9
+            ceilings["l1_ta"] = {"achieved": round(a, 1), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s", "frac": round(a / L1_PEAK_GBS, 4),
+                                 "per_launch_bytes": int(kv["SQ_INSTS_VMEM_RD"] * 1024)}
+        if kc and kc.get("l2_request_bytes_per_launch"):
+            a = kc["l2_request_bytes_per_launch"] / dur / 1e9
+            ceilings["l2"] = {"achieved": round(a, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(a / L2_PEAK_GBS, 4),
+                              "hit_rate": kc.get("l2_hit_rate"), "per_launch_bytes": int(kc["l2_request_bytes_per_launch"])}
+        if km:
+            traffic = km["hbm_bytes_per_launch_corrected"]
+            a = traffic / dur / 1e9
+            ceilings["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                               "per_launch_bytes": int(traffic), "note": "L2 fabric-side requests (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits are included, so true HBM bytes are lower still"}
+    contract = {"algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
+                "algorithmic_GBps": round(alg[dom] / dur / 1e9, 1), "hbm_peak_GBps": HBM_PEAK_GBS,
+                "measured_copy_GBps": round(bw_measured, 1) if bw_measured else None,
+                "note": "SURVEY §8(d)'s figure: bytes the rays of one launch ask for, lane by lane.  64 coherent lanes share most node fetches, so this is an UPPER bound on traffic, "
+                        "not traffic: it is reported as a rate next to the peak, not as a fraction of it",
+                "reuse_factor_vs_measured_traffic": round(alg[dom] / traffic, 1) if traffic else None,
+                "per_kernel": {k: {"ms": round(kms[k], 4), "algorithmic_GBps": round(alg[k] / (kms[k] * 1e-3) / 1e9, 1) if kms[k] > 0 else None} for k in alg},
+                "timed_region_algorithmic_GBps": round(alg_frame / (ms_step * 1e-3) / 1e9, 1)}
+    if ceilings:
+        bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
+        c = ceilings[bound]
+        r.update({"bound": bound, "kernel": dom, "achieved": c["achieved"], "peak": c["peak"], "unit": c["unit"], "frac": c["frac"], "traffic": traffic,
+                  "ceilings": ceilings, "contract": contract})
+    else:
+        # no committed counters for this configuration: only the contract's rate can be given; `frac` stays null rather than a number above 1
+        r.update({"bound": None, "kernel": dom, "achieved": contract["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": None, "traffic": None, "contract": contract})
+    return r
+
+
+def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
+    """The oracle — a CPU RESTATEMENT of the reference's rtbvh / MBVH path, not rfw-rs measured — timed on this host's cores on the
+    bench's own workload at the bench's own resolution: the frames of `check` (view, animation time) first, whose accumulators are
+    returned for the comparison with the timed frames, then more frames of the same views until about `budget_s` seconds are spent."""
     from oracle.bindings import Oracle
     cores = os.cpu_count() or 1
-    sw, sh = 480, 270
-    orc = Oracle(sw, sh, threads=cores, max_path_length=1)
+    orc = Oracle(w, h, threads=cores, max_path_length=max_path_length)
     scene.mark_all_changed()
     t0 = time.time()
     scene.sync(orc)
     build_s = time.time() - t0
-    v = scene.view(sw, sh)
-    orc.render(v)  # warm
+    frames = []
+    n, spent, rays0 = 0, 0.0, None
     s0 = orc.stats()
-    n, t0 = 0, time.perf_counter()
+    base = s0["primary"] + s0["shadow"] + s0["extension"]
+    k = 0
     while True:
+        view, t_anim = check[k % len(check)]
+        if animated and t_anim is not None and k < len(check):
+            scene.animate(t_anim / 60.0)
+            scene.mark_all_changed()
+            scene.sync(orc)
         orc.reset()
-        orc.render(v)
+        t1 = time.perf_counter()
+        orc.render(view)
+        spent += time.perf_counter() - t1
         n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
+        if k < len(check):
+            frames.append(orc.accumulator().copy())
+        k += 1
+        if k >= len(check) and (spent > budget_s or n >= 64):
             break
     s = orc.stats()
-    rays = s["primary"] + s["shadow"]
-    return {"value": round(rays * n / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same scene and camera at {sw}x{sh}, 1 spp primary+shadow, {n} frames, {cores} threads; BVH build {build_s:.1f}s excluded"}
+    rays = s["primary"] + s["shadow"] + s["extension"] - base
+    return ({"value": round(rays / spent / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+             "what": "CPU restatement of the reference's path (oracle/), not the reference binary: rfw-rs cannot be built here (no Rust toolchain, rtbvh un-vendored)",
+             "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {cores} threads, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded"},
+            frames)
 
 
 if __name__ == "__main__":

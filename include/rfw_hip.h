@@ -220,6 +220,19 @@ RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, 
  * written is [frame][slab], the gathered buffer handed to rfw_hip_assemble_batch is [rank][frame][slab]. */
 RFW_HIP_API int rfw_hip_render_batch(void* instance, const rfw_camera_view_3d* views, uint32_t count);
 RFW_HIP_API int rfw_hip_assemble_batch(void* instance, const void* gathered_device_ptr, uint32_t count);
+/* `count` consecutive SAMPLES of the one image of `view` in one launch per stage (count <= options.max_batch): sample indices
+ * n .. n + count - 1 where n = samples accumulated so far (0 after a view / scene change or a reset, exactly like rfw_hip_render), each
+ * traced into its own slab and then added to the image's accumulator in sample order.  The same paths, random numbers and contributions
+ * as `count` rfw_hip_render calls (gpu-rt's loop of one sample per render(), gpu-rt/src/lib.rs:1685-1731); the only difference is where
+ * the per-pixel partial sums are rounded: sum_f(sample f) instead of sequential accumulation — equal to a few ulp (tests: <= 1e-6 rel.
+ * L2), and bit-identical to the sum of the per-sample images.  C4's "4 spp" is one call. */
+RFW_HIP_API int rfw_hip_render_samples(void* instance, const rfw_camera_view_3d* view, uint32_t count);
+/* The tables of the reference's blue-noise sampler (gpu-rt/shaders/ray_gen.comp:72-91, shade.comp:530-545), which it uses for the
+ * first 256 samples of every image (ray_gen.comp:109-122, shade.comp:189-227): `table` = the 5 * 65536 words
+ * gpu_rt::blue_noise::create_blue_noise_buffer() returns (backends/gpu-rt/src/blue_noise.rs:40970-41005; every word a byte value),
+ * copied before the call returns.  The Rust shim passes them once after rfw_hip_create; n_words = 0 clears them.
+ * Without tables every sample draws from the xorshift generator (the reference's branch for samples >= 256).  Restarts accumulation. */
+RFW_HIP_API int rfw_hip_set_blue_noise(void* instance, const uint32_t* table, uint32_t n_words);
 RFW_HIP_API int rfw_hip_read_framebuffer_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
 RFW_HIP_API int rfw_hip_read_accumulator_at(void* instance, uint32_t frame, float* rgba, uint64_t n_floats);
 

@@ -44,6 +44,9 @@ def lib():
         l.orc_validate_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         l.orc_detmath_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         l.orc_sample_texture.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]
+        l.orc_set_blue_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        l.orc_blue_noise_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
+        l.orc_blue_noise_sample.restype = C.c_float
         l.orc_wang_hash.argtypes = [C.c_uint32]
         l.orc_wang_hash.restype = C.c_uint32
         l.orc_randi.argtypes = [C.POINTER(C.c_uint32)]
@@ -91,6 +94,16 @@ class Oracle:
     def set_option(self, key, value):
         if self._l.orc_set_option(self._h, key.encode(), float(value)) != 0:
             raise KeyError(key)
+
+    def set_blue_noise(self, table):
+        if table is None:
+            assert self._l.orc_set_blue_noise(self._h, None, 0) == 0
+        else:
+            t = np.ascontiguousarray(table, dtype=np.uint32)
+            assert self._l.orc_set_blue_noise(self._h, t.ctypes.data, t.size) == 0
+
+    def blue_noise_sample(self, sample_count, x, y, dim):
+        return float(self._l.orc_blue_noise_sample(self._h, sample_count, x, y, dim))
 
     def render(self, view):
         self._l.orc_render(self._h, C.byref(view))

@@ -31,9 +31,12 @@
  *   CPU query shape                   crates/rfw-scene/src/intersector.rs:21-75
  *
  * Documented deviations from a literal transcription (DESIGN.md §"oracle deviations"):
- *   D1  sampling uses the xorshift branch for every sample (ray_gen.comp:116-122,
- *       shade.comp:196-200, 222-226); the blue-noise branch needs the 41k-line Heitz tables
- *       of backends/gpu-rt/src/blue_noise.rs which are not restated ("next").
+ *   D1  (narrowed in round 2) the blue-noise sampler of the first 256 samples (ray_gen.comp:72-91,109-115; shade.comp:190-195,
+ *       216-221,530-545) IS restated — index arithmetic, branch structure, the unadvanced xorshift seed — but its TABLES are an
+ *       input: orc_set_blue_noise takes the 5 x 65536 words gpu_rt::blue_noise::create_blue_noise_buffer() returns (the Rust
+ *       shim passes them; tests pass seeded random tables; the 41k-line table source itself is not copied).  Without tables every
+ *       sample takes the xorshift branch.  A table read past the end of the array (the ranking lookup of dimensions 8..15 in the
+ *       last pixel of a 128 x 128 tile does that) returns 0, the robust-buffer-access result.
  *   D2  equal-t ties between triangles are resolved to the lowest (instance, triangle) id
  *       instead of "first encountered in traversal order" so that the answer is a function
  *       of the scene, not of the tree (option "tie_break"=0 restores the literal rule).
@@ -456,6 +459,7 @@ struct Oracle {
     MBVH top_mbvh;
     // render state
     std::vector<vec4> acc;
+    std::vector<int32_t> blue_noise; // empty, or the 5 x 65536 words behind gpu-rt's camera block (gpu-rt/src/lib.rs:591-616)
     uint32_t sample_count = 0;
     uint32_t max_path_length = 3;
     float clamp_value = 10.0f;
@@ -876,15 +880,41 @@ static bool unoccluded_brute(const Oracle& o, vec3 origin, vec3 direction, float
     return true;
 }
 
-// ---------------------------------------------------------------- ray_gen.comp:103-146 (xorshift branch, D1)
-static void generate_eye_ray(const rfw_camera_view_3d& cam, uint32_t width, uint32_t height, vec3& O, vec3& D, uint32_t pixelIdx, uint32_t& seed)
+// ---------------------------------------------------------------- ray_gen.comp:72-91 == shade.comp:530-545
+// blueNoise[]: [0, 65536) the 256-sample x 256-dimension Sobol bytes, [65536, 65536 + 128*128*8) the scrambling tile,
+// [3*65536, 3*65536 + 128*128*8) the ranking tile (gpu-rt/src/blue_noise.rs:40970-41005).  Out-of-range reads return 0 (D1).
+static inline int bn_at(const std::vector<int32_t>& t, int idx) { return (idx >= 0 && (size_t)idx < t.size()) ? t[(size_t)idx] : 0; }
+static inline float blueNoiseSampler(const std::vector<int32_t>& blueNoise, uint32_t sample_count, int x, int y, int sampleDimension)
+{
+    x &= 127;
+    y &= 127;
+    const int sampleIdx = (int)((sample_count + 1u) & 255u);
+    sampleDimension &= 255;
+    const int rankedSampleIndex = sampleIdx ^ bn_at(blueNoise, sampleDimension + (x + y * 128) * 8 + 65536 * 3);
+    int value = bn_at(blueNoise, sampleDimension + rankedSampleIndex * 256);
+    value ^= bn_at(blueNoise, (sampleDimension & 7) + (x + y * 128) * 8 + 65536);
+    return (0.5f + (float)value) * (1.0f / 256.0f);
+}
+static inline bool use_blue_noise(const std::vector<int32_t>& blueNoise, uint32_t sample_count) { return sample_count < 256u && !blueNoise.empty(); }
+
+// ---------------------------------------------------------------- ray_gen.comp:103-146
+static void generate_eye_ray(const rfw_camera_view_3d& cam, uint32_t width, uint32_t height, vec3& O, vec3& D, uint32_t pixelIdx, uint32_t& seed,
+                             const std::vector<int32_t>& blueNoise, uint32_t sample_count)
 {
     const int sx = (int)pixelIdx % (int)width;
     const int sy = (int)pixelIdx / (int)width;
-    float r0 = randf(seed);
-    float r1 = randf(seed);
-    float r2 = randf(seed);
-    float r3 = randf(seed);
+    float r0, r1, r2, r3;
+    if (use_blue_noise(blueNoise, sample_count)) { // ray_gen.comp:109-115
+        r0 = blueNoiseSampler(blueNoise, sample_count, sx, sy, 0);
+        r1 = blueNoiseSampler(blueNoise, sample_count, sx, sy, 1);
+        r2 = blueNoiseSampler(blueNoise, sample_count, sx, sy, 2);
+        r3 = blueNoiseSampler(blueNoise, sample_count, sx, sy, 3);
+    } else {
+        r0 = randf(seed);
+        r1 = randf(seed);
+        r2 = randf(seed);
+        r3 = randf(seed);
+    }
     const float blade = (float)f2i(r0 * 9.0f);
     r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
     float x1, y1, x2, y2;
@@ -1142,8 +1172,16 @@ static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec
     float newBsdfPdf = 0.0f;
     bool specular = false;
     vec3 R = V3(0.0f);
-    const float r1 = randf(seed);
-    const float r2 = randf(seed);
+    float r1, r2;
+    const bool blue = use_blue_noise(o.blue_noise, o.sample_count);
+    const int bx = (int)(PATH_ID % o.width), by = (int)(PATH_ID / o.width);
+    if (blue) { // shade.comp:189-195
+        r1 = blueNoiseSampler(o.blue_noise, o.sample_count, bx & 127, by & 127, (int)(4u + 4u * path_length));
+        r2 = blueNoiseSampler(o.blue_noise, o.sample_count, bx & 127, by & 127, (int)(5u + 4u * path_length));
+    } else {
+        r1 = randf(seed);
+        r2 = randf(seed);
+    }
     const vec3 bsdf = SampleBSDF(sd, N, gN, xyz(T), B, D * -1.0f, st.t, backFacing, r1, r2, R, newBsdfPdf, specular);
     throughput = throughput * bsdf * gl_abs(dot(N, R));
     throughput = gl_max(throughput, V3(0.0f));
@@ -1151,8 +1189,14 @@ static int shade(const Oracle& o, const PathState& st, uint32_t path_length, vec
 
     int pushed = 0;
     if (o.nee && light_count(o) > 0) {
-        const float r3 = randf(seed);
-        const float r4 = randf(seed);
+        float r3, r4;
+        if (blue) { // shade.comp:216-221
+            r3 = blueNoiseSampler(o.blue_noise, o.sample_count, bx, by, (int)(6u + 4u * path_length));
+            r4 = blueNoiseSampler(o.blue_noise, o.sample_count, bx, by, (int)(7u + 4u * path_length));
+        } else {
+            r3 = randf(seed);
+            r4 = randf(seed);
+        }
         vec3 lightColor = V3(0.0f);
         float pickProb = 0.0f, lightPdf = 0.0f;
         vec3 L = RandomPointOnLight(o, r3, r4, P, N, pickProb, lightPdf, lightColor) - P;
@@ -1207,7 +1251,7 @@ static void render_rows(Oracle& o, const rfw_camera_view_3d& cam, uint32_t y0, u
             if (o.sample_count == 0) acc = vec4{0.0f, 0.0f, 0.0f, 0.0f}; // ray_gen.comp:46-48
             PathState st{};
             uint32_t seed = wang_hash(path_id * 16789u + o.sample_count * 1791u + 0u * 720898027u); // ray_gen.comp:54
-            generate_eye_ray(cam, o.width, o.height, st.origin, st.direction, path_id, seed);
+            generate_eye_ray(cam, o.width, o.height, st.origin, st.direction, path_id, seed, o.blue_noise, o.sample_count);
             st.path_id = path_id;
             st.packed_normal = 0;
             bool alive = true;
@@ -1323,6 +1367,21 @@ ORC_API int orc_sample_texture(void* p, int32_t tex /* -1 = skybox */, float u, 
     const vec4 c = trilinear ? fetchTexelTrilinear(t, lod, u, v) : texture_sample(t, u, v, lod);
     rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = c.w;
     return 0;
+}
+
+// The tables of the blue-noise sampler: n == 5 * 65536 words as gpu_rt::blue_noise::create_blue_noise_buffer() returns them, or n == 0 to
+// clear (every sample then takes the xorshift branch)
+ORC_API int orc_set_blue_noise(void* p, const uint32_t* table, uint32_t n)
+{
+    Oracle& o = *(Oracle*)p;
+    if (n == 0) { o.blue_noise.clear(); return 0; }
+    if (!table || n != 5u * 65536u) return -1;
+    o.blue_noise.assign(table, table + n);
+    return 0;
+}
+ORC_API float orc_blue_noise_sample(void* p, uint32_t sample_count, int x, int y, int dim)
+{
+    return blueNoiseSampler(((Oracle*)p)->blue_noise, sample_count, x, y, dim);
 }
 
 ORC_API int orc_set_option(void* p, const char* key, double value)
@@ -1575,7 +1634,7 @@ ORC_API int orc_generate_primary_rays(void* p, const rfw_camera_view_3d* view, u
     for (uint32_t id = 0; id < o.width * o.height; id++) {
         uint32_t seed = wang_hash(id * 16789u + sample * 1791u);
         vec3 O, D;
-        generate_eye_ray(*view, o.width, o.height, O, D, id, seed);
+        generate_eye_ray(*view, o.width, o.height, O, D, id, seed, o.blue_noise, sample);
         origins[3 * id] = O.x; origins[3 * id + 1] = O.y; origins[3 * id + 2] = O.z;
         directions[3 * id] = D.x; directions[3 * id + 1] = D.y; directions[3 * id + 2] = D.z;
     }

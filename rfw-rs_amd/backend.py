@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise",
 ]
 
 _lib = None
@@ -87,6 +87,8 @@ def hip_lib():
         l.rfw_hip_depth_test.argtypes = [vp, vp, vp, f32, f32, u64, vp, vp]
         l.rfw_hip_render_batch.argtypes = [vp, vp, C.c_uint32]
         l.rfw_hip_assemble_batch.argtypes = [vp, vp, C.c_uint32]
+        l.rfw_hip_render_samples.argtypes = [vp, C.POINTER(pod.CameraView3D), C.c_uint32]
+        l.rfw_hip_set_blue_noise.argtypes = [vp, vp, C.c_uint32]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_host_alloc.restype = vp
@@ -229,6 +231,18 @@ class HipBackend:
         """k independent new images, one per view, in one launch per stage (options.max_batch >= k)."""
         arr = (pod.CameraView3D * len(views))(*views)
         self._check(self._l.rfw_hip_render_batch(self._h, arr, len(views)))
+
+    def render_samples(self, view, count):
+        """`count` consecutive samples of the image of `view` in one launch per stage (options.max_batch >= count)."""
+        self._check(self._l.rfw_hip_render_samples(self._h, C.byref(view), count))
+
+    def set_blue_noise(self, table):
+        """The blue-noise sampler's tables: the 5 * 65536 words of gpu_rt::blue_noise::create_blue_noise_buffer(), or None to clear."""
+        if table is None:
+            self._check(self._l.rfw_hip_set_blue_noise(self._h, None, 0))
+        else:
+            t = np.ascontiguousarray(table, dtype=np.uint32)
+            self._check(self._l.rfw_hip_set_blue_noise(self._h, t.ctypes.data, t.size))
 
     def assemble_batch(self, gathered_ptr, count):
         self._check(self._l.rfw_hip_assemble_batch(self._h, C.c_void_p(gathered_ptr), count))

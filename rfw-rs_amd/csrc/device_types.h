@@ -151,9 +151,13 @@ struct CameraParams {
     // a batch of independent frames traced as ONE tall virtual frame (rfw_hip_render_batch): frame f owns paths
     // [f * frame_capacity, (f + 1) * frame_capacity); a path carries f in the top byte of its path-id word
     uint32_t batch, frame_capacity, pad3, pad4;
+    // sample index of every frame of a batch (seeds the RNG / indexes the blue-noise sequence): 0 for rfw_hip_render_batch's new images,
+    // first_sample + f for rfw_hip_render_samples
+    uint32_t batch_sample[16];
 };
 
 constexpr int kMaxBatch = 16;
+constexpr uint32_t kBlueNoiseWords = 5u * 65536u; // gpu_rt::blue_noise::create_blue_noise_buffer(): Sobol bytes, scrambling tile, ranking tile
 struct FrameView { // the view-dependent part of CameraParams, one per frame of a batch
     float pos[3]; float lens_size;
     float right[3]; float pad0;

@@ -24,8 +24,11 @@ struct SceneDev {
     const TexDesc* tex_desc;
     uint32_t n_textures;
     TexDesc skybox;             // mips == 0: no skybox image, a miss adds the constant sky colour
+    const uint8_t* blue_noise;  // kBlueNoiseWords table entries (each a byte), or nullptr: every sample draws from xorshift
     uint32_t* spill;
     uint32_t spill_stride;
+    uint32_t spill_rows;        // <= kStackSpill
+    uint32_t* overflow_flag;    // pinned host word, device-visible
     QueueCounters* counters;
 };
 
@@ -56,6 +59,7 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); 
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n);
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples);
+void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,

@@ -74,6 +74,8 @@ RFW_DI SceneView scene_view(const SceneDev& sc)
     v.tri_packets = sc.tri_packets;
     v.spill = sc.spill;
     v.spill_stride = sc.spill_stride;
+    v.spill_rows = sc.spill_rows;
+    v.overflow_flag = sc.overflow_flag;
     v.counters = sc.counters;
     return v;
 }
@@ -163,13 +165,39 @@ __global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const
     nm[i] = nn;
 }
 
-// ---------------------------------------------------------------- ray_gen.comp:103-146 (xorshift branch)
-RFW_DI void generate_eye_ray(const CameraParams& cam, f3& O, f3& D, uint32_t sx, uint32_t sy, uint32_t& seed)
+// ---------------------------------------------------------------- ray_gen.comp:72-91 == shade.comp:530-545
+// The blue-noise sampler of the first 256 samples.  Its tables are run-time input (rfw_hip_set_blue_noise: the 5 x 65536 words of
+// gpu_rt::blue_noise::create_blue_noise_buffer(), kept as bytes): [0, 65536) Sobol bytes, [65536, ...) scrambling tile, [3 * 65536, ...)
+// ranking tile.  A read past the end (the ranking lookup of dimensions 8..15 in the last pixel of a tile) returns 0.
+RFW_DI int bn_at(const uint8_t* __restrict__ t, int idx) { return (uint32_t)idx < kBlueNoiseWords ? (int)t[idx] : 0; }
+RFW_DI float blueNoiseSampler(const uint8_t* __restrict__ t, uint32_t sample_count, int x, int y, int sampleDimension)
 {
-    float r0 = randf(seed);
-    float r1 = randf(seed);
-    float r2 = randf(seed);
-    float r3 = randf(seed);
+    x &= 127;
+    y &= 127;
+    const int sampleIdx = (int)((sample_count + 1u) & 255u);
+    sampleDimension &= 255;
+    const int rankedSampleIndex = sampleIdx ^ bn_at(t, sampleDimension + (x + y * 128) * 8 + 65536 * 3);
+    int value = bn_at(t, sampleDimension + rankedSampleIndex * 256);
+    value ^= bn_at(t, (sampleDimension & 7) + (x + y * 128) * 8 + 65536);
+    return (0.5f + (float)value) * (1.0f / 256.0f);
+}
+
+// ---------------------------------------------------------------- ray_gen.comp:103-146
+RFW_DI void generate_eye_ray(const CameraParams& cam, f3& O, f3& D, uint32_t sx, uint32_t sy, uint32_t& seed, const uint8_t* __restrict__ blue_noise,
+                             const uint32_t sample_count)
+{
+    float r0, r1, r2, r3;
+    if (blue_noise != nullptr && sample_count < 256u) { // ray_gen.comp:109-115 (uniform branch)
+        r0 = blueNoiseSampler(blue_noise, sample_count, (int)sx, (int)sy, 0);
+        r1 = blueNoiseSampler(blue_noise, sample_count, (int)sx, (int)sy, 1);
+        r2 = blueNoiseSampler(blue_noise, sample_count, (int)sx, (int)sy, 2);
+        r3 = blueNoiseSampler(blue_noise, sample_count, (int)sx, (int)sy, 3);
+    } else {
+        r0 = randf(seed);
+        r1 = randf(seed);
+        r2 = randf(seed);
+        r3 = randf(seed);
+    }
     const f3 pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const f3 right = mk3(cam.right[0], cam.right[1], cam.right[2]);
     const f3 up = mk3(cam.up[0], cam.up[1], cam.up[2]);
@@ -221,7 +249,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
         const uint32_t path_id = px + py * cam.width;
         uint32_t seed = wang_hash(path_id * 16789u + cam.sample_count * 1791u + 0u * 720898027u);
         f3 O, D;
-        generate_eye_ray(cam, O, D, px, py, seed);
+        generate_eye_ray(cam, O, D, px, py, seed, sc.blue_noise, cam.sample_count);
         float t = 1e26f, hu = 0.0f, hv = 0.0f;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
@@ -248,15 +276,18 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
     uint32_t px = 0, py = 0;
     const bool valid = f < cam.batch && slab_to_pixel(cam, idx - f * cam.frame_capacity, px, py);
     if (valid) {
-        p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // every frame of a batch is a new image
+        const uint32_t sample = cam.batch_sample[f];
+        // a batch of new images clears every frame; a batch of SAMPLES of one image (rfw_hip_render_samples) keeps what frame 0 has
+        // accumulated so far (sample_count = samples already in the image)
+        if (!(f == 0u && cam.sample_count != 0u)) p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         CameraParams c = cam;
         const FrameView& v = views.v[f];
         for (int k = 0; k < 3; k++) { c.pos[k] = v.pos[k]; c.right[k] = v.right[k]; c.up[k] = v.up[k]; c.p1[k] = v.p1[k]; }
         c.lens_size = v.lens_size;
         const uint32_t path_id = px + py * cam.width;
-        uint32_t seed = wang_hash(path_id * 16789u + 0u * 1791u + 0u * 720898027u);
+        uint32_t seed = wang_hash(path_id * 16789u + sample * 1791u + 0u * 720898027u);
         f3 O, D;
-        generate_eye_ray(c, O, D, px, py, seed);
+        generate_eye_ray(c, O, D, px, py, seed, sc.blue_noise, sample);
         float t = 1e26f, hu = 0.0f, hv = 0.0f;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
@@ -408,7 +439,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
             const float tri_area = bitsf(q10.w);
             ShadingData sd = extractParameters(sc.materials + mat_id);
 
-            const uint32_t sampleId = cam.sample_count; // shade.comp:102: pathId / (w * h) + sample count, and a path id is a pixel index here
+            // shade.comp:102: pathId / (w * h) + sample count, and a path id is a pixel index here; a frame of a batch carries its own sample index
+            const uint32_t sampleId = BATCH ? cam.batch_sample[path_word >> 24] : cam.sample_count;
             uint32_t seed = wang_hash(PATH_ID * 16789u + sampleId * 1791u + path_length * 720898027u);
 
             const float u = (float)(S.w & 65535u) * (1.0f / 65535.0f);
@@ -475,17 +507,25 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                 throughput = throughput * (1.0f / bsdfPdf);
                 float newBsdfPdf = 0.0f;
                 f3 R = mk3(0.0f);
-                const float r1 = randf(seed);
-                const float r2 = randf(seed);
+                float r1, r2;
+                const bool blue = sc.blue_noise != nullptr && sampleId < 256u; // shade.comp:189-195; the xorshift seed is not advanced on this branch
+                const int bx = (int)(PATH_ID % cam.width), by = (int)(PATH_ID / cam.width);
+                if (blue) {
+                    r1 = blueNoiseSampler(sc.blue_noise, sampleId, bx, by, (int)(4u + 4u * path_length));
+                    r2 = blueNoiseSampler(sc.blue_noise, sampleId, bx, by, (int)(5u + 4u * path_length));
+                } else {
+                    r1 = randf(seed);
+                    r2 = randf(seed);
+                }
                 const f3 bsdf = SampleBSDF(sd, N, gN, T, B, D * -1.0f, T_VAL, backFacing, r1, r2, R, newBsdfPdf);
                 throughput = throughput * bsdf * gl_abs(dot(N, R));
                 throughput = gl_max(throughput, mk3(0.0f));
                 if (!(newBsdfPdf <= 1e-4f || gl_isnan(newBsdfPdf))) {
                     const int lc = (int)(cam.area_light_count + cam.point_light_count + cam.spot_light_count + cam.directional_light_count);
                     if (!(cam.flags & kFlagNoNee) && lc > 0) {
-                        const float r3 = randf(seed);
-                        const float r4 = randf(seed);
-                        (void)r4;
+                        float r3; // r4 (dimension 7 + 4 * path length, or the next xorshift draw) is drawn by the reference and never used
+                        if (blue) r3 = blueNoiseSampler(sc.blue_noise, sampleId, bx, by, (int)(6u + 4u * path_length)); // shade.comp:216-221
+                        else r3 = randf(seed);
                         LightView lv;
                         lv.area = sc.area_lights; lv.point = sc.point_lights; lv.spot = sc.spot_lights; lv.directional = sc.directional_lights;
                         lv.n_area = (int)cam.area_light_count; lv.n_point = (int)cam.point_light_count;
@@ -584,6 +624,19 @@ __global__ __launch_bounds__(256) void k_pack_rgb(const float4* __restrict__ acc
     out[3 * i] = a.x;
     out[3 * i + 1] = a.y;
     out[3 * i + 2] = a.z;
+}
+// rfw_hip_render_samples: the k sample slabs of one image -> slab 0, added in sample order (the same left-to-right sum per pixel whatever
+// the launch geometry: deterministic; it differs from k sequential render() calls only in where the partial sums are rounded)
+__global__ __launch_bounds__(256) void k_sum_batch(float4* __restrict__ acc, const uint64_t n, const uint32_t count)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 a = acc[i];
+    for (uint32_t f = 1; f < count; f++) {
+        const float4 b = acc[(uint64_t)f * n + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    acc[i] = a;
 }
 // Presentation (gpu-rt/src/lib.rs:373,560-585 + shaders/quad.frag): the RGBA32F output is drawn onto a Bgra8UnormSrgb swap chain, i.e.
 // clamped, sRGB-encoded and quantised to 8 bits per channel by the attachment write.  Encoding by comparison against the 255 linear
@@ -751,6 +804,10 @@ void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t
     for (int k = 0; k < 255; k++) st.t[k] = steps255[k];
     st.t[255] = __builtin_inff(); // never reached: lo + bit - 1 <= 254
     if (n) hipLaunchKernelGGL(k_present, dim3(narrow ? 64u : (unsigned)std::min<uint64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, s, frame, bgra, n, st);
+}
+void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count)
+{
+    if (slab_elems && count > 1) hipLaunchKernelGGL(k_sum_batch, dim3((unsigned)ceil_div(slab_elems, 256)), dim3(256), 0, s, acc_slabs, slab_elems, count);
 }
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n)
 {

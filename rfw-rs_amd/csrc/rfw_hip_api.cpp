@@ -150,6 +150,8 @@ struct Instance {
     DevBuf<TexDesc> d_tex_desc;
     TexDesc skybox_desc{};
     uint32_t n_textures = 0;
+    DevBuf<uint8_t> d_blue_noise; // the blue-noise sampler's tables as bytes (rfw_hip_set_blue_noise)
+    bool has_blue_noise = false;
     DevBuf<uint32_t> d_valid_gids, d_tlas_order, d_node_count;
     DevBuf<DevBox> d_inst_boxes, d_mesh_local, d_tri_boxes;
     DevBuf<char> d_lbvh_ws;
@@ -168,6 +170,16 @@ struct Instance {
     DevBuf<uint32_t> d_mesh_node_counts;
     DevBuf<uint32_t> d_refit_parent, d_refit_nint, d_refit_arrive; // per raw node of the skinned copies
     DevBuf<QueueCounters> d_counters;
+    // traversal stack overflow: a word of pinned host memory the kernels set (device-visible mapping), so every later call can report
+    // RFW_HIP_E_STATE without a read-back; cleared when synchronize() rebuilds the trees
+    uint32_t* overflow_host = nullptr;
+    uint32_t* overflow_dev = nullptr;
+    uint32_t spill_rows = kStackSpill; // option "spill_rows" (tests): rows of the HBM spill stack a lane may use
+    // persistent scratch of the ray-query calls (no hipMalloc / hipFree — a device-wide sync — per call)
+    DevBuf<float> d_q_o, d_q_d, d_q_t;
+    DevBuf<rfw_hip_hit> d_q_h;
+    DevBuf<uint32_t> d_q_depth;
+    DevBuf<uint8_t> d_q_r;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
@@ -235,6 +247,26 @@ int fail(Instance* I, int code, const std::string& msg)
     I->err = msg;
     return code;
 }
+
+// Did a traversal of this instance (or of one of its frame slots) run out of stack since the trees were last built?
+bool overflow_seen(const Instance* I)
+{
+    if (I->overflow_host && *(volatile const uint32_t*)I->overflow_host) return true;
+    for (const Instance* c : I->slots)
+        if (c->overflow_host && *(volatile const uint32_t*)c->overflow_host) return true;
+    return false;
+}
+void clear_overflow(Instance* I)
+{
+    if (I->overflow_host) *(volatile uint32_t*)I->overflow_host = 0u;
+    for (Instance* c : I->slots)
+        if (c->overflow_host) *(volatile uint32_t*)c->overflow_host = 0u;
+}
+#define CHECK_OVERFLOW(inst)                                                                                                          \
+    do {                                                                                                                              \
+        if (overflow_seen(inst))                                                                                                      \
+            return fail(inst, RFW_HIP_E_STATE, "traversal stack overflow: a tree is deeper than the LDS + spill stack (results of the affected rays are incomplete)"); \
+    } while (0)
 
 bool is_zero_matrix(const rfw_mat4& m)
 {
@@ -321,8 +353,11 @@ SceneDev scene_dev(Instance* I)
     s.tex_desc = S->d_tex_desc.ptr;
     s.n_textures = S->n_textures;
     s.skybox = S->skybox_desc;
+    s.blue_noise = S->has_blue_noise ? S->d_blue_noise.ptr : nullptr;
     s.spill = I->d_spill.ptr;
     s.spill_stride = spill_stride(I);
+    s.spill_rows = std::min<uint32_t>(scene_of(I)->spill_rows, (uint32_t)kStackSpill);
+    s.overflow_flag = I->overflow_dev;
     s.counters = I->d_counters.ptr;
     return s;
 }
@@ -674,8 +709,13 @@ int build_instances(Instance* I, Instance* T)
                 launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
                 HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
                 HIP_TRY(I, T->d_node_count.ensure(1));
-                HIP_TRY(I, sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, T->d_node_count.ptr, I->sah_max_leaf,
-                                     I->sah_trav_cost));
+                const hipError_t se = sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, T->d_node_count.ptr, I->sah_max_leaf,
+                                                I->sah_trav_cost);
+                if (se == hipErrorInvalidValue) { // deeper than the SAH builder's level budget: LBVH always terminates (as for static meshes)
+                    HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, raw, order, T->d_node_count.ptr));
+                } else {
+                    HIP_TRY(I, se);
+                }
                 HIP_TRY(I, hipMemcpyAsync(&d.node_count, T->d_node_count.ptr, 4, hipMemcpyDeviceToHost, s));
                 HIP_TRY(I, hipStreamSynchronize(s));
                 if (d.node_count == 0 || d.node_count > r.node_count) return fail(I, RFW_HIP_E_STATE, "skinned BLAS: node count out of range");
@@ -753,15 +793,10 @@ int do_synchronize(Instance* I)
 {
     HIP_TRY(I, hipSetDevice(I->device));
     bool any_change = false;
-    // did this call queue work on the owner's stream that the frame slots have to wait for (anything but a per-slot TLAS update)?
-    const bool shared_work = I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
     int rc;
-    if (!I->slots.empty() && (I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I)))) {
-        // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
-        for (Instance* c : I->slots)
-            if (c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->stream, c->frame_done, 0));
-    }
-    if (!I->meshes_dirty && I->instances_dirty) { // a new (mesh, skin) pair needs its region of the mega-buffers
+    // A new (mesh, skin) pair needs its region of the mega-buffers, i.e. a BLAS rebuild: decided FIRST, so that everything below —
+    // which frames to wait for, whether scene_ready is recorded — sees the final dirty flags
+    if (!I->meshes_dirty && I->instances_dirty) {
         const auto want = wanted_derived(I);
         bool same = want.size() == I->derived.size();
         if (same)
@@ -769,6 +804,15 @@ int do_synchronize(Instance* I)
                 if (a->first != b->first) { same = false; break; }
         if (!same) I->meshes_dirty = true;
     }
+    // does this call queue work on the owner's stream that the frame slots have to wait for (anything but a per-slot TLAS update)?
+    // (per_slot_tlas() may flip inside build_blas_* when skinned copies appear or disappear; meshes_dirty covers both directions)
+    const bool shared_work = I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
+    if (!I->slots.empty() && shared_work) {
+        // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
+        for (Instance* c : I->slots)
+            if (c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->stream, c->frame_done, 0));
+    }
+    if (I->meshes_dirty || I->instances_dirty) clear_overflow(I); // new trees: an earlier stack overflow no longer describes the scene
     if (I->meshes_dirty) { // BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383)
         const auto t0 = std::chrono::steady_clock::now();
         if ((rc = I->blas_on_device ? build_blas_device(I) : build_blas_host(I))) return rc;
@@ -898,7 +942,9 @@ hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.da
 
 // k == 1: one sample of the image for views[0].  k > 1 (rfw_hip_render_batch): k independent NEW images, one per view, traced as one
 // tall virtual frame — every stage is ONE launch over the paths of all k frames.
-int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
+// `samples` (rfw_hip_render_samples): the k frames are k consecutive SAMPLES of the one image of views[0] — sample indices sample_count …
+// sample_count + k - 1, each traced into its own slab, then summed into slab 0 in sample order.
+int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool samples = false)
 {
     const rfw_camera_view_3d& view = views[0];
     HIP_TRY(I, hipSetDevice(I->device));
@@ -908,16 +954,17 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
         I->waited_version = I->scene->scene_version;
     }
     if ((I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) || I->after_batch) I->sample_count = 0;
-    I->after_batch = k > 1; // the frames of a batch are complete images: whatever follows starts a new one
+    I->after_batch = k > 1 && !samples; // the frames of a batch are complete images: whatever follows starts a new one
     I->last_view = view;
     I->have_last_view = true;
     if (k > 1) {
         if (k > I->max_batch || k > (uint32_t)kMaxBatch) return fail(I, RFW_HIP_E_INVALID, "render_batch: more frames than options.max_batch");
         if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "render_batch: not available with sub-streams");
-        if (I->cap_v >= (1u << 24)) return fail(I, RFW_HIP_E_INVALID, "render_batch: more than 2^24 paths per frame");
+        // the frame index rides in bits 24..31 of the path word, next to the PIXEL index of the whole frame (not of this rank's slab)
+        if ((uint64_t)I->width * I->height >= (1ull << 24)) return fail(I, RFW_HIP_E_INVALID, "render_batch: frames of 2^24 pixels or more cannot be batched");
         for (uint32_t f = 1; f < k; f++)
             if (views[f].spread_angle != view.spread_angle) return fail(I, RFW_HIP_E_INVALID, "render_batch: the views of a batch must share one spread angle (field of view and height)");
-        I->sample_count = 0;         // every frame of a batch is a new image
+        if (!samples) I->sample_count = 0; // every frame of a batch is a new image
     }
 
     const uint32_t S = I->substreams;
@@ -953,6 +1000,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
         cam[0].batch = k;
         p[0].capacity = I->cap_v * k;
         for (uint32_t f = 0; f < k; f++) {
+            cam[0].batch_sample[f] = samples ? I->sample_count + f : 0u;
             FrameView& v = bv.v[f];
             v.pos[0] = views[f].pos.x; v.pos[1] = views[f].pos.y; v.pos[2] = views[f].pos.z; v.lens_size = views[f].lens_size;
             v.right[0] = views[f].right.x; v.right[1] = views[f].right.y; v.right[2] = views[f].right.z; v.pad0 = 0.0f;
@@ -989,15 +1037,20 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1)
             HIP_TRY(I, hipEventRecord(I->ev_join[s], st[s]));
             HIP_TRY(I, hipStreamWaitEvent(main, I->ev_join[s], 0));
         }
-    I->sample_count += 1;
+    if (samples && k > 1) { // the k sample slabs -> the image's accumulator (slab 0), in sample order
+        launch_sum_batch(main, I->d_acc_slab.ptr, I->cap_v, k);
+        cam[0].batch = 1;
+    }
+    I->sample_count += samples ? k : 1;
+    const uint32_t frames_out = samples ? 1u : k; // images this call leaves behind
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
     if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
     {
         launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, false, I->cap_v, I->d_frame_out.ptr, I->sample_count);
-        I->acc_source = I->d_acc_slab.ptr; I->acc_source_rgb = false; I->acc_source_batch = k;
+        I->acc_source = I->d_acc_slab.ptr; I->acc_source_rgb = false; I->acc_source_batch = frames_out;
     }
     if (I->external_slab) // this rank's contribution to the all-gather: RGB of the slab(s), [frame][sub-shard][slot]
-        launch_pack_rgb(main, I->d_acc_slab.ptr, (float*)I->external_slab, (uint64_t)I->capacity * k);
+        launch_pack_rgb(main, I->d_acc_slab.ptr, (float*)I->external_slab, (uint64_t)I->capacity * frames_out);
     if (tm) (void)hipEventRecord(I->events[kEvBlit + 1], main);
     if (tm) (void)hipEventRecord(I->events[EV_FRAME1], main);
     HIP_TRY(I, hipGetLastError());
@@ -1133,6 +1186,9 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     }
     for (int k = 0; k < Instance::kStages; k++)
         if ((e = hipEventCreateWithFlags(&I->stage_event[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void**)&I->overflow_host, 64, hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc (overflow flag)", e);
+    *I->overflow_host = 0u;
+    if ((e = hipHostGetDevicePointer((void**)&I->overflow_dev, I->overflow_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
         delete I;
@@ -1188,9 +1244,11 @@ void rfw_hip_destroy(void* inst)
         I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
-        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release();
+        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release(); I->d_blue_noise.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
+        I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
+        if (I->overflow_host) (void)hipHostFree(I->overflow_host);
         I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
         for (int k = 0; k < Instance::kStages; k++) {
             if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
@@ -1306,12 +1364,12 @@ int rfw_hip_synchronize(void* inst)
     return do_synchronize(I);
 }
 
-static int render_impl(Instance* I, const rfw_camera_view_3d* views, uint32_t k)
+static int render_impl(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool samples = false)
 {
-    if (I->slots.empty()) return do_render(I, views, k);
+    if (I->slots.empty()) return do_render(I, views, k, samples);
     // frames in flight: does this call add a sample to the image of the current slot, or start a new image on the next slot?
     Instance* cur = slot_ptr(I, I->cur_slot);
-    const bool same_image = k == 1 && !I->restart && cur->sample_count > 0 && cur->have_last_view &&
+    const bool same_image = (k == 1 || samples) && !I->restart && cur->sample_count > 0 && cur->have_last_view &&
                             std::memcmp(&cur->last_view, views, sizeof(*views)) == 0 && cur->rendered_version == I->scene_version;
     if (!same_image) {
         I->cur_slot = (I->cur_slot + 1) % (uint32_t)(I->slots.size() + 1);
@@ -1325,7 +1383,7 @@ static int render_impl(Instance* I, const rfw_camera_view_3d* views, uint32_t k)
         for (int c = 0; c < 3; c++) cur->sky[c] = I->sky[c];
     }
     int rc = ensure_slot_tlas(I, cur);
-    if (rc == RFW_HIP_OK) rc = do_render(cur, views, k);
+    if (rc == RFW_HIP_OK) rc = do_render(cur, views, k, samples);
     if (rc != RFW_HIP_OK && cur != I && !cur->err.empty()) I->err = cur->err;
     return rc;
 }
@@ -1334,6 +1392,7 @@ int rfw_hip_render(void* inst, const rfw_mat4* /*view_2d*/, const rfw_camera_vie
 {
     LOCK(inst);
     if (!view) return fail(I, RFW_HIP_E_INVALID, "render: null view");
+    CHECK_OVERFLOW(I); // of an earlier frame or query (sticky until synchronize() rebuilds the trees)
     return render_impl(I, view, 1);
 }
 
@@ -1341,6 +1400,7 @@ int rfw_hip_render_batch(void* inst, const rfw_camera_view_3d* views, uint32_t c
 {
     LOCK(inst);
     if (!views || count == 0) return fail(I, RFW_HIP_E_INVALID, "render_batch: no views");
+    CHECK_OVERFLOW(I);
     if (count == 1) { // a batch of one is still a NEW image
         I->sample_count = 0;
         I->restart = true;
@@ -1348,6 +1408,42 @@ int rfw_hip_render_batch(void* inst, const rfw_camera_view_3d* views, uint32_t c
     const int rc = render_impl(I, views, count);
     if (rc == RFW_HIP_OK && count == 1) (I->slots.empty() ? I : slot_ptr(I, I->cur_slot))->after_batch = true;
     return rc;
+}
+
+int rfw_hip_render_samples(void* inst, const rfw_camera_view_3d* view, uint32_t count)
+{
+    LOCK(inst);
+    if (!view || count == 0) return fail(I, RFW_HIP_E_INVALID, "render_samples: no view / no samples");
+    CHECK_OVERFLOW(I);
+    if (count > I->max_batch || count > (uint32_t)kMaxBatch) return fail(I, RFW_HIP_E_INVALID, "render_samples: more samples than options.max_batch");
+    if (count == 1) return render_impl(I, view, 1);
+    rfw_camera_view_3d views[kMaxBatch];
+    for (uint32_t f = 0; f < count; f++) views[f] = *view;
+    return render_impl(I, views, count, true);
+}
+
+int rfw_hip_set_blue_noise(void* inst, const uint32_t* table, uint32_t n_words)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    if (n_words != 0 && (!table || n_words != kBlueNoiseWords))
+        return fail(I, RFW_HIP_E_INVALID, "set_blue_noise: expected the 5 * 65536 words of gpu_rt::blue_noise::create_blue_noise_buffer() (or 0 words to clear)");
+    std::vector<uint8_t> bytes(n_words);
+    for (uint32_t k = 0; k < n_words; k++) {
+        if (table[k] > 255u) return fail(I, RFW_HIP_E_INVALID, "set_blue_noise: table entries are bytes (0..255)");
+        bytes[k] = (uint8_t)table[k];
+    }
+    // frames in flight may still sample the old tables
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream));
+    if (n_words) {
+        HIP_TRY(I, I->d_blue_noise.ensure(n_words));
+        HIP_TRY(I, hipMemcpy(I->d_blue_noise.ptr, bytes.data(), n_words, hipMemcpyHostToDevice));
+    }
+    I->has_blue_noise = n_words != 0;
+    I->sample_count = 0; // the image accumulated so far was drawn from other numbers
+    I->restart = true;
+    return RFW_HIP_OK;
 }
 
 int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
@@ -1438,6 +1534,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "count_traversal") I->flags = value != 0.0 ? (I->flags | RFW_HIP_FLAG_COUNT_TRAVERSAL) : (I->flags & ~RFW_HIP_FLAG_COUNT_TRAVERSAL);
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "timing") I->timing = value != 0.0;
+    else if (k == "spill_rows") I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill); // tests: exercise the overflow path
     else if (k == "sky_r") I->sky[0] = (float)value;
     else if (k == "sky_g") I->sky[1] = (float)value;
     else if (k == "sky_b") I->sky[2] = (float)value;
@@ -1485,6 +1582,7 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
     const float4* src = (accumulator ? I->d_frame_acc.ptr : I->d_frame_out.ptr) + (size_t)frame * I->width * I->height;
     HIP_TRY(I, hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    CHECK_OVERFLOW(I);
     return RFW_HIP_OK;
 }
 
@@ -1588,6 +1686,7 @@ int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n)
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_out.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    CHECK_OVERFLOW(I);
     return RFW_HIP_OK;
 }
 int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
@@ -1607,6 +1706,7 @@ int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
     }
     HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_acc.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    CHECK_OVERFLOW(I);
     return RFW_HIP_OK;
 }
 
@@ -1643,10 +1743,10 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     QueueCounters qc[kMaxSub];
     HIP_TRY(I, hipMemcpy(qc, I->d_counters.ptr, I->substreams * sizeof(QueueCounters), hipMemcpyDeviceToHost));
+    CHECK_OVERFLOW(I);
     const uint32_t nb = I->last_bounces;
     out->primary_rays = nb ? I->local_pixels : 0;
     for (uint32_t s = 0; s < I->substreams; s++) {
-        if (qc[s].overflow) return fail(I, RFW_HIP_E_STATE, "traversal stack overflow (tree deeper than kStackLds + kStackSpill entries)");
         for (uint32_t b = 0; b + 1 < nb; b++) out->extension_rays += qc[s].ext[b];
         if (!(I->flags & RFW_HIP_FLAG_NO_NEE))
             for (uint32_t b = 0; b < nb; b++)
@@ -1791,9 +1891,10 @@ static int intersect_impl(void* inst, const float* origins, const float* directi
     HIP_TRY(I, hipSetDevice(I->device));
     { const int trc = ensure_slot_tlas(I, I); if (trc != RFW_HIP_OK) return trc; }
     const uint64_t chunk = spill_stride(I);
-    DevBuf<float> d_o, d_d;
-    DevBuf<rfw_hip_hit> d_h;
-    DevBuf<uint32_t> d_depth;
+    // scratch kept in the instance: no hipMalloc / hipFree (a device-wide synchronisation that would stall frames in flight) per call
+    DevBuf<float>&d_o = I->d_q_o, &d_d = I->d_q_d;
+    DevBuf<rfw_hip_hit>& d_h = I->d_q_h;
+    DevBuf<uint32_t>& d_depth = I->d_q_depth;
     if (depth) HIP_TRY(I, d_depth.ensure(std::min(n, chunk)));
     HIP_TRY(I, d_o.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
@@ -1813,7 +1914,7 @@ static int intersect_impl(void* inst, const float* origins, const float* directi
         if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
         if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("intersect: ") + hipGetErrorString(e));
     }
-    d_o.release(); d_d.release(); d_h.release(); d_depth.release();
+    if (rc == RFW_HIP_OK) CHECK_OVERFLOW(I);
     return rc;
 }
 
@@ -1836,8 +1937,8 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
     HIP_TRY(I, hipSetDevice(I->device));
     { const int trc = ensure_slot_tlas(I, I); if (trc != RFW_HIP_OK) return trc; }
     const uint64_t chunk = spill_stride(I);
-    DevBuf<float> d_o, d_d, d_t;
-    DevBuf<uint8_t> d_r;
+    DevBuf<float>&d_o = I->d_q_o, &d_d = I->d_q_d, &d_t = I->d_q_t;
+    DevBuf<uint8_t>& d_r = I->d_q_r;
     HIP_TRY(I, d_o.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_t.ensure(std::min(n, chunk)));
@@ -1857,7 +1958,7 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
         if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
         if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("occludes: ") + hipGetErrorString(e));
     }
-    d_o.release(); d_d.release(); d_t.release(); d_r.release();
+    if (rc == RFW_HIP_OK) CHECK_OVERFLOW(I);
     return rc;
 }
 

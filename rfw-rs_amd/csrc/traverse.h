@@ -36,6 +36,8 @@ struct SceneView {
     const TriPacket* tri_packets;
     uint32_t* spill;            // kStackSpill x spill_stride
     uint32_t spill_stride;
+    uint32_t spill_rows;        // rows of `spill` a lane may use (kStackSpill; a test option lowers it to exercise the overflow path)
+    uint32_t* overflow_flag;    // pinned host word (mapped): set when a ray's stack would exceed LDS + spill rows
     QueueCounters* counters;
 };
 
@@ -96,8 +98,14 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 
     auto push = [&](uint32_t v) {
         if (sp < kStack) lds_stack[sp * kTraceBlock + lane_slot] = v;
-        else if (sp < kStack + kStackSpill) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
-        else sc.counters->overflow = 1ull; // overflow: reported by the host, never silently dropped
+        else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
+        else {
+            // overflow (a tree deeper than LDS + spill rows): the entry is dropped and sp does NOT advance, so pop() never indexes
+            // past the spill rows — the ray finishes deterministically on what it has (possibly missing a hit), and the host reports
+            // RFW_HIP_E_STATE from the next render / read / query (the flag lives in pinned host memory: no read-back needed)
+            *sc.overflow_flag = 1u;
+            return;
+        }
         sp++;
     };
     auto pop = [&]() -> uint32_t {

@@ -228,8 +228,8 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rays_per_frame"] >= 320 * 200
-    assert out["roofline"]["kernel"] in ("k_primary", "k_shadow", "k_shade")
     assert out["config"]["frames_per_batch"] == 8 and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
+    assert "distinct" in out["config"]["views"] or "cycled" in out["config"]["views"]
 
 
 def test_animated_instances_match_oracle():

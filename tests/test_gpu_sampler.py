@@ -1,0 +1,156 @@
+"""Round 2 additions on the device: the blue-noise sampler of the first 256 samples (tables as run-time input), several samples of
+one image in one launch per stage (rfw_hip_render_samples), and the contained traversal-stack overflow."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def blue_noise_table(seed):
+    # layout of gpu_rt::blue_noise::create_blue_noise_buffer(): 5 x 65536 words, each a byte value
+    return np.random.default_rng(seed).integers(0, 256, 5 * 65536).astype(np.uint32)
+
+
+def make(kind, w, h, a=0, b=0, seed=1, **opts):
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build(kind, a, b, 0.0, seed)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, **opts)
+    scene.sync(be)
+    orc = Oracle(w, h, threads=8, max_path_length=opts.get("max_path_length", 3))
+    scene.mark_all_changed()
+    scene.sync(orc)
+    return scene, be, orc
+
+
+@pytest.mark.parametrize("kind,a,b", [("cornell", 0, 0), ("soup", 1500, 5), ("gallery", 0, 0)])
+def test_blue_noise_frames_match_oracle(kind, a, b):
+    """ray_gen.comp:109-122, shade.comp:189-227: samples < 256 draw their 4 + 4 per bounce numbers from the tables."""
+    w, h = 160, 136   # wider than one 128 x 128 blue-noise tile in both directions
+    scene, be, orc = make(kind, w, h, a, b, seed=4, max_path_length=3)
+    view = scene.view(w, h)
+    t = blue_noise_table(5)
+    be.render(view); orc.render(view)
+    plain = be.accumulator().copy()
+    assert np.array_equal(plain.view(np.uint32), orc.accumulator().view(np.uint32))
+    be.set_blue_noise(t); orc.set_blue_noise(t); orc.reset()
+    for s in range(3):
+        be.render(view); orc.render(view)
+        assert be.frame_stats()["sample_count"] == s + 1      # set_blue_noise restarted the image
+        ga, ra = be.accumulator(), orc.accumulator()
+        assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32)), s
+    assert not np.array_equal(plain, be.accumulator())
+    # across the switch to xorshift at sample 256 (the image so far is the same on both sides)
+    be.set_option("sample_count", 254); orc.set_option("sample_count", 254)
+    for s in range(4):
+        be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), 254 + s
+    # the primary rays themselves (pixel jitter = dimensions 0 and 1 of the sampler)
+    po, pd = orc.primary_rays(view, 0)
+    assert np.array_equal(be.intersect(po, pd)["tri"], orc.intersect(po, pd)["tri"])
+    # clearing the tables restores the xorshift image
+    be.set_blue_noise(None); orc.set_blue_noise(None); orc.reset()
+    be.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), plain.view(np.uint32))
+    from rfw_rs_amd import BackendError
+    with pytest.raises(BackendError):
+        be.set_blue_noise(t[:1000])
+    with pytest.raises(BackendError):
+        be.set_blue_noise(t + 256)                             # entries are bytes
+    be.close()
+
+
+def test_blue_noise_in_batches_and_frame_slots():
+    w, h = 104, 72
+    scene, be, orc = make("soup", w, h, 1200, 4, seed=8, max_path_length=3, max_batch=6, frames_in_flight=3)
+    t = blue_noise_table(2)
+    be.set_blue_noise(t); orc.set_blue_noise(t)
+    views = []
+    for i in range(5):
+        scene.set_camera([0.35 * i - 0.7, 0.3 + 0.1 * i, -4.0 + 0.15 * i], [0.05 * i, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    be.render_batch(views)
+    for f, v in enumerate(views):
+        orc.reset(); orc.render(v)
+        assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+    for v in views[:4]:                                        # one render() per view over the slots
+        be.render(v)
+    orc.reset(); orc.render(views[3])
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    be.close()
+
+
+@pytest.mark.parametrize("tables", [False, True])
+def test_render_samples_is_k_samples_of_one_image(tables):
+    """rfw_hip_render_samples(view, k): the same paths as k render() calls, one launch per stage; the accumulator is the sum of the
+    per-sample images in sample order (bit for bit), i.e. the sequential accumulation up to the rounding of the partial sums."""
+    from oracle.bindings import Oracle
+    w, h = 120, 88
+    scene, be, orc = make("soup", w, h, 1500, 5, seed=6, max_path_length=3, max_batch=4)
+    view = scene.view(w, h)
+    t = blue_noise_table(9) if tables else None
+    be.set_blue_noise(t); orc.set_blue_noise(t); orc.reset()
+    k = 4
+    be.render_samples(view, k)
+    assert be.frame_stats()["sample_count"] == k
+    for _ in range(k):
+        orc.render(view)
+    ga = be.accumulator()
+    assert rel_l2(ga, orc.accumulator()) <= 1e-6              # gpu-rt's sequential accumulation, to rounding
+    total = np.zeros((h, w, 4), np.float32)
+    for s in range(k):                                         # the image of sample s alone: a fresh accumulator, sample index s
+        one = Oracle(w, h, threads=8, max_path_length=3)
+        scene.mark_all_changed(); scene.sync(one)
+        one.set_blue_noise(t)
+        one.set_option("sample_count", s)
+        one.render(view)
+        total = total + one.accumulator() if s else one.accumulator().copy()
+    assert np.array_equal(ga.view(np.uint32), total.view(np.uint32))
+    assert np.array_equal(be.framebuffer().view(np.uint32), np.sqrt(total * np.float32(1.0) / np.float32(k)).view(np.uint32))
+    # more samples of the same image keep accumulating: samples 4..6, then a plain render() as sample 7
+    be.render_samples(view, 3)
+    be.render(view)
+    for _ in range(4):
+        orc.render(view)
+    assert be.frame_stats()["sample_count"] == 8
+    assert rel_l2(be.accumulator(), orc.accumulator()) <= 1e-6
+    # a new view starts a new image
+    scene.set_camera([0.2, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+    v2 = scene.view(w, h)
+    be.render_samples(v2, 2)
+    orc.reset(); orc.render(v2); orc.render(v2)
+    assert be.frame_stats()["sample_count"] == 2 and rel_l2(be.accumulator(), orc.accumulator()) <= 1e-6
+    from rfw_rs_amd import BackendError
+    with pytest.raises(BackendError):
+        be.render_samples(v2, 5)                               # more than options.max_batch
+    be.close()
+
+
+def test_traversal_stack_overflow_is_contained_and_reported():
+    """a stack deeper than LDS + spill rows must not index past the spill rows; the entry is dropped, a flag in pinned host
+    memory is set and every later call reports RFW_HIP_E_STATE until synchronize() rebuilds the trees.  The test shrinks the spill
+    stack to zero rows on a deep LBVH so that the path is actually taken."""
+    from rfw_rs_amd import BackendError
+    w, h = 64, 64
+    scene, be, orc = make("soup", w, h, 40000, 1, seed=3, builder=2)   # LBVH: deeper trees than SAH
+    rng = np.random.default_rng(1)
+    o = rng.uniform(-4, 4, (40000, 3)).astype(np.float32)
+    d = rng.normal(size=(40000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = orc.intersect(o, d)
+    g = be.intersect(o, d)
+    assert np.array_equal(g["tri"], ref["tri"])
+    be.set_option("spill_rows", 0)
+    with pytest.raises(BackendError, match="stack overflow"):
+        be.intersect(o, d)                                     # completes (no fault, no out-of-bounds access) and reports
+    with pytest.raises(BackendError, match="stack overflow"):
+        be.render(scene.view(w, h))                            # sticky
+    be.set_option("spill_rows", 48)
+    scene.mark_all_changed(); scene.sync(be)                   # new trees: the flag is cleared
+    g = be.intersect(o, d)
+    assert np.array_equal(g["tri"], ref["tri"]) and np.array_equal(g["t"].view(np.uint32), ref["t"].view(np.uint32))
+    be.render(scene.view(w, h))
+    be.close()

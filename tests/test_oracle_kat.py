@@ -266,3 +266,75 @@ def test_skinning_known_answers():
             assert sk[i].view(np.uint32)[lane] == before[i].view(np.uint32)[lane]
     # identity joint with weight 1: the vertex is reproduced exactly
     assert np.array_equal(sk[0, 0:3], before[0, 0:3])
+
+
+def py_blue_noise_sampler(table, sample_count, x, y, dim):
+    """ray_gen.comp:72-91 (== shade.comp:530-545) restated in plain Python integers; an index past the array reads 0."""
+    at = lambda i: int(table[i]) if 0 <= i < len(table) else 0
+    x &= 127
+    y &= 127
+    sample_idx = (sample_count + 1) & 255
+    dim &= 255
+    ranked = sample_idx ^ at(dim + (x + y * 128) * 8 + 65536 * 3)
+    value = at(dim + ranked * 256)
+    value ^= at((dim & 7) + (x + y * 128) * 8 + 65536)
+    return np.float32(np.float32(0.5) + np.float32(value)) * np.float32(1.0 / 256.0)
+
+
+def blue_noise_table(seed):
+    """A synthetic table with the layout of gpu_rt::blue_noise::create_blue_noise_buffer() (backends/gpu-rt/src/blue_noise.rs:40970-41005):
+    5 x 65536 words, each a byte value; [2 * 65536 + 65536 ...) stays as the generator leaves it."""
+    return np.random.default_rng(seed).integers(0, 256, 5 * 65536).astype(np.uint32)
+
+
+def test_blue_noise_sampler_index_arithmetic():
+    t = blue_noise_table(7)
+    o = Oracle(8, 8)
+    o.set_blue_noise(t)
+    rng = np.random.default_rng(3)
+    cases = [(0, 0, 0, 0), (0, 127, 127, 15), (255, 127, 127, 8), (5, 128 + 3, 256 + 9, 4), (300, 1, 2, 259)]
+    cases += [tuple(int(v) for v in (rng.integers(0, 400), rng.integers(0, 2000), rng.integers(0, 2000), rng.integers(0, 16))) for _ in range(3000)]
+    for s, x, y, d in cases:
+        assert o.blue_noise_sample(s, x, y, d) == py_blue_noise_sampler(t, s, x, y, d), (s, x, y, d)
+    # the ranking lookup of dimensions 8..15 in the last pixel of a tile reads past the 5 x 65536 words: defined as 0
+    assert 15 + (127 + 127 * 128) * 8 + 65536 * 3 >= len(t)
+    # values are (k + 0.5) / 256: never 0, never 1
+    v = np.array([o.blue_noise_sample(s, x, y, d) for s, x, y, d in cases[:500]])
+    assert (v > 0).all() and (v < 1).all() and np.all((v * 256 - 0.5) == np.round(v * 256 - 0.5))
+
+
+def test_blue_noise_branch_structure():
+    """Samples < 256 draw from the tables, samples >= 256 from xorshift (ray_gen.comp:109-122); without tables always xorshift."""
+    w = h = 16
+    scene = Scene().build("cornell")
+    v = scene.view(w, h)
+    o = Oracle(w, h)
+    scene.sync(o)
+    t = blue_noise_table(11)
+    o.render(v)
+    plain = o.accumulator().copy()
+    o.set_blue_noise(t)
+    o.reset(); o.render(v)
+    blue = o.accumulator().copy()
+    assert not np.array_equal(plain, blue)
+    # primary rays of sample 0: pixel jitter = the sampler's dimensions 0 / 1
+    po, pd = o.primary_rays(v, 0)
+    o.set_blue_noise(None)
+    xo, xd = o.primary_rays(v, 0)
+    assert not np.array_equal(pd, xd)
+    # sample 256 and later: the tables are ignored
+    o.set_blue_noise(t)
+    a, _ = o.primary_rays(v, 256)
+    o.set_blue_noise(None)
+    b, _ = o.primary_rays(v, 256)
+    assert np.array_equal(a, b)
+    # a whole frame at sample index 300: identical with and without tables (fresh accumulators on both sides)
+    frames = []
+    for tables in (t, None):
+        q = Oracle(w, h)
+        scene.mark_all_changed(); scene.sync(q)
+        q.set_blue_noise(tables)
+        q.set_option("sample_count", 300)
+        q.render(v)
+        frames.append(q.accumulator().copy())
+    assert np.array_equal(frames[0], frames[1]) and frames[0][..., :3].max() > 0
