@@ -213,6 +213,15 @@ RFW_HIP_API int rfw_hip_depth_test(void* instance, const float* origins, const f
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
 RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);
 
+/* Test-only: the device functions the shade kernel is made of, evaluated one by one on caller-supplied inputs, so that each can be held
+ * against an independent formulation (tests/test_shading_kat.py compares with numpy float64).  Host pointers; per case 48 input floats:
+ *   [0,24) one rfw_device_material (its 96 bytes)  [24,27) N  [27,30) wo (op 3: D; op 4: the shaded point I)  [30,33) wi  [33,36) T
+ *   [36,39) B  [39] t  [40] backfacing (0/1)  [41] r3 (op 4: r0)  [42] r4  [43] light area (op 3)
+ * and 12 output floats.  op 0: BSDFEval -> rgb (gpu-rt/shaders/disney.glsl:110-195); 1: BSDFPdf -> pdf (:89-108); 2: BSDFSample -> wi.xyz,
+ * pdf, type (:197-263); 3: CalculateLightPDF -> pdf (shade.comp:325-328); 4: RandomPointOnLight with the lights set on this instance
+ * (synchronize first) -> P.xyz, pickProb, lightPdf, colour.rgb, picked light (shade.comp:413-528). */
+RFW_HIP_API int rfw_hip_debug_eval_shading(void* instance, int op, uint64_t n, const float* in48, float* out12);
+
 /* A batch of `count` independent NEW images, one per view, traced as one tall virtual frame: every stage of the wavefront loop is ONE
  * launch over the paths of all frames (bigger launches, fewer of them; with a sharded frame also ONE all-gather per batch).  Each
  * frame is exactly what rfw_hip_render of that view on a freshly reset instance produces.  count <= options.max_batch; the views must

@@ -47,6 +47,7 @@ def lib():
         l.orc_set_blue_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         l.orc_blue_noise_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
         l.orc_blue_noise_sample.restype = C.c_float
+        l.orc_eval_shading.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         l.orc_wang_hash.argtypes = [C.c_uint32]
         l.orc_wang_hash.restype = C.c_uint32
         l.orc_randi.argtypes = [C.POINTER(C.c_uint32)]
@@ -104,6 +105,12 @@ class Oracle:
 
     def blue_noise_sample(self, sample_count, x, y, dim):
         return float(self._l.orc_blue_noise_sample(self._h, sample_count, x, y, dim))
+
+    def eval_shading(self, op, inputs):
+        a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 48)
+        out = np.zeros((len(a), 12), dtype=np.float32)
+        assert self._l.orc_eval_shading(self._h, op, len(a), a.ctypes.data, out.ctypes.data) == 0
+        return out
 
     def render(self, view):
         self._l.orc_render(self._h, C.byref(view))

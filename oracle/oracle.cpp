@@ -1384,6 +1384,49 @@ ORC_API float orc_blue_noise_sample(void* p, uint32_t sample_count, int x, int y
     return blueNoiseSampler(((Oracle*)p)->blue_noise, sample_count, x, y, dim);
 }
 
+
+// ---- shading functions one by one, for the independent float64 known-answer tests (tests/test_shading_kat.py) and the device's
+// twin of this entry point (rfw_hip_debug_eval_shading).  Per case 48 input floats:
+//   [0,24) a rfw_device_material (its 96 bytes)   [24,27) N   [27,30) wo (op 3: D; op 4: I)   [30,33) wi   [33,36) T   [36,39) B
+//   [39] t   [40] backfacing (0 / 1)   [41] r3 (op 4: r0)   [42] r4   [43] light area (op 3)
+// and 12 output floats.  op 0: BSDFEval -> rgb;  1: BSDFPdf -> pdf;  2: BSDFSample -> wi.xyz, pdf, type;
+// 3: CalculateLightPDF -> pdf;  4: RandomPointOnLight (the lights set on this instance) -> P.xyz, pickProb, lightPdf, color.rgb, picked
+ORC_API int orc_eval_shading(void* p, int op, uint64_t n, const float* in, float* out)
+{
+    const Oracle& o = *(Oracle*)p;
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = in + 48 * i;
+        float* r = out + 12 * i;
+        for (int k = 0; k < 12; k++) r[k] = 0.0f;
+        rfw_device_material m;
+        std::memcpy(&m, q, sizeof(m));
+        const ShadingData sd = extractParameters(m);
+        const vec3 N = V3(q[24], q[25], q[26]), wo = V3(q[27], q[28], q[29]), wi = V3(q[30], q[31], q[32]);
+        const vec3 T = V3(q[33], q[34], q[35]), B = V3(q[36], q[37], q[38]);
+        switch (op) {
+        case 0: { const vec3 f = BSDFEval(sd, N, wo, wi, q[39], q[40] != 0.0f); r[0] = f.x; r[1] = f.y; r[2] = f.z; break; }
+        case 1: r[0] = BSDFPdf(sd, N, wo, wi); break;
+        case 2: {
+            vec3 w = V3(0.0f); float pdf = 0.0f; int type = BSDF_TYPE_REFLECTED;
+            BSDFSample(sd, T, B, N, wo, w, pdf, type, q[39], q[40] != 0.0f, q[41], q[42]);
+            r[0] = w.x; r[1] = w.y; r[2] = w.z; r[3] = pdf; r[4] = (float)type; break;
+        }
+        case 3: r[0] = CalculateLightPDF(wo, q[39], q[43], N); break;
+        case 4: {
+            if (light_count(o) == 0) return -2;
+            float pick = 0.0f, lpdf = 0.0f; vec3 col = V3(0.0f);
+            const vec3 P = RandomPointOnLight(o, q[41], q[42], wo, N, pick, lpdf, col);
+            const uint32_t lc = light_count(o);
+            int idx = f2i(q[41] * (float)lc);
+            idx = idx < 0 ? 0 : (idx > (int)lc - 1 ? (int)lc - 1 : idx);
+            r[0] = P.x; r[1] = P.y; r[2] = P.z; r[3] = pick; r[4] = lpdf; r[5] = col.x; r[6] = col.y; r[7] = col.z; r[8] = (float)idx; break;
+        }
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
 ORC_API int orc_set_option(void* p, const char* key, double value)
 {
     Oracle& o = *(Oracle*)p;

@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def hip_lib():
         l.rfw_hip_assemble_batch.argtypes = [vp, vp, C.c_uint32]
         l.rfw_hip_render_samples.argtypes = [vp, C.POINTER(pod.CameraView3D), C.c_uint32]
         l.rfw_hip_set_blue_noise.argtypes = [vp, vp, C.c_uint32]
+        l.rfw_hip_debug_eval_shading.argtypes = [vp, C.c_int, u64, vp, vp]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_host_alloc.restype = vp
@@ -243,6 +244,13 @@ class HipBackend:
         else:
             t = np.ascontiguousarray(table, dtype=np.uint32)
             self._check(self._l.rfw_hip_set_blue_noise(self._h, t.ctypes.data, t.size))
+
+    def eval_shading(self, op, inputs):
+        """Test-only: the shade kernel's device functions on caller-supplied inputs, (n, 48) float32 -> (n, 12) float32."""
+        a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 48)
+        out = np.zeros((len(a), 12), dtype=np.float32)
+        self._check(self._l.rfw_hip_debug_eval_shading(self._h, op, len(a), a.ctypes.data, out.ctypes.data))
+        return out
 
     def assemble_batch(self, gathered_ptr, count):
         self._check(self._l.rfw_hip_assemble_batch(self._h, C.c_void_p(gathered_ptr), count))

@@ -62,6 +62,7 @@ void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathere
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);
+void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& cam, int op, uint32_t n, const float* in, float* out);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,

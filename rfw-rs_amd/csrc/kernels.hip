@@ -813,6 +813,50 @@ void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t
 {
     if (n) hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, acc_slab, out, n);
 }
+
+// ---------------------------------------------------------------- shading functions one by one (rfw_hip_debug_eval_shading)
+// The device functions k_shade is made of, evaluated on caller-supplied inputs so that tests can hold each of them against an independent
+// float64 formulation (tests/test_shading_kat.py).  Layout per case: 48 input floats, 12 output floats (include/rfw_hip.h).
+__global__ __launch_bounds__(64) void k_eval_shading(const SceneDev sc, const CameraParams cam, const int op, const uint32_t n, const float* __restrict__ in,
+                                                     float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in + 48u * i;
+    float* r = out + 12u * i;
+    for (int k = 0; k < 12; k++) r[k] = 0.0f;
+    const ShadingData sd = extractParameters(reinterpret_cast<const rfw_device_material*>(q));
+    const f3 N = mk3(q[24], q[25], q[26]), wo = mk3(q[27], q[28], q[29]), wi = mk3(q[30], q[31], q[32]);
+    const f3 T = mk3(q[33], q[34], q[35]), B = mk3(q[36], q[37], q[38]);
+    if (op == 0) {
+        const f3 f = BSDFEval(sd, N, wo, wi, q[39], q[40] != 0.0f);
+        r[0] = f.x; r[1] = f.y; r[2] = f.z;
+    } else if (op == 1) {
+        r[0] = BSDFPdf(sd, N, wo, wi);
+    } else if (op == 2) {
+        f3 w = mk3(0.0f);
+        float pdf = 0.0f;
+        int type = BSDF_TYPE_REFLECTED;
+        BSDFSample(sd, T, B, N, wo, w, pdf, type, q[41], q[42]);
+        r[0] = w.x; r[1] = w.y; r[2] = w.z; r[3] = pdf; r[4] = (float)type;
+    } else if (op == 3) {
+        r[0] = CalculateLightPDF(wo, q[39], q[43], N);
+    } else if (op == 4) {
+        LightView lv;
+        lv.area = sc.area_lights; lv.point = sc.point_lights; lv.spot = sc.spot_lights; lv.directional = sc.directional_lights;
+        lv.n_area = (int)cam.area_light_count; lv.n_point = (int)cam.point_light_count;
+        lv.n_spot = (int)cam.spot_light_count; lv.n_directional = (int)cam.directional_light_count;
+        float pick = 0.0f, lpdf = 0.0f;
+        f3 col = mk3(0.0f);
+        int picked = 0;
+        const f3 P = RandomPointOnLight(lv, q[41], wo, N, pick, lpdf, col, picked);
+        r[0] = P.x; r[1] = P.y; r[2] = P.z; r[3] = pick; r[4] = lpdf; r[5] = col.x; r[6] = col.y; r[7] = col.z; r[8] = (float)picked;
+    }
+}
+void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& cam, int op, uint32_t n, const float* in, float* out)
+{
+    if (n) hipLaunchKernelGGL(k_eval_shading, dim3(ceil_div(n, 64)), dim3(64), 0, s, sc, cam, op, n, in, out);
+}
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth)
 {

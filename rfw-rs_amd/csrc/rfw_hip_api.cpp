@@ -2004,6 +2004,31 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     return RFW_HIP_OK;
 }
 
+
+// The device functions of k_shade one by one on caller-supplied inputs (tests only; layout in include/rfw_hip.h)
+int rfw_hip_debug_eval_shading(void* inst, int op, uint64_t n, const float* in48, float* out12)
+{
+    LOCK(inst);
+    if (op < 0 || op > 4 || (n && (!in48 || !out12)) || n > (1u << 24)) return fail(I, RFW_HIP_E_INVALID, "debug_eval_shading: bad arguments");
+    HIP_TRY(I, hipSetDevice(I->device));
+    if (op == 4) {
+        if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "debug_eval_shading: light sampling needs a synchronized scene");
+        if (I->area_lights.size() + I->point_lights.size() + I->spot_lights.size() + I->directional_lights.size() == 0)
+            return fail(I, RFW_HIP_E_STATE, "debug_eval_shading: no lights set");
+    }
+    HIP_TRY(I, I->d_q_o.ensure(48 * n));
+    HIP_TRY(I, I->d_q_d.ensure(12 * n));
+    rfw_camera_view_3d v;
+    std::memset(&v, 0, sizeof(v));
+    const CameraParams cam = camera_params(I, v);
+    if (n) HIP_TRY(I, hipMemcpyAsync(I->d_q_o.ptr, in48, 48 * n * sizeof(float), hipMemcpyHostToDevice, I->stream));
+    launch_eval_shading(I->stream, scene_dev(I), cam, op, (uint32_t)n, I->d_q_o.ptr, I->d_q_d.ptr);
+    HIP_TRY(I, hipGetLastError());
+    if (n) HIP_TRY(I, hipMemcpyAsync(out12, I->d_q_d.ptr, 12 * n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    return RFW_HIP_OK;
+}
+
 int rfw_hip_bandwidth_probe(void* inst, uint64_t bytes, uint32_t iterations, double* gb_per_s)
 {
     LOCK(inst);
