@@ -581,9 +581,8 @@ def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
     scene.sync(orc)
     build_s = time.time() - t0
     frames = []
-    n, spent, rays0 = 0, 0.0, None
-    s0 = orc.stats()
-    base = s0["primary"] + s0["shadow"] + s0["extension"]
+    n, spent, rays = 0, 0.0, 0
+    count = lambda s_: s_["primary"] + s_["shadow"] + s_["extension"]
     k = 0
     while True:
         view, t_anim = check[k % len(check)]
@@ -592,17 +591,17 @@ def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
             scene.mark_all_changed()
             scene.sync(orc)
         orc.reset()
+        before = count(orc.stats())   # (reset may or may not clear the ray counters: count this frame's rays as a difference)
         t1 = time.perf_counter()
         orc.render(view)
         spent += time.perf_counter() - t1
+        rays += count(orc.stats()) - before
         n += 1
         if k < len(check):
             frames.append(orc.accumulator().copy())
         k += 1
         if k >= len(check) and (spent > budget_s or n >= 64):
             break
-    s = orc.stats()
-    rays = s["primary"] + s["shadow"] + s["extension"] - base
     return ({"value": round(rays / spent / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
              "what": "CPU restatement of the reference's path (oracle/), not the reference binary: rfw-rs cannot be built here (no Rust toolchain, rtbvh un-vendored)",
              "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {cores} threads, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded"},
