@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
 L1_PEAK_GBS = 256 * 64 * 2.4  # 64 B per clock and CU out of the vector L1 / TA return path x 256 CUs x 2.4 GHz = 39.3 TB/s
 VALU_PEAK_GIPS = 1228.8      # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 FP32 instruction (= the 157 TFLOP/s vector peak)
+CLOCK_GHZ = 2.4              # peak engine clock (the busy-cycle fractions below are conservative if the chip clocks lower under load)
 N_VIEWS = 16                 # distinct camera views the frames cycle through
 
 
@@ -444,7 +445,9 @@ def main():
         # triangle test, and what lanes that finished before their wavefront cost (nodes / (64 x max per wave))
         roofline["lane_utilisation"] = {name: {"node_test": round(mean("nodes_visited", k) / max(64 * mean("node_test_executions", k), 1), 3),
                                                "triangle_test": round(mean("tris_tested", k) / max(64 * mean("tri_test_executions", k), 1), 3),
-                                               "finished_lanes_bound": round(mean("nodes_visited", k) / max(64 * mean("wave_max_nodes", k), 1), 3)}
+                                               "finished_lanes_bound": round(mean("nodes_visited", k) / max(64 * mean("wave_max_nodes", k), 1), 3),
+                                               # share of the wavefront-level node tests in which all active lanes visit ONE node
+                                               "wave_uniform_node_tests": round(mean("uniform_node_test_executions", k) / max(mean("node_test_executions", k), 1), 3)}
                                         for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if mean("node_test_executions", k)}
         out = {
             "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
@@ -525,31 +528,65 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
                   "note": "no isolated per-kernel durations in this configuration (kernels of frames in flight overlap)"})
         return r
     dom = max(kms, key=lambda k: kms[k])
-    dur = kms[dom] * 1e-3
-    ceilings = {}
     traffic = None
-    if usable:
-        kv = profile_kernel(pv[0]["kernels"], dom) if pv else None
-        km = profile_kernel(pm[0]["kernels"], dom) if pm else None
-        kc = profile_kernel(pc[0]["kernels"], dom) if pc else None
-        if kv and kv.get("SQ_INSTS_VALU"):
-            a = kv["SQ_INSTS_VALU"] / dur / 1e9
-            ceilings["valu_issue"] = {"achieved": round(a, 1), "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s", "frac": round(a / VALU_PEAK_GIPS, 4),
-                                      "per_launch": int(kv["SQ_INSTS_VALU"])}
-        if kv and kv.get("SQ_INSTS_VMEM_RD"):
-            # every vector-memory read instruction of these kernels is a 16-B-per-lane load: 1 KiB of L1 / TA return path per wave instruction
-            a = kv["SQ_INSTS_VMEM_RD"] * 1024.0 / dur / 1e9
-            ceilings["l1_ta"] = {"achieved": round(a, 1), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s", "frac": round(a / L1_PEAK_GBS, 4),
-                                 "per_launch_bytes": int(kv["SQ_INSTS_VMEM_RD"] * 1024)}
-        if kc and kc.get("l2_request_bytes_per_launch"):
-            a = kc["l2_request_bytes_per_launch"] / dur / 1e9
-            ceilings["l2"] = {"achieved": round(a, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(a / L2_PEAK_GBS, 4),
-                              "hit_rate": kc.get("l2_hit_rate"), "per_launch_bytes": int(kc["l2_request_bytes_per_launch"])}
-        if km:
-            traffic = km["hbm_bytes_per_launch_corrected"]
-            a = traffic / dur / 1e9
-            ceilings["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                               "per_launch_bytes": int(traffic), "note": "L2 fabric-side requests (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits are included, so true HBM bytes are lower still"}
+
+    def ceilings_of(names, seconds):
+        """Every ceiling as a fraction <= 1 for the launches `names` (one launch each) taking `seconds` together."""
+        nonlocal traffic
+        c = {}
+        if not usable:
+            return c
+        tot = {"valu": 0.0, "vmem": 0.0, "ta_busy": 0.0, "l2": 0.0, "l2_hit": [], "hbm": 0.0, "l1_hit": []}
+        have = {"valu": True, "ta": True, "l2": True, "hbm": True}
+        for n in names:
+            kv = profile_kernel(pv[0]["kernels"], n) if pv else None
+            km = profile_kernel(pm[0]["kernels"], n) if pm else None
+            kc = profile_kernel(pc[0]["kernels"], n) if pc else None
+            if kv and kv.get("SQ_INSTS_VALU"):
+                tot["valu"] += kv["SQ_INSTS_VALU"]; tot["vmem"] += kv.get("SQ_INSTS_VMEM_RD", 0)
+            else:
+                have["valu"] = False
+            if kc and kc.get("TA_BUSY_avr"):
+                tot["ta_busy"] += kc["TA_BUSY_avr"]
+                if kc.get("l1_hit_rate") is not None:
+                    tot["l1_hit"].append(kc["l1_hit_rate"])
+            else:
+                have["ta"] = False
+            if kc and kc.get("l2_request_bytes_per_launch"):
+                tot["l2"] += kc["l2_request_bytes_per_launch"]; tot["l2_hit"].append(kc.get("l2_hit_rate"))
+            else:
+                have["l2"] = False
+            if km:
+                tot["hbm"] += km["hbm_bytes_per_launch_corrected"]
+            else:
+                have["hbm"] = False
+        if have["valu"] and tot["valu"]:
+            a = tot["valu"] / seconds / 1e9
+            c["valu_issue"] = {"achieved": round(a, 1), "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s", "frac": round(a / VALU_PEAK_GIPS, 4),
+                               "per_launch": int(tot["valu"])}
+        if have["ta"] and tot["ta_busy"]:
+            # the texture-address / vector-L1 path of a CU, the unit every 16-B-per-lane load goes through: busy cycles (mean over the CUs)
+            # of the launches over the cycles they took.  Its cost per wave instruction grows with the cache lines the 64 lanes touch
+            # (tools/probes/mem_probe.hip: ~11 cycles when all lanes read one line, ~75 when every lane reads its own)
+            busy_s = tot["ta_busy"] / (CLOCK_GHZ * 1e9)
+            c["l1_ta"] = {"achieved": round(busy_s * 1e3, 4), "peak": round(seconds * 1e3, 4), "unit": "ms busy (TA_BUSY, mean over CUs) of ms elapsed", "frac": round(busy_s / seconds, 4),
+                          "vmem_read_instructions": int(tot["vmem"]), "l1_hit_rate": (round(sum(tot["l1_hit"]) / len(tot["l1_hit"]), 4) if tot["l1_hit"] else None)}
+        if have["l2"] and tot["l2"]:
+            a = tot["l2"] / seconds / 1e9
+            c["l2"] = {"achieved": round(a, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(a / L2_PEAK_GBS, 4), "hit_rate": tot["l2_hit"], "per_launch_bytes": int(tot["l2"])}
+        if have["hbm"] and tot["hbm"]:
+            a = tot["hbm"] / seconds / 1e9
+            c["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "per_launch_bytes": int(tot["hbm"]),
+                        "note": "L2 fabric-side requests (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits are included, so true HBM bytes are lower still"}
+            if len(names) == 1:
+                traffic = int(tot["hbm"])
+        return c
+
+    dur = kms[dom] * 1e-3
+    ceilings = ceilings_of([dom], dur)
+    # the timed region as a whole: one launch of every kernel of a frame over the wall time per frame (frames in flight overlap, so this is
+    # the utilisation the chip actually runs at, where the per-kernel figures above are launches with the machine to themselves)
+    steady = ceilings_of(["k_primary", "k_shade", "k_shadow", "k_assemble"], ms_step * 1e-3)
     contract = {"algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                 "algorithmic_GBps": round(alg[dom] / dur / 1e9, 1), "hbm_peak_GBps": HBM_PEAK_GBS,
                 "measured_copy_GBps": round(bw_measured, 1) if bw_measured else None,
@@ -563,6 +600,9 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
         c = ceilings[bound]
         r.update({"bound": bound, "kernel": dom, "achieved": c["achieved"], "peak": c["peak"], "unit": c["unit"], "frac": c["frac"], "traffic": traffic,
                   "ceilings": ceilings, "contract": contract})
+        if steady:
+            sb = max(steady, key=lambda k: steady[k]["frac"])
+            r["timed_region"] = {"bound": sb, "frac": steady[sb]["frac"], "ms_per_frame": round(ms_step, 4), "ceilings": steady}
     else:
         # no committed counters for this configuration: only the contract's rate can be given; `frac` stays null rather than a number above 1
         r.update({"bound": None, "kernel": dom, "achieved": contract["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": None, "traffic": None, "contract": contract})

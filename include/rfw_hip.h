@@ -100,6 +100,8 @@ typedef struct {
     uint64_t node_test_executions[3];
     uint64_t tri_test_executions[3];
     uint64_t wave_max_nodes[3];
+    /* node-test executions in which every active lane of the wavefront visited the SAME node (coherent rays near the top of a tree) */
+    uint64_t uniform_node_test_executions[3];
 } rfw_hip_frame_stats;
 
 /* Sizes of the device-resident acceleration structures (for DESIGN.md byte accounting). */

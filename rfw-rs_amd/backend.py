@@ -313,7 +313,7 @@ class HipBackend:
     def frame_stats(self):
         s = pod.FrameStats()
         self._check(self._l.rfw_hip_get_frame_stats(self._h, C.byref(s)))
-        return {n: (list(getattr(s, n)) if n in ("nodes_visited", "tris_tested", "instances_entered", "node_test_executions", "tri_test_executions", "wave_max_nodes") else getattr(s, n)) for n, _ in pod.FrameStats._fields_}
+        return {n: (list(getattr(s, n)) if n in ("nodes_visited", "tris_tested", "instances_entered", "node_test_executions", "tri_test_executions", "wave_max_nodes", "uniform_node_test_executions") else getattr(s, n)) for n, _ in pod.FrameStats._fields_}
 
     def drain_timing(self):
         """Summed per-kernel HIP-event milliseconds of the frames rendered since the last drain, and their count."""

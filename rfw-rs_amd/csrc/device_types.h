@@ -133,8 +133,14 @@ static_assert(sizeof(TexDesc) == 32, "TexDesc");
 
 struct MeshRecord {
     uint32_t node_base, node_count;
-    uint32_t tri_base, tri_count; // tri_base doubles as the global triangle id offset (same concatenation order)
+    uint32_t tri_base, tri_count; // tri_base = first triangle / packet of the mesh in the mega-buffers = offset of the ids the packets carry
+    // The triangle id the boundary reports (rfw_hip_hit.tri): offset of the mesh in the concatenation of all meshes in mesh-id order, then
+    // the skinned copies (gpu-rt's numbering, ray_gen.comp:231).  After a full build it equals tri_base; after an incremental synchronize
+    // (one mesh rebuilt in place or appended behind the others) the storage order differs and the query kernels translate.
+    uint32_t tri_logical;
+    uint32_t pad[3];
 };
+static_assert(sizeof(MeshRecord) == 32, "MeshRecord");
 
 // Camera block handed to the kernels (CameraData of backends/gpu-rt/src/lib.rs:147-175 without the queue counters).
 struct CameraParams {
@@ -180,6 +186,8 @@ struct QueueCounters {
     unsigned long long wave_exec[3][2];   // COUNT mode: wavefront-level executions of the node test / of the triangle test
     unsigned long long max_nodes[3];      // COUNT mode: the largest per-ray node count
     unsigned long long pad2;
+    unsigned long long wave_uniform[3];   // COUNT mode: node-test executions in which every active lane visited the SAME node
+    unsigned long long pad3;
 };
 
 enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };

@@ -12,6 +12,7 @@ struct SceneDev {
     const uint32_t* tlas_prims;
     const InstanceXform* instances;
     const InstanceNormal* instance_normals;
+    const MeshRecord* meshes;         // per mesh record: where it lives, and the triangle-id offset the boundary reports
     const Node4Q* blas_nodes;
     const TriPacket* tri_packets;
     const rfw_rt_triangle* triangles; // shading attributes, global triangle id order

@@ -84,7 +84,7 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
 {
     if (!COUNT) return;
     // wave reduction, then one atomic per wave
-    unsigned long long n = tc.nodes, t = tc.tris, i = tc.insts, wn = tc.wave_nodes, wt = tc.wave_tris;
+    unsigned long long n = tc.nodes, t = tc.tris, i = tc.insts, wn = tc.wave_nodes, wt = tc.wave_tris, wu = tc.wave_uniform;
     uint32_t mx = tc.nodes;
     for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = __shfl_down(mx, off);
@@ -94,6 +94,7 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
         n += __shfl_down(n, off);
         wn += __shfl_down(wn, off);
         wt += __shfl_down(wt, off);
+        wu += __shfl_down(wu, off);
         t += __shfl_down(t, off);
         i += __shfl_down(i, off);
     }
@@ -105,6 +106,7 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
         atomicMax(&qc->max_nodes[kind], (unsigned long long)mx);
         atomicAdd(&qc->wave_exec[kind][0], wn);
         atomicAdd(&qc->wave_exec[kind][1], wt);
+        atomicAdd(&qc->wave_uniform[kind], wu);
     }
 }
 
@@ -706,6 +708,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
     const SceneView sv = scene_view(sc);
     traverse<false, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
     rfw_hip_hit h;
+    if (hi >= 0) { // storage order -> the boundary's triangle numbering (identical after a full build)
+        const MeshRecord r = sc.meshes[sc.instances[hi].mesh];
+        ht = (int32_t)((uint32_t)ht - r.tri_base + r.tri_logical);
+    }
     h.inst = hi; h.tri = ht; h.t = t; h.u = hu; h.v = hv;
     hits[idx] = h;
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes this ray visited, TLAS and BLAS
@@ -774,14 +780,32 @@ void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
     } else if (count) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, s, cam, sc, p, bounce);
 }
-// bandwidth probe: 16 B per lane per access, grid-stride, enough workgroups to cover the 256 CUs several times
-__global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, const uint64_t n)
+// bandwidth probe: 16 B per lane per access; every workgroup owns chunks of 4 x 256 elements, 4 loads in flight per lane before the first
+// store, non-temporal on both sides (a copy streams: nothing is read again).  tools/probes/mem_probe.hip measured the variants on MI355X:
+// grid-stride 1-deep 4.6-5.4 TB/s, 4-deep 5.0-5.6, 4-deep non-temporal with 16 384 workgroups 5.9 (hipMemcpy device-to-device: 4.7)
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src4, float4* __restrict__ dst4, const uint64_t n)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) dst[i] = src[i];
+    const copy_v4f* __restrict__ src = reinterpret_cast<const copy_v4f*>(src4);
+    copy_v4f* __restrict__ dst = reinterpret_cast<copy_v4f*>(dst4);
+    constexpr uint64_t kChunk = 4u * 256u;
+    for (uint64_t base = (uint64_t)blockIdx.x * kChunk; base < n; base += (uint64_t)gridDim.x * kChunk) {
+        copy_v4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + (uint64_t)u * 256u + threadIdx.x;
+            if (i < n) v[u] = __builtin_nontemporal_load(src + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + (uint64_t)u * 256u + threadIdx.x;
+            if (i < n) __builtin_nontemporal_store(v[u], dst + i);
+        }
+    }
 }
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
-    if (n) hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, s, src, dst, n);
+    if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
 }
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n)
 {

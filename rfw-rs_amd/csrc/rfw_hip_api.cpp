@@ -41,11 +41,65 @@ template <typename T> struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // capacity for n elements, KEEPING the first `keep` elements (an append to a mega-buffer): new allocation, device-to-device copy on
+    // `s`, then the old one is freed (hipFree waits for the device, so work still reading the old pointer finishes first)
+    hipError_t grow_keep(size_t n, size_t keep, hipStream_t s)
+    {
+        if (n <= cap) return hipSuccess;
+        const size_t want = std::max<size_t>(n + n / 2, 16);
+        T* np = nullptr;
+        hipError_t e = hipMalloc((void**)&np, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (ptr && keep) e = hipMemcpyAsync(np, ptr, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (ptr) (void)hipFree(ptr);
+        ptr = np;
+        cap = want;
+        return e;
+    }
     void release()
     {
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
+    }
+};
+// Small host -> device uploads whose source may change before the copy runs (materials, lights, mesh records ...): staged through pinned
+// blocks that are reused once the copy that read them has completed (an event per block; no stream synchronisation anywhere)
+struct PinnedRing {
+    struct Block { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    std::vector<Block> blocks;
+    hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s)
+    {
+        if (bytes == 0) return hipSuccess;
+        Block* b = nullptr;
+        for (Block& c : blocks) {
+            if (c.cap < bytes) continue;
+            if (c.pending && hipEventQuery(c.ev) == hipSuccess) c.pending = false;
+            if (!c.pending) { b = &c; break; }
+        }
+        if (!b) {
+            Block n;
+            hipError_t e = hipHostMalloc(&n.p, std::max<size_t>(bytes, 64 << 10), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            n.cap = std::max<size_t>(bytes, 64 << 10);
+            if ((e = hipEventCreateWithFlags(&n.ev, hipEventDisableTiming)) != hipSuccess) { (void)hipHostFree(n.p); return e; }
+            blocks.push_back(n);
+            b = &blocks.back();
+        }
+        std::memcpy(b->p, src, bytes);
+        hipError_t e = hipMemcpyAsync(dst, b->p, bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(b->ev, s);
+        b->pending = e == hipSuccess;
+        return e;
+    }
+    void release()
+    {
+        for (Block& c : blocks) {
+            if (c.ev) (void)hipEventDestroy(c.ev);
+            if (c.p) (void)hipHostFree(c.p);
+        }
+        blocks.clear();
     }
 };
 
@@ -140,11 +194,26 @@ struct Instance {
     DevBuf<uint32_t> d_mesh_of_instance, d_tlas_prims;
     DevBuf<InstanceXform> d_xforms;
     DevBuf<InstanceNormal> d_normals;
-    DevBuf<rfw_device_material> d_materials;
-    DevBuf<rfw_area_light> d_area;
-    DevBuf<rfw_point_light> d_point;
-    DevBuf<rfw_spot_light> d_spot;
-    DevBuf<rfw_directional_light> d_dir;
+    // Materials and lights: small tables that an application edits while frames are in flight.  Every synchronize() that changes them
+    // writes a NEW version (kTableVersions buffers used round-robin) on a separate upload stream — the previous version copied on the
+    // device, then only the changed elements from the host (the trait's `changed` bit slices) — so frames in flight keep reading the
+    // version they started with, nothing waits for them, and later frames wait only for the upload (tables_ready).
+    static constexpr int kTableVersions = 4;
+    struct Tables {
+        DevBuf<rfw_device_material> materials;
+        DevBuf<rfw_area_light> area;
+        DevBuf<rfw_point_light> point;
+        DevBuf<rfw_spot_light> spot;
+        DevBuf<rfw_directional_light> dir;
+        size_t n_mat = 0, n_area = 0, n_point = 0, n_spot = 0, n_dir = 0;
+    } tables[kTableVersions];
+    uint64_t tables_version = 0;             // owner: version frames rendered from now on read (buffer = version % kTableVersions)
+    uint64_t tables_waited = 0, tables_used = 0; // per slot: version its stream has waited for / version its latest frame reads
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t tables_ready = nullptr;
+    // what the set_* calls since the last synchronize changed: all, or a list of element indices
+    struct Dirty { bool any = false, all = true; std::vector<uint32_t> idx; void clear() { any = false; all = true; idx.clear(); } };
+    Dirty mat_dirty, area_dirty, point_dirty, spot_dirty, dir_dirty;
     DevBuf<uint32_t> d_spill;
     DevBuf<uint32_t> d_tex_data;
     DevBuf<TexDesc> d_tex_desc;
@@ -182,6 +251,15 @@ struct Instance {
     DevBuf<uint8_t> d_q_r;
     std::vector<MeshRecord> mesh_records;
     std::map<uint32_t, uint32_t> mesh_index; // mesh id -> index in mesh_records
+    // incremental synchronize (device builders, no skinned copies): a changed mesh is rebuilt in its own region of the mega-buffers (or
+    // appended behind the others when it grew), the other meshes are not touched (gpu-rt/src/lib.rs:1345-1383 refits only changed meshes)
+    std::vector<uint32_t> record_tri_cap;     // triangles the region of record k can hold (its node region holds max(cap, 1) nodes)
+    uint32_t tri_end = 0, node_end = 0;       // first free triangle / node slot behind the regions in use
+    uint64_t hole_tris = 0;                   // triangles' worth of regions abandoned since the last full build
+    bool layout_valid = false;                // a full device build has laid the buffers out; cleared by anything the incremental path does not cover
+    bool node_counts_stale = false;           // n_blas_nodes is re-read lazily (get_scene_stats) after an incremental build
+    uint32_t incremental_builds = 0, full_builds = 0;
+    PinnedRing pins;
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
 
@@ -341,14 +419,16 @@ SceneDev scene_dev(Instance* I)
     s.tlas_prims = TL->d_tlas_prims.ptr;
     s.instances = TL->d_xforms.ptr;
     s.instance_normals = TL->d_normals.ptr;
+    s.meshes = S->d_mesh_records.ptr;
     s.blas_nodes = S->d_blas_nodes.ptr;
     s.tri_packets = S->d_packets.ptr;
     s.triangles = S->d_triangles.ptr;
-    s.materials = S->d_materials.ptr;
-    s.area_lights = S->d_area.ptr;
-    s.point_lights = S->d_point.ptr;
-    s.spot_lights = S->d_spot.ptr;
-    s.directional_lights = S->d_dir.ptr;
+    const Instance::Tables& tb = S->tables[S->tables_version % Instance::kTableVersions];
+    s.materials = tb.materials.ptr;
+    s.area_lights = tb.area.ptr;
+    s.point_lights = tb.point.ptr;
+    s.spot_lights = tb.spot.ptr;
+    s.directional_lights = tb.dir.ptr;
     s.tex_data = S->d_tex_data.ptr;
     s.tex_desc = S->d_tex_desc.ptr;
     s.n_textures = S->n_textures;
@@ -464,6 +544,7 @@ int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
         }
         d.skin_offset = so->second;
         MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
         r.tri_base = tri_total;
         r.tri_count = (uint32_t)src.tris.size();
         r.node_base = node_total;
@@ -485,14 +566,59 @@ int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
     return upload(I, I->d_skin_data, skin_all.data(), skin_all.size());
 }
 
-// BLAS for every mesh on the device (builder = DEVICE_LBVH): upload the triangles, then boxes -> LBVH -> packets, all on-stream
-int build_blas_device(Instance* I)
+// One static mesh on the device, into the region its record names: boxes -> BVH (binned SAH, or LBVH) -> leaf-ordered packets ->
+// quantised nodes.  The triangles are already in d_triangles.  `quantise_count` nodes of the region are quantised (the region is sized for
+// the worst case, one node per primitive; nodes behind the tree's own are never referenced).
+int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
+{
+    const MeshRecord& r = I->mesh_records[q];
+    if (r.tri_count == 0) return RFW_HIP_OK;
+    launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+    if (I->blas_sah_on_device) {
+        HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
+        const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                        I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
+        if (se == hipErrorInvalidValue) { // a tree deeper than the SAH builder's level budget above its LDS phase: LBVH always terminates
+            HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                  I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+        } else {
+            HIP_TRY(I, se);
+        }
+    } else {
+        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                              I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+    }
+    launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, quantise_count);
+    return RFW_HIP_OK;
+}
+
+// The triangle-id offsets the boundary reports: meshes in mesh-id order, then the skinned copies (= the order of a full build)
+void assign_logical_ids(Instance* I)
+{
+    uint32_t logical = 0;
+    for (auto& kv : I->meshes) {
+        const auto it = I->mesh_index.find(kv.first);
+        if (it == I->mesh_index.end()) continue;
+        I->mesh_records[it->second].tri_logical = logical;
+        logical += I->mesh_records[it->second].tri_count;
+    }
+    for (auto& kv : I->derived) {
+        I->mesh_records[kv.second.record].tri_logical = logical;
+        logical += I->mesh_records[kv.second.record].tri_count;
+    }
+}
+
+// BLAS for every mesh on the device: lay the mega-buffers out afresh, upload all triangles, build every mesh
+int build_blas_device_full(Instance* I)
 {
     I->mesh_records.clear();
     I->mesh_index.clear();
+    I->record_tri_cap.clear();
     uint32_t tri_total = 0, node_total = 0;
     for (auto& kv : I->meshes) {
         MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
         r.tri_base = tri_total;
         r.tri_count = (uint32_t)kv.second.tris.size();
         r.node_base = node_total;
@@ -501,13 +627,15 @@ int build_blas_device(Instance* I)
         node_total += r.node_count;
         I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
         I->mesh_records.push_back(r);
+        I->record_tri_cap.push_back(r.tri_count);
         kv.second.dirty = false;
     }
-    const uint32_t static_tris = tri_total, static_nodes = node_total;
+    const uint32_t static_nodes = node_total, static_tris = tri_total;
     const size_t n_static = I->mesh_records.size();
     I->raw_node_origin = 0;
     int rc;
     if ((rc = layout_derived(I, tri_total, node_total))) return rc;
+    assign_logical_ids(I);
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
@@ -525,28 +653,9 @@ int build_blas_device(Instance* I)
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
     HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
-    for (size_t q = 0; q < n_static; q++) {
-        const MeshRecord& r = I->mesh_records[q];
-        launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
-        if (I->blas_sah_on_device) {
-            HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
-            const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
-                                            I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
-            if (se == hipErrorInvalidValue) { // a tree deeper than the SAH builder's level budget above its LDS phase: LBVH always terminates
-                HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
-                                      I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
-            } else {
-                HIP_TRY(I, se);
-            }
-        } else {
-            HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
-                                  I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
-        }
-        launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base,
-                            I->d_packets.ptr + r.tri_base);
-    }
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes);
-    (void)static_tris;
+    for (size_t q = 0; q < n_static; q++)
+        if ((rc = build_mesh_device(I, (uint32_t)q, 0u))) return rc;
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
@@ -556,8 +665,113 @@ int build_blas_device(Instance* I)
     if (n_static) HIP_TRY(I, hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
     I->n_blas_nodes = node_total - static_nodes;
     for (uint32_t c : counts) I->n_blas_nodes += c;
+    I->node_counts_stale = false;
     I->d_sah_ws.release(); // ~350 B per triangle of build scratch: not kept between scene changes
+    I->tri_end = static_tris;
+    I->node_end = static_nodes;
+    I->hole_tris = 0;
+    I->layout_valid = I->derived.empty(); // the incremental path does not move skinned copies around
+    I->full_builds++;
     return RFW_HIP_OK;
+}
+
+// Only the meshes that changed (gpu-rt/src/lib.rs:1345-1383 rebuilds / refits `mesh.dirty` ones only): a changed mesh keeps its region of the
+// mega-buffers when it still fits and gets a new one behind the others when it grew; a new mesh is appended; an unloaded mesh leaves a hole.
+// Returns 1 when the layout has to be redone by a full build (too many holes), 0 on success, < 0 on error.
+int build_blas_device_incremental(Instance* I)
+{
+    // what went away
+    for (auto it = I->mesh_index.begin(); it != I->mesh_index.end();) {
+        if (I->meshes.find(it->first) == I->meshes.end()) {
+            I->hole_tris += I->record_tri_cap[it->second];
+            I->mesh_records[it->second].tri_count = 0;
+            it = I->mesh_index.erase(it);
+        } else ++it;
+    }
+    std::vector<uint32_t> todo; // record indices to (re)build
+    uint32_t max_n = 0;
+    for (auto& kv : I->meshes) {
+        MeshHost& m = kv.second;
+        if (!m.dirty) continue;
+        const uint32_t n = (uint32_t)m.tris.size();
+        uint32_t q;
+        const auto it = I->mesh_index.find(kv.first);
+        if (it != I->mesh_index.end() && n <= I->record_tri_cap[it->second]) {
+            q = it->second; // rebuilt in place
+        } else {
+            if (it != I->mesh_index.end()) { // grew: the old region becomes a hole, the record moves behind the others
+                q = it->second;
+                I->hole_tris += I->record_tri_cap[q];
+            } else {
+                q = (uint32_t)I->mesh_records.size();
+                MeshRecord r;
+                std::memset(&r, 0, sizeof(r));
+                I->mesh_records.push_back(r);
+                I->record_tri_cap.push_back(0);
+                I->mesh_index[kv.first] = q;
+            }
+            if ((uint64_t)I->tri_end + n > kLeafFirstMask || (uint64_t)I->node_end + std::max(n, 1u) > 0x7fffffffu) return 1;
+            I->mesh_records[q].tri_base = I->tri_end;
+            I->mesh_records[q].node_base = I->node_end;
+            I->record_tri_cap[q] = n;
+            I->tri_end += n;
+            I->node_end += std::max(n, 1u);
+        }
+        I->mesh_records[q].tri_count = n;
+        I->mesh_records[q].node_count = std::max(I->record_tri_cap[q], 1u);
+        todo.push_back(q);
+        max_n = std::max(max_n, n);
+        m.dirty = false;
+    }
+    if (I->hole_tris > std::max<uint64_t>(I->tri_end / 2, 1u << 16)) return 1; // mostly holes: compact by a full build
+    assign_logical_ids(I);
+    HIP_TRY(I, I->d_triangles.grow_keep(I->tri_end, I->d_triangles.cap, I->stream));
+    HIP_TRY(I, I->d_packets.grow_keep(I->tri_end, I->d_packets.cap, I->stream));
+    HIP_TRY(I, I->d_blas_order.grow_keep(I->tri_end, I->d_blas_order.cap, I->stream));
+    HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
+    HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
+    HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
+    HIP_TRY(I, I->d_mesh_records.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), 0, I->stream));
+    HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, 1u)));
+    int rc;
+    if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
+    for (const uint32_t q : todo) {
+        const MeshRecord& r = I->mesh_records[q];
+        const MeshHost* mh = nullptr;
+        for (auto& kv : I->mesh_index)
+            if (kv.second == q) mh = &I->meshes[kv.first];
+        if (r.tri_count && mh) {
+            // through the pinned ring when small (the host copy may be replaced by the next set_3d_mesh before a pageable copy has run)
+            if ((size_t)r.tri_count * sizeof(rfw_rt_triangle) <= (8u << 20))
+                HIP_TRY(I, I->pins.upload(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), I->stream));
+            else {
+                HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), hipMemcpyHostToDevice, I->stream));
+                HIP_TRY(I, hipStreamSynchronize(I->stream));
+            }
+        }
+        if ((rc = build_mesh_device(I, q, std::max(r.tri_count, 1u)))) return rc;
+    }
+    HIP_TRY(I, hipGetLastError());
+    HIP_TRY(I, I->pins.upload(I->d_mesh_records.ptr, I->mesh_records.data(), I->mesh_records.size() * sizeof(MeshRecord), I->stream));
+    uint64_t live = 0;
+    for (auto& kv : I->mesh_index) live += I->mesh_records[kv.second].tri_count;
+    I->n_tris = live;
+    I->node_counts_stale = true;
+    I->incremental_builds++;
+    return RFW_HIP_OK;
+}
+
+int build_blas_device(Instance* I)
+{
+    bool any_dirty = false, removed = false;
+    for (auto& kv : I->meshes) any_dirty = any_dirty || kv.second.dirty;
+    for (auto& kv : I->mesh_index) removed = removed || I->meshes.find(kv.first) == I->meshes.end();
+    if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed)) {
+        const int rc = build_blas_device_incremental(I);
+        if (rc <= 0) return rc;
+        for (auto& kv : I->meshes) kv.second.dirty = true; // (only matters for the host builder; the full device build takes every mesh)
+    }
+    return build_blas_device_full(I);
 }
 
 // BLAS on the host cores (binned SAH, multi-threaded), flattened into the mega-buffers (gpu-rt/src/lib.rs:1387-1548)
@@ -567,12 +781,14 @@ int build_blas_host(Instance* I)
         if (kv.second.dirty) build_mesh(I, kv.second);
     I->mesh_records.clear();
     I->mesh_index.clear();
+    I->layout_valid = false;
     std::vector<Node4> nodes;
     std::vector<TriPacket> packets;
     std::vector<rfw_rt_triangle> tris;
     for (auto& kv : I->meshes) {
         MeshHost& m = kv.second;
         MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
         r.node_base = (uint32_t)nodes.size();
         r.node_count = (uint32_t)m.bvh.nodes.size();
         r.tri_base = (uint32_t)tris.size();
@@ -588,6 +804,7 @@ int build_blas_host(Instance* I)
     uint32_t tri_total = (uint32_t)tris.size(), node_total = (uint32_t)nodes.size();
     int rc;
     if ((rc = layout_derived(I, tri_total, node_total))) return rc;
+    assign_logical_ids(I);
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
@@ -789,6 +1006,62 @@ int build_instances(Instance* I, Instance* T)
     return RFW_HIP_OK;
 }
 
+// one table of the new version: the old version copied on the device, then the changed elements (runs of consecutive indices) from
+// the host copy through the pinned ring; everything from the host when the table was handed over whole or its length changed
+template <typename T> int write_table(Instance* I, DevBuf<T>& dst, size_t& dst_n, const DevBuf<T>& old, size_t old_n, const std::vector<T>& host, const Instance::Dirty& d)
+{
+    const size_t n = host.size();
+    HIP_TRY(I, dst.ensure(std::max<size_t>(n, 1)));
+    dst_n = n;
+    hipStream_t s = I->upload_stream;
+    const bool partial = d.any && !d.all && old.ptr && old_n == n;
+    if ((!d.any || partial) && old.ptr && old_n == n && n) HIP_TRY(I, hipMemcpyAsync(dst.ptr, old.ptr, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (!d.any && old_n == n) return RFW_HIP_OK; // unchanged table: the copy is all
+    if (!partial) {
+        if (n) HIP_TRY(I, I->pins.upload(dst.ptr, host.data(), n * sizeof(T), s));
+        return RFW_HIP_OK;
+    }
+    std::vector<uint32_t> idx = d.idx;
+    std::sort(idx.begin(), idx.end());
+    for (size_t a = 0; a < idx.size();) {
+        size_t b = a + 1;
+        while (b < idx.size() && idx[b] <= idx[b - 1] + 1) b++;
+        const size_t lo = idx[a], hi = std::min<size_t>((size_t)idx[b - 1] + 1, n);
+        if (lo < hi) HIP_TRY(I, I->pins.upload(dst.ptr + lo, host.data() + lo, (hi - lo) * sizeof(T), s));
+        a = b;
+    }
+    return RFW_HIP_OK;
+}
+
+int upload_tables(Instance* I)
+{
+    if (!I->upload_stream) HIP_TRY(I, hipStreamCreateWithFlags(&I->upload_stream, hipStreamNonBlocking));
+    if (!I->tables_ready) HIP_TRY(I, hipEventCreateWithFlags(&I->tables_ready, hipEventDisableTiming));
+    const uint64_t nv = I->tables_version + 1;
+    Instance::Tables& dst = I->tables[nv % Instance::kTableVersions];
+    const Instance::Tables& old = I->tables[I->tables_version % Instance::kTableVersions];
+    // the buffer being recycled last held version nv - kTableVersions: a frame still reading it (possible only when more than
+    // kTableVersions - 1 edits were synchronized since that frame was issued) has to finish first — a dependency of the UPLOAD on that
+    // frame, on the device; the host does not wait
+    if (nv >= (uint64_t)Instance::kTableVersions) {
+        const uint64_t stale = nv - Instance::kTableVersions;
+        if (I->tables_used <= stale && I->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, I->frame_done, 0));
+        for (Instance* c : I->slots)
+            if (c->tables_used <= stale && c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, c->frame_done, 0));
+        if (I->slots.empty() && I->tables_used <= stale) HIP_TRY(I, hipStreamSynchronize(I->stream)); // no frame_done event without slots
+    }
+    int rc;
+    if ((rc = write_table(I, dst.materials, dst.n_mat, old.materials, old.n_mat, I->materials, I->mat_dirty))) return rc;
+    if ((rc = write_table(I, dst.area, dst.n_area, old.area, old.n_area, I->area_lights, I->area_dirty))) return rc;
+    if ((rc = write_table(I, dst.point, dst.n_point, old.point, old.n_point, I->point_lights, I->point_dirty))) return rc;
+    if ((rc = write_table(I, dst.spot, dst.n_spot, old.spot, old.n_spot, I->spot_lights, I->spot_dirty))) return rc;
+    if ((rc = write_table(I, dst.dir, dst.n_dir, old.dir, old.n_dir, I->directional_lights, I->dir_dirty))) return rc;
+    HIP_TRY(I, hipEventRecord(I->tables_ready, I->upload_stream));
+    I->tables_version = nv;
+    I->mat_dirty.clear(); I->area_dirty.clear(); I->point_dirty.clear(); I->spot_dirty.clear(); I->dir_dirty.clear();
+    return RFW_HIP_OK;
+}
+
 int do_synchronize(Instance* I)
 {
     HIP_TRY(I, hipSetDevice(I->device));
@@ -806,7 +1079,8 @@ int do_synchronize(Instance* I)
     }
     // does this call queue work on the owner's stream that the frame slots have to wait for (anything but a per-slot TLAS update)?
     // (per_slot_tlas() may flip inside build_blas_* when skinned copies appear or disappear; meshes_dirty covers both directions)
-    const bool shared_work = I->meshes_dirty || I->materials_dirty || I->lights_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
+    // (material and light edits do not count: they go into a new version of their tables, see upload_tables)
+    const bool shared_work = I->meshes_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
     if (!I->slots.empty() && shared_work) {
         // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
         for (Instance* c : I->slots)
@@ -833,10 +1107,10 @@ int do_synchronize(Instance* I)
         I->instances_dirty = false;
         any_change = true;
     }
-    if (I->materials_dirty) {
-        if ((rc = upload(I, I->d_materials, I->materials.data(), I->materials.size()))) return rc;
-        HIP_TRY(I, hipStreamSynchronize(I->stream));
+    if (I->materials_dirty || I->lights_dirty) {
+        if ((rc = upload_tables(I))) return rc;
         I->materials_dirty = false;
+        I->lights_dirty = false;
         any_change = true;
     }
     if (I->textures_dirty) { // texels of every texture, then the skybox, in one array + descriptor table
@@ -857,15 +1131,6 @@ int do_synchronize(Instance* I)
         if ((rc = upload(I, I->d_tex_desc, desc.data(), desc.size()))) return rc;
         HIP_TRY(I, hipStreamSynchronize(I->stream));
         I->textures_dirty = false;
-        any_change = true;
-    }
-    if (I->lights_dirty) {
-        if ((rc = upload(I, I->d_area, I->area_lights.data(), I->area_lights.size()))) return rc;
-        if ((rc = upload(I, I->d_point, I->point_lights.data(), I->point_lights.size()))) return rc;
-        if ((rc = upload(I, I->d_spot, I->spot_lights.data(), I->spot_lights.size()))) return rc;
-        if ((rc = upload(I, I->d_dir, I->directional_lights.data(), I->directional_lights.size()))) return rc;
-        HIP_TRY(I, hipStreamSynchronize(I->stream));
-        I->lights_dirty = false;
         any_change = true;
     }
     if (any_change) {
@@ -952,6 +1217,14 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
     if (I->scene && I->scene->scene_ready && I->waited_version != I->scene->scene_version) { // a slot must not read a scene still being written
         HIP_TRY(I, hipStreamWaitEvent(I->stream, I->scene->scene_ready, 0));
         I->waited_version = I->scene->scene_version;
+    }
+    {   // the material / light tables this frame reads: wait (on the device) for their upload, once per version
+        Instance* S = scene_of(I);
+        if (S->tables_ready && I->tables_waited != S->tables_version) {
+            HIP_TRY(I, hipStreamWaitEvent(I->stream, S->tables_ready, 0));
+            I->tables_waited = S->tables_version;
+        }
+        I->tables_used = S->tables_version;
     }
     if ((I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) || I->after_batch) I->sample_count = 0;
     I->after_batch = k > 1 && !samples; // the frames of a batch are complete images: whatever follows starts a new one
@@ -1243,12 +1516,16 @@ void rfw_hip_destroy(void* inst)
         if (I->download_done) (void)hipEventDestroy(I->download_done);
         I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
-        I->d_xforms.release(); I->d_normals.release(); I->d_materials.release(); I->d_area.release(); I->d_point.release();
-        I->d_spot.release(); I->d_dir.release(); I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release(); I->d_blue_noise.release();
+        I->d_xforms.release(); I->d_normals.release();
+        for (auto& tb : I->tables) { tb.materials.release(); tb.area.release(); tb.point.release(); tb.spot.release(); tb.dir.release(); }
+        if (I->tables_ready) (void)hipEventDestroy(I->tables_ready);
+        if (I->upload_stream) (void)hipStreamDestroy(I->upload_stream);
+        I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release(); I->d_blue_noise.release();
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->overflow_host) (void)hipHostFree(I->overflow_host);
+        I->pins.release();
         I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
         for (int k = 0; k < Instance::kStages; k++) {
             if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
@@ -1319,12 +1596,30 @@ int rfw_hip_set_3d_instances(void* inst, uint32_t mesh, const rfw_instances_data
     return RFW_HIP_OK;
 }
 
-int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, const uint32_t* /*changed*/)
+// The trait's `changed` bit slice (packed u32 words, bit i = element i; NULL = everything) folded into what the next synchronize() uploads
+static void mark_dirty(Instance::Dirty& d, size_t old_n, uint32_t n, const uint32_t* changed)
+{
+    if (!changed || old_n != n) { // handed over whole, or the list changed its length
+        d.any = true; d.all = true; d.idx.clear();
+        return;
+    }
+    const bool was_all = d.any && d.all;
+    bool some = false;
+    for (uint32_t i = 0; i < n; i++)
+        if (changed[i >> 5] & (1u << (i & 31u))) {
+            some = true;
+            if (!was_all) d.idx.push_back(i);
+        }
+    if (some && !was_all) { d.any = true; d.all = false; }
+}
+
+int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !m) return fail(I, RFW_HIP_E_INVALID, "set_materials: null data");
+    mark_dirty(I->mat_dirty, I->materials.size(), n, changed);
     I->materials.assign(m, m + n);
-    I->materials_dirty = true;
+    I->materials_dirty = I->materials_dirty || I->mat_dirty.any;
     return RFW_HIP_OK;
 }
 
@@ -1462,36 +1757,40 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     return alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
 }
 
-int rfw_hip_set_point_lights(void* inst, const rfw_point_light* l, uint32_t n, const uint32_t*)
+int rfw_hip_set_point_lights(void* inst, const rfw_point_light* l, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_point_lights: null data");
+    mark_dirty(I->point_dirty, I->point_lights.size(), n, changed);
     I->point_lights.assign(l, l + n);
-    I->lights_dirty = true;
+    I->lights_dirty = I->lights_dirty || I->point_dirty.any;
     return RFW_HIP_OK;
 }
-int rfw_hip_set_spot_lights(void* inst, const rfw_spot_light* l, uint32_t n, const uint32_t*)
+int rfw_hip_set_spot_lights(void* inst, const rfw_spot_light* l, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_spot_lights: null data");
+    mark_dirty(I->spot_dirty, I->spot_lights.size(), n, changed);
     I->spot_lights.assign(l, l + n);
-    I->lights_dirty = true;
+    I->lights_dirty = I->lights_dirty || I->spot_dirty.any;
     return RFW_HIP_OK;
 }
-int rfw_hip_set_area_lights(void* inst, const rfw_area_light* l, uint32_t n, const uint32_t*)
+int rfw_hip_set_area_lights(void* inst, const rfw_area_light* l, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_area_lights: null data");
+    mark_dirty(I->area_dirty, I->area_lights.size(), n, changed);
     I->area_lights.assign(l, l + n);
-    I->lights_dirty = true;
+    I->lights_dirty = I->lights_dirty || I->area_dirty.any;
     return RFW_HIP_OK;
 }
-int rfw_hip_set_directional_lights(void* inst, const rfw_directional_light* l, uint32_t n, const uint32_t*)
+int rfw_hip_set_directional_lights(void* inst, const rfw_directional_light* l, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_directional_lights: null data");
+    mark_dirty(I->dir_dirty, I->directional_lights.size(), n, changed);
     I->directional_lights.assign(l, l + n);
-    I->lights_dirty = true;
+    I->lights_dirty = I->lights_dirty || I->dir_dirty.any;
     return RFW_HIP_OK;
 }
 
@@ -1757,6 +2056,7 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
             out->instances_entered[k] += qc[s].trav[k][2];
             out->node_test_executions[k] += qc[s].wave_exec[k][0];
             out->tri_test_executions[k] += qc[s].wave_exec[k][1];
+            out->uniform_node_test_executions[k] += qc[s].wave_uniform[k];
             out->wave_max_nodes[k] += qc[s].wave_max_nodes[k];
         }
     }
@@ -1805,6 +2105,17 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
         (void)hipSetDevice(I->device);
         const int trc = ensure_slot_tlas(I, I); // the owner's own TLAS may be stale: its slots rebuild theirs independently
         if (trc != RFW_HIP_OK) return trc;
+    }
+    if (I->node_counts_stale && I->d_mesh_node_counts.ptr) { // after an incremental build: the builders' node counts, read when somebody asks
+        (void)hipSetDevice(I->device);
+        (void)hipStreamSynchronize(I->stream);
+        std::vector<uint32_t> counts(I->mesh_records.size(), 0u);
+        if (!counts.empty() && hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, counts.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t n = 0;
+            for (auto& kv : I->mesh_index) n += counts[kv.second];
+            I->n_blas_nodes = n;
+            I->node_counts_stale = false;
+        }
     }
     out->triangles = I->n_tris;
     out->instances = I->n_valid_instances;
@@ -2018,6 +2329,7 @@ int rfw_hip_debug_eval_shading(void* inst, int op, uint64_t n, const float* in48
     }
     HIP_TRY(I, I->d_q_o.ensure(48 * n));
     HIP_TRY(I, I->d_q_d.ensure(12 * n));
+    if (I->tables_ready) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->tables_ready, 0));
     rfw_camera_view_3d v;
     std::memset(&v, 0, sizeof(v));
     const CameraParams cam = camera_params(I, v);

@@ -54,6 +54,7 @@ struct TravCounters {
     // COUNT mode: times this lane was the first active lane of a node test / triangle test; summed over a wavefront = how often the
     // wavefront executed that code (lane utilisation of the node test = nodes / (64 * wave_nodes))
     uint32_t wave_nodes = 0, wave_tris = 0;
+    uint32_t wave_uniform = 0; // node-test executions whose active lanes all visit one node (a scalar fetch would serve them)
 };
 
 // Closest hit (ANY_HIT = false): on return t/hu/hv/hit_inst/hit_tri describe the nearest accepted hit, ties resolved
@@ -123,7 +124,14 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             const uint4 w0 = np[0], w1 = np[1], w2 = np[2], ch = np[3];
             if (COUNT) {
                 tc.nodes++;
-                if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) tc.wave_nodes++;
+                if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) {
+                    tc.wave_nodes++;
+                }
+                {
+                    const uint64_t first_ptr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)np >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)np);
+                    const bool all_same = __ballot((uintptr_t)np == first_ptr) == __ballot(1);
+                    if (all_same && __builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) tc.wave_uniform++;
+                }
             }
             // plane = origin + q * scale  =>  t = q * (scale * inv) + (origin - o) * inv : one cvt + one fma per plane
             const float Ax = bitsf(w0.w) * inv.x, Ay = bitsf(w2.z) * inv.y, Az = bitsf(w2.w) * inv.z;

@@ -274,6 +274,7 @@ rfw_camera_view_3d Camera3D::get_view(uint32_t width, uint32_t height) const
 uint32_t Scene::add_material(const Material& m)
 {
     materials.push_back(m);
+    material_changed_bits.clear(); // the list grew: everything is handed over again
     materials_changed = true;
     return (uint32_t)materials.size() - 1;
 }
@@ -284,6 +285,28 @@ uint32_t Scene::add_mesh(const Mesh3D& m)
     instances_3d[id];
     mesh_changed[id] = true;
     return id;
+}
+void Scene::replace_mesh(uint32_t id, const Mesh3D& m)
+{
+    meshes_3d[id] = m;
+    mesh_changed[id] = true;
+    instances_changed[id] = true; // the local bounds travel with the instance list
+}
+void Scene::remove_mesh(uint32_t id)
+{
+    if (!meshes_3d.erase(id)) return;
+    instances_3d.erase(id);
+    mesh_changed.erase(id);
+    instances_changed.erase(id);
+    removed_meshes.push_back(id);
+}
+void Scene::set_material(uint32_t index, const Material& m)
+{
+    if (index >= materials.size()) return;
+    materials[index] = m;
+    if (!materials_changed) material_changed_bits.assign((materials.size() + 31) / 32, 0u); // first edit since the last synchronize
+    if (!material_changed_bits.empty()) material_changed_bits[index / 32] |= 1u << (index % 32);
+    materials_changed = true;
 }
 size_t Scene::add_instance(uint32_t mesh, const rfw_mat4& m)
 {
@@ -403,6 +426,11 @@ void synchronize_system(Scene& scene, Backend& renderer)
         scene.skins_changed = false;
         changed = true;
     }
+    if (!scene.removed_meshes.empty()) {
+        renderer.unload_3d_meshes(std::vector<size_t>(scene.removed_meshes.begin(), scene.removed_meshes.end()));
+        scene.removed_meshes.clear();
+        changed = true;
+    }
     for (auto& kv : scene.meshes_3d) { // :63-76 changed meshes
         if (!scene.mesh_changed[kv.first]) continue;
         renderer.set_3d_mesh(kv.first, kv.second.as_data());
@@ -437,7 +465,8 @@ void synchronize_system(Scene& scene, Backend& renderer)
         changed = true;
     }
     if (scene.materials_changed) { // :138-147
-        renderer.set_materials(scene.device_materials(), nullptr);
+        renderer.set_materials(scene.device_materials(), scene.material_changed_bits.empty() ? nullptr : &scene.material_changed_bits);
+        scene.material_changed_bits.clear();
         scene.materials_changed = false;
         changed = true;
     }
@@ -777,7 +806,28 @@ void atrium_geometry(Builder& b, float s, uint32_t seed, const std::vector<int>&
 } // namespace
 
 // C2 ("Sponza-class", target 262 267) and C4 (target ~1 048 576: atrium + 64 displaced icospheres)
-void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed)
+// One of C4's 64 displaced icospheres, in place (k: 16 per row along x, two rows in z, two storeys)
+MeshDescriptor make_displaced_sphere(int k, uint32_t seed, int quality, uint32_t mat_id)
+{
+    MeshDescriptor out;
+    out.name = "displaced-sphere";
+    const MeshDescriptor base = make_icosphere(quality, mat_id);
+    const float cx = -13.0f + 26.0f * ((k % 16) + 0.5f) / 16.0f, cz = ((k / 16) % 2 ? 4.6f : -4.6f), cy = (k / 32) ? 5.6f : 0.65f;
+    const float rad = 0.55f;
+    for (size_t i = 0; i < base.vertices.size(); i++) {
+        const V3 n = v3(base.vertices[i].x, base.vertices[i].y, base.vertices[i].z);
+        const float disp = 1.0f + 0.18f * vnoise(n.x * 4.0f + 10.0f, n.y * 4.0f + n.z * 3.0f + 10.0f, seed);
+        const V3 p = v3(cx, cy, cz) + n * (rad * disp);
+        out.vertices.push_back(rfw_vec4{p.x, p.y, p.z, 1.0f});
+        out.normals.push_back(rfw_vec3{0, 0, 0}); // regenerate: displacement changed the surface
+        out.uvs.push_back(base.uvs[i]);
+        out.tangents.push_back(base.tangents[i]);
+        out.material_ids.push_back((int32_t)mat_id);
+    }
+    return out;
+}
+
+void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, bool separate_spheres)
 {
     std::vector<int> mats;
     Rng rng(seed);
@@ -816,7 +866,13 @@ void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32
     const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
     scene.add_instance(mesh, mat4_identity());
 
-    if (with_spheres) {
+    if (with_spheres && separate_spheres) {
+        // SURVEY §8d C4 literally: 64 displaced icospheres as 64 meshes, one instance each
+        for (int k = 0; k < 64; k++) {
+            const uint32_t m2 = scene.add_mesh(Mesh3D::from(make_displaced_sphere(k, seed + 1000 + k, 4, (uint32_t)mats[(k * 7) % mats.size()])));
+            scene.add_instance(m2, mat4_identity());
+        }
+    } else if (with_spheres) {
         // 64 displaced icospheres (Quality::VeryHigh = 5120 triangles each), baked into one static mesh
         MeshDescriptor all;
         all.name = "displaced-spheres";
@@ -1149,9 +1205,9 @@ struct TableBackend : rfw::Backend {
         acc(t.unload_3d_meshes(t.instance, v.data(), (uint32_t)v.size()));
     }
     void set_3d_instances(size_t mesh, const rfw_instances_data_3d& d) override { acc(t.set_3d_instances(t.instance, (uint32_t)mesh, &d)); }
-    void set_materials(const std::vector<rfw_device_material>& m, const std::vector<uint32_t>*) override
+    void set_materials(const std::vector<rfw_device_material>& m, const std::vector<uint32_t>* ch) override
     {
-        acc(t.set_materials(t.instance, m.data(), (uint32_t)m.size(), nullptr));
+        acc(t.set_materials(t.instance, m.data(), (uint32_t)m.size(), ch ? ch->data() : nullptr));
     }
     void set_textures(const std::vector<rfw_texture_data>& t, const std::vector<uint32_t>*) override
     {
@@ -1195,7 +1251,7 @@ HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, fl
     HostScene& h = *(HostScene*)p;
     const std::string k(kind);
     if (k == "cornell") rfw::build_cornell_box(h.scene, h.cam);
-    else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed);
+    else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed, b != 0);
     else if (k == "soup") rfw::build_soup(h.scene, h.cam, a, b, seed);
     else if (k == "gallery") rfw::build_gallery(h.scene, h.cam, seed);
     else if (k == "skinned") rfw::build_skinned(h.scene, h.cam, seed);
@@ -1228,6 +1284,35 @@ HOST_API int rfwhost_save_glb(void* p, const char* path)
     if (!rfw::save_glb(path, h.scene, &h.cam, err)) { h.error = err; return -1; }
     return 0;
 }
+// Scene edits for the incremental-synchronize tests.  op 0: replace mesh `id` by displaced sphere number a (surface seeded by `seed`),
+// quality q (4 = 5120 triangles); 1: remove mesh `id` and its instances; 2: add displaced sphere number a as a NEW mesh with one instance
+// (returns its id); 3: recolour material `id` (r, g, b from seed's bytes, roughness a / 255) and mark only that material changed
+HOST_API int rfwhost_edit(void* p, uint32_t op, uint32_t id, uint32_t a, uint32_t q, uint32_t seed)
+{
+    HostScene& h = *(HostScene*)p;
+    if (op == 0) {
+        if (h.scene.meshes_3d.find(id) == h.scene.meshes_3d.end()) return -1;
+        const rfw::Mesh3D& old = h.scene.meshes_3d[id];
+        const uint32_t mat = old.triangles.empty() ? 0u : (uint32_t)old.triangles[0].mat_id;
+        h.scene.replace_mesh(id, rfw::Mesh3D::from(rfw::make_displaced_sphere((int)a, seed, (int)q, mat)));
+        return (int)id;
+    }
+    if (op == 1) { h.scene.remove_mesh(id); return 0; }
+    if (op == 2) {
+        const uint32_t m = h.scene.add_mesh(rfw::Mesh3D::from(rfw::make_displaced_sphere((int)a, seed, (int)q, 0u)));
+        h.scene.add_instance(m, rfw::mat4_identity());
+        return (int)m;
+    }
+    if (op == 3) {
+        if (id >= h.scene.materials.size()) return -1;
+        rfw::Material m = h.scene.materials[id];
+        m.color[0] = (float)(seed & 255u) / 255.0f; m.color[1] = (float)((seed >> 8) & 255u) / 255.0f; m.color[2] = (float)((seed >> 16) & 255u) / 255.0f;
+        m.roughness = (float)a / 255.0f;
+        h.scene.set_material(id, m);
+        return 0;
+    }
+    return -1;
+}
 HOST_API const char* rfwhost_last_error(void* p) { return ((HostScene*)p)->error.c_str(); }
 HOST_API int rfwhost_animate(void* p, float time)
 {
@@ -1258,6 +1343,7 @@ HOST_API int rfwhost_mark_all_changed(void* p)
     for (auto& kv : h.scene.meshes_3d) h.scene.mesh_changed[kv.first] = true;
     for (auto& kv : h.scene.instances_3d) h.scene.instances_changed[kv.first] = true;
     h.scene.materials_changed = true;
+    h.scene.material_changed_bits.clear();
     h.scene.lights_changed = true;
     h.scene.textures_changed = !h.scene.textures.empty();
     h.scene.skybox_changed = h.scene.skybox.width != 0;

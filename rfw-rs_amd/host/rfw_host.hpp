@@ -200,9 +200,16 @@ struct Scene {
     // change tracking (rfw-utils TrackedStorage/FlaggedStorage bits)
     std::map<uint32_t, bool> mesh_changed, instances_changed;
     bool materials_changed = true, lights_changed = true;
+    // which materials changed since the last synchronize_system (the reference's TrackedStorage bits, crates/rfw-scene/src/material/list.rs);
+    // empty = all of them (a new scene, a resized list)
+    std::vector<uint32_t> material_changed_bits;
+    std::vector<uint32_t> removed_meshes; // unloaded since the last synchronize_system (rfw/src/system/mod.rs: unload_3d_meshes)
 
     uint32_t add_material(const Material& m);
     uint32_t add_mesh(const Mesh3D& m);
+    void replace_mesh(uint32_t id, const Mesh3D& m);   // same id, new geometry (set_3d_mesh again at the next synchronize_system)
+    void remove_mesh(uint32_t id);                      // the mesh and its instances
+    void set_material(uint32_t index, const Material& m); // marks only this material changed
     size_t add_instance(uint32_t mesh, const rfw_mat4& m);
     void set_matrix(uint32_t mesh, size_t slot, const rfw_mat4& m);
     // crates/rfw-scene/src/lib.rs:575-648
@@ -224,7 +231,10 @@ void render_system(const Camera3D& camera, uint32_t width, uint32_t height, Back
 // ---- synthetic scenes standing in for the assets the reference does not ship ----
 MeshDescriptor make_icosphere(int quality, uint32_t mat_id);                       // objects_3d/sphere.rs:365-519
 void build_cornell_box(Scene& scene, Camera3D& cam);                               // C1
-void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed); // C2 ("Sponza-class") / C4
+// separate_spheres: C4's 64 displaced icospheres as 64 meshes with one instance each (65 meshes in all) instead of one baked mesh
+void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, bool separate_spheres = false); // C2 ("Sponza-class") / C4
+// one of C4's displaced icospheres (k = 0..63): the 5120-triangle sphere at its place in the atrium, surface noise seeded by `seed`; quality 4 = 5120 triangles
+MeshDescriptor make_displaced_sphere(int k, uint32_t seed, int quality, uint32_t mat_id);
 void add_sphere_grid(Scene& scene, uint32_t nx, uint32_t nz, float spacing);       // C3: instances of a 320-tri icosphere
 void animate_sphere_grid(Scene& scene, uint32_t mesh, uint32_t nx, uint32_t nz, float spacing, float time); // examples/animated/src/main.rs:197-219
 void build_soup(Scene& scene, Camera3D& cam, uint32_t triangles, uint32_t instances, uint32_t seed); // random soups for BVH equivalence tests

@@ -119,6 +119,7 @@ class FrameStats(C.Structure):
         ("instances_entered", u64 * 3), ("ms_total", f32), ("ms_trace_primary", f32), ("ms_trace_extend", f32), ("ms_trace_shadow", f32),
         ("ms_shade", f32), ("ms_other", f32), ("sample_count", u32), ("bounces", u32), ("substreams", u32), ("pad", u32),
         ("node_test_executions", u64 * 3), ("tri_test_executions", u64 * 3), ("wave_max_nodes", u64 * 3),
+        ("uniform_node_test_executions", u64 * 3),
     ]
 
 

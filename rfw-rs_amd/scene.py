@@ -45,6 +45,7 @@ def host_lib():
         l.rfwhost_counts.argtypes = [C.c_void_p, C.c_uint32]
         l.rfwhost_counts.restype = C.c_uint32
         l.rfwhost_mesh_data.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(pod.MeshData3D)]
+        l.rfwhost_edit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
         _lib = l
     return _lib
@@ -102,6 +103,23 @@ class Scene:
         v = pod.CameraView3D()
         self._l.rfwhost_camera_view(self._h, width, height, C.byref(v))
         return v
+
+    def replace_mesh_with_sphere(self, mesh_id, sphere_no, seed, quality=4):
+        """Mesh `mesh_id` becomes displaced sphere number `sphere_no` of the atrium (quality 4 = 5120 triangles); marked changed."""
+        if self._l.rfwhost_edit(self._h, 0, mesh_id, sphere_no, quality, seed) < 0:
+            raise KeyError(mesh_id)
+
+    def remove_mesh(self, mesh_id):
+        self._l.rfwhost_edit(self._h, 1, mesh_id, 0, 0, 0)
+
+    def add_sphere_mesh(self, sphere_no, seed, quality=4):
+        return int(self._l.rfwhost_edit(self._h, 2, 0, sphere_no, quality, seed))
+
+    def recolour_material(self, index, rgb_bytes, roughness_byte):
+        """Changes ONE material and marks only it changed (set_materials then carries a `changed` bit slice)."""
+        seed = rgb_bytes[0] | (rgb_bytes[1] << 8) | (rgb_bytes[2] << 16)
+        if self._l.rfwhost_edit(self._h, 3, index, roughness_byte, 0, seed) < 0:
+            raise KeyError(index)
 
     def mark_all_changed(self):
         self._l.rfwhost_mark_all_changed(self._h)

@@ -1,0 +1,123 @@
+"""Incremental synchronize (gpu-rt/src/lib.rs:1345-1383): a changed mesh is rebuilt in its own region of the mega-buffers,
+the other meshes are not touched; material / light edits honour the trait's `changed` bit slices and go into a new version of their
+tables, so frames in flight are neither waited for nor disturbed.  Everything is checked against the oracle, which rebuilds the whole
+scene every time."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(8, os.cpu_count() or 8)
+
+
+def rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = np.stack([rng.uniform(-14, 14, n), rng.uniform(0.2, 11.5, n), rng.uniform(-5.5, 5.5, n)], axis=1).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # half of them aimed at the two rows of spheres (z = +-4.6, y = 0.65 / 5.6), so that edits of single spheres are seen
+    k = n // 2
+    tgt = np.stack([rng.uniform(-13, 13, k), rng.choice([0.65, 5.6], k), rng.choice([-4.6, 4.6], k)], axis=1).astype(np.float32)
+    d[:k] = tgt - o[:k]
+    d[:k] /= np.linalg.norm(d[:k], axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def assert_same(be, orc, o, d, view, what):
+    g, r = be.intersect(o, d), orc.intersect(o, d)
+    assert np.array_equal(g["inst"], r["inst"]), what
+    assert np.array_equal(g["tri"], r["tri"]), what          # the boundary's triangle numbering survives the storage order
+    hit = r["inst"] >= 0
+    assert np.array_equal(g["t"][hit].view(np.uint32), r["t"][hit].view(np.uint32)), what
+    orc.reset()
+    be.render(view); orc.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), what
+    assert be.scene_stats()["triangles"] == orc.stats()["n_tris"], what
+
+
+def test_one_mesh_of_c4_changes_without_rebuilding_the_rest():
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 320, 180
+    scene = Scene().build("atrium", 1048576, 1, 0.0, 0xC0FFEE)   # C4 with its 64 displaced icospheres as 64 meshes: 65 meshes
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    assert scene.counts()["meshes"] == 65
+    be = HipBackend.init(w, h, 1.0, max_path_length=2, frames_in_flight=3)
+    orc = Oracle(w, h, threads=THREADS, max_path_length=2)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    o, d = rays(40000, 1)
+    assert_same(be, orc, o, d, view, "full build")
+    assert (be.intersect(o, d)["inst"] > 0).sum() > 2000        # rays do land on sphere instances
+    nodes0 = be.scene_stats()["blas_nodes"]
+
+    def edit(fn, what, budget_ms):
+        fn()
+        be.device_synchronize()
+        t0 = time.perf_counter()
+        scene.sync(be)                                           # set_3d_mesh of the changed meshes only + synchronize()
+        host_ms = (time.perf_counter() - t0) * 1e3
+        be.device_synchronize()
+        total_ms = (time.perf_counter() - t0) * 1e3
+        scene.mark_all_changed(); scene.sync(orc)                # the oracle rebuilds everything
+        assert_same(be, orc, o, d, view, what)
+        print(f"{what}: synchronize {host_ms:.2f} ms on the host, {total_ms:.2f} ms until the device is done")
+        assert total_ms < budget_ms, (what, total_ms)
+        return total_ms
+
+    # 1. one sphere gets a new shape, same triangle count: rebuilt in place (the full build of this scene takes ~60 ms)
+    t1 = edit(lambda: scene.replace_mesh_with_sphere(7, 6, 4242), "one mesh of 65 rebuilt in place", 8.0)
+    # 2. the same again (warm: buffers and workspaces exist)
+    t2 = edit(lambda: scene.replace_mesh_with_sphere(30, 29, 99), "one mesh of 65 rebuilt in place, warm", 5.0)
+    # 3. a mesh that grows (5120 -> 20480 triangles) moves behind the others
+    edit(lambda: scene.replace_mesh_with_sphere(12, 11, 7, quality=5), "one mesh grows and is appended", 60.0)
+    # 4. a mesh that shrinks stays where it is; a mesh is unloaded; a new mesh appears
+    edit(lambda: scene.replace_mesh_with_sphere(50, 49, 3, quality=3), "one mesh shrinks in place", 8.0)
+    edit(lambda: scene.remove_mesh(20), "one mesh unloaded", 8.0)
+    edit(lambda: scene.add_sphere_mesh(19, 5), "one mesh added", 60.0)
+    assert be.scene_stats()["blas_nodes"] != nodes0
+    be.close()
+
+
+def test_material_edits_reach_later_frames_only_and_honour_changed_bits():
+    """Frames in flight keep the material table they started with (a new version is written beside it); the next frames see the edit.
+    More edits than table versions (4) in a row exercise the recycling of version buffers."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 160, 120
+    scene = Scene().build("soup", 3000, 4, 0.0, 5)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=4)
+    orc = Oracle(w, h, threads=8, max_path_length=3)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    views = []
+    for k in range(7):
+        scene.set_camera([0.3 * k - 0.9, 0.4, -4.0 + 0.1 * k], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    frames = [be.host_frame() for _ in views]
+    edits = [None] + [(int(rng_k.integers(0, 6)), [int(x) for x in rng_k.integers(30, 250, 3)], int(rng_k.integers(20, 250)))
+                      for rng_k in [np.random.default_rng(100 + k) for k in range(1, len(views))]]
+    for k, v in enumerate(views):                                # edit, synchronize, render, queue the download; never wait:
+        if k:                                                    # several frames, each with ITS material table, are in flight together
+            scene.recolour_material(*edits[k])
+            scene.sync(be)                                       # set_materials(changed = one bit) + synchronize
+        be.render(v)
+        be.download_frame(frames[k], accumulator=True)
+    # the oracle replays the same edits on its own copy of the scene
+    scene_o = Scene().build("soup", 3000, 4, 0.0, 5)
+    scene_o.set_aspect(w / h)
+    want = []
+    for k, v in enumerate(views):
+        if k:
+            scene_o.recolour_material(*edits[k])
+        scene_o.mark_all_changed(); scene_o.sync(orc)
+        orc.reset(); orc.render(v)
+        want.append(orc.accumulator().copy())
+    be.wait_downloads()
+    for k in range(len(views)):
+        assert np.array_equal(frames[k].view(np.uint32), want[k].view(np.uint32)), k
+    assert not np.array_equal(want[0], want[-1])
+    be.close()
