@@ -155,7 +155,7 @@ def main():
             scene.mark_all_changed()
             scene.sync(be)
             g = None
-            if world > 1 or args.emulate_shard:
+            if (world > 1 and not native) or args.emulate_shard:
                 nslab = be.shard_info()["slab_floats"]
                 wn = world if not args.emulate_shard else args.emulate_shard
                 send = torch.zeros(batch * nslab, dtype=torch.float32, device="cuda")           # this rank's tiles of `batch` frames (written by render())
@@ -168,11 +168,12 @@ def main():
     inst = make_instances(F, B, use_slots)
     sync_s = (time.time() - t0) / len(inst)
     if native:
-        # the communicator lives inside the library (librccl): rank 0's unique id travels through torch's store once
-        uid = [inst[0][0].comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        for be, _, _ in inst:
-            be.comm_init(uid[0], rank, world)
+        # the communicators live inside the library (librccl; one per instance, i.e. per frame / batch in flight): rank 0's unique ids
+        # travel through torch's store once, after that torch.distributed is only used for the barrier around the timed region
+        uids = [[HipBackend.comm_unique_id() for _ in inst] if rank == 0 else None]
+        dist.broadcast_object_list(uids, src=0)
+        for (be_, _, _), uid in zip(inst, uids[0]):
+            be_.comm_init(uid, rank, world)
     bes = [i[0] for i in inst]
     be = bes[0]
     sstats = be.scene_stats()
@@ -236,12 +237,12 @@ def main():
                 b.render(views[frames[0] % N_VIEWS])
             else:
                 b.render(views[frames[0] % N_VIEWS])  # THE headline call: Backend::render, nothing else
-            if world > 1:
+            if world > 1 and native:
+                pass  # render() / render_batch() gathered and assembled the frame(s) themselves: ncclAllGather on the instance's stream
+            elif world > 1:
                 send, recv, nslab, wn = g
                 send, recv = send[:nf * nslab], recv[:wn * nf * nslab]  # slab = [frame][tile pixels]; gathered = [rank][frame][tile pixels]
-                if native:
-                    b.comm_all_gather(send.data_ptr(), recv.data_ptr(), nf * nslab)  # librccl, on the instance's own stream
-                elif dist_backend == "nccl":
+                if dist_backend == "nccl":
                     dist.all_gather_into_tensor(recv, send)  # the ONE collective per batch (RCCL over xGMI)
                 else:
                     host = torch.empty(recv.shape, dtype=recv.dtype)

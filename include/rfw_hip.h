@@ -199,6 +199,18 @@ RFW_HIP_API int rfw_hip_shard_info(void* instance, uint64_t* slab_floats, uint32
 RFW_HIP_API int rfw_hip_set_slab_output(void* instance, void* device_ptr);
 RFW_HIP_API int rfw_hip_assemble_frame(void* instance, const void* gathered_device_ptr);
 
+/* The collective inside the library (one process per GPU): a RCCL communicator owned by the instance.  Rank 0 obtains a
+ * 128-byte id (rfw_hip_comm_unique_id = ncclGetUniqueId) and hands it to every rank by whatever means the host has; every rank creates
+ * its instance with options.rank / options.world and calls rfw_hip_comm_init (collective: = ncclCommInitRank on the instance's device).
+ * From then on rfw_hip_render / rfw_hip_render_batch leave the COMPLETE frame(s) on every rank: the rank's tiles are traced, the RGB of
+ * its slab is packed, ONE ncclAllGather per call runs on the instance's own stream (RCCL over xGMI) and the gathered slabs are de-tiled —
+ * no buffer, stream or collective on the host's side (rfw_hip_set_slab_output / rfw_hip_assemble_* stay for hosts that bring their own
+ * collective, e.g. torch.distributed).  world = 1 is allowed (a one-rank communicator).  librccl is opened at run time, on first use.
+ * Not available on instances with frame slots or sub-streams: pipeline sharded frames over several instances, each with its communicator. */
+RFW_HIP_API int rfw_hip_comm_unique_id(void* out128);
+RFW_HIP_API int rfw_hip_comm_init(void* instance, const void* id128, uint32_t rank, uint32_t world);
+RFW_HIP_API int rfw_hip_comm_destroy(void* instance);
+
 /* Ray queries against the synchronized scene — the C form of the reference's CPU query
  * interface TIntersector::{intersect, occludes} (crates/rfw-scene/src/intersector.rs:45-75,
  * 21-43).  Host pointers; origins/directions are n x 3 floats. */

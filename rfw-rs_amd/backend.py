@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy",
 ]
 
 _lib = None
@@ -90,6 +90,9 @@ def hip_lib():
         l.rfw_hip_render_samples.argtypes = [vp, C.POINTER(pod.CameraView3D), C.c_uint32]
         l.rfw_hip_set_blue_noise.argtypes = [vp, vp, C.c_uint32]
         l.rfw_hip_debug_eval_shading.argtypes = [vp, C.c_int, u64, vp, vp]
+        l.rfw_hip_comm_unique_id.argtypes = [vp]
+        l.rfw_hip_comm_init.argtypes = [vp, vp, u32, u32]
+        l.rfw_hip_comm_destroy.argtypes = [vp]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_host_alloc.restype = vp
@@ -251,6 +254,22 @@ class HipBackend:
         out = np.zeros((len(a), 12), dtype=np.float32)
         self._check(self._l.rfw_hip_debug_eval_shading(self._h, op, len(a), a.ctypes.data, out.ctypes.data))
         return out
+
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands the bytes to every rank)."""
+        buf = (C.c_uint8 * 128)()
+        if hip_lib().rfw_hip_comm_unique_id(buf) != 0:
+            raise BackendError("rfw_hip_comm_unique_id failed: " + hip_lib().rfw_hip_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective: the instance gets its own RCCL communicator; render() then gathers and assembles the frame itself."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._l.rfw_hip_comm_init(self._h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._check(self._l.rfw_hip_comm_destroy(self._h))
 
     def assemble_batch(self, gathered_ptr, count):
         self._check(self._l.rfw_hip_assemble_batch(self._h, C.c_void_p(gathered_ptr), count))

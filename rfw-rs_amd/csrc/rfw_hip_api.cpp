@@ -3,6 +3,8 @@
 // (synchronize :1309-1683, render :1685-1780) with every buffer resident in HBM and no per-bounce
 // host read-back.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl is opened at run time by rfw_hip_comm_* (no link-time dependency for single-GPU hosts)
 
 #include <algorithm>
 #include <chrono>
@@ -26,6 +28,35 @@ using namespace rfwhip;
 namespace {
 
 thread_local std::string g_create_error;
+
+// RCCL, resolved lazily: a process that already carries a librccl (PyTorch bundles one under the same SONAME) keeps using that one
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string error;
+    bool load()
+    {
+        if (all_gather) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return false; }
+        get_unique_id = (decltype(get_unique_id))dlsym(lib, "ncclGetUniqueId");
+        comm_init_rank = (decltype(comm_init_rank))dlsym(lib, "ncclCommInitRank");
+        comm_destroy = (decltype(comm_destroy))dlsym(lib, "ncclCommDestroy");
+        error_string = (decltype(error_string))dlsym(lib, "ncclGetErrorString");
+        all_gather = (decltype(all_gather))dlsym(lib, "ncclAllGather");
+        if (!get_unique_id || !comm_init_rank || !comm_destroy || !all_gather || !error_string) { error = "librccl lacks a symbol"; all_gather = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
 
 template <typename T> struct DevBuf {
     T* ptr = nullptr;
@@ -268,6 +299,9 @@ struct Instance {
     DevBuf<uint32_t> d_present; // BGRA8 sRGB frame, made on demand by rfw_hip_download_frame(what = 2)
     DevBuf<uint4> d_hit[2];
     void* external_slab = nullptr;
+    // multi-GPU inside the library (rfw_hip_comm_init): this rank's RGB slab(s) -> ncclAllGather on the instance's stream -> assemble
+    ncclComm_t comm = nullptr;
+    DevBuf<float> d_send, d_recv;
     uint32_t tiles_x = 0, tiles_y = 0, local_tiles = 0, capacity = 0;
     uint64_t local_pixels = 0;
     uint32_t sample_count = 0;
@@ -1317,7 +1351,17 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
     I->sample_count += samples ? k : 1;
     const uint32_t frames_out = samples ? 1u : k; // images this call leaves behind
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
-    if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
+    if (I->comm) {
+        // the frame's ONE collective, issued by the library itself: RGB of this rank's slab(s) -> all ranks (RCCL over xGMI) -> de-tile
+        const uint64_t n_send = (uint64_t)I->capacity * frames_out * 3u;
+        launch_pack_rgb(main, I->d_acc_slab.ptr, I->d_send.ptr, (uint64_t)I->capacity * frames_out);
+        const ncclResult_t nr = g_rccl.all_gather(I->d_send.ptr, I->d_recv.ptr, n_send, ncclFloat, I->comm, main);
+        if (nr != ncclSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("ncclAllGather: ") + g_rccl.error_string(nr));
+        CameraParams ac = cam[0];
+        ac.batch = frames_out;
+        launch_assemble(main, ac, I->d_recv.ptr, true, false, I->cap_v, I->d_frame_out.ptr, std::max(1u, I->sample_count)); // gathered = [rank][frame][slab]
+        I->acc_source = I->d_recv.ptr; I->acc_source_rgb = true; I->acc_source_batch = frames_out;
+    } else if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
     {
         launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, false, I->cap_v, I->d_frame_out.ptr, I->sample_count);
         I->acc_source = I->d_acc_slab.ptr; I->acc_source_rgb = false; I->acc_source_batch = frames_out;
@@ -1524,6 +1568,8 @@ void rfw_hip_destroy(void* inst)
         I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
+        if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
+        I->d_send.release(); I->d_recv.release();
         if (I->overflow_host) (void)hipHostFree(I->overflow_host);
         I->pins.release();
         I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
@@ -1717,6 +1763,55 @@ int rfw_hip_render_samples(void* inst, const rfw_camera_view_3d* view, uint32_t 
     return render_impl(I, views, count, true);
 }
 
+int rfw_hip_comm_unique_id(void* out128)
+{
+    if (!out128) return RFW_HIP_E_INVALID;
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (!g_rccl.load()) { g_create_error = g_rccl.error; return RFW_HIP_E_DEVICE; }
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.get_unique_id(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.error_string(r); return RFW_HIP_E_DEVICE; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId");
+    std::memcpy(out128, &id, 128);
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_comm_init(void* inst, const void* id128, uint32_t rank, uint32_t world)
+{
+    LOCK(inst);
+    if (!id128 || world == 0 || rank >= world) return fail(I, RFW_HIP_E_INVALID, "comm_init: bad arguments");
+    if (rank != I->rank || world != I->world) return fail(I, RFW_HIP_E_INVALID, "comm_init: rank / world differ from the shard this instance was created with (rfw_hip_options.rank / world)");
+    if (!I->slots.empty() || I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "comm_init: an instance with frame slots or sub-streams cannot own a communicator (use one instance per frame in flight)");
+    if (I->comm) return fail(I, RFW_HIP_E_STATE, "comm_init: this instance already has a communicator");
+    {
+        std::lock_guard<std::mutex> g(g_rccl_mu);
+        if (!g_rccl.load()) return fail(I, RFW_HIP_E_DEVICE, g_rccl.error);
+    }
+    HIP_TRY(I, hipSetDevice(I->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    const ncclResult_t r = g_rccl.comm_init_rank(&I->comm, (int)world, id, (int)rank);
+    if (r != ncclSuccess) { I->comm = nullptr; return fail(I, RFW_HIP_E_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.error_string(r)); }
+    const size_t n = (size_t)I->capacity * I->max_batch * 3u;
+    HIP_TRY(I, I->d_send.ensure(n));
+    HIP_TRY(I, I->d_recv.ensure(n * world));
+    HIP_TRY(I, hipMemsetAsync(I->d_recv.ptr, 0, n * world * sizeof(float), I->stream));
+    I->sample_count = 0;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_comm_destroy(void* inst)
+{
+    LOCK(inst);
+    if (!I->comm) return RFW_HIP_OK;
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    (void)g_rccl.comm_destroy(I->comm);
+    I->comm = nullptr;
+    I->acc_source = nullptr;
+    return RFW_HIP_OK;
+}
+
 int rfw_hip_set_blue_noise(void* inst, const uint32_t* table, uint32_t n_words)
 {
     LOCK(inst);
@@ -1754,7 +1849,13 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     I->restart = true;
     I->width = w;
     I->height = h;
-    return alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
+    const int arc = alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
+    if (arc == RFW_HIP_OK && I->comm) { // the gather buffers follow the slab size
+        const size_t n = (size_t)I->capacity * I->max_batch * 3u;
+        HIP_TRY(I, I->d_send.ensure(n));
+        HIP_TRY(I, I->d_recv.ensure(n * I->world));
+    }
+    return arc;
 }
 
 int rfw_hip_set_point_lights(void* inst, const rfw_point_light* l, uint32_t n, const uint32_t* changed)

@@ -18,6 +18,9 @@
 #ifndef RFW_ANY_PARK
 #define RFW_ANY_PARK 1 // any hit parks its ray too, over a 12-row stack (measured: no spills at 8 waves per SIMD, +0.6 %)
 #endif
+#ifndef RFW_SCALAR_NODES
+#define RFW_SCALAR_NODES 0
+#endif
 #ifndef RFW_RAY_IN_LDS
 #define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
 #endif
@@ -121,7 +124,27 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         if (!(cur & kLeafBit)) {
             // ---- interior node: 4-wide slab test on the quantised child boxes (64 B = 4 dwordx4 per lane)
             const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+#if RFW_SCALAR_NODES
+            // experiment: when every active lane of the wavefront visits the SAME node (68 % of the primary rays' node tests, 20 % of the
+            // shadow rays'), fetch it once through the scalar cache instead of 4 vector loads through the texture-address unit
+            uint4 w0, w1, w2, ch;
+            {
+                typedef uint32_t su4 __attribute__((ext_vector_type(4)));
+                typedef const su4 __attribute__((address_space(4))) * scalar_ptr;
+                const uintptr_t mine = (uintptr_t)np;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mine), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mine >> 32));
+                const uintptr_t first = ((uintptr_t)hi << 32) | lo;
+                if (__ballot(mine != first) == 0ull) {
+                    scalar_ptr sp = (scalar_ptr)first;
+                    const su4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+                    w0 = make_uint4(a.x, a.y, a.z, a.w); w1 = make_uint4(b.x, b.y, b.z, b.w); w2 = make_uint4(c.x, c.y, c.z, c.w); ch = make_uint4(d.x, d.y, d.z, d.w);
+                } else {
+                    w0 = np[0]; w1 = np[1]; w2 = np[2]; ch = np[3];
+                }
+            }
+#else
             const uint4 w0 = np[0], w1 = np[1], w2 = np[2], ch = np[3];
+#endif
             if (COUNT) {
                 tc.nodes++;
                 if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) {

@@ -298,3 +298,48 @@ def test_batch_and_accumulator_corner_cases():
     b2.resize((24, 16), 1.0)                                                 # resize drops the frames: zeros again
     assert not b2.accumulator().any()
     b2.close()
+
+
+def test_library_owned_collective_with_a_one_rank_communicator():
+    """the all-gather inside the library (rfw_hip_comm_init: librccl opened at run time, ncclAllGather on the instance's
+    stream).  One GPU allows a one-rank communicator: render() then packs, gathers (to itself) and de-tiles the frame on its own, and the
+    result must be the frame of an instance without a communicator, for single frames, accumulation and batches."""
+    from rfw_rs_amd import BackendError, HipBackend, Scene
+    w, h = 200, 136
+    scene = Scene().build("soup", 1500, 5, 0.0, 4)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    plain = HipBackend.init(w, h, 1.0, max_path_length=3, max_batch=3)
+    scene.sync(plain)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, max_batch=3)
+    scene.mark_all_changed(); scene.sync(be)
+    uid = HipBackend.comm_unique_id()
+    assert len(uid) == 128
+    with pytest.raises(BackendError):
+        be.comm_init(uid, 1, 2)                       # not the shard this instance was created with
+    be.comm_init(uid, 0, 1)
+    with pytest.raises(BackendError):
+        be.comm_init(uid, 0, 1)                       # already has one
+    for _ in range(2):
+        plain.render(view); be.render(view)
+    assert be.frame_stats()["sample_count"] == 2
+    assert np.array_equal(be.framebuffer().view(np.uint32), plain.framebuffer().view(np.uint32))
+    a, b = be.accumulator(), plain.accumulator()
+    assert np.array_equal(a[..., :3].view(np.uint32), b[..., :3].view(np.uint32))   # the gathered slabs carry RGB (alpha is never written)
+    views = []
+    for i in range(3):
+        scene.set_camera([0.3 * i - 0.3, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    plain.render_batch(views); be.render_batch(views)
+    for f in range(3):
+        assert np.array_equal(be.framebuffer_at(f).view(np.uint32), plain.framebuffer_at(f).view(np.uint32)), f
+    be.resize((96, 64)); plain.resize((96, 64))
+    scene.set_aspect(96 / 64)
+    v2 = scene.view(96, 64)
+    be.render(v2); plain.render(v2)
+    assert np.array_equal(be.framebuffer().view(np.uint32), plain.framebuffer().view(np.uint32))
+    be.comm_destroy()
+    be.reset_accumulation(); plain.reset_accumulation()
+    be.render(v2); plain.render(v2)
+    assert np.array_equal(be.framebuffer().view(np.uint32), plain.framebuffer().view(np.uint32))
+    be.close(); plain.close()

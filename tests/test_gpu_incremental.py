@@ -76,7 +76,11 @@ def test_one_mesh_of_c4_changes_without_rebuilding_the_rest():
     edit(lambda: scene.replace_mesh_with_sphere(12, 11, 7, quality=5), "one mesh grows and is appended", 60.0)
     # 4. a mesh that shrinks stays where it is; a mesh is unloaded; a new mesh appears
     edit(lambda: scene.replace_mesh_with_sphere(50, 49, 3, quality=3), "one mesh shrinks in place", 8.0)
-    edit(lambda: scene.remove_mesh(20), "one mesh unloaded", 8.0)
+    def unload_20():
+        import ctypes as C
+        scene.remove_mesh(20)                                    # synchronize_system hands the unload to `be`; the oracle gets it directly
+        orc._l.orc_unload_3d_meshes(orc._h, (C.c_uint32 * 1)(20), 1)
+    edit(unload_20, "one mesh unloaded", 8.0)
     edit(lambda: scene.add_sphere_mesh(19, 5), "one mesh added", 60.0)
     assert be.scene_stats()["blas_nodes"] != nodes0
     be.close()
