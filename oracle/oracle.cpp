@@ -43,8 +43,9 @@
  *   D3  texture filtering is implementation-defined in GLSL/Vulkan (weight precision, rounding), so one meaning is
  *       fixed here and in the kernels (texture_sample below): the sampler of gpu-rt/src/lib.rs:1026-1038 — repeat
  *       addressing, linear filter at LOD 0 (magnification), nearest at LOD >= 1 — with f32 weights and
- *       byte * (1/255) unorm decoding; textures are sampled at the size and mip count the trait hands over (gpu-rt
- *       resamples every texture to 1024^2 x 5 mips on the host first, lib.rs:1230-1246: not restated).  With no
+ *       byte * (1/255) unorm decoding.  gpu-rt's host-side normalisation of every material texture to a 1024^2 x 5-mip array layer
+ *       (lib.rs:1230-1246) IS restated (round 2, texture_array_layer; option "texture_array" = 0 samples at native size); its two
+ *       helpers come from the un-vendored crate l3d 0.3 and are pinned as point resampling + 2 x 2 box filter.  With no
  *       skybox set a miss adds the constant sky colour (default black = gpu-rt's zero-initialised 64x64 skybox,
  *       lib.rs:424-436).
  *   D4  instance ids follow the live API numbering mesh_base[mesh] + slot.
@@ -464,6 +465,7 @@ struct Oracle {
     uint32_t max_path_length = 3;
     float clamp_value = 10.0f;
     bool nee = true;
+    bool texture_array = true; // gpu-rt's 1024 x 1024 x 5-mip texture array (option "texture_array" = 0: textures at their native size)
     bool tie_break = true;
     vec3 sky{0.0f, 0.0f, 0.0f};
     int threads = 1;
@@ -1352,11 +1354,46 @@ static void copy_tex(Tex& t, const rfw_texture_data* d)
     t.mips = levels;
     t.bytes.assign(d->bytes, d->bytes + texels * 4);
 }
+// gpu-rt/src/lib.rs:1230-1246: every material texture that is not 1024 x 1024 is resized to that and gets a fresh 5-level mip chain
+// (l3d 0.3's Texture::resized + generate_mipmaps, crate not vendored: pinned here as point resampling at texel centres and a 2 x 2 box
+// filter per channel with round-to-nearest, D3)
+static void texture_array_layer(Tex& t)
+{
+    const uint32_t S = 1024, LEVELS = 5;
+    if (t.w == 0 || t.h == 0 || (t.w == S && t.h == S)) return;
+    std::vector<uint8_t> out((size_t)S * S * 4);
+    for (uint32_t y = 0; y < S; y++)
+        for (uint32_t x = 0; x < S; x++) {
+            const uint32_t sx = (uint32_t)(((uint64_t)(2 * x + 1) * t.w) / (2 * S)), sy = (uint32_t)(((uint64_t)(2 * y + 1) * t.h) / (2 * S));
+            for (int c = 0; c < 4; c++) out[((size_t)y * S + x) * 4 + c] = t.bytes[((size_t)sy * t.w + sx) * 4 + c];
+        }
+    size_t src = 0;
+    uint32_t w = S, h = S;
+    for (uint32_t l = 1; l < LEVELS; l++) {
+        const uint32_t nw = w / 2, nh = h / 2;
+        const size_t dst = out.size();
+        out.resize(dst + (size_t)nw * nh * 4);
+        for (uint32_t y = 0; y < nh; y++)
+            for (uint32_t x = 0; x < nw; x++)
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t sum = out[src + ((size_t)(2 * y) * w + 2 * x) * 4 + c] + out[src + ((size_t)(2 * y) * w + 2 * x + 1) * 4 + c] +
+                                         out[src + ((size_t)(2 * y + 1) * w + 2 * x) * 4 + c] + out[src + ((size_t)(2 * y + 1) * w + 2 * x + 1) * 4 + c];
+                    out[dst + ((size_t)y * nw + x) * 4 + c] = (uint8_t)((sum + 2u) / 4u);
+                }
+        src = dst;
+        w = nw; h = nh;
+    }
+    t.bytes.swap(out);
+    t.w = S; t.h = S; t.mips = LEVELS;
+}
 ORC_API int orc_set_textures(void* p, const rfw_texture_data* t, uint32_t n, const uint32_t* /*changed*/)
 {
     Oracle& o = *(Oracle*)p;
     o.textures.resize(n);
-    for (uint32_t i = 0; i < n; i++) copy_tex(o.textures[i], t + i);
+    for (uint32_t i = 0; i < n; i++) {
+        copy_tex(o.textures[i], t + i);
+        if (o.texture_array) texture_array_layer(o.textures[i]);
+    }
     return 0;
 }
 ORC_API int orc_set_skybox(void* p, const rfw_texture_data* t) { copy_tex(((Oracle*)p)->skybox, t); return 0; }
@@ -1435,6 +1472,7 @@ ORC_API int orc_set_option(void* p, const char* key, double value)
     else if (k == "clamp_value") o.clamp_value = (float)value;
     else if (k == "nee") o.nee = value != 0.0;
     else if (k == "tie_break") o.tie_break = value != 0.0;
+    else if (k == "texture_array") o.texture_array = value != 0.0;
     else if (k == "threads") o.threads = value < 1 ? 1 : (int)value;
     else if (k == "sample_count") o.sample_count = (uint32_t)value;
     else if (k == "sky_r") o.sky.x = (float)value;

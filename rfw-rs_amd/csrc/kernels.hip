@@ -552,7 +552,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                                     sh_e = contribution;
                                     sh_slot = slot;
                                     push_shadow = true;
+#if RFW_SHADOW_BUCKETS == 16
+                                    {
+                                        const float ax = gl_abs(gN.x), ay = gl_abs(gN.y), az = gl_abs(gN.z);
+                                        const int cls = (ay >= ax && ay >= az) ? (gN.y > 0.0f ? 1 : 2) : (ax >= az ? 0 : 3);
+                                        light_bucket = (picked & 3) | (cls << 2);
+                                    }
+#else
                                     light_bucket = picked & (kShadowBuckets - 1);
+#endif
                                 }
                             }
                         }

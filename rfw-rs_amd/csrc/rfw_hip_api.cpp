@@ -188,6 +188,7 @@ struct Instance {
     std::vector<const void*> download_dst; // destinations of the copies queued since the last wait on this slot
     uint32_t max_batch = 1; // frames one render_batch() call may trace together (buffers are sized for it)
     uint32_t builder = RFW_HIP_BUILDER_AUTO;
+    bool texture_array = true; // material textures as layers of gpu-rt's 1024 x 1024 x 5-mip array (option "texture_array")
     uint32_t flags = 0;
     float sky[3] = {0, 0, 0};
     bool timing = true;
@@ -1669,6 +1670,50 @@ int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, 
     return RFW_HIP_OK;
 }
 
+// gpu-rt keeps every material texture as one layer of a 1024 x 1024 array with 5 mip levels: a texture of another size is resampled to
+// 1024^2 and its mip chain regenerated on the host (backends/gpu-rt/src/lib.rs:1230-1246: `t.resized(1024, 1024)` +
+// `generate_mipmaps(Texture::MIP_LEVELS)`, both from the un-vendored crate l3d 0.3, crates/rfw-scene/Cargo.toml), so shade.comp's LOD
+// arithmetic (MIPLEVELCOUNT 5, shade.comp:39,273-281) always sees that geometry.  Restated here with the one meaning this project pins
+// for l3d's two helpers: point resampling (source texel of the destination texel's centre) and a 2 x 2 box filter per channel, rounded to
+// nearest — the filter rfw-rs_amd/host already uses for the mips it hands over.  Option "texture_array" = 0 samples at native size.
+constexpr uint32_t kTexArraySize = 1024, kTexArrayMips = 5;
+static void normalise_texture(TexHost& t)
+{
+    if (t.w == 0 || t.h == 0 || (t.w == kTexArraySize && t.h == kTexArraySize)) return; // already an array layer: kept as handed over
+    std::vector<uint32_t> out;
+    out.reserve((size_t)kTexArraySize * kTexArraySize * 4 / 3 + 16);
+    out.resize((size_t)kTexArraySize * kTexArraySize);
+    for (uint32_t y = 0; y < kTexArraySize; y++) {
+        const uint32_t sy = (uint32_t)(((uint64_t)(2 * y + 1) * t.h) / (2 * kTexArraySize)); // floor((y + 0.5) * h / 1024)
+        for (uint32_t x = 0; x < kTexArraySize; x++) {
+            const uint32_t sx = (uint32_t)(((uint64_t)(2 * x + 1) * t.w) / (2 * kTexArraySize));
+            out[(size_t)y * kTexArraySize + x] = t.texels[(size_t)sy * t.w + sx];
+        }
+    }
+    size_t src = 0;
+    uint32_t w = kTexArraySize, h = kTexArraySize;
+    for (uint32_t l = 1; l < kTexArrayMips; l++) {
+        const uint32_t nw = w >> 1, nh = h >> 1;
+        const size_t dst = out.size();
+        out.resize(dst + (size_t)nw * nh);
+        for (uint32_t y = 0; y < nh; y++)
+            for (uint32_t x = 0; x < nw; x++) {
+                const uint32_t a = out[src + (size_t)(2 * y) * w + 2 * x], b = out[src + (size_t)(2 * y) * w + 2 * x + 1],
+                               c = out[src + (size_t)(2 * y + 1) * w + 2 * x], d = out[src + (size_t)(2 * y + 1) * w + 2 * x + 1];
+                uint32_t r = 0;
+                for (int ch = 0; ch < 4; ch++) {
+                    const uint32_t sum = ((a >> (8 * ch)) & 255u) + ((b >> (8 * ch)) & 255u) + ((c >> (8 * ch)) & 255u) + ((d >> (8 * ch)) & 255u);
+                    r |= ((sum + 2u) / 4u) << (8 * ch);
+                }
+                out[dst + (size_t)y * nw + x] = r;
+            }
+        src = dst;
+        w = nw; h = nh;
+    }
+    t.texels.swap(out);
+    t.w = kTexArraySize; t.h = kTexArraySize; t.mips = kTexArrayMips;
+}
+
 static bool copy_texture(TexHost& t, const rfw_texture_data* d)
 {
     t = TexHost();
@@ -1693,8 +1738,10 @@ int rfw_hip_set_textures(void* inst, const rfw_texture_data* textures, uint32_t 
     LOCK(inst);
     if (n && !textures) return fail(I, RFW_HIP_E_INVALID, "set_textures: null data");
     I->textures.resize(n);
-    for (uint32_t k = 0; k < n; k++)
+    for (uint32_t k = 0; k < n; k++) {
         if (!copy_texture(I->textures[k], textures + k)) return fail(I, RFW_HIP_E_INVALID, "set_textures: unknown texel format");
+        if (I->texture_array) normalise_texture(I->textures[k]);
+    }
     I->textures_dirty = true;
     return RFW_HIP_OK;
 }
@@ -1934,6 +1981,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "count_traversal") I->flags = value != 0.0 ? (I->flags | RFW_HIP_FLAG_COUNT_TRAVERSAL) : (I->flags & ~RFW_HIP_FLAG_COUNT_TRAVERSAL);
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "timing") I->timing = value != 0.0;
+    else if (k == "texture_array") I->texture_array = value != 0.0; // applies to textures set from now on
     else if (k == "spill_rows") I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill); // tests: exercise the overflow path
     else if (k == "sky_r") I->sky[0] = (float)value;
     else if (k == "sky_g") I->sky[1] = (float)value;

@@ -113,7 +113,12 @@ def test_png_textures_reach_the_sampler(tmp_path, glb):
     for (x, y) in [(0, 0), (3, 5), (7, 7), (6, 1)]:
         got = orc.sample_texture(0, (x + 0.5) / 8, (y + 0.5) / 8, 0.0)
         assert np.array_equal(got, tex[y, x].astype(np.float32) * np.float32(1.0 / 255.0)), (x, y)
-    assert np.allclose(orc.sample_texture(0, 0.3, 0.3, 3.0)[:3], tex[..., :3].reshape(-1, 3).mean(axis=0) / 255.0, atol=0.02)   # 1x1 mip = the mean
+    # as a layer of gpu-rt's 1024 x 1024 x 5 texture array every level still resolves the 8 x 8 source texels (level 4 is 64 x 64)
+    assert np.array_equal(orc.sample_texture(0, 0.3, 0.3, 4.0), tex[2, 2].astype(np.float32) * np.float32(1.0 / 255.0))
+    orc2 = Oracle(48, 32, threads=2)
+    orc2.set_option("texture_array", 0)                          # at its native size the importer's own mip chain is sampled
+    scene.mark_all_changed(); scene.sync(orc2)
+    assert np.allclose(orc2.sample_texture(0, 0.3, 0.3, 3.0)[:3], tex[..., :3].reshape(-1, 3).mean(axis=0) / 255.0, atol=0.02)   # 1x1 mip = the mean
     # the floor is lit and textured: a render is not uniform grey
     v = scene.view(48, 32)
     orc.render(v)

