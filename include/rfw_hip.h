@@ -223,6 +223,16 @@ RFW_HIP_API int rfw_hip_occludes(void* instance, const float* origins, const flo
 RFW_HIP_API int rfw_hip_depth_test(void* instance, const float* origins, const float* directions,
                                    float t_min, float t_max, uint64_t n, rfw_hip_hit* hits, uint32_t* depth);
 
+/* TIntersector::intersect4 / occludes4 (intersector.rs:129-166): the reference's 4-wide CPU packets.  SoA as rtbvh's RayPacket4 —
+ * origin_xyz4 = x[4] y[4] z[4], direction_xyz4 likewise; t4 = far limits on entry, hit distances on return; ids -1 for a miss.  On this
+ * backend a packet is four single-ray queries (each lane may have its own interval); batches of rays belong in rfw_hip_intersect /
+ * rfw_hip_occludes.  The reference's occludes4 is a stub that answers `true` four times (intersector.rs:129-131); this one answers.
+ * TIntersector::get_hit_record has no counterpart: the mesh side of it is commented out in the reference (crates/rfw-backend/src/structs.rs:1253). */
+RFW_HIP_API int rfw_hip_intersect4(void* instance, const float* origin_xyz4, const float* direction_xyz4, const float* t_min4, float* t4,
+                                   int32_t* instance_ids4, int32_t* prim_ids4);
+RFW_HIP_API int rfw_hip_occludes4(void* instance, const float* origin_xyz4, const float* direction_xyz4, const float* t_min4, const float* t_max4,
+                                  uint8_t* occluded4);
+
 /* Debug read-back of the wavefront queues after the last render() bounce `bounce`
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
 RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);

@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_intersect4", "rfw_hip_occludes4",
 ]
 
 _lib = None
@@ -93,6 +93,8 @@ def hip_lib():
         l.rfw_hip_comm_unique_id.argtypes = [vp]
         l.rfw_hip_comm_init.argtypes = [vp, vp, u32, u32]
         l.rfw_hip_comm_destroy.argtypes = [vp]
+        l.rfw_hip_intersect4.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        l.rfw_hip_occludes4.argtypes = [vp, vp, vp, vp, vp, vp]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_read_accumulator_at.argtypes = [vp, C.c_uint32, vp, u64]
         l.rfw_hip_host_alloc.restype = vp
@@ -390,6 +392,24 @@ class HipBackend:
         tm = np.ascontiguousarray(t_max, dtype=np.float32)
         out = np.empty(len(o), dtype=np.uint8)
         self._check(self._l.rfw_hip_occludes(self._h, o.ctypes.data, d.ctypes.data, t_min, tm.ctypes.data, len(o), out.ctypes.data))
+        return out
+
+    def intersect4(self, origins, directions, t_min, t_max):
+        """TIntersector::intersect4 (intersector.rs:133-166): (4, 3) origins / directions, per-lane intervals -> (instance ids, prim ids, t)."""
+        o = np.ascontiguousarray(np.asarray(origins, np.float32).T)   # SoA: x[4] y[4] z[4]
+        d = np.ascontiguousarray(np.asarray(directions, np.float32).T)
+        tmin = np.ascontiguousarray(t_min, dtype=np.float32)
+        t = np.array(t_max, dtype=np.float32)
+        ii, pp = np.empty(4, np.int32), np.empty(4, np.int32)
+        self._check(self._l.rfw_hip_intersect4(self._h, o.ctypes.data, d.ctypes.data, tmin.ctypes.data, t.ctypes.data, ii.ctypes.data, pp.ctypes.data))
+        return ii, pp, t
+
+    def occludes4(self, origins, directions, t_min, t_max):
+        o = np.ascontiguousarray(np.asarray(origins, np.float32).T)
+        d = np.ascontiguousarray(np.asarray(directions, np.float32).T)
+        tmin, tmax = np.ascontiguousarray(t_min, dtype=np.float32), np.ascontiguousarray(t_max, dtype=np.float32)
+        out = np.empty(4, np.uint8)
+        self._check(self._l.rfw_hip_occludes4(self._h, o.ctypes.data, d.ctypes.data, tmin.ctypes.data, tmax.ctypes.data, out.ctypes.data))
         return out
 
     def bandwidth_probe(self, nbytes=1 << 30, iterations=20):

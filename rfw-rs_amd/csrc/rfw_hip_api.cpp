@@ -2422,6 +2422,37 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
     return rc;
 }
 
+
+// TIntersector::intersect4 / occludes4 (crates/rfw-scene/src/intersector.rs:129-166): the reference's 4-wide CPU packets, as calls of the
+// batch queries with n = 4.  A packet is SoA as rtbvh's RayPacket4: origin_x[4], origin_y[4], origin_z[4], direction_x[4], ... ; t[4] holds
+// the far limits on entry and the hit distances on return (unchanged where nothing was hit), ids are -1 for a miss.
+int rfw_hip_intersect4(void* inst, const float* origin_xyz4, const float* direction_xyz4, const float* t_min4, float* t4, int32_t* instance_ids4, int32_t* prim_ids4)
+{
+    if (!inst) return RFW_HIP_E_INVALID;
+    if (!origin_xyz4 || !direction_xyz4 || !t_min4 || !t4 || !instance_ids4 || !prim_ids4) { LOCK(inst); return fail(I, RFW_HIP_E_INVALID, "intersect4: null pointer"); }
+    for (int k = 0; k < 4; k++) { // every lane may carry its own interval: one single-ray query each (the device form of a packet is a batch)
+        const float o[3] = {origin_xyz4[k], origin_xyz4[4 + k], origin_xyz4[8 + k]}, d[3] = {direction_xyz4[k], direction_xyz4[4 + k], direction_xyz4[8 + k]};
+        rfw_hip_hit h;
+        const int rc = rfw_hip_intersect(inst, o, d, t_min4[k], t4[k], 1, &h);
+        if (rc != RFW_HIP_OK) return rc;
+        instance_ids4[k] = h.inst;
+        prim_ids4[k] = h.tri;
+        if (h.inst >= 0) t4[k] = h.t;
+    }
+    return RFW_HIP_OK;
+}
+int rfw_hip_occludes4(void* inst, const float* origin_xyz4, const float* direction_xyz4, const float* t_min4, const float* t_max4, uint8_t* occluded4)
+{
+    if (!inst) return RFW_HIP_E_INVALID;
+    if (!origin_xyz4 || !direction_xyz4 || !t_min4 || !t_max4 || !occluded4) { LOCK(inst); return fail(I, RFW_HIP_E_INVALID, "occludes4: null pointer"); }
+    for (int k = 0; k < 4; k++) {
+        const float o[3] = {origin_xyz4[k], origin_xyz4[4 + k], origin_xyz4[8 + k]}, d[3] = {direction_xyz4[k], direction_xyz4[4 + k], direction_xyz4[8 + k]};
+        const int rc = rfw_hip_occludes(inst, o, d, t_min4[k], t_max4 + k, 1, occluded4 + k);
+        if (rc != RFW_HIP_OK) return rc;
+    }
+    return RFW_HIP_OK;
+}
+
 // what: "hit0"/"hit1" (uint4), "ray_o0"/"ray_o1", "ray_d0"/"ray_d1", "thr0"/"thr1", "sh_o", "sh_d", "sh_e" (float4), "counters",
 //       "xforms" (InstanceXform), "normals" (InstanceNormal)
 int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, uint64_t* written)

@@ -343,3 +343,28 @@ def test_library_owned_collective_with_a_one_rank_communicator():
     be.render(v2); plain.render(v2)
     assert np.array_equal(be.framebuffer().view(np.uint32), plain.framebuffer().view(np.uint32))
     be.close(); plain.close()
+
+
+def test_packet_queries_are_four_single_ray_queries():
+    """TIntersector::intersect4 / occludes4 (intersector.rs:129-166) in rtbvh's SoA packet layout."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("soup", 1200, 3, 0.0, 2)
+    be = HipBackend.init(32, 32)
+    orc = Oracle(32, 32)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        o = rng.uniform(-3, 3, (4, 3)).astype(np.float32)
+        d = rng.normal(size=(4, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        tmin = rng.uniform(1e-4, 0.5, 4).astype(np.float32)
+        tmax = rng.uniform(1.0, 30.0, 4).astype(np.float32)
+        ii, pp, t = be.intersect4(o, d, tmin, tmax)
+        occ = be.occludes4(o, d, tmin, tmax)
+        for k in range(4):
+            r = orc.intersect(o[k:k + 1], d[k:k + 1], t_min=float(tmin[k]), t_max=float(tmax[k]), brute=True)
+            assert ii[k] == r["inst"][0] and pp[k] == r["tri"][0]
+            assert t[k] == (r["t"][0] if r["inst"][0] >= 0 else tmax[k])
+            assert bool(occ[k]) == bool(orc.occludes(o[k:k + 1], d[k:k + 1], tmax[k:k + 1], t_min=float(tmin[k]), brute=True)[0])
+    be.close()
