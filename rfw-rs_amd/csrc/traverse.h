@@ -18,6 +18,10 @@
 #ifndef RFW_ANY_PARK
 #define RFW_ANY_PARK 1 // any hit parks its ray too, over a 12-row stack (measured: no spills at 8 waves per SIMD, +0.6 %)
 #endif
+#ifndef RFW_POP_DS_READ
+#define RFW_POP_DS_READ 1 // bit 0: any hit, bit 1: closest hit — pops read LDS with ds_read_b32 instead of the flat load the compiler merges the two stack homes into
+#endif
+
 #ifndef RFW_SCALAR_NODES
 #define RFW_SCALAR_NODES 0
 #endif
@@ -100,6 +104,10 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     uint32_t cur = 0;          // TLAS root (interior ref 0)
     const Node4Q* nodes = sc.tlas_nodes; // node array of the current space (TLAS, or the entered instance's BLAS)
 
+    // pops of the any-hit kernel read LDS with ds_read_b32 (measured +0.7 % frame rate); the closest-hit kernels keep the flat load the
+    // compiler builds, because every other formulation of their pop tried (ds_read, top of stack in a register) changed their loop nest
+    // for the worse (k_primary 0.335 -> 0.39 ms)
+    constexpr bool kDsPop = ((RFW_POP_DS_READ >> (ANY_HIT ? 0 : 1)) & 1) != 0;
     auto push = [&](uint32_t v) {
         if (sp < kStack) lds_stack[sp * kTraceBlock + lane_slot] = v;
         else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
@@ -114,6 +122,17 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     };
     auto pop = [&]() -> uint32_t {
         sp--;
+        if (kDsPop) {
+            // The LDS read is unconditional (row clamped) and the HBM spill row overrides it in a branch that is almost never taken.  Written
+            // as `sp < kStack ? lds[...] : spill[...]` the compiler selects between the two ADDRESSES and issues one flat_load_dword — a
+            // vector-memory instruction through the texture-address unit, for every pop, although the entry is in LDS
+            uint32_t v = lds_stack[(sp < kStack ? sp : kStack - 1) * kTraceBlock + lane_slot];
+            if (__builtin_expect(sp >= kStack, 0)) {
+                v = sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
+                asm volatile("" : "+v"(v)); // the merged value is not a load: keeps the compiler from folding both loads into one flat load again
+            }
+            return v;
+        }
         if (sp < kStack) return lds_stack[sp * kTraceBlock + lane_slot];
         return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
     };
