@@ -25,7 +25,12 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kBins = 16;
-constexpr uint32_t kSmall = 256;   // primitives a workgroup finishes in LDS (one per thread)
+constexpr uint32_t kSmall = 256;   // primitives a workgroup finishes in LDS (one per thread): the CAPACITY of phase 2
+// The range size at which phase 1 hands over to phase 2.  A workgroup of phase 2 walks its subtree one split after the other (~15 us
+// each), so a 256-primitive range takes ~2 ms — invisible next to thousands of such workgroups of a large mesh, but the whole latency of
+// a small one (a 5120-triangle mesh: 0.5 ms of levels + 2.0 ms of phase 2).  Small meshes therefore hand over at 64 primitives: two more
+// levels (~0.1 ms each, launch- and read-back-bound), a quarter of the serial walk (measured: 2.5 -> 1.7 ms for that mesh, device done)
+inline uint32_t small_limit_for(uint32_t n) { return n <= 32768u ? 64u : kSmall; }
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr int kMaxLevels = 96;
 
@@ -106,7 +111,7 @@ __global__ void k_root_bounds(const DevBox* __restrict__ boxes, uint32_t n, Coun
             atomicMin(&ctr->root_bounds[6 + a], f_order(clo[a])); atomicMax(&ctr->root_bounds[9 + a], f_order(chi[a]));
         }
 }
-__global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins)
+__global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins, uint32_t small_limit)
 {
     if (threadIdx.x != 0) return;
     SNode r;
@@ -116,7 +121,7 @@ __global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* a
     }
     r.first = 0; r.count = n; r.left = kNone; r.parent = kNone;
     nodes[0] = r;
-    if (n > kSmall) {
+    if (n > small_limit) {
         active[0] = 0; bin_slot[0] = 0; is_big[0] = 1; ctr->n_active[0] = 1;
         Bin e; e.count = 0;
         for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
@@ -336,14 +341,14 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevBox* __restrict__
 }
 
 __global__ void k_classify(const uint32_t* __restrict__ active_in, uint32_t* active_out, uint32_t level_parity, Counters* ctr, const SNode* __restrict__ nodes,
-                           uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins)
+                           uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins, uint32_t small_limit)
 {
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     if (k >= 2u * ctr->n_active[level_parity]) return;
     const uint32_t parent = active_in[k >> 1];
     const uint32_t nd = nodes[parent].left + (k & 1u);
     if ((k & 1u) == 0u) is_big[parent] = 0; // the parent's range now belongs to its children
-    if (nodes[nd].count > kSmall) {
+    if (nodes[nd].count > small_limit) {
         const uint32_t slot = atomicAdd(&ctr->n_active[level_parity ^ 1u], 1u);
         active_out[slot] = nd;
         bin_slot[nd] = slot;
@@ -635,7 +640,7 @@ Layout make_layout(uint32_t n)
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t m = n > 0 ? n : 1;
     L.node_cap = (uint32_t)(4 * m + 64); // phase 1 makes < 2 nodes per queued range, phase 2 reserves 2c ids for a range of c primitives
-    L.big_cap = (uint32_t)(2 * m / kSmall + 2); // ranges above kSmall that can coexist on one level
+    L.big_cap = (uint32_t)(2 * m / small_limit_for(n) + 2); // ranges above the hand-over size that can coexist on one level
     L.ctr = take(sizeof(Counters));
     L.nodes = take((size_t)L.node_cap * sizeof(SNode));
     for (int k = 0; k < 2; k++) { L.order[k] = take(m * 4); L.nop[k] = take(m * 4); L.active[k] = take((size_t)L.big_cap * 4); }
@@ -688,7 +693,8 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     }
     hipLaunchKernelGGL(k_root_init, dim3(1), dim3(64), 0, s, ctr);
     if (n) hipLaunchKernelGGL(k_root_bounds, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, n, ctr, order[0], nop[0]);
-    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, is_big, bins);
+    const uint32_t small_limit = small_limit_for(n);
+    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, is_big, bins, small_limit);
     static const bool dbg = getenv("RFW_SAH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto msf = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
@@ -697,13 +703,13 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     int levels = 0;
     // phase 1: level by level while nodes above kSmall remain (the count comes back to the host once per level)
     int cur = 0;
-    uint32_t n_active = n > kSmall ? 1u : 0u;
+    uint32_t n_active = n > small_limit ? 1u : 0u;
     for (int level = 0; level < kMaxLevels && n_active > 0; level++) {
         const uint32_t par = (uint32_t)(level & 1);
         hipLaunchKernelGGL(k_bin, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order[cur], nop[cur], nodes, bin_slot, is_big, bins, n);
         hipLaunchKernelGGL(k_split, dim3(blocks(n_active, 64)), dim3(64), 0, s, active[par], par, ctr, nodes, bins, bin_slot, splits, fill);
         hipLaunchKernelGGL(k_partition, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1], nodes, splits, is_big, fill, n);
-        hipLaunchKernelGGL(k_classify, dim3(blocks(2 * n_active, 64)), dim3(64), 0, s, active[par], active[par ^ 1], par, ctr, nodes, small, bin_slot, is_big, bins);
+        hipLaunchKernelGGL(k_classify, dim3(blocks(2 * n_active, 64)), dim3(64), 0, s, active[par], active[par ^ 1], par, ctr, nodes, small, bin_slot, is_big, bins, small_limit);
         hipLaunchKernelGGL(k_next_level, dim3(1), dim3(64), 0, s, ctr, par);
         cur ^= 1;
         uint32_t next = 0;

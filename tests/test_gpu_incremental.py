@@ -69,9 +69,9 @@ def test_one_mesh_of_c4_changes_without_rebuilding_the_rest():
         return total_ms
 
     # 1. one sphere gets a new shape, same triangle count: rebuilt in place (the full build of this scene takes ~60 ms)
-    t1 = edit(lambda: scene.replace_mesh_with_sphere(7, 6, 4242), "one mesh of 65 rebuilt in place", 8.0)
+    t1 = edit(lambda: scene.replace_mesh_with_sphere(7, 6, 4242), "one mesh of 65 rebuilt in place", 4.0)
     # 2. the same again (warm: buffers and workspaces exist)
-    t2 = edit(lambda: scene.replace_mesh_with_sphere(30, 29, 99), "one mesh of 65 rebuilt in place, warm", 5.0)
+    t2 = edit(lambda: scene.replace_mesh_with_sphere(30, 29, 99), "one mesh of 65 rebuilt in place, warm", 3.0)
     # 3. a mesh that grows (5120 -> 20480 triangles) moves behind the others
     edit(lambda: scene.replace_mesh_with_sphere(12, 11, 7, quality=5), "one mesh grows and is appended", 60.0)
     # 4. a mesh that shrinks stays where it is; a mesh is unloaded; a new mesh appears
