@@ -149,7 +149,7 @@ def main():
             # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created), so RCCL's
             # all-gather is ordered against the kernels
             st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
-            for key in ("sah_max_leaf", "sah_trav_cost"):  # builder experiments
+            for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays"):  # builder / queue-order experiments
                 if os.environ.get("RFW_" + key.upper()):
                     be.set_option(key, float(os.environ["RFW_" + key.upper()]))
             scene.mark_all_changed()
@@ -362,14 +362,17 @@ def main():
             b_.close()
         inst, bes = [], []
 
-        def run_mode(slots, batch, frames, timing):
-            ins = make_instances(max(slots, 1), batch, slots > 1)
+        def run_mode(slots, batch, frames, timing, spp=1):
+            ins = make_instances(max(slots, 1), max(batch, spp), slots > 1)
             mb = ins[0][0]
             mb.set_option("timing", 1 if timing else 0)
             seq = list(range(frames))
 
             def go(ids):
-                if batch > 1:
+                if spp > 1:  # `spp` samples of ONE image per call (C4's "4 spp"): one launch per stage over all samples
+                    for i in ids:
+                        mb.render_samples(views[i % N_VIEWS], spp)
+                elif batch > 1:
                     for j in range(0, len(ids), batch):
                         mb.render_batch([views[i % N_VIEWS] for i in ids[j:j + batch]])
                 else:
@@ -386,7 +389,7 @@ def main():
             el = time.perf_counter() - t_s
             ms, n = mb.drain_timing() if timing else ({}, 0)
             mb.close()
-            rays = sum(view_rays(i) for i in seq)
+            rays = sum(view_rays(i) for i in seq) * spp  # (samples 1 .. spp - 1 trace within a fraction of a percent of sample 0's ray count)
             return {"Mrays_per_s": round(rays / el / 1e6, 1), "ms_per_frame": round(el / frames * 1e3, 4), "frames": frames}, ms, n
 
         nf_mode = max(args.mode_frames, 16)
@@ -398,6 +401,8 @@ def main():
             modes["render() per frame, 8 frame slots"] = run_mode(8, 1, nf_mode, False)[0]
         if not (B == 8 and use_slots and F == 3):
             modes["render_batch of 8, 3 frame slots (extension call)"] = run_mode(3, 8, nf_mode - nf_mode % 8, False)[0]
+        if args.max_path_length > 1:
+            modes["render_samples: 4 spp of one image per call, 3 frame slots (extension call)"] = run_mode(3, 1, max(nf_mode // 4, 8), False, spp=4)[0]
     elif F == 1 and B == 1 and single:
         ms, n = bes[0].drain_timing()
         iso = (ms, n)

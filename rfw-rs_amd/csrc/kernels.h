@@ -53,7 +53,8 @@ void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uin
                               InstanceXform* xf, InstanceNormal* nm);
 void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count);
 void launch_primary_batch(hipStream_t s, const CameraParams& cam, const BatchViews& views, const SceneDev& sc, const PathDev& p, bool count);
-void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
+void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count, const uint32_t* order = nullptr);
+void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, uint32_t bounce, uint32_t* keys, uint32_t* vals);
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe

@@ -47,4 +47,9 @@ void launch_skin_triangles(hipStream_t s, const rfw_rt_triangle* src, const rfw_
 // bounds of n triangles' vertices -> out (one DevBox); scratch = 6 uint32
 void launch_mesh_bounds(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, uint32_t* scratch, DevBox* out);
 
+// (key, value) radix sort of n 32-bit pairs on `s` (hipCUB); bits [0, end_bit) of the keys take part
+size_t sort_pairs_workspace_bytes(uint32_t n);
+hipError_t sort_pairs_u32(hipStream_t s, void* workspace, size_t workspace_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, int end_bit);
+
 } // namespace rfwhip

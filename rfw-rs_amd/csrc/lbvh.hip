@@ -417,6 +417,19 @@ inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 size_t lbvh_workspace_bytes(uint32_t n) { return make_layout(n, cub_temp_bytes(n)).total; }
 
+size_t sort_pairs_workspace_bytes(uint32_t n)
+{
+    size_t a = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)std::max<uint32_t>(n, 1u), 0, 32);
+    return a + 256;
+}
+hipError_t sort_pairs_u32(hipStream_t s, void* workspace, size_t workspace_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, int end_bit)
+{
+    if (n == 0) return hipSuccess;
+    return hipcub::DeviceRadixSort::SortPairs(workspace, workspace_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, s);
+}
+
 hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out, uint32_t* order_out,
                       uint32_t* node_count_out)
 {

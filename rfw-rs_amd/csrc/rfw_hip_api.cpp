@@ -299,6 +299,10 @@ struct Instance {
     DevBuf<float4> d_ray_o[2], d_ray_d[2], d_thr[2], d_sh_o, d_sh_d, d_sh_e, d_acc_slab, d_frame_acc, d_frame_out;
     DevBuf<uint32_t> d_present; // BGRA8 sRGB frame, made on demand by rfw_hip_download_frame(what = 2)
     DevBuf<uint4> d_hit[2];
+    // extension rays traced in spatial order (option "sort_extension_rays"): (key, queue index) pairs, sorted with hipCUB on the frame's stream
+    DevBuf<uint32_t> d_sort_keys[2], d_sort_vals[2];
+    DevBuf<char> d_sort_ws;
+    int sort_extension_rays = 2; // 0 never, 1 always, 2 only where it pays: batches of frames / samples (see do_render)
     void* external_slab = nullptr;
     // multi-GPU inside the library (rfw_hip_comm_init): this rank's RGB slab(s) -> ncclAllGather on the instance's stream -> assemble
     ncclComm_t comm = nullptr;
@@ -1323,7 +1327,23 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
             if (b == 0 && k > 1) launch_primary_batch(st[s], cam[s], bv, sc[s], p[s], count);
             else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
-            else launch_extend(st[s], cam[s], sc[s], p[s], b, count);
+            else {
+                const uint32_t* order = nullptr;
+                // Measured on C4, max path length 3: a single 1-spp frame has too few rays per cell and direction for the sort
+                // to form coherent wavefronts (+1.5 % with frames in flight, -2.7 % alone: it costs a 2 M-pair sort per bounce); a batch of 8
+                // frames — or k samples of one image — sorts 8 x / k x as many rays of the same surfaces together: +17 %
+                const int mode = scene_of(I)->sort_extension_rays;
+                if ((mode == 1 || (mode == 2 && k > 1)) && S == 1) { // (sub-shards keep the queue order: one sort buffer per instance)
+                    const size_t n = p[s].capacity;
+                    for (int q = 0; q < 2; q++) { HIP_TRY(I, I->d_sort_keys[q].ensure(n)); HIP_TRY(I, I->d_sort_vals[q].ensure(n)); }
+                    HIP_TRY(I, I->d_sort_ws.ensure(sort_pairs_workspace_bytes((uint32_t)n)));
+                    launch_extension_keys(st[s], sc[s], p[s], b, I->d_sort_keys[0].ptr, I->d_sort_vals[0].ptr);
+                    HIP_TRY(I, sort_pairs_u32(st[s], I->d_sort_ws.ptr, I->d_sort_ws.cap, I->d_sort_keys[0].ptr, I->d_sort_keys[1].ptr, I->d_sort_vals[0].ptr,
+                                              I->d_sort_vals[1].ptr, (uint32_t)n, 32));
+                    order = I->d_sort_vals[1].ptr;
+                }
+                launch_extend(st[s], cam[s], sc[s], p[s], b, count, order);
+            }
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 1)], st[s]);
         }
         for (uint32_t s = 0; s < S; s++) {
@@ -1571,6 +1591,8 @@ void rfw_hip_destroy(void* inst)
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
         I->d_send.release(); I->d_recv.release();
+        for (int q = 0; q < 2; q++) { I->d_sort_keys[q].release(); I->d_sort_vals[q].release(); }
+        I->d_sort_ws.release();
         if (I->overflow_host) (void)hipHostFree(I->overflow_host);
         I->pins.release();
         I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
@@ -1981,6 +2003,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "count_traversal") I->flags = value != 0.0 ? (I->flags | RFW_HIP_FLAG_COUNT_TRAVERSAL) : (I->flags & ~RFW_HIP_FLAG_COUNT_TRAVERSAL);
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "timing") I->timing = value != 0.0;
+    else if (k == "sort_extension_rays") I->sort_extension_rays = std::max(0, std::min(2, (int)value));
     else if (k == "texture_array") I->texture_array = value != 0.0; // applies to textures set from now on
     else if (k == "spill_rows") I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill); // tests: exercise the overflow path
     else if (k == "sky_r") I->sky[0] = (float)value;
