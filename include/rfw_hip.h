@@ -243,7 +243,8 @@ RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, 
  *   [36,39) B  [39] t  [40] backfacing (0/1)  [41] r3 (op 4: r0)  [42] r4  [43] light area (op 3)
  * and 12 output floats.  op 0: BSDFEval -> rgb (gpu-rt/shaders/disney.glsl:110-195); 1: BSDFPdf -> pdf (:89-108); 2: BSDFSample -> wi.xyz,
  * pdf, type (:197-263); 3: CalculateLightPDF -> pdf (shade.comp:325-328); 4: RandomPointOnLight with the lights set on this instance
- * (synchronize first) -> P.xyz, pickProb, lightPdf, colour.rgb, picked light (shade.comp:413-528). */
+ * (synchronize first) -> P.xyz, pickProb, lightPdf, colour.rgb, picked light (shade.comp:413-528); 5: RandomBarycentrics(r0 = [41]) -> barycentrics
+ * (shade.comp:371-411). */
 RFW_HIP_API int rfw_hip_debug_eval_shading(void* instance, int op, uint64_t n, const float* in48, float* out12);
 
 /* A batch of `count` independent NEW images, one per view, traced as one tall virtual frame: every stage of the wavefront loop is ONE

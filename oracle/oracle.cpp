@@ -1427,7 +1427,8 @@ ORC_API float orc_blue_noise_sample(void* p, uint32_t sample_count, int x, int y
 //   [0,24) a rfw_device_material (its 96 bytes)   [24,27) N   [27,30) wo (op 3: D; op 4: I)   [30,33) wi   [33,36) T   [36,39) B
 //   [39] t   [40] backfacing (0 / 1)   [41] r3 (op 4: r0)   [42] r4   [43] light area (op 3)
 // and 12 output floats.  op 0: BSDFEval -> rgb;  1: BSDFPdf -> pdf;  2: BSDFSample -> wi.xyz, pdf, type;
-// 3: CalculateLightPDF -> pdf;  4: RandomPointOnLight (the lights set on this instance) -> P.xyz, pickProb, lightPdf, color.rgb, picked
+// 3: CalculateLightPDF -> pdf;  4: RandomPointOnLight (the lights set on this instance) -> P.xyz, pickProb, lightPdf, color.rgb, picked;
+// 5: RandomBarycentrics(r0 = [41]) -> barycentrics
 ORC_API int orc_eval_shading(void* p, int op, uint64_t n, const float* in, float* out)
 {
     const Oracle& o = *(Oracle*)p;
@@ -1458,6 +1459,7 @@ ORC_API int orc_eval_shading(void* p, int op, uint64_t n, const float* in, float
             idx = idx < 0 ? 0 : (idx > (int)lc - 1 ? (int)lc - 1 : idx);
             r[0] = P.x; r[1] = P.y; r[2] = P.z; r[3] = pick; r[4] = lpdf; r[5] = col.x; r[6] = col.y; r[7] = col.z; r[8] = (float)idx; break;
         }
+        case 5: { const vec3 b = RandomBarycentrics(q[41]); r[0] = b.x; r[1] = b.y; r[2] = b.z; break; }
         default: return -1;
         }
     }

@@ -921,6 +921,9 @@ __global__ __launch_bounds__(64) void k_eval_shading(const SceneDev sc, const Ca
         int picked = 0;
         const f3 P = RandomPointOnLight(lv, q[41], wo, N, pick, lpdf, col, picked);
         r[0] = P.x; r[1] = P.y; r[2] = P.z; r[3] = pick; r[4] = lpdf; r[5] = col.x; r[6] = col.y; r[7] = col.z; r[8] = (float)picked;
+    } else if (op == 5) {
+        const f3 b = RandomBarycentrics(q[41]);
+        r[0] = b.x; r[1] = b.y; r[2] = b.z;
     }
 }
 void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& cam, int op, uint32_t n, const float* in, float* out)

@@ -2523,7 +2523,7 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
 int rfw_hip_debug_eval_shading(void* inst, int op, uint64_t n, const float* in48, float* out12)
 {
     LOCK(inst);
-    if (op < 0 || op > 4 || (n && (!in48 || !out12)) || n > (1u << 24)) return fail(I, RFW_HIP_E_INVALID, "debug_eval_shading: bad arguments");
+    if (op < 0 || op > 5 || (n && (!in48 || !out12)) || n > (1u << 24)) return fail(I, RFW_HIP_E_INVALID, "debug_eval_shading: bad arguments");
     HIP_TRY(I, hipSetDevice(I->device));
     if (op == 4) {
         if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "debug_eval_shading: light sampling needs a synchronized scene");

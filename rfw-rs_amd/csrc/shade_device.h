@@ -269,17 +269,24 @@ RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, f
         }
     } else {
         const float r1 = (r3 - sd.transmission) / (1.0f - sd.transmission);
+        // sin / cos of the azimuth 2 pi r1: the diffuse lobe (utils.glsl:55-70: TWOPI * r0) and the specular lobe (r1 * TWOPI) evaluate the
+        // same product, so it is computed once in front of the branch — half the lanes of a wavefront take either side, and the ~80
+        // instructions of the shared sin / cos would otherwise run twice per wavefront
+        float sinPhiHalf, cosPhiHalf;
+        rfw_sincosf(r1 * RFW_TWOPI, &sinPhiHalf, &cosPhiHalf);
         if (r4 < 0.5f) {
             const float r2 = r4 * 2.0f;
             f3 d;
             if (r2 < sd.subsurface) {
                 const float r5 = r2 / sd.subsurface;
-                d = DiffuseReflectionUniform(r1, r5);
+                const float term2 = __builtin_sqrtf(1.0f - r5 * r5); // DiffuseReflectionUniform(r1, r5)
+                d = mk3(cosPhiHalf * term2, sinPhiHalf * term2, r5);
                 type = BSDF_TYPE_TRANSMITTED;
                 d.z *= -1.0f;
             } else {
                 const float r5 = (r2 - sd.subsurface) / (1.0f - sd.subsurface);
-                d = DiffuseReflectionCosWeighted(r1, r5);
+                const float term2 = __builtin_sqrtf(1.0f - r5);      // DiffuseReflectionCosWeighted(r1, r5)
+                d = mk3(cosPhiHalf * term2, sinPhiHalf * term2, __builtin_sqrtf(r5));
                 type = BSDF_TYPE_REFLECTED;
             }
             wi = T * d.x + B * d.y + N * d.z;
@@ -287,8 +294,6 @@ RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, f
             const float r2 = (r4 - 0.5f) * 2.0f;
             const float cosThetaHalf = __builtin_sqrtf((1.0f - r2) / (1.0f + (sqr(sd.roughness) - 1.0f) * r2));
             const float sinThetaHalf = __builtin_sqrtf(gl_max(0.0f, 1.0f - sqr(cosThetaHalf)));
-            float sinPhiHalf, cosPhiHalf;
-            rfw_sincosf(r1 * RFW_TWOPI, &sinPhiHalf, &cosPhiHalf);
             f3 halfway = T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
             if (dot(halfway, wo) <= 0.0f) halfway = halfway * -1.0f;
             wi = gl_reflect(wo * -1.0f, halfway);
@@ -381,22 +386,36 @@ RFW_DI f3 ld3(const rfw_vec3& v) { return mk3(v.x, v.y, v.z); }
 // shade.comp:325-328
 RFW_DI float CalculateLightPDF(f3 D, float t, float lightArea, f3 lightNormal) { return (t * t) / (-dot(D, lightNormal) * lightArea); }
 
-// shade.comp:371-411
+// shade.comp:371-411.  The reference walks 16 levels of a 4-way triangle subdivision, one base-4 digit of r0's 32 bits per level, and
+// returns the centroid of the last cell.  Every vertex on the way is a dyadic rational, so the walk is exact in float32 and any exact
+// evaluation gives the same bits.  Closed form: a digit d != 0 moves the centroid half-way towards vertex d - 1 of the current cell, a
+// digit 0 (the middle cell) leaves it and flips the cell's orientation for all later levels; with the cell shrinking by 2 per level,
+//   3 * centroid = (1, 1) + sum_i sign_i * 2^-(i+1) * c[d_i],   c[1] = (2, -1), c[2] = (-1, 2), c[3] = (-1, -1), sign_i = (-1)^(zeros before i).
+// The three digit classes as 16-bit masks (digit i at bit 15 - i) ARE the weighted sums; the sign is a prefix parity.  ~50 integer
+// instructions without a branch instead of 16 rounds of a divergent 4-way switch (~320 vector + ~200 scalar instructions of k_shade's
+// ~2400 per wavefront); tests/test_oracle_kat.py::test_random_barycentrics_closed_form proves the identity on the oracle's loop.
+RFW_DI uint32_t bary_even_bits(uint32_t x) // bits 0, 2, 4, ..., 30 -> bits 0 ... 15
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
 RFW_DI f3 RandomBarycentrics(float r0)
 {
     const uint32_t uf = f2u(r0 * 4294967296.0f);
-    f2 A{1.0f, 0.0f}, B{0.0f, 1.0f}, C{0.0f, 0.0f};
-    for (int i = 0; i < 16; ++i) {
-        const int d = (int)((uf >> (2u * (15u - (uint32_t)i))) & 0x3u);
-        f2 An, Bn, Cn;
-        if (d == 0) { An = (B + C) * 0.5f; Bn = (A + C) * 0.5f; Cn = (A + B) * 0.5f; }
-        else if (d == 1) { An = A; Bn = (A + B) * 0.5f; Cn = (A + C) * 0.5f; }
-        else if (d == 2) { An = (B + A) * 0.5f; Bn = B; Cn = (B + C) * 0.5f; }
-        else { An = (C + A) * 0.5f; Bn = (C + B) * 0.5f; Cn = C; }
-        A = An; B = Bn; C = Cn;
-    }
-    const f2 r = (A + B + C) * 0.3333333f;
-    return mk3(r.x, r.y, 1.0f - r.x - r.y);
+    const uint32_t L = bary_even_bits(uf), H = bary_even_bits(uf >> 1);
+    const uint32_t M1 = ~H & L, M2 = H & ~L & 0xffffu, M3 = H & L, Z = ~(H | L) & 0xffffu;
+    uint32_t t = Z; // bit p <- parity of the zero digits at bits >= p, i.e. at this and more significant digits
+    t ^= t >> 1; t ^= t >> 2; t ^= t >> 4; t ^= t >> 8;
+    const uint32_t N = (t >> 1) & 0xffffu; // digits whose cell is flipped: an odd number of zero digits BEFORE them
+    const int32_t d1 = (int32_t)(M1 & ~N) - (int32_t)(M1 & N), d2 = (int32_t)(M2 & ~N) - (int32_t)(M2 & N), d3 = (int32_t)(M3 & ~N) - (int32_t)(M3 & N);
+    const float sx = (float)(65536 + 2 * d1 - d2 - d3) * (1.0f / 65536.0f); // = A.x + B.x + C.x of the last cell, exactly
+    const float sy = (float)(65536 - d1 + 2 * d2 - d3) * (1.0f / 65536.0f);
+    const float rx = sx * 0.3333333f, ry = sy * 0.3333333f;
+    return mk3(rx, ry, 1.0f - rx - ry);
 }
 
 // shade.comp:413-528

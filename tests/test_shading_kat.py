@@ -328,3 +328,60 @@ def test_device_pdf_mass_sampling_and_white_furnace():
     for op in (0, 1, 2, 3):
         assert np.array_equal(be.eval_shading(op, rows).view(np.uint32), orc.eval_shading(op, rows).view(np.uint32)), op
     be.close()
+
+
+def bary_rows(n, seed):
+    rng = np.random.default_rng(seed)
+    r0 = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    r0[:8] = np.float32([0.0, 0.25, 0.5, 0.75, 1.0 - 2.0 ** -24, 2.0 ** -32, 1.0 / 3.0, 0.1])
+    rows = np.zeros((n, 48), np.float32)
+    rows[:, 41] = r0
+    return rows, r0
+
+
+def closed_form_barycentrics(r0):
+    """The identity the device's RandomBarycentrics uses (csrc/shade_device.h): 3 * centroid of the last cell of the 16-level walk =
+    (1, 1) + sum_i sign_i 2^-(i+1) c[d_i] — in exact integer arithmetic."""
+    bits = min(int(float(np.float32(r0)) * 4294967296.0), 0xFFFFFFFF)
+
+    def even_bits(x):
+        x &= 0x55555555
+        x = (x | (x >> 1)) & 0x33333333
+        x = (x | (x >> 2)) & 0x0F0F0F0F
+        x = (x | (x >> 4)) & 0x00FF00FF
+        return (x | (x >> 8)) & 0xFFFF
+    L, H = even_bits(bits), even_bits(bits >> 1)
+    M1, M2, M3, Z = ~H & L & 0xFFFF, H & ~L & 0xFFFF, H & L, ~(H | L) & 0xFFFF
+    t = Z
+    for sh in (1, 2, 4, 8):
+        t ^= t >> sh
+    N = (t >> 1) & 0xFFFF
+    d1, d2, d3 = ((M & ~N & 0xFFFF) - (M & N) for M in (M1, M2, M3))
+    f = np.float32
+    sx, sy = f(65536 + 2 * d1 - d2 - d3) * f(1.0 / 65536.0), f(65536 - d1 + 2 * d2 - d3) * f(1.0 / 65536.0)
+    rx, ry = sx * f(0.3333333), sy * f(0.3333333)
+    return np.array([rx, ry, f(1.0) - rx - ry], np.float32)
+
+
+def test_random_barycentrics_closed_form():
+    """shade.comp:371-411 is a 16-round walk with a 4-way switch per round; the device evaluates a branch-free closed form of it.  The
+    closed form equals the oracle's literal loop bit for bit (every vertex of the walk is a dyadic rational: float32 is exact)."""
+    from oracle.bindings import Oracle
+    rows, r0 = bary_rows(20000, 2)
+    got = Oracle(8, 8).eval_shading(5, rows)[:, :3]
+    want = np.stack([closed_form_barycentrics(x) for x in r0])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.allclose(got.sum(axis=1), 1.0, atol=1e-6) and (got > -1e-6).all()
+    # and the float64 formulation of the walk agrees
+    for k in range(0, 2000, 7):
+        assert np.allclose(got[k], ref.random_barycentrics(r0[k]), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_random_barycentrics_equal_the_oracle_loop():
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend
+    rows, _ = bary_rows(200000, 3)
+    be = HipBackend.init(16, 16)
+    assert np.array_equal(be.eval_shading(5, rows)[:, :3].view(np.uint32), Oracle(8, 8).eval_shading(5, rows)[:, :3].view(np.uint32))
+    be.close()
