@@ -477,7 +477,7 @@ def main():
                        "per_frame_synchronize_wall_ms_in_timed_region": round(sync_ms[0] / args.steps, 3) if animated else None},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the contract's CPU leg)
             check = []
             if timed_frames_gpu is not None:
                 check = [(views[vi % N_VIEWS], (frame0_time + k_ * (args.steps - 1)) if animated else None) for k_, (vi, _) in enumerate(timed_frames_gpu)]
