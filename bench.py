@@ -71,6 +71,7 @@ def main():
                          "run on what the glTF importer (host/gltf.cpp) reads back — the configurations of BASELINE.json are glTF scenes")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (CPU baseline + check of the timed frames)")
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary modes (one frame at a time / batches) after the timed region")
+    ap.add_argument("--separate-spheres", action="store_true", help="atrium1m: C4's 64 displaced icospheres as 64 meshes with one instance each (65 meshes, SURVEY §8d literally) instead of one baked mesh")
     ap.add_argument("--identical-frames", action="store_true", help="every frame the same view (round 1's configuration; frames then share every cache line)")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
@@ -107,7 +108,7 @@ def main():
 
     w, h = args.width, args.height
     tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267}[args.workload]
-    scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 0, 0.0, 0xC0FFEE)
+    scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 1 if args.separate_spheres else 0, 0.0, 0xC0FFEE)
     scene_source = "procedural"
     if not args.procedural:
         # the synthetic scene as a real glTF file, read back through the importer (a lossless round trip: tests/test_gltf.py)

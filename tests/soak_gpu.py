@@ -1,6 +1,7 @@
 """Randomised differential soak, GPU against the oracle (not collected by pytest; run on an MI355X: `ITERS=300 python tests/soak_gpu.py`).
 Random soups x instance counts x builders x frame slots x frame batches x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
-accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 and, on the final kernels of the round, 300 + 2 more with frame batches and downloads in the mix: 0 mismatches."""
+accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 and, on the final kernels of the round, 300 + 2 more with frame batches and downloads in the mix: 0 mismatches.
+Round 2 (blue-noise tables, sorted extension rays, single-material edits with `changed` bits and rfw_hip_render_samples in the mix): 250 + 2 configurations, 0 mismatches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,7 +17,16 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     mb = int(rng.choice([0, 5]))
     be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif, max_batch=mb)
     orc = Oracle(w, h, threads=8, max_path_length=3)
+    # round 2: the blue-noise sampler with seeded tables, extension rays in sorted order, a material edit with a `changed` bit
+    bn = int(rng.integers(0, 3))
+    if bn:
+        t = np.random.default_rng(seed).integers(0, 256, 5 * 65536).astype(np.uint32)
+        be.set_blue_noise(t); orc.set_blue_noise(t)
+    be.set_option("sort_extension_rays", int(rng.integers(0, 3)))
     scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    if rng.integers(0, 2):
+        scene.recolour_material(int(rng.integers(0, 6)), [int(x) for x in rng.integers(20, 250, 3)], int(rng.integers(10, 250)))
+        scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
     o = rng.uniform(-5, 5, (20000, 3)).astype(np.float32); d = rng.normal(size=(20000, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)] * rng.choice([-1, 1], (50, 1))  # axis-parallel
@@ -40,6 +50,14 @@ for it in range(int(os.environ.get("ITERS", "24"))):
             ok = ok and np.array_equal(be.accumulator_at(k).view(np.uint32), orc.accumulator().view(np.uint32))
             be.download_frame(host, frame=k); be.wait_downloads(host)
             ok = ok and np.array_equal(host.view(np.uint32), orc.framebuffer().view(np.uint32))
+    if mb:  # k samples of one image in one launch per stage: the sum of the per-sample images, i.e. k render() calls up to rounding
+        k = int(rng.integers(2, mb + 1))
+        be.render_samples(view, k)     # a different call sequence after the batch above: a new image of `view`
+        orc.reset()
+        for _ in range(k):
+            orc.render(view)
+        ga, ra = be.accumulator().astype(np.float64), orc.accumulator().astype(np.float64)
+        ok = ok and np.linalg.norm(ga - ra) <= 1e-6 * max(np.linalg.norm(ra), 1e-30)
     s, so = be.frame_stats(), orc.stats()
     print(it, "tris", tris, "batch", mb, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "OK" if ok else "MISMATCH", flush=True)
     bad += 0 if ok else 1
