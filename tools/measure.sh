@@ -14,6 +14,7 @@ python3 bench.py --workload spheres10k                    > $OUT/bench_c3_sphere
 python3 bench.py --max-path-length 3                      > $OUT/bench_c4_path3.json       2>> $OUT/bench_atrium1m.err
 python3 bench.py --identical-frames --no-cpu-baseline     > $OUT/bench_atrium1m_identical_frames.json 2>> $OUT/bench_atrium1m.err
 fi
+[ -x tools/probes/mem_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/mem_probe tools/probes/mem_probe.hip 2> $OUT/mem_probe_build.err
 tools/probes/mem_probe > $OUT/mem_probe.json 2> $OUT/mem_probe.err
 # profiler passes: the program itself after `--`, kernel trace and counters in separate runs.  The profiled command is the DEFAULT
 # configuration of bench.py (one render() per frame over 8 frame slots, 16 views), shortened, without the oracle leg and the extra modes
