@@ -108,7 +108,7 @@ def main():
 
     w, h = args.width, args.height
     tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267}[args.workload]
-    scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, 1 if args.separate_spheres else 0, 0.0, 0xC0FFEE)
+    scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, int(os.environ.get("RFW_SPHERE_MESHES", "1" if args.separate_spheres else "0")), 0.0, 0xC0FFEE)
     scene_source = "procedural"
     if not args.procedural:
         # the synthetic scene as a real glTF file, read back through the importer (a lossless round trip: tests/test_gltf.py)

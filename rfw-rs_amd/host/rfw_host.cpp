@@ -827,8 +827,9 @@ MeshDescriptor make_displaced_sphere(int k, uint32_t seed, int quality, uint32_t
     return out;
 }
 
-void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, bool separate_spheres)
+void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, int sphere_meshes)
 {
+    const bool separate_spheres = sphere_meshes == 1, one_mesh = sphere_meshes == 2;
     std::vector<int> mats;
     Rng rng(seed);
     for (int i = 0; i < 23; i++) {
@@ -863,10 +864,21 @@ void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32
     Builder b;
     b.d.name = "atrium";
     atrium_geometry(b, s, seed, mats, m_light);
+    if (with_spheres && one_mesh) { // (measurement aid) the spheres baked into the atrium's own mesh: what a single-level BVH would traverse
+        for (int k = 0; k < 64; k++) {
+            const MeshDescriptor sp = make_displaced_sphere(k, seed + 1000 + k, 4, (uint32_t)mats[(k * 7) % mats.size()]);
+            b.d.vertices.insert(b.d.vertices.end(), sp.vertices.begin(), sp.vertices.end());
+            b.d.normals.insert(b.d.normals.end(), sp.normals.begin(), sp.normals.end());
+            b.d.uvs.insert(b.d.uvs.end(), sp.uvs.begin(), sp.uvs.end());
+            b.d.tangents.insert(b.d.tangents.end(), sp.tangents.begin(), sp.tangents.end());
+            b.d.material_ids.insert(b.d.material_ids.end(), sp.material_ids.begin(), sp.material_ids.end());
+        }
+    }
     const uint32_t mesh = scene.add_mesh(Mesh3D::from(b.d));
     scene.add_instance(mesh, mat4_identity());
 
-    if (with_spheres && separate_spheres) {
+    if (with_spheres && one_mesh) {
+    } else if (with_spheres && separate_spheres) {
         // SURVEY §8d C4 literally: 64 displaced icospheres as 64 meshes, one instance each
         for (int k = 0; k < 64; k++) {
             const uint32_t m2 = scene.add_mesh(Mesh3D::from(make_displaced_sphere(k, seed + 1000 + k, 4, (uint32_t)mats[(k * 7) % mats.size()])));
@@ -1251,7 +1263,7 @@ HOST_API int rfwhost_build(void* p, const char* kind, uint32_t a, uint32_t b, fl
     HostScene& h = *(HostScene*)p;
     const std::string k(kind);
     if (k == "cornell") rfw::build_cornell_box(h.scene, h.cam);
-    else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed, b != 0);
+    else if (k == "atrium") rfw::build_atrium(h.scene, h.cam, a, seed, (int)b);
     else if (k == "soup") rfw::build_soup(h.scene, h.cam, a, b, seed);
     else if (k == "gallery") rfw::build_gallery(h.scene, h.cam, seed);
     else if (k == "skinned") rfw::build_skinned(h.scene, h.cam, seed);

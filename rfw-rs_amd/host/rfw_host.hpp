@@ -232,7 +232,7 @@ void render_system(const Camera3D& camera, uint32_t width, uint32_t height, Back
 MeshDescriptor make_icosphere(int quality, uint32_t mat_id);                       // objects_3d/sphere.rs:365-519
 void build_cornell_box(Scene& scene, Camera3D& cam);                               // C1
 // separate_spheres: C4's 64 displaced icospheres as 64 meshes with one instance each (65 meshes in all) instead of one baked mesh
-void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, bool separate_spheres = false); // C2 ("Sponza-class") / C4
+void build_atrium(Scene& scene, Camera3D& cam, uint32_t target_triangles, uint32_t seed, int sphere_meshes = 0); // C2 ("Sponza-class") / C4; sphere_meshes: 0 one baked sphere mesh (2 meshes), 1 = 64 sphere meshes (65), 2 = everything in ONE mesh
 // one of C4's displaced icospheres (k = 0..63): the 5120-triangle sphere at its place in the atrium, surface noise seeded by `seed`; quality 4 = 5120 triangles
 MeshDescriptor make_displaced_sphere(int k, uint32_t seed, int quality, uint32_t mat_id);
 void add_sphere_grid(Scene& scene, uint32_t nx, uint32_t nz, float spacing);       // C3: instances of a 320-tri icosphere

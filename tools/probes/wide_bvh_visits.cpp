@@ -33,7 +33,7 @@ static Box node_box(const BVHNode& n)
     return b;
 }
 
-static void collapse(const BVH& bvh, int k, std::vector<WNode>& out)
+static void collapse(const BVH& bvh, int k, std::vector<WNode>& out, bool even_depth = false)
 {
     out.clear();
     struct Job { uint32_t bvh2; uint32_t wide; };
@@ -47,6 +47,14 @@ static void collapse(const BVH& bvh, int k, std::vector<WNode>& out)
         const BVHNode& root = bvh.nodes[j.bvh2];
         if (root.count >= 0) { kids.push_back(j.bvh2); }
         else { kids.push_back((uint32_t)root.left_first); kids.push_back((uint32_t)root.left_first + 1); }
+        if (even_depth) { // what csrc/sah_build.hip and csrc/lbvh.hip do: every child that is interior is replaced by ITS two children, once
+            std::vector<uint32_t> g;
+            for (uint32_t c : kids) {
+                if (bvh.nodes[c].count >= 0 || root.count >= 0) g.push_back(c);
+                else { g.push_back((uint32_t)bvh.nodes[c].left_first); g.push_back((uint32_t)bvh.nodes[c].left_first + 1); }
+            }
+            kids = g;
+        } else
         for (;;) { // open the interior child with the largest surface area while there is room
             int best = -1;
             float area = -1.0f;
@@ -114,9 +122,9 @@ int main(int argc, char** argv)
     rfw_camera_view_3d cv;
     view(sc, W, H, &cv);
     printf("{\"triangles\": %u, \"bvh2_nodes\": %zu", n, bvh.nodes.size());
-    for (int k : {2, 4, 8}) {
+    for (int k : {2, 4, 8, 44}) { // 44: 4-wide by the even-depth rule of the device builders
         std::vector<WNode> wide;
-        collapse(bvh, k, wide);
+        collapse(bvh, k == 44 ? 4 : k, wide, k == 44);
         double visits = 0, tests = 0, children = 0;
         for (const WNode& w : wide) children += w.n;
         for (uint32_t py = 0; py < H; py++)
