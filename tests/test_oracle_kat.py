@@ -377,3 +377,53 @@ def test_blue_noise_branch_structure():
         q.render(v)
         frames.append(q.accumulator().copy())
     assert np.array_equal(frames[0], frames[1]) and frames[0][..., :3].max() > 0
+
+
+def reference_blue_noise_buffer():
+    """gpu_rt::blue_noise::create_blue_noise_buffer() (backends/gpu-rt/src/blue_noise.rs:40970-41005) evaluated on the reference's OWN
+    tables, read in place from /root/reference (absent on the GPU box: the caller skips).  The three `static …: [u64; N]` arrays are viewed
+    as bytes, but only `len * size_of::<u32>()` of them (the Rust code's own slip: half of every table), and indexed modulo that length."""
+    import os
+    import re
+    path = "/root/reference/backends/gpu-rt/src/blue_noise.rs"
+    if not os.path.exists(path):
+        return None
+    text = open(path).read()
+    tables = {}
+    for name in ("SOB256_64", "SCR256_64", "RNK256_64"):
+        m = re.search(r"static %s: \[u64; (\d+)\] = \[(.*?)\];" % name, text, re.S)
+        vals = np.array([int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(2))], dtype=np.uint64)
+        assert len(vals) == int(m.group(1))
+        tables[name] = vals.view(np.uint8)[: len(vals) * 4]            # size_of::<u32>() bytes per u64 element
+    buf = np.zeros(5 * 65536, np.uint32)
+    i = np.arange(65536)
+    buf[:65536] = tables["SOB256_64"][i % len(tables["SOB256_64"])]
+    j = np.arange(128 * 128 * 8)
+    buf[65536:65536 + len(j)] = tables["SCR256_64"][j % len(tables["SCR256_64"])]
+    buf[3 * 65536:3 * 65536 + len(j)] = tables["RNK256_64"][j % len(tables["RNK256_64"])]
+    return buf
+
+
+def test_blue_noise_sampler_on_the_references_own_tables():
+    """The sampler's index arithmetic against the structure of the REAL tables (not copied: read from the reference where it lies).  The
+    Sobol table is [sample][dimension]: for a fixed pixel and dimension the values over the sample index must be stratified — with the
+    reference's half-length table, 128 distinct samples each used twice, one per 1/128 stratum.  A transposed or mis-strided lookup fails this."""
+    import pytest
+    t = reference_blue_noise_buffer()
+    if t is None:
+        pytest.skip("/root/reference is not present on this machine")
+    assert t.max() <= 255
+    o = Oracle(8, 8)
+    o.set_blue_noise(t)
+    for (x, y) in [(0, 0), (5, 77), (127, 3), (64, 64)]:
+        for dim in range(8):                                        # the dimensions the tiles are optimised for
+            v = np.array([o.blue_noise_sample(s, x, y, dim) for s in range(256)])
+            k = np.round(v * 256 - 0.5).astype(int)
+            assert np.array_equal((k + 0.5) / 256, v)
+            strata, counts = np.unique(k >> 1, return_counts=True)
+            assert len(strata) == 128 and (counts == 2).all(), (x, y, dim)
+    # python restatement == oracle on the real tables too
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        s, x, y, d = (int(v) for v in (rng.integers(0, 300), rng.integers(0, 4000), rng.integers(0, 4000), rng.integers(0, 16)))
+        assert o.blue_noise_sample(s, x, y, d) == py_blue_noise_sampler(t, s, x, y, d)
