@@ -146,7 +146,7 @@ def main():
         for f in range(n_inst):
             be = HipBackend.init(w, h, 1.0, device=dev, max_path_length=args.max_path_length, rank=rank if not args.emulate_shard else 0,
                                  world=world if not args.emulate_shard else args.emulate_shard,
-                                 streams=int(os.environ.get("RFW_STREAMS", "0")), frames_in_flight=n_slots_or_inst if slots else 0, max_batch=batch)
+                                 streams=int(os.environ.get("RFW_STREAMS", "0")), builder=int(os.environ.get("RFW_BUILDER", "0")), frames_in_flight=n_slots_or_inst if slots else 0, max_batch=batch)
             # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created), so RCCL's
             # all-gather is ordered against the kernels
             st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)

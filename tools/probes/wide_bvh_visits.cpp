@@ -85,6 +85,85 @@ static void collapse(const BVH& bvh, int k, std::vector<WNode>& out, bool even_d
     }
 }
 
+// Collapse by dynamic programming over the SAH cost (Ylitie, Karras, Laine 2017, section 3.1, for k = 4 and leaves of up to max_leaf
+// triangles addressed from the parent's slot): C(n, i) = cheapest way to stand for BVH2 subtree n with at most i slots of a parent.
+static void collapse_dp(const BVH& bvh, int k, float c_prim, int max_leaf, std::vector<WNode>& out)
+{
+    const size_t N = bvh.nodes.size();
+    std::vector<float> area(N);
+    std::vector<int32_t> first(N), prims(N);
+    std::vector<float> C(N * 8, 0.0f); // C[n*8 + i], i = 1..k-1
+    std::vector<uint8_t> leaf1(N, 0);  // C(n,1) is the leaf alternative
+    std::vector<uint8_t> split(N * 8, 0); // split[n*8 + j] = m of the best distribution of j slots (j = 2..k)
+    // children have larger indices than their parent in this builder's array? not guaranteed: explicit post-order
+    std::vector<uint32_t> order; order.reserve(N);
+    { std::vector<uint32_t> st{0u}; while (!st.empty()) { uint32_t n = st.back(); st.pop_back(); order.push_back(n); if (bvh.nodes[n].count < 0) { st.push_back((uint32_t)bvh.nodes[n].left_first); st.push_back((uint32_t)bvh.nodes[n].left_first + 1); } } }
+    for (size_t q = order.size(); q-- > 0;) {
+        const uint32_t n = order[q];
+        const BVHNode& b = bvh.nodes[n];
+        area[n] = node_box(b).half_area();
+        if (b.count >= 0) {
+            first[n] = b.left_first; prims[n] = b.count;
+            for (int i = 1; i < k; i++) C[n * 8 + i] = area[n] * b.count * c_prim;
+            leaf1[n] = 1;
+            continue;
+        }
+        const uint32_t l = (uint32_t)b.left_first, r = l + 1;
+        first[n] = std::min(first[l], first[r]); prims[n] = prims[l] + prims[r];
+        auto dist = [&](int j, uint8_t& m_out) { // best split of j slots over the two children
+            float best = INFINITY;
+            for (int m = 1; m < j; m++) {
+                const int a = std::min(m, k - 1), c = std::min(j - m, k - 1);
+                const float v = C[l * 8 + a] + C[r * 8 + c];
+                if (v < best) { best = v; m_out = (uint8_t)m; }
+            }
+            return best;
+        };
+        uint8_t m = 1;
+        const float internal = area[n] * 1.0f + dist(k, m);
+        split[n * 8 + k] = m;
+        const float leaf = prims[n] <= max_leaf ? area[n] * prims[n] * c_prim : INFINITY;
+        leaf1[n] = leaf <= internal;
+        C[n * 8 + 1] = std::min(leaf, internal);
+        for (int i = 2; i < k; i++) {
+            const float d = dist(i, m);
+            split[n * 8 + i] = m;
+            if (d < C[n * 8 + i - 1]) C[n * 8 + i] = d; else { C[n * 8 + i] = C[n * 8 + i - 1]; split[n * 8 + i] = 0; } // 0: use fewer slots
+        }
+    }
+    out.clear();
+    struct Job { uint32_t bvh2; uint32_t wide; };
+    std::vector<Job> jobs;
+    out.emplace_back();
+    jobs.push_back({0u, 0u});
+    while (!jobs.empty()) {
+        const Job j = jobs.back(); jobs.pop_back();
+        std::vector<uint32_t> roots; // BVH2 nodes standing in this wide node's slots
+        struct F { uint32_t n; int i; };
+        std::vector<F> st;
+        const BVHNode& rn = bvh.nodes[j.bvh2];
+        if (rn.count >= 0 || leaf1[j.bvh2]) roots.push_back(j.bvh2); // whole tree is one leaf
+        else { const int m = split[j.bvh2 * 8 + k]; st.push_back({(uint32_t)rn.left_first, m}); st.push_back({(uint32_t)rn.left_first + 1, k - m}); }
+        while (!st.empty()) {
+            F f = st.back(); st.pop_back();
+            f.i = std::min(f.i, k - 1);
+            const BVHNode& b = bvh.nodes[f.n];
+            while (f.i > 1 && split[f.n * 8 + f.i] == 0) f.i--;
+            if (f.i == 1 || b.count >= 0) { roots.push_back(f.n); continue; }
+            const int m = split[f.n * 8 + f.i];
+            st.push_back({(uint32_t)b.left_first, m}); st.push_back({(uint32_t)b.left_first + 1, f.i - m});
+        }
+        WNode w; w.n = (int)roots.size();
+        for (int c = 0; c < w.n; c++) {
+            const uint32_t n = roots[c];
+            w.box[c] = node_box(bvh.nodes[n]);
+            if (leaf1[n]) { w.child[c] = -1; w.first[c] = first[n]; w.count[c] = prims[n]; }
+            else { w.child[c] = (int32_t)out.size(); out.emplace_back(); jobs.push_back({n, (uint32_t)w.child[c]}); }
+        }
+        out[j.wide] = w;
+    }
+}
+
 struct Tri { float v0[3], e1[3], e2[3]; };
 
 int main(int argc, char** argv)
@@ -122,9 +201,10 @@ int main(int argc, char** argv)
     rfw_camera_view_3d cv;
     view(sc, W, H, &cv);
     printf("{\"triangles\": %u, \"bvh2_nodes\": %zu", n, bvh.nodes.size());
-    for (int k : {2, 4, 8, 44}) { // 44: 4-wide by the even-depth rule of the device builders
+    for (int k : {4, 44, 451, 452, 453, 454, 455}) { // 45x: DP collapse, c_prim / max_leaf variants // 44: 4-wide by the even-depth rule of the device builders
         std::vector<WNode> wide;
-        collapse(bvh, k == 44 ? 4 : k, wide, k == 44);
+        if (k >= 450) { const float cp[] = {0, 0.3f, 0.5f, 0.3f, 0.5f, 1.0f}; const int ml[] = {0, 3, 3, 8, 8, 8}; collapse_dp(bvh, 4, cp[k - 450], ml[k - 450], wide); }
+        else collapse(bvh, k == 44 ? 4 : k, wide, k == 44);
         double visits = 0, tests = 0, children = 0;
         for (const WNode& w : wide) children += w.n;
         for (uint32_t py = 0; py < H; py++)
