@@ -367,6 +367,11 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 }
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
+// Buckets are walked from the LAST light index down: directional lights come last in the reference's light order (shade.comp:471-527) and their
+// rays leave the scene — the longest any-hit traversals — so the launch starts with them and ends on the short rays towards the area lights.
+#ifndef RFW_SHADOW_ORDER_REV
+#define RFW_SHADOW_ORDER_REV 1
+#endif
 template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
@@ -378,7 +383,8 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
     uint32_t bucket = 0, count = 0;
     {
         bool found = false;
-        for (int k = 0; k < kShadowBuckets; k++) {
+        for (int kk = 0; kk < kShadowBuckets; kk++) {
+            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
             if (!found) {
