@@ -1,12 +1,14 @@
 // example_animated.cpp — the reference's `examples/animated` (examples/animated/src/main.rs) as a headless C++ program on the MI355X
-// backend: a static scene (a glTF file, or the synthetic atrium) plus a grid of icosphere instances that bounce every frame
-// (bounce_spheres, main.rs:197-219), driven exactly the way rfw drives a backend — synchronize_system, then render_system, every frame
-// (rfw/src/system/mod.rs:19-206, rfw/src/lib.rs:411-430) — through the rfw::Backend interface of rfw_host.hpp.
+// backend: a scene (a glTF file, or the synthetic atrium), a grid of icosphere instances that bounce every frame (bounce_spheres,
+// main.rs:197-219), animated glTF models placed the way the reference places its two CesiumMan graphs (main.rs:79-103; `--actor`, up to
+// twice) and the animation timer system (set_animation_timers, main.rs:221-223: Scene::set_animations_time every frame -> joint matrices
+// -> skinning and BLAS refit on the device), driven exactly the way rfw drives a backend — synchronize_system, then render_system, every
+// frame (rfw/src/system/mod.rs:19-206, rfw/src/lib.rs:411-430) — through the rfw::Backend interface of rfw_host.hpp.
 //
 // Where the reference presents to a window, this program downloads the presented (Bgra8UnormSrgb) frame of every frame into a ring of
 // pinned host buffers without stalling the frames in flight, and writes the last one as a PPM image.
 //
-//   example_animated [--gltf scene.glb] [--frames N] [--size WxH] [--spheres NXxNZ] [--path-length L] [--out last.ppm]
+//   example_animated [--gltf scene.glb] [--actor animated.gltf]... [--frames N] [--size WxH] [--spheres NXxNZ] [--path-length L] [--out last.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,11 +22,13 @@
 int main(int argc, char** argv)
 {
     std::string gltf, out = "example_animated.ppm";
+    std::vector<std::string> actors;
     uint32_t frames = 240, width = 1280, height = 720, nx = 100, nz = 100, path_length = 2;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "--gltf") gltf = next();
+        else if (a == "--actor") actors.push_back(next());
         else if (a == "--frames") frames = (uint32_t)std::atoi(next());
         else if (a == "--size") std::sscanf(next(), "%ux%u", &width, &height);
         else if (a == "--spheres") std::sscanf(next(), "%ux%u", &nx, &nz);
@@ -42,6 +46,14 @@ int main(int argc, char** argv)
         } else {
             rfw::build_atrium(scene, camera, 262267, 0xC0FFEE);
         }
+        for (size_t k = 0; k < actors.size(); k++) { // main.rs:84-103: the first graph scaled by 3, the second moved to x = -3, both turned by 180 degrees about y
+            std::string err;
+            if (!rfw::load_gltf(actors[k], scene, nullptr, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            const double turn[4] = {0.0, 1.0, 0.0, 6.123233995736766e-17}; // quaternion of a half turn about y
+            const double t0[3] = {0, 0, 0}, t1[3] = {-3.0 * (double)k, 0, 0}, s3[3] = {3, 3, 3}, s1[3] = {1, 1, 1};
+            scene.graphs.back().set_root_transform(scene, k == 0 ? t0 : t1, turn, k == 0 ? s3 : s1);
+        }
+        scene.set_animations_time(0.0); // main.rs:112
         camera.aspect_ratio = (float)width / (float)height;
         const float spacing = 0.28f;
         rfw::add_sphere_grid(scene, nx, nz, spacing);
@@ -66,6 +78,7 @@ int main(int argc, char** argv)
         uint64_t rays = 0;
         for (uint32_t f = 0; f < frames; f++) {
             rfw::animate_sphere_grid(scene, grid_mesh, nx, nz, spacing, (float)f / 60.0f); // bounce_spheres at 60 Hz
+            scene.set_animations_time((double)f / 60.0);                                   // set_animation_timers
             rfw::synchronize_system(scene, *renderer);                                    // changed instance lists -> TLAS of this frame
             rfw::render_system(camera, width, height, *renderer);
             uint32_t* dst = ring[f % ring.size()];

@@ -492,7 +492,134 @@ bool open_document(const std::string& path, Doc& doc)
     return true;
 }
 
+M4 m4_from(const double* v) { M4 r; std::memcpy(r.m, v, sizeof(r.m)); return r; }
+M4 m4_from_f32(const rfw_mat4& a) { M4 r; for (int i = 0; i < 16; i++) r.m[i] = (double)a.m[i]; return r; }
+M4 local_matrix(const GraphNode& n) { return n.has_matrix ? m4_from(n.matrix) : m4_trs(n.translation, n.rotation, n.scale); }
+
+// value of one sampler at time t (glTF 2.0 section 3.11 / appendix C): nc components, rotations (nc == 4) by spherical interpolation
+void sample_channel(const AnimationSampler& s, int nc, double t, double* out)
+{
+    const size_t keys = s.times.size();
+    const size_t per_key = (size_t)nc * (s.interpolation == 2 ? 3u : 1u), value_at = s.interpolation == 2 ? (size_t)nc : 0u;
+    auto value = [&](size_t k) { return s.values.data() + k * per_key + value_at; };
+    auto finish = [&]() {
+        if (nc != 4) return;
+        const double len = std::sqrt(out[0] * out[0] + out[1] * out[1] + out[2] * out[2] + out[3] * out[3]);
+        if (len > 0.0) for (int c = 0; c < 4; c++) out[c] /= len;
+    };
+    if (t <= s.times.front() || keys == 1) { for (int c = 0; c < nc; c++) out[c] = value(0)[c]; finish(); return; }
+    if (t >= s.times.back()) { for (int c = 0; c < nc; c++) out[c] = value(keys - 1)[c]; finish(); return; }
+    size_t k = (size_t)(std::upper_bound(s.times.begin(), s.times.end(), t) - s.times.begin()) - 1; // times[k] <= t < times[k + 1]
+    const double dt = s.times[k + 1] - s.times[k], u = dt > 0.0 ? (t - s.times[k]) / dt : 0.0;
+    const double* a = value(k);
+    const double* b = value(k + 1);
+    if (s.interpolation == 1) { for (int c = 0; c < nc; c++) out[c] = a[c]; finish(); return; }
+    if (s.interpolation == 2) { // cubic Hermite spline: out-tangent of key k, in-tangent of key k + 1, both scaled by the key distance
+        const double* bk = s.values.data() + k * per_key + 2 * (size_t)nc;
+        const double* ak1 = s.values.data() + (k + 1) * per_key;
+        const double u2 = u * u, u3 = u2 * u;
+        for (int c = 0; c < nc; c++)
+            out[c] = (2.0 * u3 - 3.0 * u2 + 1.0) * a[c] + dt * (u3 - 2.0 * u2 + u) * bk[c] + (-2.0 * u3 + 3.0 * u2) * b[c] + dt * (u3 - u2) * ak1[c];
+        finish();
+        return;
+    }
+    if (nc == 4) { // slerp along the shorter arc; nearly parallel quaternions interpolate linearly
+        double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        const double sign = d < 0.0 ? -1.0 : 1.0;
+        d = std::fabs(d);
+        double wa = 1.0 - u, wb = u;
+        if (d <= 0.9995) {
+            const double theta = std::acos(d), st = std::sin(theta);
+            wa = std::sin((1.0 - u) * theta) / st;
+            wb = std::sin(u * theta) / st;
+        }
+        for (int c = 0; c < 4; c++) out[c] = wa * a[c] + wb * sign * b[c];
+        finish();
+        return;
+    }
+    for (int c = 0; c < nc; c++) out[c] = a[c] + u * (b[c] - a[c]);
+}
+
 } // namespace
+
+bool decode_image(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err)
+{
+    if (size >= 8 && data[0] == 0x89 && data[1] == 'P' && data[2] == 'N' && data[3] == 'G') return decode_png(data, size, width, height, rgba, err);
+    if (size >= 3 && data[0] == 0xFF && data[1] == 0xD8) return decode_jpeg(data, size, width, height, rgba, err);
+    err = "image: neither PNG nor JPEG";
+    return false;
+}
+
+// graph/mod.rs:540-630 traverse_children, restated on the flattened parents-first order: combined = parent's combined x local.  A skinned
+// instance keeps the identity as its instance matrix and its joints carry the whole transform, joint = combined(joint node) x inverse bind
+// (glTF 2.0 section 3.7.3.3: the skinned mesh node's own transform is ignored) — the reference hands the node's combined matrix to the
+// instance and multiplies the joints by its inverse (:587-600): the same product up to rounding, without the 4x4 inverse.
+void NodeGraph::update(Scene& scene)
+{
+    bool lights_stale = false;
+    for (const uint32_t ni : order) {
+        GraphNode& n = nodes[ni];
+        const M4 parent = parent_of[ni] == UINT32_MAX ? m4_from(root) : m4_from(nodes[parent_of[ni]].world);
+        const M4 w = m4_mul(parent, local_matrix(n));
+        std::memcpy(n.world, w.m, sizeof(n.world));
+    }
+    for (const uint32_t ni : order) {
+        const GraphNode& n = nodes[ni];
+        if (n.mesh < 0 || n.instance < 0 || n.skin >= 0) continue;
+        auto it = scene.instances_3d.find((uint32_t)n.mesh);
+        if (it == scene.instances_3d.end() || (size_t)n.instance >= it->second.matrices.size()) continue;
+        const rfw_mat4 m = to_f32(m4_from(n.world));
+        if (!std::memcmp(&m, &it->second.matrices[(size_t)n.instance], sizeof(m))) continue;
+        scene.set_matrix((uint32_t)n.mesh, (size_t)n.instance, m);
+        auto mit = scene.meshes_3d.find((uint32_t)n.mesh);
+        if (mit != scene.meshes_3d.end())
+            for (const rfw_vertex_mesh& r : mit->second.ranges)
+                lights_stale = lights_stale || (r.mat_id < scene.materials.size() && is_emissive(scene.materials[r.mat_id]));
+    }
+    for (const auto& sk : skins) {
+        if (sk.first < 0 || (size_t)sk.first >= scene.skins.size()) continue;
+        Skin& skin = scene.skins[(size_t)sk.first];
+        for (size_t j = 0; j < sk.second.size() && j < skin.joint_matrices.size(); j++) {
+            const int64_t jn = sk.second[j];
+            const M4 jw = (jn >= 0 && (size_t)jn < nodes.size()) ? m4_from(nodes[(size_t)jn].world) : m4_identity();
+            skin.joint_matrices[j] = to_f32(m4_mul(jw, m4_from_f32(skin.inverse_bind_matrices[j])));
+        }
+        scene.skins_changed = true;
+    }
+    if (lights_stale) scene.update_lights(); // an emitter moved: its area lights are world-space triangles (lib.rs:575-648)
+}
+
+void NodeGraph::set_root_transform(Scene& scene, const double translation[3], const double rotation_xyzw[4], const double scale[3])
+{
+    const M4 r = m4_trs(translation, rotation_xyzw, scale);
+    std::memcpy(root, r.m, sizeof(root));
+    update(scene);
+}
+
+void NodeGraph::set_animation_time(Scene& scene, double time)
+{
+    if (active_animation < 0 || (size_t)active_animation >= animations.size()) return;
+    const Animation& a = animations[(size_t)active_animation];
+    double t = 0.0;
+    if (a.duration > 0.0) { // the animation loops
+        t = std::fmod(time, a.duration);
+        if (t < 0.0) t += a.duration;
+    }
+    for (const AnimationChannel& ch : a.channels) {
+        if (ch.node >= nodes.size() || ch.sampler >= a.samplers.size()) continue;
+        GraphNode& n = nodes[ch.node];
+        const AnimationSampler& s = a.samplers[ch.sampler];
+        if (n.has_matrix || s.times.empty()) continue;
+        double* dst = ch.path == 0 ? n.translation : (ch.path == 1 ? n.rotation : n.scale);
+        sample_channel(s, ch.path == 1 ? 4 : 3, t, dst);
+    }
+    update(scene);
+}
+
+void Scene::set_animations_time(double time)
+{
+    for (NodeGraph& g : graphs) g.set_animation_time(*this, time);
+}
 
 // Adds the document's materials, meshes, instances and skins to `scene` (on top of what it already holds) and, when the
 // document has a perspective camera and `cam` is given, aims `cam` like it.  Returns false and sets `err` on any malformed input.
@@ -507,8 +634,8 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
         return j && j->kind == Json::Arr ? j->arr : empty;
     };
 
-    // ---- images -> scene textures (PNG only: BGRA8 with a 5-level mip chain, what l3d hands the trait); texture -> scene texture id
-    std::vector<int> image_tex; // glTF image index -> scene texture id, -1 = not readable here (JPEG, KTX, ...)
+    // ---- images -> scene textures (PNG and baseline JPEG: BGRA8 with a 5-level mip chain, what l3d hands the trait); texture -> scene texture id
+    std::vector<int> image_tex; // glTF image index -> scene texture id, -1 = not readable here (progressive JPEG, KTX, ...)
     for (const Json& im : arr("images")) {
         std::vector<uint8_t> file;
         const std::string uri = im.string("uri");
@@ -537,7 +664,7 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
         uint32_t w = 0, h = 0;
         std::vector<uint8_t> rgba;
         std::string perr;
-        if (have && decode_png(file.data(), file.size(), w, h, rgba, perr)) {
+        if (have && decode_image(file.data(), file.size(), w, h, rgba, perr)) {
             Texture t;
             t.width = w; t.height = h; t.format = RFW_FORMAT_BGRA8;
             t.bytes.resize(rgba.size());
@@ -754,6 +881,36 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
                 if (it->kind == Json::Num && it->num >= 0 && (size_t)it->num < nodes.size()) stack.emplace_back((size_t)it->num, world[ni]);
     }
 
+    // ---- the graph is kept: animations move its nodes later (NodeGraph::set_animation_time)
+    NodeGraph graph;
+    graph.nodes.resize(nodes.size());
+    graph.parent_of.assign(nodes.size(), UINT32_MAX);
+    for (const size_t ni : order) graph.order.push_back((uint32_t)ni);
+    {
+        std::vector<char> is_root(nodes.size(), 1), placed(nodes.size(), 0);
+        for (const size_t ni : order) {
+            placed[ni] = 1;
+            if (const Json* ch = nodes[ni].get("children"))
+                for (const Json& j : ch->arr)
+                    if (j.kind == Json::Num && j.num >= 0 && (size_t)j.num < nodes.size()) {
+                        const size_t c = (size_t)j.num;
+                        if (graph.parent_of[c] == UINT32_MAX && !placed[c] && visited[c]) { graph.parent_of[c] = (uint32_t)ni; graph.nodes[ni].children.push_back((uint32_t)c); }
+                    }
+        }
+    }
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+        GraphNode& g = graph.nodes[ni];
+        const Json& nd = nodes[ni];
+        if (const Json* mj = nd.get("matrix")) {
+            g.has_matrix = true;
+            for (size_t k = 0; k < 16 && k < mj->size(); k++) g.matrix[k] = mj->arr[k].num;
+        }
+        if (const Json* j = nd.get("translation")) for (size_t k = 0; k < 3 && k < j->size(); k++) g.translation[k] = j->arr[k].num;
+        if (const Json* j = nd.get("rotation")) for (size_t k = 0; k < 4 && k < j->size(); k++) g.rotation[k] = j->arr[k].num;
+        if (const Json* j = nd.get("scale")) for (size_t k = 0; k < 3 && k < j->size(); k++) g.scale[k] = j->arr[k].num;
+        std::memcpy(g.world, world[ni].m, sizeof(g.world));
+    }
+
     // ---- skins: joint_matrices = world(joint) * inverseBind
     std::vector<int32_t> skin_ids;
     for (const Json& sk : arr("skins")) {
@@ -771,6 +928,12 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             skin.inverse_bind_matrices.push_back(to_f32(inv_bind));
             skin.joint_matrices.push_back(to_f32(m4_mul(jw, inv_bind)));
         }
+        std::vector<int64_t> joint_nodes;
+        for (size_t j = 0; j < nj; j++) {
+            const double jn = js->arr[j].kind == Json::Num ? js->arr[j].num : -1.0;
+            joint_nodes.push_back((jn >= 0 && (size_t)jn < nodes.size()) ? (int64_t)jn : -1);
+        }
+        graph.skins.emplace_back((int32_t)scene.skins.size(), std::move(joint_nodes));
         skin_ids.push_back((int32_t)scene.skins.size());
         scene.skins.push_back(std::move(skin));
         scene.skins_changed = true;
@@ -848,6 +1011,9 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
                 if (l.skin_ids.size() <= slot) l.skin_ids.resize(slot + 1, -1);
                 l.skin_ids[slot] = skin_ids[(size_t)si];
             }
+            graph.nodes[ni].mesh = (int64_t)mesh;
+            graph.nodes[ni].instance = (int64_t)slot;
+            graph.nodes[ni].skin = skinned ? skin_ids[(size_t)si] : -1;
         }
         const int64_t ci = nd.integer("camera", -1);
         if (cam && !cam_set && ci >= 0 && (size_t)ci < arr("cameras").size()) {
@@ -868,6 +1034,47 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             }
         }
     }
+    // ---- animations: channels (node, path) + samplers (key times, values, interpolation)
+    for (const Json& an : arr("animations")) {
+        Animation anim;
+        anim.name = an.string("name");
+        const Json* sj = an.get("samplers");
+        const Json* cj = an.get("channels");
+        std::vector<int> sampler_comps;
+        for (size_t i = 0; sj && i < sj->size(); i++) {
+            const Json& sm = sj->arr[i];
+            AnimationSampler smp;
+            const std::string ip = sm.string("interpolation");
+            smp.interpolation = ip == "STEP" ? 1 : (ip == "CUBICSPLINE" ? 2 : 0);
+            size_t nk = 0, nv = 0;
+            if (!doc.read_accessor(sm.integer("input", -1), 1, false, smp.times, nk)) { err = doc.err; return false; }
+            const Json* accs = root.get("accessors");
+            const int64_t oi = sm.integer("output", -1);
+            const int nc = (accs && oi >= 0 && (size_t)oi < accs->size()) ? Doc::components(accs->arr[(size_t)oi].string("type")) : 0;
+            if (!doc.read_accessor(oi, 0, true, smp.values, nv)) { err = doc.err; return false; } // normalised integers -> [-1, 1] / [0, 1]
+            for (size_t k = 1; k < nk; k++)
+                if (!(smp.times[k] >= smp.times[k - 1])) { err = "gltf: animation key times must not decrease"; return false; }
+            if (nv != nk * (smp.interpolation == 2 ? 3u : 1u)) { err = "gltf: animation sampler output does not match its key times"; return false; }
+            if (nk) anim.duration = std::max(anim.duration, smp.times.back());
+            sampler_comps.push_back(nc);
+            anim.samplers.push_back(std::move(smp));
+        }
+        for (size_t i = 0; cj && i < cj->size(); i++) {
+            const Json& ch = cj->arr[i];
+            const Json* tg = ch.get("target");
+            if (!tg) continue;
+            const int64_t node = tg->integer("node", -1), smp = ch.integer("sampler", -1);
+            const std::string path = tg->string("path");
+            const int pi = path == "translation" ? 0 : (path == "rotation" ? 1 : (path == "scale" ? 2 : -1));
+            if (pi < 0 || node < 0 || (size_t)node >= nodes.size() || smp < 0 || (size_t)smp >= anim.samplers.size()) continue; // weights, or a target of an extension
+            if (sampler_comps[(size_t)smp] != (pi == 1 ? 4 : 3)) { err = "gltf: animation output has the wrong type for its path"; return false; }
+            AnimationChannel c;
+            c.node = (uint32_t)node; c.sampler = (uint32_t)smp; c.path = pi;
+            anim.channels.push_back(c);
+        }
+        graph.animations.push_back(std::move(anim));
+    }
+    scene.graphs.push_back(std::move(graph));
     scene.update_lights(); // emissive triangles -> area lights (crates/rfw-scene/src/lib.rs:575-648)
     return true;
 }

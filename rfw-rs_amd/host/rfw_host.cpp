@@ -1340,6 +1340,72 @@ HOST_API int rfwhost_pose(void* p, float time)
     rfw::pose_skins(h.scene, time);
     return 0;
 }
+// crates/rfw-scene/src/lib.rs:685-687 set_animations_time: the active animation of every loaded glTF graph at `time` seconds (looping);
+// returns the number of animations the scene holds (0: nothing moved)
+HOST_API int rfwhost_set_animation_time(void* p, double time)
+{
+    HostScene& h = *(HostScene*)p;
+    int n = 0;
+    for (const rfw::NodeGraph& g : h.scene.graphs) n += (int)g.animations.size();
+    h.scene.set_animations_time(time);
+    return n;
+}
+// GraphHandle::get_transform() of loaded graph `graph` (in load order): translation, rotation quaternion (x, y, z, w), scale
+HOST_API int rfwhost_set_graph_transform(void* p, uint32_t graph, const double* t, const double* q, const double* s)
+{
+    HostScene& h = *(HostScene*)p;
+    if (graph >= h.scene.graphs.size() || !t || !q || !s) return -1;
+    h.scene.graphs[graph].set_root_transform(h.scene, t, q, s);
+    return 0;
+}
+HOST_API int rfwhost_graph_count(void* p) { return (int)((HostScene*)p)->scene.graphs.size(); }
+// duration (seconds) and channel count of animation `index` counted over the loaded graphs; -1: no such animation
+HOST_API int rfwhost_animation_info(void* p, uint32_t index, double* duration, uint32_t* channels)
+{
+    HostScene& h = *(HostScene*)p;
+    for (const rfw::NodeGraph& g : h.scene.graphs) {
+        if (index < g.animations.size()) {
+            if (duration) *duration = g.animations[index].duration;
+            if (channels) *channels = (uint32_t)g.animations[index].channels.size();
+            return 0;
+        }
+        index -= (uint32_t)g.animations.size();
+    }
+    return -1;
+}
+// joint matrices of skin `skin` (16 floats each, column-major) -> out; returns the number of joints (copies at most `cap` of them), -1: no such skin
+HOST_API int rfwhost_skin_matrices(void* p, uint32_t skin, float* out, uint32_t cap)
+{
+    HostScene& h = *(HostScene*)p;
+    if (skin >= h.scene.skins.size()) return -1;
+    const std::vector<rfw_mat4>& jm = h.scene.skins[skin].joint_matrices;
+    for (size_t j = 0; j < jm.size() && j < cap && out; j++) std::memcpy(out + 16 * j, &jm[j], 16 * sizeof(float));
+    return (int)jm.size();
+}
+HOST_API int rfwhost_instance_matrix(void* p, uint32_t mesh, uint32_t slot, float* out16)
+{
+    HostScene& h = *(HostScene*)p;
+    auto it = h.scene.instances_3d.find(mesh);
+    if (it == h.scene.instances_3d.end() || slot >= it->second.matrices.size() || !out16) return -1;
+    std::memcpy(out16, &it->second.matrices[slot], 16 * sizeof(float));
+    return it->second.skin_ids.size() > slot ? it->second.skin_ids[slot] + 1 : 0; // 0: unskinned, else skin id + 1
+}
+// PNG or baseline JPEG bytes -> RGBA8; returns 0 and the size, -1 with the reason in *err_out (static storage, valid until the next call on this thread)
+HOST_API int rfwhost_decode_image(const uint8_t* data, uint64_t n, uint32_t* w, uint32_t* hgt, uint8_t* rgba_out, uint64_t cap, const char** err_out)
+{
+    static thread_local std::string err;
+    std::vector<uint8_t> rgba;
+    uint32_t ww = 0, hh = 0;
+    err.clear();
+    if (!data || !rfw::decode_image(data, (size_t)n, ww, hh, rgba, err)) {
+        if (err_out) *err_out = err.c_str();
+        return -1;
+    }
+    if (w) *w = ww;
+    if (hgt) *hgt = hh;
+    if (rgba_out && cap >= rgba.size()) std::memcpy(rgba_out, rgba.data(), rgba.size());
+    return 0;
+}
 HOST_API int rfwhost_set_camera(void* p, const float* pos, const float* dir, float fov, float aperture, float aspect)
 {
     HostScene& h = *(HostScene*)p;

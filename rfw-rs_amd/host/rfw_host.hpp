@@ -184,7 +184,54 @@ struct Skin {
     std::vector<rfw_mat4> inverse_bind_matrices, joint_matrices;
 };
 
+// The node graph of a loaded glTF document, kept so that its animations can run (crates/rfw-scene/src/graph/mod.rs:100-115 Node,
+// :338-344 NodeGraph, :835-840 Skin::joint_nodes; channels and samplers are l3d's Animation, sampled as glTF 2.0 section 3.11 says).
+struct GraphNode {
+    double translation[3] = {0, 0, 0}, rotation[4] = {0, 0, 0, 1}, scale[3] = {1, 1, 1};
+    bool has_matrix = false;       // a node given as a matrix is not animated (glTF: animated nodes use TRS)
+    double matrix[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double world[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; // combined_matrix
+    std::vector<uint32_t> children;
+    int64_t mesh = -1, instance = -1; // scene mesh id and the instance slot this node owns (-1: none)
+    int32_t skin = -1;                // scene skin id worn by that instance
+};
+struct AnimationSampler {
+    std::vector<double> times, values; // values: components per key (x 3 for cubic splines: in-tangent, value, out-tangent)
+    int interpolation = 0;             // 0 LINEAR, 1 STEP, 2 CUBICSPLINE
+};
+struct AnimationChannel {
+    uint32_t node = 0, sampler = 0;
+    int path = 0; // 0 translation, 1 rotation, 2 scale (morph-target weights are not animated: graph/mod.rs:577 "TODO: Morph animations")
+};
+struct Animation {
+    std::string name;
+    std::vector<AnimationSampler> samplers;
+    std::vector<AnimationChannel> channels;
+    double duration = 0.0; // the largest key time
+};
+struct Scene;
+struct NodeGraph {
+    std::vector<GraphNode> nodes;
+    std::vector<uint32_t> order;                       // nodes reachable from the scene's roots, parents first
+    std::vector<uint32_t> parent_of;                   // per node: parent index or UINT32_MAX
+    std::vector<std::pair<int32_t, std::vector<int64_t>>> skins; // (scene skin id, joint node per joint; -1: none)
+    std::vector<Animation> animations;
+    int active_animation = 0;                          // graph/mod.rs:643-647 set_active_animation
+    // the transform of the whole graph, what GraphHandle::get_transform() edits (graph/mod.rs:127-147; examples/animated/src/main.rs:84-103
+    // places two CesiumMan graphs this way): parent of the document's root nodes.  Cameras and punctual lights of the file were placed at
+    // load time and do not follow it.
+    double root[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    void set_root_transform(Scene& scene, const double translation[3], const double rotation_xyzw[4], const double scale[3]);
+    // graph/mod.rs:636-641 update_animation + :477-507 update: channel values at `time` (wrapped into the animation's duration) -> node
+    // TRS -> combined matrices -> instance matrices and joint matrices of `scene`, which are marked changed
+    void set_animation_time(Scene& scene, double time);
+    void update(Scene& scene); // combined matrices from the nodes' current TRS -> instances and skins
+};
+
 struct Scene {
+    std::vector<NodeGraph> graphs;
+    // crates/rfw-scene/src/lib.rs:685-687 set_animations_time: every loaded graph's active animation
+    void set_animations_time(double time);
     std::vector<Skin> skins;
     bool skins_changed = false;
     std::vector<Texture> textures;
@@ -244,6 +291,9 @@ void build_gallery(Scene& scene, Camera3D& cam, uint32_t seed);
 void build_skinned(Scene& scene, Camera3D& cam, uint32_t seed);
 // glTF 2.0 (.gltf / .glb) -> meshes, materials, instances, skins (gltf.cpp; crates/rfw-scene/src/loaders/gltf.rs:26-90 via l3d)
 bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string& err);
+// jpeg.cpp: baseline JPEG -> RGBA8 (the reference's CesiumMan sample carries a JPEG texture); gltf.cpp: PNG -> RGBA8
+bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
+bool decode_image(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
 // gltf_export.cpp: the scene (static meshes, instances, materials, punctual lights, camera) as a binary glTF 2.0 file
 bool save_glb(const std::string& path, const Scene& scene, const Camera3D* cam, std::string& err);
 void pose_skins(Scene& scene, float time); // textured walls (diffuse + normal maps), an emissive-mapped panel, open sky with a lat-long skybox

@@ -47,8 +47,27 @@ def host_lib():
         l.rfwhost_mesh_data.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(pod.MeshData3D)]
         l.rfwhost_edit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
+        l.rfwhost_set_animation_time.argtypes = [C.c_void_p, C.c_double]
+        l.rfwhost_set_graph_transform.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        l.rfwhost_graph_count.argtypes = [C.c_void_p]
+        l.rfwhost_animation_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        l.rfwhost_skin_matrices.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.c_uint32]
+        l.rfwhost_instance_matrix.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        l.rfwhost_decode_image.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p)]
         _lib = l
     return _lib
+
+
+def decode_image(data):
+    """PNG or baseline JPEG bytes -> (h, w, 4) uint8 RGBA through the importer's own decoders (host/gltf.cpp, host/jpeg.cpp)."""
+    import numpy as np
+    l = host_lib()
+    w, h, err = C.c_uint32(), C.c_uint32(), C.c_char_p()
+    if l.rfwhost_decode_image(data, len(data), C.byref(w), C.byref(h), None, 0, C.byref(err)) != 0:
+        raise ValueError((err.value or b"").decode(errors="replace"))
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    l.rfwhost_decode_image(data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes, C.byref(err))
+    return out
 
 
 class Scene:
@@ -90,6 +109,42 @@ class Scene:
     def pose(self, time):
         if self._l.rfwhost_pose(self._h, time) != 0:
             raise RuntimeError("scene has no skins")
+
+    def set_animation_time(self, time):
+        """Scene::set_animations_time (crates/rfw-scene/src/lib.rs:685-687): the loaded glTF graphs' animations at `time` seconds (looping):
+        node TRS -> instance matrices and joint matrices, marked changed for the next sync().  Returns the number of animations."""
+        return int(self._l.rfwhost_set_animation_time(self._h, float(time)))
+
+    def set_graph_transform(self, graph, translation=(0, 0, 0), rotation=(0, 0, 0, 1), scale=(1, 1, 1)):
+        """GraphHandle::get_transform() of the graph-th loaded glTF document (rotation: quaternion x, y, z, w); -1 = the latest."""
+        if graph < 0:
+            graph += int(self._l.rfwhost_graph_count(self._h))
+        t, q, sc = (C.c_double * 3)(*translation), (C.c_double * 4)(*rotation), (C.c_double * 3)(*scale)
+        if self._l.rfwhost_set_graph_transform(self._h, graph, t, q, sc) != 0:
+            raise KeyError(graph)
+
+    def animation_info(self, index=0):
+        d, c = C.c_double(), C.c_uint32()
+        if self._l.rfwhost_animation_info(self._h, index, C.byref(d), C.byref(c)) != 0:
+            raise KeyError(index)
+        return {"duration": d.value, "channels": c.value}
+
+    def skin_matrices(self, skin):
+        import numpy as np
+        n = self._l.rfwhost_skin_matrices(self._h, skin, None, 0)
+        if n < 0:
+            raise KeyError(skin)
+        out = np.zeros((n, 16), np.float32)
+        self._l.rfwhost_skin_matrices(self._h, skin, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return out.reshape(n, 4, 4).transpose(0, 2, 1)   # column-major storage -> [joint, row, column]
+
+    def instance_matrix(self, mesh, slot):
+        import numpy as np
+        out = np.zeros(16, np.float32)
+        rc = self._l.rfwhost_instance_matrix(self._h, mesh, slot, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc < 0:
+            raise KeyError((mesh, slot))
+        return out.reshape(4, 4).T, rc - 1                # (matrix, skin id or -1)
 
     def set_camera(self, pos, direction, fov=40.0, aperture=0.0, aspect=1.0):
         p = (C.c_float * 3)(*pos)

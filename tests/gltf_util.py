@@ -274,3 +274,136 @@ def write_textured_gltf(directory, glb=False, png=None):
     path = directory / "textured.gltf"
     path.write_text(json.dumps(doc))
     return path, tex
+
+
+def write_animated_gltf(directory, jpeg=None):
+    """A small lit room with everything the animation importer handles: a skinned tube (8-sided, 3 joints in a chain) whose joints turn
+    (LINEAR rotation keys, one as normalised int16 with a sign flip between keys: shortest-arc slerp) and whose root joint slides (LINEAR
+    translation), a rigid cube under a parent node moved by a CUBICSPLINE translation and a STEP scale, a static matrix node, a floor, an
+    emissive lamp, a camera.  One animation of 2 s.  `jpeg`: bytes of a JPEG file for the floor's base colour (None: untextured).
+    Returns the path of animated.gltf (buffers embedded)."""
+    cp, cn, cuv, ci = cube()
+    rings, sides = 9, 8
+    ys = np.linspace(0.0, 2.0, rings)
+    pos = np.array([[0.15 * np.cos(2 * np.pi * k / sides), y, 0.15 * np.sin(2 * np.pi * k / sides)] for y in ys for k in range(sides)], np.float32)
+    idx = []
+    for r in range(rings - 1):
+        for k in range(sides):
+            a, b = r * sides + k, r * sides + (k + 1) % sides
+            c, d = a + sides, b + sides
+            idx += [a, d, b, a, c, d]
+    idx = np.array(idx, np.uint16)
+    # joints at y = 0, 0.8, 1.4; weights blend over 0.4 around each joint's height
+    w1 = np.clip((pos[:, 1] - 0.6) / 0.4, 0.0, 1.0)
+    w2 = np.clip((pos[:, 1] - 1.2) / 0.4, 0.0, 1.0)
+    weights = np.stack([1.0 - w1, w1 - w2, w2, np.zeros_like(w1)], axis=1).astype(np.float32)
+    joints = np.tile(np.array([0, 1, 2, 0], np.uint8), (len(pos), 1))
+    ibm = np.stack([np.eye(4, dtype=np.float32)] * 3)
+    ibm[1][1, 3] = -0.8
+    ibm[2][1, 3] = -1.4
+    floor = np.array([[-4, 0, -4], [-4, 0, 4], [4, 0, 4], [-4, 0, -4], [4, 0, 4], [4, 0, -4]], np.float32)
+    floor_uv = np.array([[0, 0], [0, 1], [1, 1], [0, 0], [1, 1], [1, 0]], np.float32)
+    lamp = np.array([[-0.7, 0, -0.7], [0.7, 0, -0.7], [0.7, 0, 0.7], [-0.7, 0, 0.7]], np.float32)
+    lamp_idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    chunks, views, accessors = [], [], []
+    offset = 0
+
+    def add(arr, ctype, atype, normalized=False):
+        nonlocal offset
+        raw = np.ascontiguousarray(arr).tobytes()
+        pad = (-len(raw)) % 4
+        views.append({"buffer": 0, "byteOffset": offset, "byteLength": len(raw)})
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(arr.shape[0]), "type": atype}
+        if normalized:
+            acc["normalized"] = True
+        if atype == "SCALAR" and ctype == 5126:
+            acc["min"], acc["max"] = [float(arr.min())], [float(arr.max())]
+        accessors.append(acc)
+        chunks.append(raw + b"\0" * pad)
+        offset += len(raw) + pad
+        return len(accessors) - 1
+
+    def qz(a):
+        return [0.0, 0.0, float(np.sin(a / 2)), float(np.cos(a / 2))]
+
+    def qx(a):
+        return [float(np.sin(a / 2)), 0.0, 0.0, float(np.cos(a / 2))]
+
+    a_p = add(pos, 5126, "VEC3"); a_j = add(joints, 5121, "VEC4"); a_w = add(weights, 5126, "VEC4"); a_i = add(idx, 5123, "SCALAR")
+    a_m = add(np.stack([m.T for m in ibm]).reshape(3, 16).astype(np.float32), 5126, "MAT4")
+    a_cp = add(cp, 5126, "VEC3"); a_cn = add(cn, 5126, "VEC3"); a_ci = add(ci, 5123, "SCALAR")
+    a_fl = add(floor, 5126, "VEC3"); a_fuv = add(floor_uv, 5126, "VEC2")
+    a_lp = add(lamp, 5126, "VEC3"); a_li = add(lamp_idx, 5125, "SCALAR")
+    # samplers
+    t5 = add(np.array([0.0, 0.5, 1.0, 1.5, 2.0], np.float32), 5126, "SCALAR")
+    t3 = add(np.array([0.25, 1.0, 1.75], np.float32), 5126, "SCALAR")
+    r1 = add(np.array([qz(0.0), qz(0.7), qz(-0.5), qz(0.9), qz(0.0)], np.float32), 5126, "VEC4")            # joint 1 about z
+    q2 = np.array([qx(0.0), qx(0.8), qx(-0.6)], np.float64)
+    q2[1] *= -1.0                                                                                            # same rotation, opposite sign
+    r2 = add(np.round(q2 * 32767.0).astype(np.int16), 5122, "VEC4", normalized=True)                          # joint 2 about x, int16 keys
+    tr0 = add(np.array([[0, 0, 0], [0.3, 0, 0], [0.3, 0, 0.4], [-0.2, 0, 0.4], [0, 0, 0]], np.float32), 5126, "VEC3")  # root joint slides
+    # cubic spline: (in-tangent, value, out-tangent) per key
+    cs = np.array([[[0, 0, 0], [1.5, 0.5, 0.0], [0.0, 1.0, 0.0]],
+                   [[0.5, 0.0, 0.0], [1.5, 1.2, 0.6], [0.5, 0.0, -0.5]],
+                   [[0.0, -1.0, 0.0], [1.2, 0.5, -0.4], [0, 0, 0]]], np.float32).reshape(9, 3)
+    tc = add(cs, 5126, "VEC3")
+    sc = add(np.array([[1, 1, 1], [1.5, 0.5, 1.5], [0.8, 1.6, 0.8]], np.float32), 5126, "VEC3")
+    blob = b"".join(chunks)
+    doc = {
+        "asset": {"version": "2.0", "generator": "tests/gltf_util.py"},
+        "scene": 0,
+        "scenes": [{"nodes": [0, 1, 4, 6, 7, 8, 9]}],
+        "nodes": [
+            {"name": "tube", "mesh": 0, "skin": 0},
+            {"name": "joint0", "translation": [0.0, 0.0, 0.0], "children": [2]},
+            {"name": "joint1", "translation": [0.0, 0.8, 0.0], "children": [3]},
+            {"name": "joint2", "translation": [0.0, 0.6, 0.0]},
+            {"name": "arm", "translation": [0.0, 0.0, -0.5], "rotation": quat_y(0.4), "children": [5]},
+            {"name": "cube", "mesh": 1, "translation": [1.5, 0.5, 0.0], "scale": [1.0, 1.0, 1.0]},
+            {"name": "cube static", "mesh": 1, "matrix": [0.4, 0, 0, 0, 0, 0.4, 0, 0, 0, 0, 0.4, 0, -1.5, 0.2, 0.3, 1]},
+            {"name": "floor", "mesh": 2},
+            {"name": "lamp", "mesh": 3, "translation": [0.0, 3.2, 0.5]},
+            {"name": "eye", "camera": 0, "translation": [0.0, 1.3, 5.5]},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.75, "znear": 0.01, "aspectRatio": 1.5}}],
+        "skins": [{"joints": [1, 2, 3], "inverseBindMatrices": a_m}],
+        "meshes": [
+            {"name": "tube", "primitives": [{"attributes": {"POSITION": a_p, "JOINTS_0": a_j, "WEIGHTS_0": a_w}, "indices": a_i, "material": 0}]},
+            {"name": "cube", "primitives": [{"attributes": {"POSITION": a_cp, "NORMAL": a_cn}, "indices": a_ci, "material": 1}]},
+            {"name": "floor", "primitives": [{"attributes": {"POSITION": a_fl, "TEXCOORD_0": a_fuv}, "material": 2}]},
+            {"name": "lamp", "primitives": [{"attributes": {"POSITION": a_lp}, "indices": a_li, "material": 3}]},
+        ],
+        "materials": [
+            {"name": "skin", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.6, 0.8, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.7}},
+            {"name": "red", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.1, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.6}},
+            {"name": "grey", "pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.7, 0.7, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.9}},
+            {"name": "emitter", "emissiveFactor": [1.0, 0.9, 0.8], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 14.0}}},
+        ],
+        "animations": [{
+            "name": "all",
+            "samplers": [
+                {"input": t5, "output": r1, "interpolation": "LINEAR"},
+                {"input": t3, "output": r2},                                  # LINEAR is the default
+                {"input": t5, "output": tr0, "interpolation": "LINEAR"},
+                {"input": t3, "output": tc, "interpolation": "CUBICSPLINE"},
+                {"input": t3, "output": sc, "interpolation": "STEP"},
+            ],
+            "channels": [
+                {"sampler": 0, "target": {"node": 2, "path": "rotation"}},
+                {"sampler": 1, "target": {"node": 3, "path": "rotation"}},
+                {"sampler": 2, "target": {"node": 1, "path": "translation"}},
+                {"sampler": 3, "target": {"node": 5, "path": "translation"}},
+                {"sampler": 4, "target": {"node": 5, "path": "scale"}},
+                {"sampler": 0, "target": {"node": 0, "path": "weights"}},      # morph weights: ignored (no morph targets anywhere)
+            ],
+        }],
+        "accessors": accessors, "bufferViews": views,
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+    }
+    if jpeg is not None:
+        doc["images"] = [{"uri": "data:image/jpeg;base64," + base64.b64encode(jpeg).decode()}]
+        doc["textures"] = [{"source": 0}]
+        doc["materials"][2]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    path = directory / "animated.gltf"
+    path.write_text(json.dumps(doc))
+    return path

@@ -220,3 +220,172 @@ def test_save_glb_round_trip_is_lossless(tmp_path, kind, a, b):
     oa.render(va); ob.render(vb)
     assert oa.stats()["shadow"] > 50
     assert np.array_equal(oa.accumulator().view(np.uint32), ob.accumulator().view(np.uint32))
+
+
+# ---------------------------------------------------------------- animations (glTF 3.11) and JPEG images: what examples/animated loads
+def _jpeg(img, **kw):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil_decode(data, mode="RGB"):
+    import io
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert(mode))
+
+
+def _test_image(h=97, w=131):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 128 + 90 * np.cos(xx / 5.0 + yy / 11.0), xx * 255.0 / (w - 1)], -1).clip(0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling,restart", [(0, 0), (1, 0), (2, 0), (0, 3), (2, 5)])
+def test_jpeg_decoder_agrees_with_pillow(subsampling, restart):
+    """host/jpeg.cpp (baseline sequential JPEG) against libjpeg through Pillow: 4:4:4 / 4:2:2 / 4:2:0, odd sizes (partial MCUs), restart
+    intervals.  The inverse DCT is evaluated in double precision here and in fixed point there: a level or two after the colour
+    conversion, nothing systematic."""
+    pytest.importorskip("PIL")
+    from rfw_rs_amd.scene import decode_image
+    img = _test_image()
+    kw = {"quality": 90, "subsampling": subsampling}
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    data = _jpeg(img, **kw)
+    mine, ref = decode_image(data), _pil_decode(data)
+    assert mine.shape == (97, 131, 4) and (mine[..., 3] == 255).all()
+    diff = np.abs(mine[..., :3].astype(int) - ref.astype(int))
+    assert diff.max() <= 3 and diff.mean() < 0.1
+
+
+def test_jpeg_grey_optimised_tables_and_refusals():
+    pytest.importorskip("PIL")
+    from rfw_rs_amd.scene import decode_image
+    img = _test_image(40, 56)
+    grey = _jpeg(img[..., 0], quality=85)
+    got = decode_image(grey)
+    assert np.abs(got[..., 0].astype(int) - _pil_decode(grey, "L")).max() <= 1 and np.array_equal(got[..., 0], got[..., 2])
+    opt = _jpeg(img, quality=75, optimize=True)                    # per-image Huffman tables
+    assert np.abs(decode_image(opt)[..., :3].astype(int) - _pil_decode(opt).astype(int)).max() <= 3
+    with pytest.raises(ValueError, match="progressive"):
+        decode_image(_jpeg(img, quality=90, progressive=True))
+    good = _jpeg(img, quality=90)
+    for name, bad in {"truncated": good[: len(good) // 2], "no tables": good[:2] + good[good.index(b"\xff\xc0"):], "garbage": b"\xff\xd8" + bytes(range(256))}.items():
+        with pytest.raises(ValueError):
+            decode_image(bad)
+    # deterministic mutations of a good file: decode or refuse, never crash
+    rng = np.random.default_rng(5)
+    for it in range(200):
+        raw = bytearray(good)
+        for _ in range(int(rng.integers(1, 5))):
+            raw[int(rng.integers(2, len(raw)))] = int(rng.integers(0, 256))
+        try:
+            decode_image(bytes(raw))
+        except ValueError:
+            pass
+
+
+def test_animation_sampling_matches_the_specification(tmp_path):
+    """The importer keeps the node graph; set_animation_time evaluates the channels (LINEAR incl. shortest-arc slerp over normalised int16
+    keys, STEP, CUBICSPLINE), loops the time, and rebuilds instance and joint matrices.  Held against tests/gltf_anim.py, an independent
+    float64 evaluation of the same document written from the glTF specification."""
+    from gltf_anim import evaluate
+    from gltf_util import write_animated_gltf
+    path = write_animated_gltf(tmp_path)
+    scene = Scene().load_gltf(str(path))
+    assert scene.animation_info(0) == {"duration": 2.0, "channels": 5}       # the weights channel is dropped
+    with pytest.raises(KeyError):
+        scene.animation_info(1)
+    load_pose = scene.skin_matrices(0).copy()
+    world, skins = evaluate(str(path), 0.0)
+    for t in (0.0, 0.1, 0.25, 0.6, 0.99, 1.0, 1.3, 1.75, 1.9, 2.0, 2.6, -0.4, 41.3):
+        assert scene.set_animation_time(t) == 1
+        world, skins = evaluate(str(path), t)
+        assert np.allclose(scene.skin_matrices(0), skins[0], rtol=0, atol=2e-7), t
+        m, skin = scene.instance_matrix(1, 0)                                # the animated cube (node 5 under "arm")
+        assert skin == -1 and np.allclose(m, world[5], rtol=0, atol=3e-7), t
+        m, _ = scene.instance_matrix(1, 1)                                   # the matrix node never moves
+        assert np.allclose(m, world[6], rtol=0, atol=1e-7)
+        m, skin = scene.instance_matrix(0, 0)                                # the skinned instance: identity, the joints carry the transform
+        assert skin == 0 and np.array_equal(m, np.eye(4, dtype=np.float32))
+    scene.set_animation_time(0.6)
+    assert np.abs(scene.skin_matrices(0) - load_pose).max() > 0.1
+    # the whole graph under a transform (GraphHandle::get_transform): joints and instances follow
+    scene.set_graph_transform(-1, translation=(1.0, 0.5, -2.0), rotation=(0.0, np.sin(0.3), 0.0, np.cos(0.3)), scale=(2.0, 2.0, 2.0))
+    world, skins = evaluate(str(path), 0.6)
+    c, s = np.cos(0.6), np.sin(0.6)
+    root = np.array([[2 * c, 0, 2 * s, 1.0], [0, 2, 0, 0.5], [-2 * s, 0, 2 * c, -2.0], [0, 0, 0, 1]])
+    assert np.allclose(scene.skin_matrices(0), root @ skins[0], atol=1e-6)
+    assert np.allclose(scene.instance_matrix(1, 0)[0], root @ world[5], atol=1e-6)
+
+
+def test_animated_scene_renders_differently_over_time(tmp_path):
+    """set_animation_time -> sync -> render on the oracle: skinned triangles and moved instances reach the image; the JPEG base colour
+    of the floor reaches the sampler."""
+    pytest.importorskip("PIL")
+    from gltf_util import write_animated_gltf
+    tex = _test_image(64, 64)
+    data = _jpeg(tex, quality=95, subsampling=0)
+    scene = Scene().load_gltf(str(write_animated_gltf(tmp_path, jpeg=data)))
+    orc = Oracle(60, 40, threads=4, max_path_length=2)
+    scene.set_aspect(1.5)
+    view = scene.view(60, 40)
+    images = []
+    for t in (0.0, 0.6, 1.3):
+        scene.set_animation_time(t)
+        scene.sync(orc)
+        orc.reset(); orc.render(view)
+        images.append(orc.accumulator().copy())
+        assert orc.validate_bvh() == 0 and orc.stats()["shadow"] > 0
+    assert not np.array_equal(images[0], images[1]) and not np.array_equal(images[1], images[2])
+    scene.set_animation_time(2.0)                                            # one full loop later: the first image again, bit for bit
+    scene.sync(orc); orc.reset(); orc.render(view)
+    assert np.array_equal(orc.accumulator().view(np.uint32), images[0].view(np.uint32))
+    want = _pil_decode(data)[10, 20].astype(np.float32) / 255.0              # texel (x = 20, y = 10) of the decoded JPEG, within the decoders' tolerance
+    got = orc.sample_texture(0, (20 + 0.5) / 64, (10 + 0.5) / 64, 0.0)
+    assert np.abs(got[:3] - want).max() <= 3.5 / 255.0
+
+
+REF_MODELS = "/root/reference/assets/models"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REF_MODELS + "/CesiumMan/CesiumMan.gltf"), reason="the reference checkout is not on this machine")
+def test_reference_sample_assets_import_in_place():
+    """The two models the reference's examples/animated loads (examples/animated/src/main.rs:80,108), read where they lie: CesiumMan
+    (skinned, animated, JPEG texture) and pica (170 nodes, PNG textures).  Counts are checked against the documents' own JSON, the
+    animated joints against the independent evaluation, the texture against Pillow."""
+    import json
+    from gltf_anim import evaluate
+    man = REF_MODELS + "/CesiumMan/CesiumMan.gltf"
+    doc = json.load(open(man))
+    scene = Scene().load_gltf(man)
+    acc = doc["accessors"]
+    tris = sum(acc[p["indices"]]["count"] // 3 for m in doc["meshes"] for p in m["primitives"])
+    assert scene.triangle_count == tris == 4672 and scene.counts()["materials"] == len(doc["materials"])
+    info = scene.animation_info(0)
+    assert info["channels"] == len(doc["animations"][0]["channels"]) == 57 and abs(info["duration"] - 2.0) < 1e-6
+    assert len(scene.skin_matrices(0)) == len(doc["skins"][0]["joints"]) == 19
+    for t in (0.0, 0.37, 1.1, 1.99, 2.5):
+        scene.set_animation_time(t)
+        _, skins = evaluate(man, t)
+        assert np.allclose(scene.skin_matrices(0), skins[0], rtol=0, atol=2e-7), t
+    orc = Oracle(48, 64, threads=4, max_path_length=1)
+    scene.sync(orc)
+    pytest.importorskip("PIL")
+    ref = _pil_decode(open(REF_MODELS + "/CesiumMan/CesiumMan.jpg", "rb").read())   # 1024 x 1024: one layer of the texture array as it is
+    for (x, y) in ((100, 200), (512, 512), (900, 40)):
+        got = orc.sample_texture(0, (x + 0.5) / 1024, (y + 0.5) / 1024, 0.0)
+        assert np.abs(got[:3] - ref[y, x] / 255.0).max() <= 3.5 / 255.0
+    pica = REF_MODELS + "/pica/scene.gltf"
+    doc = json.load(open(pica))
+    scene = Scene().load_gltf(pica)
+    with_mesh = [n for n in doc["nodes"] if "mesh" in n]
+    tris = 0
+    for n in with_mesh:
+        for p in doc["meshes"][n["mesh"]]["primitives"]:
+            tris += (doc["accessors"][p["indices"]]["count"] if "indices" in p else doc["accessors"][p["attributes"]["POSITION"]]["count"]) // 3
+    c = scene.counts()
+    assert c["instances"] == len(with_mesh) and scene.triangle_count == tris
+    assert c["materials"] >= len(doc["materials"])

@@ -263,6 +263,16 @@ def test_cpp_example_animated_runs_the_reference_frame_loop(tmp_path):
     assert img.mean() > 8 and img.std() > 8          # a lit, structured image
     bad = subprocess.run([exe, "--gltf", str(tmp_path / "missing.glb")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert bad.returncode == 1 and "missing.glb" in bad.stderr
+    # the reference's two animated actors (main.rs:79-103) and its animation timer system: two graphs of an animated, skinned glTF document,
+    # Scene::set_animations_time every frame -> skinning and refit on the device; the image differs from the run without them
+    from gltf_util import write_animated_gltf
+    actor = str(write_animated_gltf(tmp_path))
+    out2 = tmp_path / "actors.ppm"
+    r2 = subprocess.run([exe, "--gltf", glb, "--actor", actor, "--actor", actor, "--frames", "40", "--size", "320x200", "--spheres", "20x20", "--out", str(out2)],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    img2 = np.frombuffer(out2.read_bytes()[len(head):], np.uint8).reshape(200, 320, 3)
+    assert (img2 != img).mean() > 0.01
 
 
 def test_batch_and_accumulator_corner_cases():
