@@ -48,7 +48,8 @@ int main(int argc, char** argv)
         }
         for (size_t k = 0; k < actors.size(); k++) { // main.rs:84-103: the first graph scaled by 3, the second moved to x = -3, both turned by 180 degrees about y
             std::string err;
-            if (!rfw::load_gltf(actors[k], scene, nullptr, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            if (k > 0 && actors[k] == actors[0]) scene.instantiate_graph(scene.graphs.size() - k); // add_3d(&descriptor) again: same meshes, new instances and skins
+            else if (!rfw::load_gltf(actors[k], scene, nullptr, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
             const double turn[4] = {0.0, 1.0, 0.0, 6.123233995736766e-17}; // quaternion of a half turn about y
             const double t0[3] = {0, 0, 0}, t1[3] = {-3.0 * (double)k, 0, 0}, s3[3] = {3, 3, 3}, s1[3] = {1, 1, 1};
             scene.graphs.back().set_root_transform(scene, k == 0 ? t0 : t1, turn, k == 0 ? s3 : s1);

@@ -616,6 +616,38 @@ void NodeGraph::set_animation_time(Scene& scene, double time)
     update(scene);
 }
 
+size_t Scene::instantiate_graph(size_t graph)
+{
+    if (graph >= graphs.size()) return graphs.size();
+    NodeGraph g = graphs[graph]; // nodes, animations, clock and transform copied
+    std::map<int32_t, int32_t> new_skin; // skin of the original -> its copy
+    for (auto& sk : g.skins) {
+        if (sk.first < 0 || (size_t)sk.first >= skins.size()) continue;
+        const Skin copy = skins[(size_t)sk.first];
+        new_skin[sk.first] = (int32_t)skins.size();
+        sk.first = (int32_t)skins.size();
+        skins.push_back(copy);
+    }
+    for (GraphNode& n : g.nodes) {
+        if (n.mesh < 0 || n.instance < 0) continue;
+        const uint32_t mesh = (uint32_t)n.mesh;
+        const bool skinned = n.skin >= 0 && new_skin.count(n.skin);
+        const size_t slot = add_instance(mesh, skinned ? mat4_identity() : to_f32(m4_from(n.world)));
+        n.instance = (int64_t)slot;
+        if (skinned) {
+            InstanceList3D& l = instances_3d[mesh];
+            if (l.skin_ids.size() <= slot) l.skin_ids.resize(slot + 1, -1);
+            n.skin = new_skin[n.skin];
+            l.skin_ids[slot] = n.skin;
+        }
+    }
+    skins_changed = skins_changed || !new_skin.empty();
+    graphs.push_back(std::move(g));
+    graphs.back().update(*this);
+    update_lights(); // a copied emitter is a new set of area lights (as at the end of load_gltf)
+    return graphs.size() - 1;
+}
+
 void Scene::set_animations_time(double time)
 {
     for (NodeGraph& g : graphs) g.set_animation_time(*this, time);

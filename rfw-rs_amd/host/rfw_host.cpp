@@ -1358,6 +1358,13 @@ HOST_API int rfwhost_set_graph_transform(void* p, uint32_t graph, const double* 
     h.scene.graphs[graph].set_root_transform(h.scene, t, q, s);
     return 0;
 }
+// Scene::instantiate_graph: a second instance of loaded graph `graph` over the same meshes; returns the new graph's index, -1: no such graph
+HOST_API int rfwhost_instantiate_graph(void* p, uint32_t graph)
+{
+    HostScene& h = *(HostScene*)p;
+    if (graph >= h.scene.graphs.size()) return -1;
+    return (int)h.scene.instantiate_graph(graph);
+}
 HOST_API int rfwhost_graph_count(void* p) { return (int)((HostScene*)p)->scene.graphs.size(); }
 // duration (seconds) and channel count of animation `index` counted over the loaded graphs; -1: no such animation
 HOST_API int rfwhost_animation_info(void* p, uint32_t index, double* duration, uint32_t* channels)

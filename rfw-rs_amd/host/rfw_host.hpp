@@ -232,6 +232,10 @@ struct Scene {
     std::vector<NodeGraph> graphs;
     // crates/rfw-scene/src/lib.rs:685-687 set_animations_time: every loaded graph's active animation
     void set_animations_time(double time);
+    // Scene::add_3d(&SceneDescriptor) a second time (examples/animated/src/main.rs:84-103 adds the CesiumMan descriptor twice): a new graph
+    // over the SAME meshes — new instances, new skins (two instances of one mesh may wear different skins), its own transform and clock.
+    // Returns the new graph's index.
+    size_t instantiate_graph(size_t graph);
     std::vector<Skin> skins;
     bool skins_changed = false;
     std::vector<Texture> textures;

@@ -50,6 +50,7 @@ def host_lib():
         l.rfwhost_set_animation_time.argtypes = [C.c_void_p, C.c_double]
         l.rfwhost_set_graph_transform.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         l.rfwhost_graph_count.argtypes = [C.c_void_p]
+        l.rfwhost_instantiate_graph.argtypes = [C.c_void_p, C.c_uint32]
         l.rfwhost_animation_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         l.rfwhost_skin_matrices.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.c_uint32]
         l.rfwhost_instance_matrix.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
@@ -122,6 +123,15 @@ class Scene:
         t, q, sc = (C.c_double * 3)(*translation), (C.c_double * 4)(*rotation), (C.c_double * 3)(*scale)
         if self._l.rfwhost_set_graph_transform(self._h, graph, t, q, sc) != 0:
             raise KeyError(graph)
+
+    def instantiate_graph(self, graph=-1):
+        """Scene::add_3d(&descriptor) once more: a new graph over the same meshes (new instances, new skins); returns its index."""
+        if graph < 0:
+            graph += int(self._l.rfwhost_graph_count(self._h))
+        g = int(self._l.rfwhost_instantiate_graph(self._h, graph))
+        if g < 0:
+            raise KeyError(graph)
+        return g
 
     def animation_info(self, index=0):
         d, c = C.c_double(), C.c_uint32()

@@ -321,6 +321,32 @@ def test_animation_sampling_matches_the_specification(tmp_path):
     assert np.allclose(scene.instance_matrix(1, 0)[0], root @ world[5], atol=1e-6)
 
 
+def test_a_graph_instantiated_twice_shares_meshes_not_skins(tmp_path):
+    """examples/animated/src/main.rs:84-103 adds the CesiumMan descriptor to the scene twice, each with its own transform: the second graph
+    reuses the meshes, gets its own instances and its own skin (the backend skins a copy per (mesh, skin) pair), and follows the clock."""
+    from gltf_anim import evaluate
+    from gltf_util import write_animated_gltf
+    path = write_animated_gltf(tmp_path)
+    scene = Scene().load_gltf(str(path))
+    before = scene.counts()
+    g = scene.instantiate_graph()
+    after = scene.counts()
+    assert g == 1 and after["meshes"] == before["meshes"] and after["instances"] == 2 * before["instances"] and after["area_lights"] == 2 * before["area_lights"]
+    scene.set_graph_transform(g, translation=(2.0, 0.0, 0.0))
+    scene.set_animation_time(0.6)
+    world, skins = evaluate(str(path), 0.6)
+    shift = np.eye(4); shift[0, 3] = 2.0
+    assert np.allclose(scene.skin_matrices(0), skins[0], atol=2e-7) and np.allclose(scene.skin_matrices(1), shift @ skins[0], atol=3e-7)
+    assert scene.instance_matrix(0, 0)[1] == 0 and scene.instance_matrix(0, 1)[1] == 1          # two instances of the tube, two skins
+    assert np.allclose(scene.instance_matrix(1, 2)[0], shift @ world[5], atol=3e-7)             # the second graph's animated cube
+    orc = Oracle(60, 40, threads=4, max_path_length=2)
+    scene.set_aspect(1.5)
+    scene.sync(orc)
+    assert orc.stats()["n_tris"] == (128 + 12 + 2 + 2) + 2 * 128 and orc.validate_bvh() == 0   # the four meshes once + one skinned copy of the tube per skin
+    with pytest.raises(KeyError):
+        scene.instantiate_graph(7)
+
+
 def test_animated_scene_renders_differently_over_time(tmp_path):
     """set_animation_time -> sync -> render on the oracle: skinned triangles and moved instances reach the image; the JPEG base colour
     of the floor reaches the sampler."""
