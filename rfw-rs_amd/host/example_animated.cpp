@@ -8,7 +8,7 @@
 // Where the reference presents to a window, this program downloads the presented (Bgra8UnormSrgb) frame of every frame into a ring of
 // pinned host buffers without stalling the frames in flight, and writes the last one as a PPM image.
 //
-//   example_animated [--gltf scene.glb] [--actor animated.gltf]... [--frames N] [--size WxH] [--spheres NXxNZ] [--path-length L] [--out last.ppm]
+//   example_animated [--gltf scene.glb | scene.obj] [--actor animated.gltf]... [--frames N] [--size WxH] [--spheres NXxNZ] [--path-length L] [--out last.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +42,8 @@ int main(int argc, char** argv)
         rfw::Camera3D camera;
         if (!gltf.empty()) {
             std::string err;
-            if (!rfw::load_gltf(gltf, scene, &camera, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            const bool obj = gltf.size() > 4 && gltf.compare(gltf.size() - 4, 4, ".obj") == 0; // Scene::load picks the loader by extension
+            if (!(obj ? rfw::load_obj(gltf, scene, err) : rfw::load_gltf(gltf, scene, &camera, err))) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
         } else {
             rfw::build_atrium(scene, camera, 262267, 0xC0FFEE);
         }

@@ -1288,6 +1288,50 @@ HOST_API int rfwhost_load_gltf(void* p, const char* path, int use_camera)
     }
     return 0;
 }
+// Wavefront OBJ (+ its material libraries and textures) added to the scene as one mesh with one instance; returns the mesh id, -1 with the
+// message in rfwhost_last_error
+HOST_API int rfwhost_load_obj(void* p, const char* path)
+{
+    HostScene& h = *(HostScene*)p;
+    if (!path) { h.error = "load_obj: null path"; return -1; }
+    try {
+        std::string err;
+        uint32_t mesh = 0;
+        if (!rfw::load_obj(path, h.scene, err, true, &mesh)) { h.error = err; return -1; }
+        return (int)mesh;
+    } catch (const std::exception& e) {
+        h.error = std::string("load_obj: ") + e.what();
+        return -1;
+    }
+}
+// material `index` as the scene holds it: colour(4), specular(4), then metallic, subsurface, specular_f, roughness, specular_tint, anisotropic,
+// sheen, sheen_tint, clearcoat, clearcoat_gloss, transmission, eta (20 floats) and the five texture ids (diffuse, normal,
+// metallic-roughness, emissive, sheen)
+HOST_API int rfwhost_material(void* p, uint32_t index, float* out20, int32_t* tex5)
+{
+    HostScene& h = *(HostScene*)p;
+    if (index >= h.scene.materials.size()) return -1;
+    const rfw::Material& m = h.scene.materials[index];
+    if (out20) {
+        std::memcpy(out20, m.color, 16); std::memcpy(out20 + 4, m.specular, 16);
+        const float v[12] = {m.metallic, m.subsurface, m.specular_f, m.roughness, m.specular_tint, m.anisotropic, m.sheen, m.sheen_tint, m.clearcoat, m.clearcoat_gloss, m.transmission, m.eta};
+        std::memcpy(out20 + 8, v, sizeof(v));
+    }
+    if (tex5) { tex5[0] = m.diffuse_tex; tex5[1] = m.normal_tex; tex5[2] = m.metallic_roughness_tex; tex5[3] = m.emissive_tex; tex5[4] = m.sheen_tex; }
+    return 0;
+}
+// texture `index`: size of level 0; with `bgra_out` (w * h * 4 bytes) also its texels
+HOST_API int rfwhost_texture(void* p, uint32_t index, uint32_t* w, uint32_t* hgt, uint8_t* bgra_out, uint64_t cap)
+{
+    HostScene& h = *(HostScene*)p;
+    if (index >= h.scene.textures.size()) return -1;
+    const rfw::Texture& t = h.scene.textures[index];
+    if (w) *w = t.width;
+    if (hgt) *hgt = t.height;
+    const uint64_t n = (uint64_t)t.width * t.height * 4;
+    if (bgra_out && cap >= n && t.bytes.size() >= n) std::memcpy(bgra_out, t.bytes.data(), n);
+    return (int)h.scene.textures.size();
+}
 HOST_API int rfwhost_save_glb(void* p, const char* path)
 {
     HostScene& h = *(HostScene*)p;

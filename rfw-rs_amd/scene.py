@@ -48,6 +48,9 @@ def host_lib():
         l.rfwhost_edit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
         l.rfwhost_set_animation_time.argtypes = [C.c_void_p, C.c_double]
+        l.rfwhost_load_obj.argtypes = [C.c_void_p, C.c_char_p]
+        l.rfwhost_material.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        l.rfwhost_texture.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
         l.rfwhost_set_graph_transform.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         l.rfwhost_graph_count.argtypes = [C.c_void_p]
         l.rfwhost_instantiate_graph.argtypes = [C.c_void_p, C.c_uint32]
@@ -96,6 +99,43 @@ class Scene:
         if self._l.rfwhost_load_gltf(self._h, os.fsencode(path), 1 if use_camera else 0) != 0:
             raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
         return self
+
+    def load(self, path):
+        """Scene::load (crates/rfw-scene/src/lib.rs): the loader is picked by the file's extension — .gltf / .glb or .obj."""
+        ext = os.path.splitext(str(path))[1].lower()
+        if ext in (".gltf", ".glb"):
+            return self.load_gltf(path)
+        if ext == ".obj":
+            self.load_obj(path)
+            return self
+        raise ValueError(f"no loader for {ext!r} files")
+
+    def load_obj(self, path):
+        """ObjLoader (crates/rfw-scene/src/loaders/obj.rs): a Wavefront OBJ file with its material libraries and textures as ONE mesh with one
+        instance at the identity.  Returns the mesh id."""
+        mesh = self._l.rfwhost_load_obj(self._h, os.fsencode(path))
+        if mesh < 0:
+            raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
+        return int(mesh)
+
+    def material(self, index):
+        v, t = (C.c_float * 20)(), (C.c_int32 * 5)()
+        if self._l.rfwhost_material(self._h, index, v, t) != 0:
+            raise KeyError(index)
+        names = ["metallic", "subsurface", "specular_f", "roughness", "specular_tint", "anisotropic", "sheen", "sheen_tint", "clearcoat", "clearcoat_gloss", "transmission", "eta"]
+        out = {"color": list(v[0:4]), "specular": list(v[4:8]), **{n: v[8 + i] for i, n in enumerate(names)}}
+        out.update(dict(zip(["diffuse_tex", "normal_tex", "metallic_roughness_tex", "emissive_tex", "sheen_tex"], list(t))))
+        return out
+
+    def texture(self, index):
+        """Level 0 of scene texture `index` as (h, w, 4) uint8 in B, G, R, A order (what set_textures hands the backend)."""
+        import numpy as np
+        w, h = C.c_uint32(), C.c_uint32()
+        if self._l.rfwhost_texture(self._h, index, C.byref(w), C.byref(h), None, 0) < 0:
+            raise KeyError(index)
+        out = np.empty((h.value, w.value, 4), np.uint8)
+        self._l.rfwhost_texture(self._h, index, C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
+        return out
 
     def save_glb(self, path):
         """Writes the scene (static meshes, instances, materials, punctual lights, camera) as a binary glTF 2.0 file."""

@@ -407,3 +407,33 @@ def write_animated_gltf(directory, jpeg=None):
     path = directory / "animated.gltf"
     path.write_text(json.dumps(doc))
     return path
+
+
+def encode_tga(img, rle=False, top_down=False):
+    """(h, w, 4) RGBA, (h, w, 3) RGB or (h, w) grey uint8 -> TGA bytes (types 2 / 3, run-length encoded 10 / 11)."""
+    img = np.asarray(img, np.uint8)
+    grey = img.ndim == 2
+    h, w = img.shape[:2]
+    ch = 1 if grey else img.shape[2]
+    px = img.reshape(h, w, 1) if grey else img[..., [2, 1, 0] + ([3] if ch == 4 else [])]        # stored B, G, R (, A)
+    rows = px if top_down else px[::-1]
+    flat = rows.reshape(-1, ch)
+    head = struct.pack("<BBBHHBHHHHBB", 0, 0, (3 if grey else 2) + (8 if rle else 0), 0, 0, 0, 0, 0, w, h, 8 * ch, (0x20 if top_down else 0) | (8 if ch == 4 else 0))
+    if not rle:
+        return head + flat.tobytes()
+    out = bytearray()
+    i, n = 0, len(flat)
+    while i < n:
+        run = 1
+        while i + run < n and run < 128 and (flat[i + run] == flat[i]).all():
+            run += 1
+        if run > 1:
+            out += bytes([0x80 | (run - 1)]) + flat[i].tobytes()
+            i += run
+        else:
+            lit = 1
+            while i + lit < n and lit < 128 and not (i + lit + 1 < n and (flat[i + lit] == flat[i + lit + 1]).all()):
+                lit += 1
+            out += bytes([lit - 1]) + flat[i:i + lit].tobytes()
+            i += lit
+    return head + bytes(out)
