@@ -399,6 +399,30 @@ def test_gltf_scenes_match_oracle(tmp_path, which):
     assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
 
 
+def test_obj_scene_matches_oracle(tmp_path):
+    """A Wavefront OBJ with its material library and textures (PNG base colour, run-length TGA normal map, an emitter) through the host's
+    ObjLoader restatement, lit by its own emissive pentagon and a Cornell box around it: same hits, same image."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    from test_obj import write_scene
+    path, _, _ = write_scene(tmp_path)
+    scene = Scene().load(str(path))
+    scene.build("cornell")
+    w, h = 96, 72
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3)
+    orc = Oracle(w, h, threads=4, max_path_length=3)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    o, d = random_rays(5000, 4, extent=3.0)
+    assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
+    for _ in range(2):
+        be.render(view); orc.render(view)
+    assert orc.stats()["shadow"] > 0
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    be.close()
+
+
 @pytest.mark.parametrize("frames_in_flight", [0, 3])
 def test_animated_gltf_matches_oracle_over_time(tmp_path, frames_in_flight):
     """examples/animated's set_animation_timers system (main.rs:221-223): Scene::set_animations_time every frame, then synchronize and
