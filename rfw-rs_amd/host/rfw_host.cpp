@@ -580,6 +580,27 @@ float vnoise(float x, float y, uint32_t seed)
 }
 } // namespace
 
+// objects_3d/quad.rs:52-75 Quad3D::generate_render_data: two triangles spanned by a tangent (normal x helper axis, half the width) and a
+// bitangent (half the height) around `position`; uvs are all zero there ("TODO: uvs", :28)
+MeshDescriptor make_quad(const float n_in[3], const float p_in[3], float width, float height, uint32_t mat_id)
+{
+    const V3 normal = normalize(v3(n_in[0], n_in[1], n_in[2])), pos = v3(p_in[0], p_in[1], p_in[2]);
+    const V3 tmp = normal.x > 0.9f ? v3(0, 1, 0) : v3(1, 0, 0);
+    const V3 tangent = normalize(cross(normal, tmp)) * (0.5f * width);
+    const V3 bi_tangent = cross(normalize(tangent), normal) * (0.5f * height);
+    const V3 v[6] = {pos - bi_tangent - tangent, pos + bi_tangent - tangent, pos - bi_tangent + tangent,
+                     pos + bi_tangent - tangent, pos + bi_tangent + tangent, pos - bi_tangent + tangent};
+    MeshDescriptor d;
+    d.name = "quad";
+    for (const V3& q : v) {
+        d.vertices.push_back(rfw_vec4{q.x, q.y, q.z, 1.0f});
+        d.normals.push_back(pod(normal));
+        d.uvs.push_back(rfw_vec2{0, 0});
+        d.material_ids.push_back((int32_t)mat_id);
+    }
+    return d;
+}
+
 MeshDescriptor make_icosphere(int quality, uint32_t mat_id)
 {
     const float PI = 3.14159265358979323846f;
@@ -1287,6 +1308,17 @@ HOST_API int rfwhost_load_gltf(void* p, const char* path, int use_camera)
         return -1;
     }
     return 0;
+}
+// Quad3D::new(normal, position, width, height, material) added as a mesh with one instance (examples/nphysics/src/main.rs:92 builds its
+// ground this way); returns the mesh id
+HOST_API int rfwhost_add_quad(void* p, const float* normal, const float* position, float width, float height, uint32_t material)
+{
+    HostScene& h = *(HostScene*)p;
+    if (!normal || !position || material >= h.scene.materials.size()) return -1;
+    const uint32_t mesh = h.scene.add_mesh(rfw::Mesh3D::from(rfw::make_quad(normal, position, width, height, material)));
+    h.scene.add_instance(mesh, rfw::mat4_identity());
+    h.scene.update_lights();
+    return (int)mesh;
 }
 // Wavefront OBJ (+ its material libraries and textures) added to the scene as one mesh with one instance; returns the mesh id, -1 with the
 // message in rfwhost_last_error

@@ -280,6 +280,7 @@ void synchronize_system(Scene& scene, Backend& renderer);
 void render_system(const Camera3D& camera, uint32_t width, uint32_t height, Backend& renderer);
 
 // ---- synthetic scenes standing in for the assets the reference does not ship ----
+MeshDescriptor make_quad(const float normal[3], const float position[3], float width, float height, uint32_t mat_id); // objects_3d/quad.rs:19-75 Quad3D
 MeshDescriptor make_icosphere(int quality, uint32_t mat_id);                       // objects_3d/sphere.rs:365-519
 void build_cornell_box(Scene& scene, Camera3D& cam);                               // C1
 // separate_spheres: C4's 64 displaced icospheres as 64 meshes with one instance each (65 meshes in all) instead of one baked mesh

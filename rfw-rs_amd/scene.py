@@ -49,6 +49,7 @@ def host_lib():
         l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
         l.rfwhost_set_animation_time.argtypes = [C.c_void_p, C.c_double]
         l.rfwhost_load_obj.argtypes = [C.c_void_p, C.c_char_p]
+        l.rfwhost_add_quad.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_uint32]
         l.rfwhost_material.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         l.rfwhost_texture.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
         l.rfwhost_set_graph_transform.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -99,6 +100,13 @@ class Scene:
         if self._l.rfwhost_load_gltf(self._h, os.fsencode(path), 1 if use_camera else 0) != 0:
             raise ValueError((self._l.rfwhost_last_error(self._h) or b"").decode(errors="replace"))
         return self
+
+    def add_quad(self, normal, position, width, height, material):
+        """Quad3D::new (crates/rfw-scene/src/objects_3d/quad.rs) as a mesh with one instance; returns the mesh id."""
+        mesh = self._l.rfwhost_add_quad(self._h, (C.c_float * 3)(*normal), (C.c_float * 3)(*position), width, height, material)
+        if mesh < 0:
+            raise ValueError("add_quad: unknown material")
+        return int(mesh)
 
     def load(self, path):
         """Scene::load (crates/rfw-scene/src/lib.rs): the loader is picked by the file's extension — .gltf / .glb or .obj."""

@@ -1,5 +1,6 @@
 """The C++ host mirror of the rfw-scene pieces that define the backend's inputs."""
 import numpy as np
+import pytest
 
 from rfw_rs_amd import Scene
 
@@ -58,3 +59,26 @@ def test_skinned_scene_poses_change_only_the_skinned_copies():
     assert np.array_equal(a[:454].view(np.uint32), b[:454].view(np.uint32))      # static meshes: unchanged
     assert not np.array_equal(a[454:], b[454:])                                  # skinned copies: moved
     assert not np.array_equal(b[454:902], b[902:])                               # two skins, two shapes
+
+
+def test_quad3d_matches_the_reference_construction():
+    """objects_3d/quad.rs:52-75: tangent = 0.5 w normalize(n x helper), bitangent = 0.5 h normalize(tangent) x n; two triangles, the given
+    normal at every vertex; an emissive material makes it two area lights."""
+    from oracle.bindings import Oracle
+    scene = Scene().build("cornell")
+    first = scene.counts()
+    light = next(i for i in range(first["materials"]) if max(scene.material(i)["color"][:3]) > 1.0)    # the Cornell box's emitter
+    mesh = scene.add_quad((0.0, 2.0, 0.0), (0.5, 1.0, -0.25), 3.0, 2.0, light)
+    assert scene.counts()["meshes"] == first["meshes"] + 1 and scene.counts()["area_lights"] == first["area_lights"] + 2
+    orc = Oracle(16, 16, threads=1)
+    scene.sync(orc)
+    tris = orc.triangles()[-2:]
+    n = np.array([0.0, 1.0, 0.0]); pos = np.array([0.5, 1.0, -0.25])
+    t = np.cross(n, [1.0, 0.0, 0.0]); t = 1.5 * t / np.linalg.norm(t)
+    b = 1.0 * np.cross(t / np.linalg.norm(t), n)
+    want = [pos - b - t, pos + b - t, pos - b + t, pos + b - t, pos + b + t, pos - b + t]
+    got = np.concatenate([tris[:, [0, 1, 2]], tris[:, [4, 5, 6]], tris[:, [8, 9, 10]]], axis=1).reshape(2, 3, 3).reshape(6, 3)
+    assert np.allclose(got, np.array(want, np.float32), atol=1e-6)
+    assert np.allclose(tris[:, 16:19], n)                                       # the vertex normals are the given normal, normalised
+    with pytest.raises(ValueError):
+        scene.add_quad((0, 1, 0), (0, 0, 0), 1.0, 1.0, 999)
