@@ -235,6 +235,35 @@ void Texture::generate_mipmaps(uint32_t levels)
     }
 }
 
+// ------------------------------------------------------------------ camera/mod.rs:164-186, frame from calculate_matrix (:246-252)
+static void camera_frame(const Camera3D& c, V3& x, V3& y, V3& z)
+{
+    z = normalize(v3(c.direction[0], c.direction[1], c.direction[2]));
+    x = normalize(cross(z, v3(0, 1, 0)));
+    y = normalize(cross(x, z));
+}
+void Camera3D::translate_relative(const float delta[3])
+{
+    V3 x, y, z;
+    camera_frame(*this, x, y, z);
+    const V3 d = v3(delta[0], delta[1], delta[2]) * speed;
+    const V3 p = v3(pos[0], pos[1], pos[2]) + (d.x * x + d.y * y + d.z * z);
+    pos[0] = p.x; pos[1] = p.y; pos[2] = p.z;
+}
+void Camera3D::translate_target(const float delta[3])
+{
+    V3 x, y, z;
+    camera_frame(*this, x, y, z);
+    const V3 d = normalize(v3(direction[0], direction[1], direction[2]) + delta[0] * x + delta[1] * y + delta[2] * z);
+    direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
+}
+void Camera3D::look_at(const float origin[3], const float target[3])
+{
+    const V3 d = normalize(v3(target[0] - origin[0], target[1] - origin[1], target[2] - origin[2]));
+    for (int k = 0; k < 3; k++) pos[k] = origin[k];
+    direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
+}
+
 // ------------------------------------------------------------------ Camera3D::get_view (camera/mod.rs:77-115, 246-252)
 rfw_camera_view_3d Camera3D::get_view(uint32_t width, uint32_t height) const
 {
@@ -1494,6 +1523,18 @@ HOST_API int rfwhost_set_camera(void* p, const float* pos, const float* dir, flo
     HostScene& h = *(HostScene*)p;
     for (int i = 0; i < 3; i++) { h.cam.pos[i] = pos[i]; h.cam.direction[i] = dir[i]; }
     h.cam.fov = fov; h.cam.aperture = aperture; h.cam.aspect_ratio = aspect;
+    return 0;
+}
+// op 0: translate_relative(a), 1: translate_target(a), 2: look_at(a, b); pos_dir_out (6 floats, optional): the camera afterwards
+HOST_API int rfwhost_camera_move(void* p, int op, const float* a, const float* b, float* pos_dir_out)
+{
+    HostScene& h = *(HostScene*)p;
+    if (!a || (op == 2 && !b)) return -1;
+    if (op == 0) h.cam.translate_relative(a);
+    else if (op == 1) h.cam.translate_target(a);
+    else if (op == 2) h.cam.look_at(a, b);
+    else return -1;
+    if (pos_dir_out) { std::memcpy(pos_dir_out, h.cam.pos, 12); std::memcpy(pos_dir_out + 3, h.cam.direction, 12); }
     return 0;
 }
 HOST_API int rfwhost_set_aspect(void* p, float aspect) { ((HostScene*)p)->cam.aspect_ratio = aspect; return 0; }

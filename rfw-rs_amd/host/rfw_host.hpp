@@ -166,7 +166,12 @@ struct Camera3D {
     float pos[3] = {0, 0, 0};
     float direction[3] = {0, 0, 1};
     float fov = 40.0f, aspect_ratio = 1.0f, aperture = 0.0001f, focal_distance = 1.0f, near_plane = 1e-2f, far_plane = 1e5f;
+    float speed = 1.0f;
     rfw_camera_view_3d get_view(uint32_t width, uint32_t height) const;
+    // camera/mod.rs:164-186: the moves the reference's examples make from their key handlers (examples/animated/src/main.rs:146-195)
+    void translate_relative(const float delta[3]); // along the camera's right / up / forward, scaled by `speed`
+    void translate_target(const float delta[3]);   // turns: direction += delta in the camera's frame, normalised
+    void look_at(const float origin[3], const float target[3]);
 };
 
 // crates/rfw-backend/src/structs.rs:69-121 TextureData: 4 bytes per texel, mip levels concatenated (level i is (w >> i) x (h >> i))

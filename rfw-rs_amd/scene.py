@@ -48,6 +48,7 @@ def host_lib():
         l.rfwhost_edit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         l.rfwhost_into_device_material.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(pod.DeviceMaterial)]
         l.rfwhost_set_animation_time.argtypes = [C.c_void_p, C.c_double]
+        l.rfwhost_camera_move.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.rfwhost_load_obj.argtypes = [C.c_void_p, C.c_char_p]
         l.rfwhost_add_quad.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_uint32]
         l.rfwhost_material.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -208,6 +209,22 @@ class Scene:
         p = (C.c_float * 3)(*pos)
         d = (C.c_float * 3)(*direction)
         self._l.rfwhost_set_camera(self._h, p, d, fov, aperture, aspect)
+
+    def _camera_move(self, op, a, b=None):
+        out = (C.c_float * 6)()
+        if self._l.rfwhost_camera_move(self._h, op, (C.c_float * 3)(*a), (C.c_float * 3)(*b) if b is not None else None, out) != 0:
+            raise ValueError("camera move")
+        return list(out[0:3]), list(out[3:6])
+
+    def translate_relative(self, delta):
+        """Camera3D::translate_relative (camera/mod.rs:164-170); returns (position, direction)."""
+        return self._camera_move(0, delta)
+
+    def translate_target(self, delta):
+        return self._camera_move(1, delta)
+
+    def look_at(self, origin, target):
+        return self._camera_move(2, origin, target)
 
     def set_aspect(self, aspect):
         self._l.rfwhost_set_aspect(self._h, aspect)

@@ -82,3 +82,16 @@ def test_quad3d_matches_the_reference_construction():
     assert np.allclose(tris[:, 16:19], n)                                       # the vertex normals are the given normal, normalised
     with pytest.raises(ValueError):
         scene.add_quad((0, 1, 0), (0, 0, 0), 1.0, 1.0, 999)
+
+
+def test_camera_moves_follow_the_reference():
+    """camera/mod.rs:164-186 in the frame of calculate_matrix (:246-252): x = normalize(z x Y), y = normalize(x x z)."""
+    scene = Scene().build("cornell")
+    pos, d = scene.look_at((1.0, 2.0, 3.0), (1.0, 2.0, 7.0))
+    assert pos == [1.0, 2.0, 3.0] and d == [0.0, 0.0, 1.0]
+    pos, d = scene.translate_relative((0.5, 0.25, 2.0))             # x = z x Y = (-1, 0, 0) for z = +Z
+    assert np.allclose(pos, [0.5, 2.25, 5.0]) and d == [0.0, 0.0, 1.0]
+    pos, d = scene.translate_target((1.0, 0.0, 0.0))                # towards the camera's right
+    assert np.allclose(d, np.array([-1.0, 0.0, 1.0]) / np.sqrt(2.0), atol=1e-7) and np.allclose(pos, [0.5, 2.25, 5.0])
+    v = scene.view(64, 32)
+    assert np.allclose([v.direction.x, v.direction.y, v.direction.z], d, atol=1e-7)
