@@ -369,6 +369,9 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
 // Buckets are walked from the LAST light index down: directional lights come last in the reference's light order (shade.comp:471-527) and their
 // rays leave the scene — the longest any-hit traversals — so the launch starts with them and ends on the short rays towards the area lights.
+#ifndef RFW_STAGE_PRIO
+#define RFW_STAGE_PRIO 0
+#endif
 #ifndef RFW_SHADOW_ORDER_REV
 #define RFW_SHADOW_ORDER_REV 1
 #endif
@@ -376,6 +379,9 @@ template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
+#if RFW_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO); // experiment: the later stages of a frame win the issue arbitration over younger frames' primary rays
+#endif
     // the queue is bucketed by light (shade pushes into region light & 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
     uint32_t block = xcd_block(blockIdx.x);
@@ -421,6 +427,9 @@ constexpr int kShadeBlock = 512; // 8 wavefronts share ONE atomic per queue (a r
 template <bool BATCH>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
+#if RFW_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO);
+#endif
     const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
     const uint32_t count = bounce == 0 ? p.capacity : sc.counters->ext[bounce - 1];
     if (blockIdx.x * kShadeBlock >= count) return;
