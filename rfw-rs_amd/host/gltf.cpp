@@ -666,8 +666,8 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
         return j && j->kind == Json::Arr ? j->arr : empty;
     };
 
-    // ---- images -> scene textures (PNG and baseline JPEG: BGRA8 with a 5-level mip chain, what l3d hands the trait); texture -> scene texture id
-    std::vector<int> image_tex; // glTF image index -> scene texture id, -1 = not readable here (progressive JPEG, KTX, ...)
+    // ---- images -> scene textures (PNG and JPEG: BGRA8 with a 5-level mip chain, what l3d hands the trait); texture -> scene texture id
+    std::vector<int> image_tex; // glTF image index -> scene texture id, -1 = not readable here (KTX, WebP, ...)
     for (const Json& im : arr("images")) {
         std::vector<uint8_t> file;
         const std::string uri = im.string("uri");

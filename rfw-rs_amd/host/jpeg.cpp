@@ -1,12 +1,13 @@
-// jpeg.cpp — baseline JPEG (ITU-T T.81 sequential DCT, Huffman, 8 bit) -> RGBA8 for the glTF importer.
+// jpeg.cpp — JPEG (ITU-T T.81: sequential and progressive DCT, Huffman, 8 bit) -> RGBA8 for the glTF / OBJ importers.
 //
 // The reference reads images through the `image` crate inside the un-vendored crate l3d 0.3 (crates/rfw-scene/src/loaders/gltf.rs:26-90),
 // and its own sample asset assets/models/CesiumMan/CesiumMan.jpg — the texture of the skinned model examples/animated loads
 // (examples/animated/src/main.rs:80) — is a baseline 4:4:4 JPEG with restart intervals.  This decoder follows the standard: marker
 // segments (DQT, DHT, SOF0/SOF1, DRI, SOS, APP14), interleaved and single-component scans, restart markers, any sampling factors
 // (2x1 and 2x2 chroma through the usual triangle filter, other ratios by replication), the JFIF YCbCr -> RGB conversion in the 16-bit fixed
-// point every libjpeg descendant uses.  Progressive and arithmetic-coded files are refused (the material then stays untextured, like any
-// image the importer cannot read).  The inverse DCT is evaluated in double precision and rounded once, so samples can differ by one
+// point every libjpeg descendant uses.  Progressive files (SOF2: spectral selection and successive approximation, T.81 annex G) are decoded
+// into the same coefficient store, scan by scan; arithmetic-coded, lossless and 12-bit files are refused (the material then stays
+// untextured, like any image the importer cannot read).  The inverse DCT is evaluated in double precision and rounded once, so samples can differ by one
 // level from decoders with an integer IDCT; tests/test_gltf.py holds it against Pillow with that tolerance.
 #include <cmath>
 #include <cstdint>
@@ -44,6 +45,7 @@ struct Component {
     int blocks_w = 0, blocks_h = 0; // allocated blocks (whole MCUs)
     int width = 0, height = 0;      // samples that carry image data: ceil(image * h / hmax)
     std::vector<uint8_t> samples;   // blocks_w * 8 per row
+    std::vector<int32_t> coef;      // blocks_w * blocks_h blocks of 64 quantised coefficients, natural order (dequantised at the end)
     int dc_pred = 0;
 };
 
@@ -135,7 +137,7 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
     std::vector<Component> comps;
     int W = 0, H = 0, hmax = 1, vmax = 1, restart_interval = 0;
     int adobe_transform = -1;
-    bool have_frame = false, decoded_any = false;
+    bool have_frame = false, decoded_any = false, progressive = false;
     static const Idct idct;
     size_t pos = 2;
     while (pos + 4 <= size) {
@@ -179,7 +181,8 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
                 h.build();
                 h.present = true;
             }
-        } else if (m == 0xC0 || m == 0xC1) { // SOF0 / SOF1: sequential DCT, Huffman
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) { // SOF0 / SOF1: sequential DCT; SOF2: progressive DCT; Huffman
+            progressive = m == 0xC2;
             if (have_frame) return fail("jpeg: more than one frame");
             if (n < 6 || s[0] != 8) return fail("jpeg: only 8-bit samples are supported");
             H = (s[1] << 8) | s[2];
@@ -205,10 +208,11 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
                 c.width = (W * c.h + hmax - 1) / hmax;
                 c.height = (H * c.v + vmax - 1) / vmax;
                 c.samples.assign((size_t)c.blocks_w * 8 * (size_t)c.blocks_h * 8, 128);
+                c.coef.assign((size_t)c.blocks_w * (size_t)c.blocks_h * 64, 0);
             }
             have_frame = true;
-        } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-            return fail(m == 0xC2 ? "jpeg: progressive files are not supported" : "jpeg: unsupported coding process");
+        } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+            return fail("jpeg: unsupported coding process (lossless, hierarchical or arithmetic)");
         } else if (m == 0xDD) { // DRI
             if (n < 2) return fail("jpeg: bad DRI");
             restart_interval = (s[0] << 8) | s[1];
@@ -227,12 +231,23 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
                 if (!c) return fail("jpeg: scan names an unknown component");
                 c->td = s[2 + 2 * i] >> 4;
                 c->ta = s[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present || !qt_present[c->tq]) return fail("jpeg: scan uses a missing table");
+                if (c->td > 3 || c->ta > 3 || !qt_present[c->tq]) return fail("jpeg: scan uses a missing table");
                 sc.push_back(c);
             }
-            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return fail("jpeg: not a sequential scan");
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (!progressive) {
+                if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return fail("jpeg: not a sequential scan");
+            } else {
+                if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1))
+                    return fail("jpeg: bad progressive scan parameters");
+            }
+            for (Component* c : sc) {
+                const bool need_dc = !progressive || Ss == 0, need_ac = !progressive || Ss > 0;
+                if ((need_dc && Ah == 0 && !dc[c->td].present) || (need_ac && !ac[c->ta].present)) return fail("jpeg: scan uses a missing table");
+            }
             BitReader br{data + pos, data + size};
             for (Component* c : sc) c->dc_pred = 0;
+            int eobrun = 0;
             // units of the scan: MCUs (interleaved) or the component's own blocks that carry image data (single component, T.81 A.2.2)
             const int mcus_x = (W + 8 * hmax - 1) / (8 * hmax), mcus_y = (H + 8 * vmax - 1) / (8 * vmax);
             const int ux = ns > 1 ? mcus_x : (sc[0]->width + 7) / 8, uy = ns > 1 ? mcus_y : (sc[0]->height + 7) / 8;
@@ -249,36 +264,101 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
                         br.p = q + 2;
                         br.reset();
                         for (Component* c : sc) c->dc_pred = 0;
+                        eobrun = 0;
                         until_restart = restart_interval;
                     }
                     for (Component* c : sc) {
                         const int bw = ns > 1 ? c->h : 1, bh = ns > 1 ? c->v : 1;
                         for (int by = 0; by < bh; by++)
                             for (int bx = 0; bx < bw; bx++) {
-                                int32_t coef[64] = {};
-                                int t = 0;
-                                if (!decode_symbol(br, dc[c->td], t) || t > 11) return fail("jpeg: bad DC code");
-                                c->dc_pred += extend(br.receive(t), t);
-                                coef[0] = c->dc_pred * (int32_t)qt[c->tq][0];
-                                for (int k = 1; k < 64;) {
-                                    int rs = 0;
-                                    if (!decode_symbol(br, ac[c->ta], rs)) return fail("jpeg: bad AC code");
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r == 15) { k += 16; continue; }
-                                        break; // EOB
-                                    }
-                                    k += r;
-                                    if (k > 63) return fail("jpeg: AC run past the block");
-                                    coef[kZigzag[k]] = extend(br.receive(sz), sz) * (int32_t)qt[c->tq][kZigzag[k]];
-                                    k++;
-                                }
                                 const int gx = mx * bw + bx, gy = my * bh + by;
-                                if (gx < c->blocks_w && gy < c->blocks_h)
-                                    idct.run(coef, c->samples.data() + ((size_t)gy * 8 * (size_t)c->blocks_w + (size_t)gx) * 8, c->blocks_w * 8);
+                                int32_t scratch[64];
+                                const bool inside = gx < c->blocks_w && gy < c->blocks_h;
+                                int32_t* coef = inside ? c->coef.data() + ((size_t)gy * (size_t)c->blocks_w + (size_t)gx) * 64 : scratch;
+                                if (!inside) std::memset(scratch, 0, sizeof(scratch));
+                                if (!progressive) { // T.81 F.2.2
+                                    int t = 0;
+                                    if (!decode_symbol(br, dc[c->td], t) || t > 11) return fail("jpeg: bad DC code");
+                                    c->dc_pred += extend(br.receive(t), t);
+                                    coef[0] = c->dc_pred;
+                                    for (int k = 1; k < 64;) {
+                                        int rs = 0;
+                                        if (!decode_symbol(br, ac[c->ta], rs)) return fail("jpeg: bad AC code");
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) {
+                                            if (r == 15) { k += 16; continue; }
+                                            break; // EOB
+                                        }
+                                        k += r;
+                                        if (k > 63) return fail("jpeg: AC run past the block");
+                                        coef[kZigzag[k]] = extend(br.receive(sz), sz);
+                                        k++;
+                                    }
+                                } else if (Ss == 0) { // DC scan (G.1.2.1): first pass = the sequential DC code, scaled; refinement = one bit
+                                    if (Ah == 0) {
+                                        int t = 0;
+                                        if (!decode_symbol(br, dc[c->td], t) || t > 11) return fail("jpeg: bad DC code");
+                                        c->dc_pred += extend(br.receive(t), t);
+                                        coef[0] = c->dc_pred * (1 << Al);
+                                    } else if (br.bit()) {
+                                        coef[0] |= 1 << Al;
+                                    }
+                                } else if (Ah == 0) { // AC scan, first pass (G.1.2.2): runs of zeros, end-of-band runs over several blocks
+                                    if (eobrun > 0) { eobrun--; continue; }
+                                    for (int k = Ss; k <= Se;) {
+                                        int rs = 0;
+                                        if (!decode_symbol(br, ac[c->ta], rs)) return fail("jpeg: bad AC code");
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) {
+                                            if (r < 15) { eobrun = (1 << r) - 1 + (r ? br.receive(r) : 0); break; }
+                                            k += 16;
+                                            continue;
+                                        }
+                                        k += r;
+                                        if (k > Se) return fail("jpeg: AC run past the band");
+                                        coef[kZigzag[k]] = extend(br.receive(sz), sz) * (1 << Al);
+                                        k++;
+                                    }
+                                } else { // AC scan, refinement (G.1.2.3): new coefficients of magnitude 1 << Al, correction bits for the known ones
+                                    const int p1 = 1 << Al, m1 = -(1 << Al);
+                                    int k = Ss;
+                                    auto refine = [&](int32_t& v) {
+                                        if (br.bit() && (v & p1) == 0) v += v >= 0 ? p1 : m1;
+                                    };
+                                    if (eobrun == 0) {
+                                        for (; k <= Se; k++) {
+                                            int rs = 0;
+                                            if (!decode_symbol(br, ac[c->ta], rs)) return fail("jpeg: bad AC code");
+                                            int r = rs >> 4;
+                                            const int sz = rs & 15;
+                                            int value = 0;
+                                            if (sz) {
+                                                if (sz != 1) return fail("jpeg: bad refinement code");
+                                                value = br.bit() ? p1 : m1;
+                                            } else if (r != 15) {
+                                                eobrun = 1 << r;
+                                                if (r) eobrun += br.receive(r);
+                                                break; // the rest of this block belongs to the end-of-band run
+                                            }
+                                            for (; k <= Se; k++) { // skip r still-zero coefficients, refining the non-zero ones on the way
+                                                int32_t& v = coef[kZigzag[k]];
+                                                if (v != 0) refine(v);
+                                                else if (--r < 0) break;
+                                            }
+                                            if (sz && k <= Se) coef[kZigzag[k]] = value;
+                                        }
+                                    }
+                                    if (eobrun > 0) {
+                                        for (; k <= Se; k++) {
+                                            int32_t& v = coef[kZigzag[k]];
+                                            if (v != 0) refine(v);
+                                        }
+                                        eobrun--;
+                                    }
+                                }
                             }
                     }
-                    if (br.hit_marker && !(my == uy - 1 && mx == ux - 1) && !(restart_interval && until_restart == 1))
+                    if (br.hit_marker && !(my == uy - 1 && mx == ux - 1) && !(restart_interval && until_restart == 1) && !(progressive && eobrun > 0))
                         return fail("jpeg: entropy-coded data ends early");
                     if (restart_interval) until_restart--;
                 }
@@ -291,6 +371,16 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
         // every other segment (APPn, COM, ...) is skipped
     }
     if (!have_frame || !decoded_any) return fail("jpeg: no image data");
+    for (Component& c : comps) { // dequantise, inverse DCT
+        if (!qt_present[c.tq]) return fail("jpeg: component without a quantisation table");
+        for (int gy = 0; gy < c.blocks_h; gy++)
+            for (int gx = 0; gx < c.blocks_w; gx++) {
+                int32_t* coef = c.coef.data() + ((size_t)gy * (size_t)c.blocks_w + (size_t)gx) * 64;
+                for (int i = 0; i < 64; i++) coef[i] *= (int32_t)qt[c.tq][i];
+                idct.run(coef, c.samples.data() + ((size_t)gy * 8 * (size_t)c.blocks_w + (size_t)gx) * 8, c.blocks_w * 8);
+            }
+        std::vector<int32_t>().swap(c.coef);
+    }
 
     // ---- up-sample every component to the image grid
     const size_t npx = (size_t)W * (size_t)H;

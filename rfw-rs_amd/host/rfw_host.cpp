@@ -1502,7 +1502,7 @@ HOST_API int rfwhost_instance_matrix(void* p, uint32_t mesh, uint32_t slot, floa
     std::memcpy(out16, &it->second.matrices[slot], 16 * sizeof(float));
     return it->second.skin_ids.size() > slot ? it->second.skin_ids[slot] + 1 : 0; // 0: unskinned, else skin id + 1
 }
-// PNG or baseline JPEG bytes -> RGBA8; returns 0 and the size, -1 with the reason in *err_out (static storage, valid until the next call on this thread)
+// PNG or JPEG bytes -> RGBA8; returns 0 and the size, -1 with the reason in *err_out (static storage, valid until the next call on this thread)
 HOST_API int rfwhost_decode_image(const uint8_t* data, uint64_t n, uint32_t* w, uint32_t* hgt, uint8_t* rgba_out, uint64_t cap, const char** err_out)
 {
     static thread_local std::string err;

@@ -305,7 +305,7 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
 // (crates/rfw-scene/src/loaders/obj.rs:26-252); add_instance: also place it once at the identity (scene.add_3d(&mesh))
 bool load_obj(const std::string& path, Scene& scene, std::string& err, bool add_instance = true, uint32_t* mesh_out = nullptr);
 bool decode_tga(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
-// jpeg.cpp: baseline JPEG -> RGBA8 (the reference's CesiumMan sample carries a JPEG texture); gltf.cpp: PNG -> RGBA8
+// jpeg.cpp: JPEG (sequential or progressive) -> RGBA8 (the reference's CesiumMan sample carries a JPEG texture); gltf.cpp: PNG -> RGBA8
 bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
 bool decode_image(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
 // gltf_export.cpp: the scene (static meshes, instances, materials, punctual lights, camera) as a binary glTF 2.0 file

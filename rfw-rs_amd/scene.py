@@ -65,7 +65,7 @@ def host_lib():
 
 
 def decode_image(data):
-    """PNG or baseline JPEG bytes -> (h, w, 4) uint8 RGBA through the importer's own decoders (host/gltf.cpp, host/jpeg.cpp)."""
+    """PNG or JPEG bytes -> (h, w, 4) uint8 RGBA through the importer's own decoders (host/gltf.cpp, host/jpeg.cpp)."""
     import numpy as np
     l = host_lib()
     w, h, err = C.c_uint32(), C.c_uint32(), C.c_char_p()

@@ -260,6 +260,34 @@ def test_jpeg_decoder_agrees_with_pillow(subsampling, restart):
     assert diff.max() <= 3 and diff.mean() < 0.1
 
 
+@pytest.mark.parametrize("subsampling,restart,quality", [(0, 0, 90), (2, 0, 50), (1, 4, 75), (2, 3, 95)])
+def test_progressive_jpeg_agrees_with_pillow(subsampling, restart, quality):
+    """SOF2 files: DC and AC scans, first passes and refinements (spectral selection + successive approximation), end-of-band runs,
+    restart intervals inside progressive scans; a noisy image so that the refinement scans carry many correction bits."""
+    pytest.importorskip("PIL")
+    from rfw_rs_amd.scene import decode_image
+    rng = np.random.default_rng(0)
+    img = (_test_image().astype(int) + rng.integers(-20, 20, (97, 131, 3))).clip(0, 255).astype(np.uint8)
+    kw = {"quality": quality, "subsampling": subsampling, "progressive": True}
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    data = _jpeg(img, **kw)
+    assert b"\xff\xc2" in data
+    diff = np.abs(decode_image(data)[..., :3].astype(int) - _pil_decode(data).astype(int))
+    assert diff.max() <= 3 and diff.mean() < 0.1
+    grey = _jpeg(img[..., 1], quality=80, progressive=True)
+    assert np.abs(decode_image(grey)[..., 0].astype(int) - _pil_decode(grey, "L")).max() <= 1
+    rng = np.random.default_rng(6)
+    for it in range(100):                                                      # damaged progressive files: decode or refuse
+        raw = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            raw[int(rng.integers(2, len(raw)))] = int(rng.integers(0, 256))
+        try:
+            decode_image(bytes(raw))
+        except ValueError:
+            pass
+
+
 def test_jpeg_grey_optimised_tables_and_refusals():
     pytest.importorskip("PIL")
     from rfw_rs_amd.scene import decode_image
@@ -269,9 +297,9 @@ def test_jpeg_grey_optimised_tables_and_refusals():
     assert np.abs(got[..., 0].astype(int) - _pil_decode(grey, "L")).max() <= 1 and np.array_equal(got[..., 0], got[..., 2])
     opt = _jpeg(img, quality=75, optimize=True)                    # per-image Huffman tables
     assert np.abs(decode_image(opt)[..., :3].astype(int) - _pil_decode(opt).astype(int)).max() <= 3
-    with pytest.raises(ValueError, match="progressive"):
-        decode_image(_jpeg(img, quality=90, progressive=True))
     good = _jpeg(img, quality=90)
+    with pytest.raises(ValueError, match="unsupported coding process"):
+        decode_image(good.replace(b"\xff\xc0", b"\xff\xc9", 1))      # the frame header of an arithmetic-coded file
     for name, bad in {"truncated": good[: len(good) // 2], "no tables": good[:2] + good[good.index(b"\xff\xc0"):], "garbage": b"\xff\xd8" + bytes(range(256))}.items():
         with pytest.raises(ValueError):
             decode_image(bad)
