@@ -300,7 +300,6 @@ bool decode_png(const uint8_t* data, size_t size, uint32_t& width, uint32_t& hei
         off += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || w > 16384 || h > 16384) { err = "png: bad dimensions"; return false; }
-    if (depth != 8 || interlace != 0) { err = "png: only 8-bit non-interlaced images are read"; return false; }
     int channels;
     switch (colour) {
     case 0: channels = 1; break; // grey
@@ -310,48 +309,91 @@ bool decode_png(const uint8_t* data, size_t size, uint32_t& width, uint32_t& hei
     case 6: channels = 4; break; // rgba
     default: err = "png: unknown colour type"; return false;
     }
-    const size_t stride = (size_t)w * (size_t)channels;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    const bool depth_ok = colour == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : colour == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!depth_ok || interlace > 1) { err = "png: bad bit depth or interlace method"; return false; }
+    const size_t bits_pp = (size_t)channels * (size_t)depth, bpp = bits_pp >= 8 ? bits_pp / 8 : 1; // filter distance in bytes
+    // the image is one pass, or the seven passes of Adam7 (PNG specification, section 8.2): start and step of each pass in x and y
+    static const int px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+    struct Pass { uint32_t w, h; int x0, y0, dx, dy; size_t stride; };
+    std::vector<Pass> passes;
+    size_t total = 0;
+    for (int k = 0; k < (interlace ? 7 : 1); k++) {
+        Pass q;
+        q.x0 = interlace ? px0[k] : 0; q.y0 = interlace ? py0[k] : 0; q.dx = interlace ? pdx[k] : 1; q.dy = interlace ? pdy[k] : 1;
+        q.w = (w + (uint32_t)q.dx - 1 - (uint32_t)q.x0) / (uint32_t)q.dx;
+        q.h = (h + (uint32_t)q.dy - 1 - (uint32_t)q.y0) / (uint32_t)q.dy;
+        if ((uint32_t)q.x0 >= w || (uint32_t)q.y0 >= h) q.w = q.h = 0;
+        q.stride = ((size_t)q.w * bits_pp + 7) / 8;
+        if (q.w && q.h) total += (q.stride + 1) * q.h;
+        passes.push_back(q);
+    }
+    std::vector<uint8_t> raw(total);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "png: inflate failed"; return false; }
-    std::vector<uint8_t> img(stride * h);
-    const size_t bpp = (size_t)channels;
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t filter = raw[(stride + 1) * y];
-        const uint8_t* src = raw.data() + (stride + 1) * y + 1;
-        uint8_t* dst = img.data() + stride * y;
-        const uint8_t* up = y ? dst - stride : nullptr;
-        for (size_t x = 0; x < stride; x++) {
-            const int a = x >= bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-            int v = src[x];
-            switch (filter) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-            default: err = "png: bad filter"; return false;
+    // colour-key transparency of grey / rgb images (tRNS holds one 16-bit sample per channel)
+    int key[3] = {-1, -1, -1};
+    if (colour == 0 && trns.size() >= 2) key[0] = (trns[0] << 8) | trns[1];
+    if (colour == 2 && trns.size() >= 6) for (int c = 0; c < 3; c++) key[c] = (trns[2 * c] << 8) | trns[2 * c + 1];
+    rgba.assign((size_t)w * h * 4, 0);
+    size_t off_raw = 0;
+    std::vector<uint8_t> prev, cur;
+    for (const Pass& q : passes) {
+        if (!q.w || !q.h) continue;
+        prev.assign(q.stride, 0);
+        cur.resize(q.stride);
+        for (uint32_t y = 0; y < q.h; y++) {
+            const uint8_t filter = raw[off_raw];
+            const uint8_t* src = raw.data() + off_raw + 1;
+            off_raw += q.stride + 1;
+            for (size_t x = 0; x < q.stride; x++) {
+                const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+                int v = src[x];
+                switch (filter) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: err = "png: bad filter"; return false;
+                }
+                cur[x] = (uint8_t)v;
             }
-            dst[x] = (uint8_t)v;
+            // sample s of pixel x as the file stores it (depth bits, most significant bits first)
+            auto sample = [&](uint32_t x, int s) -> int {
+                const size_t idx = (size_t)x * (size_t)channels + (size_t)s;
+                if (depth == 8) return cur[idx];
+                if (depth == 16) return (cur[2 * idx] << 8) | cur[2 * idx + 1];
+                const size_t bit = idx * (size_t)depth;
+                return (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1);
+            };
+            auto to8 = [&](int v) -> uint8_t { return depth == 16 ? (uint8_t)(v >> 8) : (depth == 8 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1))); };
+            for (uint32_t x = 0; x < q.w; x++) {
+                uint8_t r, g, bl, al = 255;
+                switch (colour) {
+                case 0: { const int v = sample(x, 0); r = g = bl = to8(v); if (v == key[0]) al = 0; break; }
+                case 2: {
+                    const int v0 = sample(x, 0), v1 = sample(x, 1), v2 = sample(x, 2);
+                    r = to8(v0); g = to8(v1); bl = to8(v2);
+                    if (v0 == key[0] && v1 == key[1] && v2 == key[2]) al = 0;
+                    break;
+                }
+                case 3: {
+                    const size_t k = (size_t)sample(x, 0);
+                    if (3 * k + 2 >= palette.size()) { err = "png: palette index out of range"; return false; }
+                    r = palette[3 * k]; g = palette[3 * k + 1]; bl = palette[3 * k + 2];
+                    if (k < trns.size()) al = trns[k];
+                    break;
+                }
+                case 4: r = g = bl = to8(sample(x, 0)); al = to8(sample(x, 1)); break;
+                default: r = to8(sample(x, 0)); g = to8(sample(x, 1)); bl = to8(sample(x, 2)); al = to8(sample(x, 3)); break;
+                }
+                uint8_t* o = rgba.data() + ((size_t)((uint32_t)q.y0 + y * (uint32_t)q.dy) * w + (size_t)((uint32_t)q.x0 + x * (uint32_t)q.dx)) * 4;
+                o[0] = r; o[1] = g; o[2] = bl; o[3] = al;
+            }
+            prev.swap(cur);
+            cur.resize(q.stride);
         }
-    }
-    rgba.resize((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        uint8_t r, g, b, a = 255;
-        switch (colour) {
-        case 0: r = g = b = img[i]; break;
-        case 2: r = img[3 * i]; g = img[3 * i + 1]; b = img[3 * i + 2]; break;
-        case 3: {
-            const size_t k = img[i];
-            if (3 * k + 2 >= palette.size()) { err = "png: palette index out of range"; return false; }
-            r = palette[3 * k]; g = palette[3 * k + 1]; b = palette[3 * k + 2];
-            if (k < trns.size()) a = trns[k];
-            break;
-        }
-        case 4: r = g = b = img[2 * i]; a = img[2 * i + 1]; break;
-        default: r = img[4 * i]; g = img[4 * i + 1]; b = img[4 * i + 2]; a = img[4 * i + 3]; break;
-        }
-        rgba[4 * i] = r; rgba[4 * i + 1] = g; rgba[4 * i + 2] = b; rgba[4 * i + 3] = a;
     }
     width = w; height = h;
     return true;

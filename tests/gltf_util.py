@@ -437,3 +437,74 @@ def encode_tga(img, rle=False, top_down=False):
             out += bytes([lit - 1]) + flat[i:i + lit].tobytes()
             i += lit
     return head + bytes(out)
+
+
+def encode_png_general(samples, colour, depth, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """PNG writer for every colour type / bit depth / interlace method of the specification.  samples: (h, w, c) integers as the file
+    stores them (0 .. 2**depth - 1; palette indices for colour 3).  Packs sub-byte depths most significant bits first, 16-bit samples
+    big-endian; Adam7 writes the seven passes in order, each with its own filter state."""
+    import zlib
+    samples = np.asarray(samples)
+    h, w, c = samples.shape
+    bits_pp = c * depth
+    bpp = max(1, bits_pp // 8)
+
+    def pack_row(row):                                      # (n, c) -> bytes
+        flat = row.reshape(-1).astype(np.int64)
+        if depth == 8:
+            return flat.astype(np.uint8)
+        if depth == 16:
+            return np.stack([flat >> 8, flat & 255], axis=1).reshape(-1).astype(np.uint8)
+        per = 8 // depth
+        pad = (-len(flat)) % per
+        flat = np.concatenate([flat, np.zeros(pad, np.int64)]).reshape(-1, per)
+        shifts = np.array([8 - depth * (k + 1) for k in range(per)])
+        return (flat << shifts).sum(axis=1).astype(np.uint8)
+
+    def filter_rows(rows, counter):
+        out = bytearray()
+        prev = None
+        for row in rows:
+            cur = pack_row(row).astype(np.int32)
+            if prev is None:
+                prev = np.zeros_like(cur)
+            f = filters[counter[0] % len(filters)]
+            counter[0] += 1
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if f == 0:
+                o = cur
+            elif f == 1:
+                o = cur - left
+            elif f == 2:
+                o = cur - prev
+            elif f == 3:
+                o = cur - ((left + prev) >> 1)
+            else:
+                p = left + prev - upleft
+                pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+                o = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out.append(f)
+            out += bytes((o & 0xFF).astype(np.uint8))
+            prev = cur
+        return out
+
+    counter = [0]
+    raw = bytearray()
+    if interlace:
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filter_rows(sub, counter)
+    else:
+        raw += filter_rows(samples, counter)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    extra = b""
+    if palette is not None:
+        extra += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        extra += chunk(b"tRNS", bytes(trns))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 1 if interlace else 0)) + extra
+            + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))

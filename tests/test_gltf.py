@@ -443,3 +443,49 @@ def test_reference_sample_assets_import_in_place():
     c = scene.counts()
     assert c["instances"] == len(with_mesh) and scene.triangle_count == tris
     assert c["materials"] >= len(doc["materials"])
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_every_colour_type_depth_and_interlace(interlace):
+    """host/gltf.cpp decode_png over the whole matrix of the PNG specification — grey 1/2/4/8/16, RGB 8/16, palette 1/2/4/8 (+ tRNS),
+    grey + alpha 8/16, RGBA 8/16, colour keys, Adam7 — on odd sizes (passes with empty rows / columns): against the source samples, and
+    the writer used here against Pillow where Pillow reads the format."""
+    from gltf_util import encode_png_general
+    from rfw_rs_amd.scene import decode_image
+    rng = np.random.default_rng(21)
+    for (h, w) in ((1, 1), (3, 5), (9, 13), (16, 8)):
+        for colour, channels, depths in ((0, 1, (1, 2, 4, 8, 16)), (2, 3, (8, 16)), (3, 1, (1, 2, 4, 8)), (4, 2, (8, 16)), (6, 4, (8, 16))):
+            for depth in depths:
+                smp = rng.integers(0, 1 << depth, (h, w, channels))
+                palette = rng.integers(0, 256, (1 << depth, 3)).astype(np.uint8) if colour == 3 else None
+                trns = None
+                if colour == 3:
+                    trns = bytes(rng.integers(0, 256, max(1, (1 << depth) // 2)).astype(np.uint8))
+                elif colour == 0:
+                    trns = int(smp[0, 0, 0]).to_bytes(2, "big")
+                elif colour == 2:
+                    trns = b"".join(int(v).to_bytes(2, "big") for v in smp[0, 0])
+                data = encode_png_general(smp, colour, depth, interlace, palette, trns)
+                got = decode_image(data)
+                to8 = (lambda v: v >> 8) if depth == 16 else ((lambda v: v) if depth == 8 else (lambda v: v * 255 // ((1 << depth) - 1)))
+                want = np.zeros((h, w, 4), np.int64)
+                if colour == 3:
+                    want[..., :3] = palette[smp[..., 0]]
+                    ta = np.frombuffer(trns, np.uint8)
+                    want[..., 3] = np.where(smp[..., 0] < len(ta), ta[np.minimum(smp[..., 0], len(ta) - 1)], 255)
+                elif colour in (0, 4):
+                    want[..., :3] = to8(smp[..., :1])
+                    want[..., 3] = to8(smp[..., 1]) if colour == 4 else np.where(smp[..., 0] == smp[0, 0, 0], 0, 255)
+                else:
+                    want[..., :3] = to8(smp[..., :3])
+                    want[..., 3] = to8(smp[..., 3]) if colour == 6 else np.where((smp == smp[0, 0]).all(axis=2), 0, 255)
+                assert np.array_equal(got, want.astype(np.uint8)), (h, w, colour, depth, interlace)
+    try:                                                     # the writer itself, checked by an independent reader
+        import io
+        from PIL import Image
+        smp = rng.integers(0, 256, (9, 13, 4))
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png_general(smp, 6, 8, interlace))).convert("RGBA")), smp.astype(np.uint8))
+        idx = rng.integers(0, 4, (9, 13, 1)); pal = rng.integers(0, 256, (4, 3)).astype(np.uint8)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png_general(idx, 3, 2, interlace, pal))).convert("RGB")), pal[idx[..., 0]])
+    except ImportError:
+        pass
