@@ -299,7 +299,7 @@ bool decode_png(const uint8_t* data, size_t size, uint32_t& width, uint32_t& hei
         else if (!std::memcmp(type, "IEND", 4)) end = true;
         off += 12 + (size_t)len;
     }
-    if (w == 0 || h == 0 || w > 16384 || h > 16384) { err = "png: bad dimensions"; return false; }
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || (uint64_t)w * h > (1ull << 26)) { err = "png: bad dimensions"; return false; }
     int channels;
     switch (colour) {
     case 0: channels = 1; break; // grey
@@ -443,11 +443,16 @@ struct Doc {
         const int cb = component_bytes(ct);
         if (nc == 0 || cb == 0) return fail("gltf: unsupported accessor type");
         if (want_comp && nc != want_comp) return fail("gltf: accessor has the wrong number of components");
-        count = (size_t)a.integer("count", 0);
+        const int64_t declared = a.integer("count", 0);
+        if (declared < 0 || declared > (int64_t)1 << 31) return fail("gltf: accessor count out of range");
+        count = (size_t)declared;
         const bool norm = normalise || (a.get("normalized") && a.get("normalized")->b);
-        out.assign(count * (size_t)nc, 0.0);
         const int64_t bv_index = a.integer("bufferView", -1);
-        if (bv_index < 0) return true; // all zeros
+        if (bv_index < 0) { // all zeros
+            if (count > ((size_t)1 << 26)) return fail("gltf: accessor without a buffer view is too large");
+            out.assign(count * (size_t)nc, 0.0);
+            return true;
+        }
         const Json* bvs = root.get("bufferViews");
         if (!bvs || (size_t)bv_index >= bvs->size()) return fail("gltf: bufferView index out of range");
         const Json& bv = bvs->arr[(size_t)bv_index];
@@ -461,6 +466,7 @@ struct Doc {
         const size_t view_len = (size_t)bv.integer("byteLength", 0), in_view = (size_t)a.integer("byteOffset", 0);
         if (count && (stride < elem || in_view + (count - 1) * stride + elem > view_len || base + (count - 1) * stride + elem > buf.size()))
             return fail("gltf: accessor reads past the end of its buffer view");
+        out.assign(count * (size_t)nc, 0.0); // only now: the count is backed by bytes that exist
         for (size_t i = 0; i < count; i++) {
             const uint8_t* src = buf.data() + base + i * stride;
             for (int c = 0; c < nc; c++) {

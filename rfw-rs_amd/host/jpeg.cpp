@@ -189,7 +189,7 @@ bool decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint32_t& he
             W = (s[3] << 8) | s[4];
             const int nc = s[5];
             if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc) return fail("jpeg: unsupported frame header");
-            if ((uint64_t)W * (uint64_t)H > (1ull << 28)) return fail("jpeg: image too large");
+            if ((uint64_t)W * (uint64_t)H > (1ull << 26)) return fail("jpeg: image too large"); // 64 M pixels: the coefficient store is 12 bytes per pixel
             comps.resize((size_t)nc);
             for (int i = 0; i < nc; i++) {
                 Component& c = comps[(size_t)i];

@@ -34,7 +34,7 @@ bool decode_tga(const uint8_t* d, size_t size, uint32_t& width, uint32_t& height
     const uint32_t w = (uint32_t)d[12] | ((uint32_t)d[13] << 8), h = (uint32_t)d[14] | ((uint32_t)d[15] << 8);
     const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
     if (!(type == 2 || type == 3 || type == 10 || type == 11)) return fail("tga: only true-colour and grey images are supported");
-    if (cmap_type > 1 || w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail("tga: bad header");
+    if (cmap_type > 1 || w == 0 || h == 0 || (uint64_t)w * h > (1ull << 26)) return fail("tga: bad header");
     if (!(grey ? bpp == 8 : (bpp == 24 || bpp == 32))) return fail("tga: unsupported pixel depth");
     const size_t bytes = bpp / 8;
     size_t pos = 18 + (size_t)id_len + (cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0);

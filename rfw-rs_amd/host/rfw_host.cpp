@@ -1509,7 +1509,13 @@ HOST_API int rfwhost_decode_image(const uint8_t* data, uint64_t n, uint32_t* w, 
     std::vector<uint8_t> rgba;
     uint32_t ww = 0, hh = 0;
     err.clear();
-    if (!data || !rfw::decode_image(data, (size_t)n, ww, hh, rgba, err)) {
+    bool ok = false;
+    try {
+        ok = data && rfw::decode_image(data, (size_t)n, ww, hh, rgba, err);
+    } catch (const std::exception& e) { // an allocation the file's header asked for
+        err = std::string("image: ") + e.what();
+    }
+    if (!ok) {
         if (err_out) *err_out = err.c_str();
         return -1;
     }
