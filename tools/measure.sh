@@ -21,6 +21,10 @@ tools/probes/mem_probe > $OUT/mem_probe.json 2> $OUT/mem_probe.err
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline --no-modes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# the same trace with ONE frame at a time: kernels of different frames do not overlap, so the per-kernel average durations of this summary
+# are kernel properties and must agree with roofline.contract.per_kernel.*.ms (HIP events) of the bench line written next to it
+B1="python3 $R/bench.py --steps 48 --warmup 8 --frames-in-flight 1 --no-cpu-baseline --no-modes"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_one -- $B1 > $OUT/bench_one_at_a_time_under_rocprof.json 2> $OUT/trace_one.err
 pmc() { # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- $B > /dev/null 2> $OUT/pmc_$name.err || echo "pmc pass $name failed" >> $OUT/pmc_failures.txt
@@ -40,7 +44,8 @@ pmc wait SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 cd $R
 python3 tools/summarize_profile.py $TAG $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_inst $OUT/pmc_valu $OUT/pmc_tcp $OUT/pmc_tcp2 $OUT/pmc_tcp3 $OUT/pmc_tcc $OUT/pmc_tcc2 $OUT/pmc_ta $OUT/pmc_ta2 $OUT/pmc_wait
-for f in bench_atrium1m bench_c2_atrium262k bench_c3_spheres10k bench_c4_path3 bench_atrium1m_identical_frames bench_under_rocprof mem_probe; do [ -s $OUT/$f.json ] && cp $OUT/$f.json profiles/${TAG}_$f.json; done
+cp $(find $OUT/trace_one -name '*_kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_one_at_a_time.csv 2>/dev/null
+for f in bench_atrium1m bench_c2_atrium262k bench_c3_spheres10k bench_c4_path3 bench_atrium1m_identical_frames bench_under_rocprof bench_one_at_a_time_under_rocprof mem_probe; do [ -s $OUT/$f.json ] && cp $OUT/$f.json profiles/${TAG}_$f.json; done
 # only the small condensed files travel back: drop the raw traces beyond the csv summaries
 find $OUT -name '*.db' -delete 2>/dev/null
 find $OUT -name '*_counter_collection.csv' -size +20M -delete 2>/dev/null
