@@ -1,7 +1,8 @@
 """Randomised differential soak, GPU against the oracle (not collected by pytest; run on an MI355X: `ITERS=300 python tests/soak_gpu.py`).
 Random soups x instance counts x builders x frame slots x frame batches x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
 accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 and, on the final kernels of the round, 300 + 2 more with frame batches and downloads in the mix: 0 mismatches.
-Round 2 (blue-noise tables, sorted extension rays, single-material edits with `changed` bits and rfw_hip_render_samples in the mix): 250 + 2 configurations, 0 mismatches."""
+Round 2 (blue-noise tables, sorted extension rays, single-material edits with `changed` bits and rfw_hip_render_samples in the mix): 250 + 2 configurations, 0 mismatches;
+on the final build of the round 300 + 2 more and 60 random times of an animated, twice-instantiated glTF document: 0 mismatches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -63,6 +64,29 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     bad += 0 if ok else 1
     be.close()
 print("mismatches:", bad, "time", round(time.time() - t0, 1))
+# a glTF document's own animation at random times (skinning + refit + TLAS on the device every step), two graphs of it
+import pathlib, tempfile
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gltf_util import write_animated_gltf
+tmp = pathlib.Path(tempfile.mkdtemp())
+scene = Scene().load_gltf(str(write_animated_gltf(tmp)))
+g = scene.instantiate_graph()
+scene.set_graph_transform(g, translation=(1.2, 0.0, -0.8), rotation=(0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))), scale=(0.8, 0.8, 0.8))
+w, h = 112, 80
+scene.set_aspect(w / h)
+view = scene.view(w, h)
+be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=3)
+orc = Oracle(w, h, threads=8, max_path_length=3)
+abad = 0
+for it in range(int(os.environ.get("ANIM_ITERS", "12"))):
+    scene.set_animation_time(float(rng.uniform(-1.0, 7.0)))
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    be.reset_accumulation(); orc.reset()
+    be.render(view); orc.render(view)
+    ok = np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    abad += 0 if ok else 1
+print("animated glTF mismatches:", abad, flush=True)
+be.close()
 # large scenes: hits and one frame
 for it, tris in enumerate((60000, 262267)):
     scene = Scene().build("atrium", tris, 0, 0.0, 77 + it); w, h = 320, 180; scene.set_aspect(w / h)
