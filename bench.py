@@ -274,6 +274,9 @@ def main():
             issue(state["pending"])
             state["pending"] = []
 
+    # frame 0 of the timed region is copied out (asynchronously, behind its kernels, into pinned memory) for the oracle check; the buffer is
+    # allocated here, before the warm-up, so that nothing but the synchronisation sits between the warm-up and the timed region
+    check0 = bes[0].host_frame() if (single and rank == 0 and not args.no_cpu_baseline and B == 1) else None
     for i in range(args.warmup):
         step(i)
     flush()
@@ -282,8 +285,6 @@ def main():
         b.device_synchronize()
         b.drain_timing()
         b.set_option("timing", 1 if (F == 1 and B == 1) else 0)  # per-kernel events only where kernels of different frames cannot overlap
-    # frame 0 of the timed region is copied out (asynchronously, behind its kernels, into pinned memory) for the oracle check
-    check0 = bes[0].host_frame() if (single and rank == 0 and not args.no_cpu_baseline and B == 1) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
