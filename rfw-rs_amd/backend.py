@@ -191,8 +191,14 @@ class HipBackend:
         self._check(self._l.rfw_hip_set_materials(self._h, arr, len(materials), None))
 
     def set_textures(self, textures, changed=None):
+        """changed: optional list of indices whose bit is set in the trait's `changed` BitSlice (None: everything)."""
         arr = (pod.TextureData * len(textures))(*textures)
-        self._check(self._l.rfw_hip_set_textures(self._h, arr, len(textures), None))
+        bits = None
+        if changed is not None:
+            bits = (C.c_uint32 * ((len(textures) + 31) // 32 or 1))()
+            for k in changed:
+                bits[k // 32] |= 1 << (k % 32)
+        self._check(self._l.rfw_hip_set_textures(self._h, arr, len(textures), bits))
 
     def synchronize(self):
         self._check(self._l.rfw_hip_synchronize(self._h))

@@ -205,6 +205,9 @@ struct Instance {
     std::vector<rfw_spot_light> spot_lights;
     std::vector<rfw_directional_light> directional_lights;
     std::vector<TexHost> textures;
+    std::vector<uint32_t> tex_offsets;  // word offset of texture k in d_tex_data as last laid out by synchronize()
+    std::vector<uint32_t> tex_dirty_idx; // textures changed in place since then (set_textures with `changed` bits)
+    bool tex_layout_dirty = true;        // count / sizes changed, or the skybox: the whole array is laid out again
     TexHost skybox;
     std::vector<std::vector<rfw_mat4>> skins; // joint matrices per skin id
     std::map<std::pair<uint32_t, int32_t>, DerivedMesh> derived;
@@ -1152,6 +1155,19 @@ int do_synchronize(Instance* I)
         I->lights_dirty = false;
         any_change = true;
     }
+    if (I->textures_dirty && !I->tex_layout_dirty && I->tex_offsets.size() == I->textures.size()) {
+        // only some textures changed and each keeps its place: their texels go over the old ones (the frame slots were drained above)
+        std::sort(I->tex_dirty_idx.begin(), I->tex_dirty_idx.end());
+        I->tex_dirty_idx.erase(std::unique(I->tex_dirty_idx.begin(), I->tex_dirty_idx.end()), I->tex_dirty_idx.end());
+        for (const uint32_t k : I->tex_dirty_idx) {
+            const TexHost& t = I->textures[k];
+            if (!t.texels.empty()) HIP_TRY(I, hipMemcpyAsync(I->d_tex_data.ptr + I->tex_offsets[k], t.texels.data(), t.texels.size() * 4, hipMemcpyHostToDevice, I->stream));
+        }
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->tex_dirty_idx.clear();
+        I->textures_dirty = false;
+        any_change = true;
+    }
     if (I->textures_dirty) { // texels of every texture, then the skybox, in one array + descriptor table
         std::vector<uint32_t> data;
         std::vector<TexDesc> desc(I->textures.size());
@@ -1163,8 +1179,11 @@ int do_synchronize(Instance* I)
             data.insert(data.end(), t.texels.begin(), t.texels.end());
             return d;
         };
-        for (size_t k = 0; k < I->textures.size(); k++) desc[k] = put(I->textures[k]);
+        I->tex_offsets.resize(I->textures.size());
+        for (size_t k = 0; k < I->textures.size(); k++) { desc[k] = put(I->textures[k]); I->tex_offsets[k] = desc[k].offset; }
         I->skybox_desc = put(I->skybox);
+        I->tex_layout_dirty = false;
+        I->tex_dirty_idx.clear();
         I->n_textures = (uint32_t)desc.size();
         if ((rc = upload(I, I->d_tex_data, data.data(), data.size()))) return rc;
         if ((rc = upload(I, I->d_tex_desc, desc.data(), desc.size()))) return rc;
@@ -1755,15 +1774,28 @@ static bool copy_texture(TexHost& t, const rfw_texture_data* d)
     return true;
 }
 
-int rfw_hip_set_textures(void* inst, const rfw_texture_data* textures, uint32_t n, const uint32_t* /*changed*/)
+// `changed` (the trait's BitSlice, bit k = texture k): textures whose bit is clear are not looked at — not copied, not resampled into the
+// 1024 x 1024 x 5 array — and synchronize() uploads only the changed ones in place when the array's layout stays the same (same count,
+// same stored size per texture; with texture_array on, every texture has the same stored size).
+int rfw_hip_set_textures(void* inst, const rfw_texture_data* textures, uint32_t n, const uint32_t* changed)
 {
     LOCK(inst);
     if (n && !textures) return fail(I, RFW_HIP_E_INVALID, "set_textures: null data");
+    const bool partial = changed && I->textures.size() == n && I->tex_offsets.size() == n; // a laid-out array of the same length exists
     I->textures.resize(n);
     for (uint32_t k = 0; k < n; k++) {
-        if (!copy_texture(I->textures[k], textures + k)) return fail(I, RFW_HIP_E_INVALID, "set_textures: unknown texel format");
-        if (I->texture_array) normalise_texture(I->textures[k]);
+        if (partial && !((changed[k / 32] >> (k % 32)) & 1u)) continue;
+        TexHost t;
+        if (!copy_texture(t, textures + k)) return fail(I, RFW_HIP_E_INVALID, "set_textures: unknown texel format");
+        if (I->texture_array) normalise_texture(t);
+        const TexHost& old = I->textures[k];
+        if (partial && !I->tex_layout_dirty && t.texels.size() == old.texels.size() && t.w == old.w && t.h == old.h && t.mips == old.mips && t.format == old.format)
+            I->tex_dirty_idx.push_back(k);
+        else
+            I->tex_layout_dirty = true;
+        I->textures[k] = std::move(t);
     }
+    if (!partial) I->tex_layout_dirty = true;
     I->textures_dirty = true;
     return RFW_HIP_OK;
 }
@@ -1969,6 +2001,7 @@ int rfw_hip_set_skybox(void* inst, const rfw_texture_data* skybox)
     LOCK(inst);
     if (!copy_texture(I->skybox, skybox)) return fail(I, RFW_HIP_E_INVALID, "set_skybox: unknown texel format");
     I->textures_dirty = true;
+    I->tex_layout_dirty = true; // the skybox lives behind the textures in the same array
     return RFW_HIP_OK;
 }
 int rfw_hip_set_skins(void* inst, const rfw_skin_data* skins, uint32_t n, const uint32_t* /*changed*/)
@@ -2004,7 +2037,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "timing") I->timing = value != 0.0;
     else if (k == "sort_extension_rays") I->sort_extension_rays = std::max(0, std::min(2, (int)value));
-    else if (k == "texture_array") I->texture_array = value != 0.0; // applies to textures set from now on
+    else if (k == "texture_array") { I->texture_array = value != 0.0; I->tex_offsets.clear(); } // applies to textures set from now on (all of them: no partial update across the switch)
     else if (k == "spill_rows") I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill); // tests: exercise the overflow path
     else if (k == "sky_r") I->sky[0] = (float)value;
     else if (k == "sky_g") I->sky[1] = (float)value;

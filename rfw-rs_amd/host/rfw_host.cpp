@@ -337,6 +337,14 @@ void Scene::set_material(uint32_t index, const Material& m)
     if (!material_changed_bits.empty()) material_changed_bits[index / 32] |= 1u << (index % 32);
     materials_changed = true;
 }
+void Scene::set_texture(uint32_t index, const Texture& t)
+{
+    if (index >= textures.size()) return;
+    textures[index] = t;
+    if (!textures_changed) texture_changed_bits.assign((textures.size() + 31) / 32, 0u); // first edit since the last synchronize
+    if (!texture_changed_bits.empty()) texture_changed_bits[index / 32] |= 1u << (index % 32);
+    textures_changed = true;
+}
 size_t Scene::add_instance(uint32_t mesh, const rfw_mat4& m)
 {
     instances_changed[mesh] = true;
@@ -484,7 +492,8 @@ void synchronize_system(Scene& scene, Backend& renderer)
     if (scene.textures_changed) { // :118-136
         std::vector<rfw_texture_data> t;
         for (const Texture& x : scene.textures) t.push_back(x.as_data());
-        renderer.set_textures(t, nullptr);
+        renderer.set_textures(t, scene.texture_changed_bits.empty() ? nullptr : &scene.texture_changed_bits);
+        scene.texture_changed_bits.clear();
         scene.textures_changed = false;
         changed = true;
     }
@@ -1428,6 +1437,18 @@ HOST_API int rfwhost_edit(void* p, uint32_t op, uint32_t id, uint32_t a, uint32_
         h.scene.set_material(id, m);
         return 0;
     }
+    if (op == 4) { // repaint texture `id`: same size, texels from `seed` (level 0; the mip chain is rebuilt); marks only this texture changed
+        if (id >= h.scene.textures.size()) return -1;
+        rfw::Texture t = h.scene.textures[id];
+        const uint32_t levels = t.mip_levels;
+        t.mip_levels = 1;
+        t.bytes.resize((size_t)t.width * t.height * 4);
+        uint32_t x = seed * 2654435761u + 1u;
+        for (size_t i = 0; i < t.bytes.size(); i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; t.bytes[i] = (i & 3) == 3 ? 255 : (uint8_t)(x >> 11); }
+        if (levels > 1) t.generate_mipmaps(levels);
+        h.scene.set_texture(id, t);
+        return 0;
+    }
     return -1;
 }
 HOST_API const char* rfwhost_last_error(void* p) { return ((HostScene*)p)->error.c_str(); }
@@ -1554,6 +1575,7 @@ HOST_API int rfwhost_mark_all_changed(void* p)
     h.scene.material_changed_bits.clear();
     h.scene.lights_changed = true;
     h.scene.textures_changed = !h.scene.textures.empty();
+    h.scene.texture_changed_bits.clear();
     h.scene.skybox_changed = h.scene.skybox.width != 0;
     h.scene.skins_changed = !h.scene.skins.empty();
     return 0;

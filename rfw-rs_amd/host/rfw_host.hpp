@@ -259,6 +259,7 @@ struct Scene {
     // which materials changed since the last synchronize_system (the reference's TrackedStorage bits, crates/rfw-scene/src/material/list.rs);
     // empty = all of them (a new scene, a resized list)
     std::vector<uint32_t> material_changed_bits;
+    std::vector<uint32_t> texture_changed_bits; // like material_changed_bits: which textures changed since the last synchronize_system; empty = all
     std::vector<uint32_t> removed_meshes; // unloaded since the last synchronize_system (rfw/src/system/mod.rs: unload_3d_meshes)
 
     uint32_t add_material(const Material& m);
@@ -266,6 +267,7 @@ struct Scene {
     void replace_mesh(uint32_t id, const Mesh3D& m);   // same id, new geometry (set_3d_mesh again at the next synchronize_system)
     void remove_mesh(uint32_t id);                      // the mesh and its instances
     void set_material(uint32_t index, const Material& m); // marks only this material changed
+    void set_texture(uint32_t index, const Texture& t);   // marks only this texture changed (set_textures then carries a `changed` bit slice)
     size_t add_instance(uint32_t mesh, const rfw_mat4& m);
     void set_matrix(uint32_t mesh, size_t slot, const rfw_mat4& m);
     // crates/rfw-scene/src/lib.rs:575-648

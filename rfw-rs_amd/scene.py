@@ -251,6 +251,11 @@ class Scene:
         if self._l.rfwhost_edit(self._h, 3, index, roughness_byte, 0, seed) < 0:
             raise KeyError(index)
 
+    def repaint_texture(self, index, seed):
+        """Changes ONE texture (same size, new texels) and marks only it changed (set_textures then carries a `changed` bit slice)."""
+        if self._l.rfwhost_edit(self._h, 4, index, 0, 0, seed) < 0:
+            raise KeyError(index)
+
     def mark_all_changed(self):
         self._l.rfwhost_mark_all_changed(self._h)
 
