@@ -148,7 +148,9 @@ RFW_HIP_API int rfw_hip_unload_3d_meshes(void* instance, const uint32_t* ids, ui
 RFW_HIP_API int rfw_hip_set_3d_instances(void* instance, uint32_t mesh, const rfw_instances_data_3d* data);
 /* :49 set_materials */
 RFW_HIP_API int rfw_hip_set_materials(void* instance, const rfw_device_material* materials, uint32_t num, const uint32_t* changed);
-/* :53 set_textures — sampled by shade for diffuse and normal maps (the two maps shade.comp reads) */
+/* :53 set_textures — sampled by shade for diffuse and normal maps (the two maps shade.comp reads).  `changed` (bit k = texture k, may be NULL =
+ * all): with the same number of textures as before, textures whose bit is clear are not read at all, and synchronize() uploads only the
+ * changed ones. */
 RFW_HIP_API int rfw_hip_set_textures(void* instance, const rfw_texture_data* textures, uint32_t num, const uint32_t* changed);
 /* :57 synchronize — builds/refits acceleration structures for what changed. */
 RFW_HIP_API int rfw_hip_synchronize(void* instance);
