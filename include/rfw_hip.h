@@ -239,6 +239,10 @@ RFW_HIP_API int rfw_hip_occludes4(void* instance, const float* origin_xyz4, cons
  * (test-only; enabled by option "keep_queues"=1).  Layout documented in DESIGN.md. */
 RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, uint64_t bytes, uint64_t* written);
 
+/* occludes() that also reports how many 4-wide nodes each any-hit traversal visited (the any-hit counterpart of rfw_hip_depth_test).  For
+ * the planning probes under tools/probes (wave-occupancy models from real per-ray traversal lengths); not part of the trait. */
+RFW_HIP_API int rfw_hip_debug_occludes_depth(void* instance, const float* origins, const float* directions, float t_min, const float* t_max,
+                                             uint64_t num_rays, uint8_t* occluded, uint32_t* depth);
 /* Test-only: the device functions the shade kernel is made of, evaluated one by one on caller-supplied inputs, so that each can be held
  * against an independent formulation (tests/test_shading_kat.py compares with numpy float64).  Host pointers; per case 48 input floats:
  *   [0,24) one rfw_device_material (its 96 bytes)  [24,27) N  [27,30) wo (op 3: D; op 4: the shaded point I)  [30,33) wi  [33,36) T

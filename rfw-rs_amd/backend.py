@@ -22,7 +22,7 @@ EXPORTS = [
     "rfw_hip_set_area_lights", "rfw_hip_set_directional_lights", "rfw_hip_set_skybox", "rfw_hip_set_skins",
     "rfw_hip_reset_accumulation", "rfw_hip_set_option", "rfw_hip_read_framebuffer", "rfw_hip_read_accumulator",
     "rfw_hip_get_frame_stats", "rfw_hip_drain_timing", "rfw_hip_get_scene_stats", "rfw_hip_set_stream", "rfw_hip_get_stream", "rfw_hip_device_synchronize",
-    "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes",
+    "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes", "rfw_hip_debug_occludes_depth",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
     "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_intersect4", "rfw_hip_occludes4",
@@ -107,6 +107,7 @@ def hip_lib():
         l.rfw_hip_srgb_steps.restype = None
         l.rfw_hip_srgb_steps.argtypes = [vp]
         l.rfw_hip_occludes.argtypes = [vp, vp, vp, f32, vp, u64, vp]
+        l.rfw_hip_debug_occludes_depth.argtypes = [vp, vp, vp, f32, vp, u64, vp, vp]
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
         l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
         _lib = l
@@ -390,6 +391,16 @@ class HipBackend:
         depth = np.empty(len(o), dtype=np.uint32)
         self._check(self._l.rfw_hip_depth_test(self._h, o.ctypes.data, d.ctypes.data, t_min, t_max, len(o), hits.ctypes.data, depth.ctypes.data))
         return hits, depth
+
+    def occludes_depth(self, origins, directions, t_max, t_min=1e-3):
+        """occludes() plus the nodes each any-hit traversal visited (rfw_hip_debug_occludes_depth; for tools/probes)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32)
+        tm = np.ascontiguousarray(t_max, dtype=np.float32)
+        out = np.empty(len(o), dtype=np.uint8)
+        depth = np.empty(len(o), dtype=np.uint32)
+        self._check(self._l.rfw_hip_debug_occludes_depth(self._h, o.ctypes.data, d.ctypes.data, t_min, tm.ctypes.data, len(o), out.ctypes.data, depth.ctypes.data))
+        return out.astype(bool), depth
 
     def occludes(self, origins, directions, t_max, t_min=1e-3):
         """TIntersector::occludes (crates/rfw-scene/src/intersector.rs:21-43) for a batch of rays."""

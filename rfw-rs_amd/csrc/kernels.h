@@ -68,6 +68,6 @@ void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& 
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,
                           rfw_hip_hit* hits, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
-                      uint8_t* occluded);
+                      uint8_t* occluded, uint32_t* depth = nullptr /* optional: nodes visited per ray */);
 
 } // namespace rfwhip

@@ -367,8 +367,12 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
 }
 
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
-// Buckets are walked from the LAST light index down: directional lights come last in the reference's light order (shade.comp:471-527) and their
-// rays leave the scene — the longest any-hit traversals — so the launch starts with them and ends on the short rays towards the area lights.
+// Buckets are walked from the LAST light index down (directional lights come last in the reference's light order, shade.comp:471-527): a
+// measured choice — k_shadow alone 0.364 -> 0.336 ms when it was made, 0.382 -> 0.329 ms with the far-to-near order of the directional
+// light's rays below; with frames in flight the order of the buckets does not matter.
+#ifndef RFW_SHADOW_FAR_FIRST
+#define RFW_SHADOW_FAR_FIRST 1
+#endif
 #ifndef RFW_STAGE_PRIO
 #define RFW_STAGE_PRIO 0
 #endif
@@ -407,9 +411,17 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
         const f3 O = mk3(o4.x, o4.y, o4.z), D = mk3(d4.x, d4.y, d4.z);
         float t = d4.w - 0.0001f, hu, hv;
+        if (t > 3.0e38f) t = 3.0e38f; // a light at infinite distance (see k_query_closest)
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
-        const bool occluded = traverse<true, COUNT>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
+        // Rays towards a directional light leave the scene: what blocks the sky is most often the LAST thing on their way (roofs, upper
+        // floors), so their occluder search starts at the far end (measured on the bench scene's real shadow queue: 21.6 -> 13.9 nodes per
+        // ray; rays towards the area lights get 5-15 % longer that way and keep the near-to-far order).  The bucket tells the light while
+        // the scene has no more lights than buckets; with more, buckets mix lights and every ray goes near to far.
+        const uint32_t n_positional = cam.area_light_count + cam.point_light_count + cam.spot_light_count;
+        const bool far_first = RFW_SHADOW_FAR_FIRST && n_positional + cam.directional_light_count <= (uint32_t)kShadowBuckets && bucket >= n_positional;
+        const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc)
+                                        : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {
             const float4 e = p.sh_e[idx];
             const uint32_t slot = fbits(e.w); // the path's accumulator slot rides in the queue entry (k_shade knows it without arithmetic)
@@ -763,11 +775,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
     if (idx >= n) return;
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
     const f3 D = mk3(directions[3 * idx], directions[3 * idx + 1], directions[3 * idx + 2]);
-    float t = t_max, hu = 0.0f, hv = 0.0f;
+    // The search interval ends at a FINITE distance.  With t = +inf a degenerate ray (zero direction components: 1 / d = inf) gives child
+    // boxes an entry distance of +inf that still passes `entry <= t`; such children tie with the +inf keys of the empty slots in the
+    // ordering network, an empty slot's reference (kInvalidRef) can be taken for a child, and it decodes as a leaf far outside the
+    // triangle array — a memory fault reproduced through rfw_hip_occludes on the 1 M-triangle scene.  A miss still reports the caller's t_max.
+    float t = t_max > 3.0e38f ? 3.0e38f : t_max, hu = 0.0f, hv = 0.0f; // below FLT_MAX, the key the ordering network gives to children that are not hit
     int32_t hi = -1, ht = -1;
     TravCounters tc{0, 0, 0};
     const SceneView sv = scene_view(sc);
     traverse<false, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    if (hi < 0) t = t_max;
     rfw_hip_hit h;
     if (hi >= 0) { // storage order -> the boundary's triangle numbering (identical after a full build)
         const MeshRecord r = sc.meshes[sc.instances[hi].mesh];
@@ -777,9 +794,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
     hits[idx] = h;
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes this ray visited, TLAS and BLAS
 }
+template <bool DEPTH>
 __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, const float* __restrict__ origins, const float* __restrict__ directions,
                                                             const float t_min, const float* __restrict__ t_max, const uint64_t n,
-                                                            uint8_t* __restrict__ occluded)
+                                                            uint8_t* __restrict__ occluded, uint32_t* __restrict__ depth)
 {
     __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
@@ -787,11 +805,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
     const f3 D = mk3(directions[3 * idx], directions[3 * idx + 1], directions[3 * idx + 2]);
     float t = t_max[idx], hu, hv;
+    if (t > 3.0e38f) t = 3.0e38f; // see k_query_closest: the interval ends at a finite distance (a NaN t_max stays NaN: nothing is hit)
     int32_t hi = -1, ht = -1;
     TravCounters tc{0, 0, 0};
     const SceneView sv = scene_view(sc);
-    const bool occ = traverse<true, false>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    const bool occ = traverse<true, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
     occluded[idx] = occ ? 1 : 0;
+    if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes visited until the first occluder / the end of the traversal
 }
 
 __global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n)
@@ -954,10 +974,11 @@ void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origin
     else hipLaunchKernelGGL(k_query_closest<false>, grid, block, 0, s, sc, origins, directions, t_min, t_max, n, hits, depth);
 }
 void launch_query_any(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n,
-                      uint8_t* occluded)
+                      uint8_t* occluded, uint32_t* depth)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_query_any, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, occluded);
+    if (depth) hipLaunchKernelGGL(k_query_any<true>, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, occluded, depth);
+    else hipLaunchKernelGGL(k_query_any<false>, dim3(ceil_div(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, origins, directions, t_min, t_max, n, occluded, depth);
 }
 
 } // namespace rfwhip

@@ -2445,9 +2445,23 @@ int rfw_hip_depth_test(void* inst, const float* origins, const float* directions
     return intersect_impl(inst, origins, directions, t_min, t_max, n, hits, depth);
 }
 
+static int occludes_impl(Instance* I, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded, uint32_t* depth);
 int rfw_hip_occludes(void* inst, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded)
 {
     LOCK(inst);
+    return occludes_impl(I, origins, directions, t_min, t_max, n, occluded, nullptr);
+}
+// occludes() that also reports the 4-wide nodes each any-hit traversal visited (the any-hit counterpart of rfw_hip_depth_test; for the
+// planning probes under tools/probes, not part of the trait)
+int rfw_hip_debug_occludes_depth(void* inst, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded,
+                                 uint32_t* depth)
+{
+    LOCK(inst);
+    if (n && !depth) return fail(I, RFW_HIP_E_INVALID, "occludes_depth: null pointer");
+    return occludes_impl(I, origins, directions, t_min, t_max, n, occluded, depth);
+}
+static int occludes_impl(Instance* I, const float* origins, const float* directions, float t_min, const float* t_max, uint64_t n, uint8_t* occluded, uint32_t* depth)
+{
     if (n && (!origins || !directions || !t_max || !occluded)) return fail(I, RFW_HIP_E_INVALID, "occludes: null pointer");
     if (!I->synchronized) return fail(I, RFW_HIP_E_STATE, "occludes: scene not synchronized");
     HIP_TRY(I, hipSetDevice(I->device));
@@ -2459,6 +2473,7 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
     HIP_TRY(I, d_d.ensure(3 * std::min(n, chunk)));
     HIP_TRY(I, d_t.ensure(std::min(n, chunk)));
     HIP_TRY(I, d_r.ensure(std::min(n, chunk)));
+    if (depth) HIP_TRY(I, I->d_q_depth.ensure(std::min(n, chunk)));
     const SceneDev sc = scene_dev(I);
     int rc = RFW_HIP_OK;
     for (uint64_t off = 0; off < n && rc == RFW_HIP_OK; off += chunk) {
@@ -2467,10 +2482,11 @@ int rfw_hip_occludes(void* inst, const float* origins, const float* directions, 
         if (e == hipSuccess) e = hipMemcpyAsync(d_d.ptr, directions + 3 * off, 3 * m * sizeof(float), hipMemcpyHostToDevice, I->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_t.ptr, t_max + off, m * sizeof(float), hipMemcpyHostToDevice, I->stream);
         if (e == hipSuccess) {
-            launch_query_any(I->stream, sc, d_o.ptr, d_d.ptr, t_min, d_t.ptr, m, d_r.ptr);
+            launch_query_any(I->stream, sc, d_o.ptr, d_d.ptr, t_min, d_t.ptr, m, d_r.ptr, depth ? I->d_q_depth.ptr : nullptr);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(occluded + off, d_r.ptr, m, hipMemcpyDeviceToHost, I->stream);
+        if (e == hipSuccess && depth) e = hipMemcpyAsync(depth + off, I->d_q_depth.ptr, m * sizeof(uint32_t), hipMemcpyDeviceToHost, I->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
         if (e != hipSuccess) rc = fail(I, RFW_HIP_E_DEVICE, std::string("occludes: ") + hipGetErrorString(e));
     }
@@ -2534,9 +2550,9 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     else if (w == "ray_d1") { src = I->d_ray_d[1].ptr; avail = q; }
     else if (w == "thr0") { src = I->d_thr[0].ptr; avail = q; }
     else if (w == "thr1") { src = I->d_thr[1].ptr; avail = q; }
-    else if (w == "sh_o") { src = I->d_sh_o.ptr; avail = q; }
-    else if (w == "sh_d") { src = I->d_sh_d.ptr; avail = q; }
-    else if (w == "sh_e") { src = I->d_sh_e.ptr; avail = q; }
+    else if (w == "sh_o") { src = I->d_sh_o.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
+    else if (w == "sh_d") { src = I->d_sh_d.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
+    else if (w == "sh_e") { src = I->d_sh_e.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
     else if (w == "counters") { src = I->d_counters.ptr; avail = sizeof(QueueCounters); }
     else if (w == "xforms") { src = I->d_xforms.ptr; avail = I->n_instances * sizeof(InstanceXform); }
     else if (w == "normals") { src = I->d_normals.ptr; avail = I->n_instances * sizeof(InstanceNormal); }

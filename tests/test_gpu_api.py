@@ -378,3 +378,35 @@ def test_packet_queries_are_four_single_ray_queries():
             assert t[k] == (r["t"][0] if r["inst"][0] >= 0 else tmax[k])
             assert bool(occ[k]) == bool(orc.occludes(o[k:k + 1], d[k:k + 1], tmax[k:k + 1], t_min=float(tmin[k]), brute=True)[0])
     be.close()
+
+
+def test_degenerate_rays_with_an_infinite_interval_do_not_fault():
+    """Regression (found by tools/probes/wave_model.py): origin far outside the scene, a direction of exact zeros (1 / d = +inf) and
+    t_max = +inf gave child boxes an entry distance of +inf that still passed `entry <= t`, such children tied with the empty slots'
+    +inf keys in the ordering network, an empty slot's reference was followed and decoded as a leaf beyond the triangle array: a GPU
+    memory fault through rfw_hip_occludes on the 1 M-triangle scene.  The search interval now ends at a finite distance."""
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("atrium", 1048576, 0, 0.0, 0xC0FFEE)
+    scene.set_aspect(16 / 9)
+    be = HipBackend.init(640, 360, 1.0, max_path_length=1)
+    scene.sync(be)
+    n = 60000
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    far = (d * np.float32(1e26)).astype(np.float32)
+    zero = np.zeros((n, 3), np.float32)
+    mixed = np.where(rng.random((n, 3)) < 0.5, zero, -zero).astype(np.float32)
+    inf = np.full(n, np.inf, np.float32)
+    for o, dd in ((far, zero), (far, mixed), (far, -zero), (d, zero), (far, d)):
+        assert not be.occludes(o, dd, inf).any()
+        occ, depth = be.occludes_depth(o, dd, inf)
+        assert not occ.any() and depth.max() <= 2
+        hits = be.intersect(o, dd, t_max=float("inf"))
+        assert (hits["inst"] < 0).all() and np.isinf(hits["t"]).all()          # a miss reports the caller's t_max
+    # ordinary rays with t_max = +inf behave as with any large finite bound
+    o = rng.uniform(-10, 10, (n, 3)).astype(np.float32); o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.3
+    a, b = be.intersect(o, d, t_max=float("inf")), be.intersect(o, d, t_max=1e30)
+    assert np.array_equal(a["inst"], b["inst"]) and np.array_equal(a["tri"], b["tri"]) and (a["inst"] >= 0).mean() > 0.5
+    assert np.array_equal(be.occludes(o, d, inf), be.occludes(o, d, np.full(n, 1e30, np.float32)))
+    be.close()
