@@ -415,8 +415,8 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
         // Rays towards a directional light leave the scene: what blocks the sky is most often the LAST thing on their way (roofs, upper
-        // floors), so their occluder search starts at the far end (measured on the bench scene's real shadow queue: 21.6 -> 13.9 nodes per
-        // ray; rays towards the area lights get 5-15 % longer that way and keep the near-to-far order).  The bucket tells the light while
+        // floors), so their occluder search starts at the far end (measured on the bench scene's real shadow queue: 21.6 -> 12.1 nodes per
+        // ray; rays towards the area lights get up to 15 % longer that way and keep the near-to-far order).  The bucket tells the light while
         // the scene has no more lights than buckets; with more, buckets mix lights and every ray goes near to far.
         const uint32_t n_positional = cam.area_light_count + cam.point_light_count + cam.spot_light_count;
         const bool far_first = RFW_SHADOW_FAR_FIRST && n_positional + cam.directional_light_count <= (uint32_t)kShadowBuckets && bucket >= n_positional;

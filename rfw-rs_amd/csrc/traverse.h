@@ -67,8 +67,8 @@ struct TravCounters {
 // Closest hit (ANY_HIT = false): on return t/hu/hv/hit_inst/hit_tri describe the nearest accepted hit, ties resolved
 // to the lowest (instance, triangle) id.  Any hit (ANY_HIT = true): returns true as soon as one triangle has
 // t_min < t' < t.
-// FAR_FIRST (any hit only): hit children are visited in order of DECREASING entry distance — the search for an occluder starts at the far
-// end of the ray.  The triangle tests, and therefore the answer, are the same in either order.
+// FAR_FIRST (any hit only): hit children are visited in order of DECREASING EXIT distance (key = -exit instead of entry) — the search for an
+// occluder starts at the far end of the ray.  The triangle tests, and therefore the answer, are the same in either order.
 template <bool ANY_HIT, bool COUNT, bool FAR_FIRST = false>
 RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_min, float& t, float& hu, float& hv, int32_t& hit_inst,
                      int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
@@ -203,7 +203,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         const bool h = (tf >= tn) & (tn <= t) & (tf >= 0.0f) & (CH != kInvalidRef);                                                   \
         nhit += h ? 1u : 0u;                                                                                                          \
         hit[i] = h;                                                                                                                   \
-        key[i] = (int32_t)((fbits(tn) & 0xfffffffcu) | (uint32_t)i); /* slot index in the 2 LSBs: equal distances go lower slot first */                                                                  \
+        key[i] = (int32_t)((fbits((ANY_HIT && FAR_FIRST) ? -tf : tn) & 0xfffffffcu) | (uint32_t)i); /* slot index in the 2 LSBs: equal distances go lower slot first */                                  \
     }
             RFW_SLAB(0, ch.x)
             RFW_SLAB(1, ch.y)
@@ -222,7 +222,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                     const uint32_t second = hit[3] ? ch.w : (hit[2] ? ch.z : ch.y);
                     const int32_t k_first = hit[0] ? key[0] : (hit[1] ? key[1] : key[2]);
                     const int32_t k_second = hit[3] ? key[3] : (hit[2] ? key[2] : key[1]);
-                    const bool swap = FAR_FIRST ? (bitsf((uint32_t)k_second) > bitsf((uint32_t)k_first)) : (bitsf((uint32_t)k_second) < bitsf((uint32_t)k_first)); // the float order the any-hit sort uses
+                    const bool swap = bitsf((uint32_t)k_second) < bitsf((uint32_t)k_first); // the float order the any-hit sort uses
                     const uint32_t far = swap ? cur : second;
                     cur = swap ? second : cur;
                     if (sp < kStack) { lds_stack[sp * kTraceBlock + lane_slot] = far; sp++; }
@@ -234,10 +234,10 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
                     // by the any-hit kernel, as integers by the closest-hit kernels (float order for the non-negative ones, some fixed order
                     // among the boxes the ray starts inside of) — each flavour measured faster in its kernel.
                     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-                    for (int i = 0; i < 4; i++) key[i] = hit[i] ? key[i] : (FAR_FIRST ? (int32_t)0xff7fffff : (int32_t)0x7f7fffff); // FLT_MAX: the largest key in either order (-FLT_MAX, the smallest, when the largest entry distance goes first)
+                    for (int i = 0; i < 4; i++) key[i] = hit[i] ? key[i] : (int32_t)0x7f7fffff; // FLT_MAX: the largest key in either order
 #define RFW_PSWAP(ka, ca, kb, cb)                                                                                                     \
     {                                                                                                                                 \
-        const bool s_ = ANY_HIT ? (FAR_FIRST ? (bitsf((uint32_t)kb) > bitsf((uint32_t)ka)) : (bitsf((uint32_t)kb) < bitsf((uint32_t)ka))) : (kb < ka); \
+        const bool s_ = ANY_HIT ? (bitsf((uint32_t)kb) < bitsf((uint32_t)ka)) : (kb < ka);                                           \
         const int32_t kl_ = s_ ? kb : ka, kh_ = s_ ? ka : kb;                                                                         \
         const uint32_t cl_ = s_ ? cb : ca, ch_ = s_ ? ca : cb;                                                                        \
         ka = kl_; kb = kh_; ca = cl_; cb = ch_;                                                                                       \
