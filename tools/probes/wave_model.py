@@ -8,7 +8,8 @@ rfw_hip_debug_occludes_depth), takes the 4-wide nodes each ray visited as its le
 
   * as the kernels run today: a wavefront runs until its longest ray is done (sum of the per-wave maxima),
   * with an early exit: when fewer than T lanes are still active the wavefront stops and its unfinished rays continue in new, densely
-    packed wavefronts (again with early exit, recursively) - state save / restore costed at C iterations per continued ray-wave,
+    packed wavefronts (again with early exit, recursively) - state save / restore costed at C iterations per continued ray-wave; or
+    ("restart") the unfinished rays are simply traced again from their start in those new wavefronts, no state saved,
   * with ideal refill: every lane always busy (sum of lengths / 64): the bound no scheme can beat.
 
 Prints one JSON object.  Nothing here is part of the product or of the tests; the oracle is not used."""
@@ -29,7 +30,7 @@ def waves_of_blocks(values, w, h):
     return v
 
 
-def early_exit_cost(lengths, threshold, overhead):
+def early_exit_cost(lengths, threshold, overhead, restart=False):
     """lengths: (n_waves, 64) with 0 for empty lanes.  Returns wave-iterations when a wavefront exits as soon as fewer than `threshold`
     lanes are active and the leftovers are re-packed (sorted by remaining length is NOT assumed: queue order)."""
     total = 0.0
@@ -45,7 +46,7 @@ def early_exit_cost(lengths, threshold, overhead):
         stop = np.where(run > 0, run, full)             # waves with fewer than `threshold` rays in total run to the end
         total += float(stop.sum())
         left = np.maximum(cur - stop[:, None], 0)
-        left = left[left > 0]
+        left = cur[left > 0] if restart else left[left > 0]   # restart: an unfinished ray is traced again from its start (no state is saved)
         if left.size == 0:
             break
         total += overhead * (left.size / 64.0)          # state save + restore, per continued wavefront's worth of rays
@@ -89,6 +90,7 @@ def main():
         for t in (8, 16, 24, 32):
             for c in (2.0, 6.0):
                 r[f"early_exit_T{t}_overhead{int(c)}"] = round(1.0 - early_exit_cost(waves, t, c) / today, 3)
+            r[f"early_exit_restart_T{t}"] = round(1.0 - early_exit_cost(waves, t, 0.5, restart=True) / today, 3)
         out[name] = r
 
     report("primary_closest_hit", waves_of_blocks(depth, w, h))
