@@ -72,7 +72,11 @@ typedef struct {
 
 enum {
     RFW_HIP_FLAG_NO_NEE = 1u << 0,        /* skip light sampling / shadow rays */
-    RFW_HIP_FLAG_COUNT_TRAVERSAL = 1u << 1 /* accumulate node/triangle visit counters (slow; for roofline bytes) */
+    RFW_HIP_FLAG_COUNT_TRAVERSAL = 1u << 1, /* accumulate node/triangle visit counters (slow; for roofline bytes) */
+    /* bits 2 and 3 are set through rfw_hip_set_option("shadow_order", 0 | 1 | 2): which end of a shadow ray the any-hit traversal starts from —
+     * 0 (default) directional lights far to near, positional lights near to far; 1 every ray near to far; 2 every ray far to near.  Speed only. */
+    RFW_HIP_FLAG_SHADOW_NEAR_FIRST_DIRECTIONAL = 1u << 2,
+    RFW_HIP_FLAG_SHADOW_FAR_FIRST_POSITIONAL = 1u << 3
 };
 
 /* Per-frame counters and timings of the last rfw_hip_render (extension; no trait equivalent). */

@@ -195,7 +195,7 @@ struct QueueCounters {
     unsigned long long pad3;
 };
 
-enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u };
+enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u, kFlagNearFirstDirectional = 4u, kFlagFarFirstPositional = 8u }; // the last two: option "shadow_order"
 
 
 } // namespace rfwhip

@@ -419,7 +419,9 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         // ray; rays towards the area lights get up to 15 % longer that way and keep the near-to-far order).  The bucket tells the light while
         // the scene has no more lights than buckets; with more, buckets mix lights and every ray goes near to far.
         const uint32_t n_positional = cam.area_light_count + cam.point_light_count + cam.spot_light_count;
-        const bool far_first = RFW_SHADOW_FAR_FIRST && n_positional + cam.directional_light_count <= (uint32_t)kShadowBuckets && bucket >= n_positional;
+        const bool one_light_per_bucket = n_positional + cam.directional_light_count <= (uint32_t)kShadowBuckets;
+        const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket >= n_positional ? (one_light_per_bucket && !(cam.flags & kFlagNearFirstDirectional))
+                                                                              : (cam.flags & kFlagFarFirstPositional) != 0u); // option "shadow_order" overrides the default per light kind
         const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc)
                                         : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {

@@ -2034,6 +2034,11 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "clamp_value") I->clamp_value = (float)value;
     else if (k == "nee") I->flags = value != 0.0 ? (I->flags & ~RFW_HIP_FLAG_NO_NEE) : (I->flags | RFW_HIP_FLAG_NO_NEE);
     else if (k == "count_traversal") I->flags = value != 0.0 ? (I->flags | RFW_HIP_FLAG_COUNT_TRAVERSAL) : (I->flags & ~RFW_HIP_FLAG_COUNT_TRAVERSAL);
+    else if (k == "shadow_order") { // which end any-hit traversals start from: 0 = default (directional lights far to near, positional near to far), 1 = all near to far, 2 = all far to near
+        I->flags &= ~(kFlagNearFirstDirectional | kFlagFarFirstPositional);
+        if ((int)value == 1) I->flags |= kFlagNearFirstDirectional;
+        else if ((int)value == 2) I->flags |= kFlagFarFirstPositional;
+    }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "timing") I->timing = value != 0.0;
     else if (k == "sort_extension_rays") I->sort_extension_rays = std::max(0, std::min(2, (int)value));

@@ -178,3 +178,27 @@ def test_sorted_extension_rays_give_the_same_image():
         orc.reset(); orc.render(v)
         assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
     be.close()
+
+
+@pytest.mark.parametrize("kind,a,b", [("atrium", 30000, 0), ("soup", 2000, 4)])
+def test_shadow_order_option_never_changes_the_image(kind, a, b):
+    """Option shadow_order: which end of a shadow ray the any-hit traversal starts from (default: directional lights far to near, positional
+    lights near to far; 1 = every ray near to far, 2 = every ray far to near).  Any hit has no 'right' order: the image, the ray counts
+    and the oracle agree under all three; only the node visits differ."""
+    w, h = 144, 96
+    scene, be, orc = make(kind, w, h, a, b, seed=21, max_path_length=3)
+    view = scene.view(w, h)
+    orc.render(view)
+    ref = orc.accumulator()
+    visits = []
+    be.set_option("count_traversal", 1)
+    for order in (0, 1, 2):
+        be.set_option("shadow_order", order)
+        be.reset_accumulation()
+        be.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), ref.view(np.uint32)), order
+        s = be.frame_stats()
+        assert s["shadow_rays"] == orc.stats()["shadow"]
+        visits.append(s["nodes_visited"][2] if "nodes_visited" in s else None)
+    assert visits[0] is None or len(set(visits)) > 1      # the orders are really different traversals
+    be.close()
