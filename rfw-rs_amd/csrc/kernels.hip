@@ -416,12 +416,10 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         const SceneView sv = scene_view(sc);
         // Rays towards a directional light leave the scene: what blocks the sky is most often the LAST thing on their way (roofs, upper
         // floors), so their occluder search starts at the far end (measured on the bench scene's real shadow queue: 21.6 -> 12.1 nodes per
-        // ray; rays towards the area lights get up to 15 % longer that way and keep the near-to-far order).  The bucket tells the light while
-        // the scene has no more lights than buckets; with more, buckets mix lights and every ray goes near to far.
-        const uint32_t n_positional = cam.area_light_count + cam.point_light_count + cam.spot_light_count;
-        const bool one_light_per_bucket = n_positional + cam.directional_light_count <= (uint32_t)kShadowBuckets;
-        const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket >= n_positional ? (one_light_per_bucket && !(cam.flags & kFlagNearFirstDirectional))
-                                                                              : (cam.flags & kFlagFarFirstPositional) != 0u); // option "shadow_order" overrides the default per light kind
+        // ray; rays towards the area lights get up to 15 % longer that way and keep the near-to-far order).  shade files every directional
+        // light's rays under the last bucket, so the bucket tells the kind of light.
+        const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional)
+                                                                                                 : (cam.flags & kFlagFarFirstPositional) != 0u); // option "shadow_order" overrides the default per light kind
         const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc)
                                         : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
         if (!occluded) {
@@ -626,7 +624,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                                         light_bucket = (picked & 3) | (cls << 2);
                                     }
 #else
-                                    light_bucket = picked & (kShadowBuckets - 1);
+                                    // directional lights share the LAST bucket (their rays are traced far to near, k_shadow), the positional lights
+                                    // are dealt over the other seven: the bucket tells the kind of light however many lights there are
+                                    light_bucket = picked >= lc - (int)cam.directional_light_count ? kShadowBuckets - 1 : (int)((uint32_t)picked % (uint32_t)(kShadowBuckets - 1));
 #endif
                                 }
                             }
