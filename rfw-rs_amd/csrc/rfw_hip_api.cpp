@@ -244,6 +244,10 @@ struct Instance {
     } tables[kTableVersions];
     uint64_t tables_version = 0;             // owner: version frames rendered from now on read (buffer = version % kTableVersions)
     uint64_t tables_waited = 0, tables_used = 0; // per slot: version its stream has waited for / version its latest frame reads
+    // per slot: the OLDEST version a frame of this slot reads that the upload stream has not yet been ordered behind (~0 = none).  A slot
+    // renders frame after frame without the host ever waiting, so an old frame can still be executing when its latest frame already reads a
+    // newer version: recycling a version buffer must look at the oldest such frame, not at the latest
+    uint64_t tables_oldest_pending = ~0ull;
     hipStream_t upload_stream = nullptr;
     hipEvent_t tables_ready = nullptr;
     // what the set_* calls since the last synchronize changed: all, or a list of element indices
@@ -1087,10 +1091,18 @@ int upload_tables(Instance* I)
     // frame, on the device; the host does not wait
     if (nv >= (uint64_t)Instance::kTableVersions) {
         const uint64_t stale = nv - Instance::kTableVersions;
-        if (I->tables_used <= stale && I->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, I->frame_done, 0));
+        // frame_done is recorded behind a slot's LATEST frame and a stream runs in order: waiting for it covers every earlier frame of the slot
+        auto order_behind = [&](Instance* c) -> int {
+            if (c->tables_oldest_pending > stale) return RFW_HIP_OK; // no frame of this slot that may still run reads the buffer
+            if (c->frame_done && !I->slots.empty()) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, c->frame_done, 0));
+            else HIP_TRY(I, hipStreamSynchronize(c->stream)); // no frame_done event without slots
+            c->tables_oldest_pending = ~0ull;
+            return RFW_HIP_OK;
+        };
+        int orc;
+        if ((orc = order_behind(I))) return orc;
         for (Instance* c : I->slots)
-            if (c->tables_used <= stale && c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, c->frame_done, 0));
-        if (I->slots.empty() && I->tables_used <= stale) HIP_TRY(I, hipStreamSynchronize(I->stream)); // no frame_done event without slots
+            if ((orc = order_behind(c))) return orc;
     }
     int rc;
     if ((rc = write_table(I, dst.materials, dst.n_mat, old.materials, old.n_mat, I->materials, I->mat_dirty))) return rc;
@@ -1283,6 +1295,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
             I->tables_waited = S->tables_version;
         }
         I->tables_used = S->tables_version;
+        if (I->tables_oldest_pending == ~0ull) I->tables_oldest_pending = S->tables_version;
     }
     if ((I->have_last_view && std::memcmp(&I->last_view, &view, sizeof(view)) != 0) || I->after_batch) I->sample_count = 0;
     I->after_batch = k > 1 && !samples; // the frames of a batch are complete images: whatever follows starts a new one

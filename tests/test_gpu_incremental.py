@@ -127,6 +127,44 @@ def test_material_edits_reach_later_frames_only_and_honour_changed_bits():
     be.close()
 
 
+def test_material_edit_before_every_render_with_two_frame_slots():
+    """with two frame slots and an edit before EVERY render a slot's older frame may still be executing when the upload of
+    version v + 4 recycles the buffer it reads while the slot's LATEST frame already reads a newer version.  The recycle check must look at
+    the oldest frame of a slot that may still run, not at the latest.  A larger image makes the frames long against the host's edit loop."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 640, 360
+    scene = Scene().build("soup", 20000, 4, 0.0, 6)
+    scene.set_aspect(w / h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=2)
+    orc = Oracle(w, h, threads=THREADS, max_path_length=3)
+    scene.sync(be)
+    n_frames = 14
+    views = []
+    for k in range(n_frames):
+        scene.set_camera([0.2 * k - 1.2, 0.4, -4.0 + 0.05 * k], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    frames = [be.host_frame() for _ in views]
+    edits = [None] + [(int(r.integers(0, 6)), [int(x) for x in r.integers(30, 250, 3)], int(r.integers(20, 250)))
+                      for r in [np.random.default_rng(700 + k) for k in range(1, n_frames)]]
+    for k, v in enumerate(views):                                # never wait: edits race ahead of the frames
+        if k:
+            scene.recolour_material(*edits[k])
+            scene.sync(be)
+        be.render(v)
+        be.download_frame(frames[k], accumulator=True)
+    scene_o = Scene().build("soup", 20000, 4, 0.0, 6)
+    scene_o.set_aspect(w / h)
+    be.wait_downloads()
+    for k, v in enumerate(views):
+        if k:
+            scene_o.recolour_material(*edits[k])
+        scene_o.mark_all_changed(); scene_o.sync(orc)
+        orc.reset(); orc.render(v)
+        assert np.array_equal(frames[k].view(np.uint32), orc.accumulator().view(np.uint32)), k
+    be.close()
+
+
 def test_texture_edits_honour_changed_bits():
     """VERDICT r01 #13, textures: set_textures with the trait's `changed` bit slice copies and resamples (gpu-rt's 1024 x 1024 x 5 array)
     only the textures whose bit is set and synchronize() writes only those over the old texels; images before and after every edit equal
