@@ -15,7 +15,7 @@ namespace rfwhip {
 size_t sah_workspace_bytes(uint32_t n);
 
 // Builds a BVH4 over boxes[0..n) on `stream`.  nodes_out needs room for max(n, 1) nodes, prim_order_out for n entries (leaf refs
-// index into it).  Synchronises the stream once per level of the upper tree (a 4-byte read-back), so it is a blocking call.
+// index into it).  Synchronises the stream ONCE (a 16-byte read-back after the levels of the upper tree), so it is a blocking call.
 // max_leaf <= kMaxLeafTris; trav_cost as in build_bvh4_host.
 hipError_t sah_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
                      uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */, int max_leaf, float trav_cost);

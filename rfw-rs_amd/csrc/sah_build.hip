@@ -1,13 +1,23 @@
 // sah_build.hip — binned-SAH BVH construction on the device (replaces the reference's per-mesh rtbvh builds on rayon,
 // backends/gpu-rt/src/lib.rs:1345-1383, and BinnedSahBuilder, :1576-1581).
 //
-// Top-down, in two phases:
-//   1. nodes with more than kSmall primitives, one LEVEL per round of four kernels over the whole primitive array:
-//      bin (16 bins x 3 axes per node, aggregated per workgroup in LDS, then a few global atomics), split (one thread per node
-//      sweeps its 48 bins), partition (wave-aggregated append into the two children's ranges), classify (children above
-//      kSmall form the next level, the others queue for phase 2);
-//   2. every queued node (<= kSmall primitives) is finished by ONE workgroup entirely in LDS: boxes and the permutation stay in
-//      LDS while the workgroup walks the subtree with a small explicit stack (larger child pushed, so depth <= log2(kSmall)).
+// Top-down, in two phases, ONE host read-back per build (round 2: one per level of the upper tree; 1 M triangles 26 ms -> 4.6 ms of kernels):
+//   1. nodes with more than 512 primitives (256 for small meshes), one LEVEL per round of three kernels, launched for a number of levels the
+//      host derives from the primitive count (the kernels of a level without such nodes return at once):
+//        bin        16 bins x 3 axes per node.  One workgroup per 256 positions; a node of this phase spans more than 256 positions, so a block
+//                   meets at most two: both get bins in LDS, filled with wave-aggregated adds (meshes arrive in a spatially coherent order: most
+//                   lanes of a wavefront share a bin, and 64 LDS atomics on one word take 64 turns), flushed with <= 336 atomics per node and
+//                   block into one of up to 32 COPIES of the node's bins (device-scope atomics on one word serialise at ~40 ns each);
+//        split      ONE WAVEFRONT per node: a row of 16 lanes is an axis, every lane loads its bin, prefix / suffix scans along the row by DPP
+//                   give the boxes left and right of all 48 planes at once; arg-min by shuffles; the winner creates the children and files
+//                   them (next level's list, or the queue of phase 2);
+//        partition  slots and centroid bounds aggregated per workgroup in LDS (2 + 12 atomics per 256-block); on the upper levels a workgroup
+//                   takes 8 blocks, counts first and takes its slots with ONE atomic per child.
+//      The primitives' BOXES travel with the order (position-ordered copy, written by partition with wave-contiguous stores): bin and
+//      partition read them coalesced instead of gathering 32 B per primitive through the order twice a level.
+//   2. every queued range is finished by ONE WORKGROUP in LDS: stage A splits, all threads together, the sub-ranges above 64 primitives;
+//      stage B lets every wavefront finish sub-ranges of <= 64 alone, wave-synchronously, with the same row-scan sweep.  (Round 2: ranges of
+//      256, one lane per axis sweeping the bins, one split at a time: 12.5 of the builder's 26 ms.)
 // The result is a BVH2 with multi-primitive leaves; every internal node at even depth becomes a 4-wide node whose children are
 // its grandchildren (as lbvh.hip does), in the Node4 layout the traversal kernels' quantiser consumes.
 // The order of primitives inside a leaf depends on atomics and is not reproducible run to run; ray results do not depend on
@@ -25,12 +35,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kBins = 16;
-constexpr uint32_t kSmall = 256;   // primitives a workgroup finishes in LDS (one per thread): the CAPACITY of phase 2
-// The range size at which phase 1 hands over to phase 2.  A workgroup of phase 2 walks its subtree one split after the other (~15 us
-// each), so a 256-primitive range takes ~2 ms — invisible next to thousands of such workgroups of a large mesh, but the whole latency of
-// a small one (a 5120-triangle mesh: 0.5 ms of levels + 2.0 ms of phase 2).  Small meshes therefore hand over at 64 primitives: two more
-// levels (~0.1 ms each, launch- and read-back-bound), a quarter of the serial walk (measured: 2.5 -> 1.7 ms for that mesh, device done)
-inline uint32_t small_limit_for(uint32_t n) { return n <= 32768u ? 64u : kSmall; }
+constexpr uint32_t kSmall = 512;   // primitives one workgroup finishes in LDS (one per thread): phase 1 hands a range over at this size ...
+constexpr uint32_t kSmallFew = 256; // ... or at this size when the mesh is small: more, shorter workgroups (a 5120-triangle mesh: 30 instead of 7)
+inline uint32_t small_cap_for(uint32_t n) { return n <= 32768u ? kSmallFew : kSmall; }
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr int kMaxLevels = 96;
 
@@ -76,9 +83,60 @@ __device__ inline int bin_of(float c, float lo, float hi)
 struct Counters {
     uint32_t node_count;     // BVH2 nodes allocated
     uint32_t n_active[2];    // big nodes of the current / next level
-    uint32_t n_small;        // nodes queued for phase 2
+    uint32_t n_small;        // ranges queued for phase 2
     uint32_t root_bounds[12];
 };
+
+// wavefront-wide min / max by DPP (row shifts inside the 16-lane rows, then the two row broadcasts: six vector instructions, no LDS
+// crossbar as __shfl would use); the result is returned to every lane
+#define RFW_DPP_STEP(OP, v, ctrl) v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false)))
+__device__ inline float wave_min(float v)
+{
+    RFW_DPP_STEP(fminf, v, 0x111); RFW_DPP_STEP(fminf, v, 0x112); RFW_DPP_STEP(fminf, v, 0x114); RFW_DPP_STEP(fminf, v, 0x118); // row_shr:1,2,4,8
+    RFW_DPP_STEP(fminf, v, 0x142); RFW_DPP_STEP(fminf, v, 0x143);                                                                 // row_bcast:15, row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ inline float wave_max(float v)
+{
+    RFW_DPP_STEP(fmaxf, v, 0x111); RFW_DPP_STEP(fmaxf, v, 0x112); RFW_DPP_STEP(fmaxf, v, 0x114); RFW_DPP_STEP(fmaxf, v, 0x118);
+    RFW_DPP_STEP(fmaxf, v, 0x142); RFW_DPP_STEP(fmaxf, v, 0x143);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef RFW_DPP_STEP
+
+// A wavefront's primitives into the 48 bins of a node.  Meshes come in a spatially coherent order, so most lanes of a wavefront share a bin
+// on every axis and 64 atomics on one word would take 64 turns (LDS) or 64 trips to the memory side (HBM): the lanes of one bin are reduced
+// in registers first and ONE lane adds the result; bins that only a few lanes hit take their atomics directly.
+template <class BinPtr> __device__ inline void wave_add_to_bins(BinPtr bins, const bool act, const int* my_bin, const float* lo, const float* hi)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long active = __ballot(act);
+    if (active == 0ull) return;
+    const int lead = __ffsll((long long)active) - 1;
+    for (int a = 0; a < 3; a++) {
+        // the bin of the first active lane: when at least 24 lanes share it they are reduced in registers and one lane adds the result
+        // (upper levels, primitives still in mesh order); everybody else — every lane, when the bins are spread — takes its atomics directly
+        const int b = __builtin_amdgcn_readlane(my_bin[a], lead);
+        const bool sel = act && my_bin[a] == b;
+        const unsigned long long m = __ballot(sel);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const bool aggregate = cnt >= 24u; // wave-uniform
+        if (aggregate) {
+            float rl[3], rh[3];
+            for (int c = 0; c < 3; c++) { rl[c] = wave_min(sel ? lo[c] : INFINITY); rh[c] = wave_max(sel ? hi[c] : -INFINITY); }
+            if ((int)lane == lead) {
+                auto* e = &bins[a * kBins + b];
+                atomicAdd(&e->count, cnt);
+                for (int c = 0; c < 3; c++) { atomicMin(&e->lo[c], f_order(rl[c])); atomicMax(&e->hi[c], f_order(rh[c])); }
+            }
+        }
+        if (act && !(aggregate && sel)) {
+            auto* e = &bins[a * kBins + my_bin[a]];
+            atomicAdd(&e->count, 1u);
+            for (int c = 0; c < 3; c++) { atomicMin(&e->lo[c], f_order(lo[c])); atomicMax(&e->hi[c], f_order(hi[c])); }
+        }
+    }
+}
 
 // ---------------------------------------------------------------- root
 __global__ void k_root_init(Counters* ctr)
@@ -87,32 +145,45 @@ __global__ void k_root_init(Counters* ctr)
     else if (threadIdx.x < 12) ctr->root_bounds[threadIdx.x] = threadIdx.x < 9 ? 0xffffffffu : 0u;    // centroids
     if (threadIdx.x == 0) { ctr->node_count = 1; ctr->n_active[0] = 0; ctr->n_active[1] = 0; ctr->n_small = 0; }
 }
-__global__ void k_root_bounds(const DevBox* __restrict__ boxes, uint32_t n, Counters* ctr, uint32_t* order, uint32_t* node_of_pos)
+// bounds of all boxes and of their centroids: grid-stride, reduced per wavefront by shuffles and per workgroup in LDS, 12 atomics per workgroup
+// (round 2: 12 per wavefront on the same 12 words — 1.1 ms for 720 k primitives)
+__global__ __launch_bounds__(kBlock) void k_root_bounds(const DevBox* __restrict__ boxes, uint32_t n, Counters* ctr, uint32_t* order, uint32_t* node_of_pos)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ uint32_t s_b[12];
+    if (threadIdx.x < 12) s_b[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (i < n) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         order[i] = i;
         node_of_pos[i] = 0;
         for (int a = 0; a < 3; a++) {
-            lo[a] = boxes[i].lo[a]; hi[a] = boxes[i].hi[a];
-            clo[a] = chi[a] = 0.5f * (lo[a] + hi[a]);
+            const float l = boxes[i].lo[a], h = boxes[i].hi[a], c = 0.5f * (l + h);
+            lo[a] = fminf(lo[a], l); hi[a] = fmaxf(hi[a], h);
+            clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
         }
     }
-    for (int off = 32; off > 0; off >>= 1)
-        for (int a = 0; a < 3; a++) {
-            lo[a] = fminf(lo[a], __shfl_down(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off));
-            clo[a] = fminf(clo[a], __shfl_down(clo[a], off)); chi[a] = fmaxf(chi[a], __shfl_down(chi[a], off));
-        }
+    for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); clo[a] = wave_min(clo[a]); chi[a] = wave_max(chi[a]); }
     if ((threadIdx.x & 63) == 0)
         for (int a = 0; a < 3; a++) {
-            atomicMin(&ctr->root_bounds[a], f_order(lo[a])); atomicMax(&ctr->root_bounds[3 + a], f_order(hi[a]));
-            atomicMin(&ctr->root_bounds[6 + a], f_order(clo[a])); atomicMax(&ctr->root_bounds[9 + a], f_order(chi[a]));
+            atomicMin(&s_b[a], f_order(lo[a])); atomicMax(&s_b[3 + a], f_order(hi[a]));
+            atomicMin(&s_b[6 + a], f_order(clo[a])); atomicMax(&s_b[9 + a], f_order(chi[a]));
         }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        if ((threadIdx.x % 6) < 3) atomicMin(&ctr->root_bounds[threadIdx.x], s_b[threadIdx.x]);
+        else atomicMax(&ctr->root_bounds[threadIdx.x], s_b[threadIdx.x]);
+    }
 }
-__global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins, uint32_t small_limit)
+// stamp[node] = the level at which the node is split (it is "active" on that level only); 255 = never (a range of phase 2, or not a node)
+__global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* stamp, Bin* bins, uint32_t replicas,
+                            uint32_t small_cap)
 {
+    if (n > small_cap) { // the root's bins (every replica)
+        Bin e; e.count = 0;
+        for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
+        for (uint32_t k = threadIdx.x; k < replicas * 3 * kBins; k += blockDim.x) bins[k] = e;
+    }
     if (threadIdx.x != 0) return;
     SNode r;
     for (int a = 0; a < 3; a++) {
@@ -121,120 +192,123 @@ __global__ void k_root_node(uint32_t n, Counters* ctr, SNode* nodes, uint32_t* a
     }
     r.first = 0; r.count = n; r.left = kNone; r.parent = kNone;
     nodes[0] = r;
-    if (n > small_limit) {
-        active[0] = 0; bin_slot[0] = 0; is_big[0] = 1; ctr->n_active[0] = 1;
-        Bin e; e.count = 0;
-        for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
-        for (int k = 0; k < 3 * kBins; k++) bins[k] = e;
+    if (n > small_cap) {
+        active[0] = 0; bin_slot[0] = 0; stamp[0] = 0; ctr->n_active[0] = 1;
     } else {
-        small[0] = 0; is_big[0] = 0; ctr->n_small = 1;
+        small[0] = 0; ctr->n_small = 1;
     }
 }
 
 // ---------------------------------------------------------------- phase 1: one level
-__global__ __launch_bounds__(kBlock) void k_bin(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of_pos,
-                                               const SNode* __restrict__ nodes, const uint32_t* __restrict__ bin_slot, const uint8_t* __restrict__ is_big,
-                                               Bin* bins, uint32_t n)
+// One workgroup per 256 positions of the primitive order.  A node that is split on this level has more than small_cap >= 256 primitives in
+// consecutive positions, so a block meets at most TWO such nodes: both get a set of bins in LDS (wave-aggregated adds, see above), and the
+// block flushes what it gathered into the nodes' bins in HBM — 336 atomics per node and block at most, into copy blockIdx.x % replicas.
+__global__ __launch_bounds__(kBlock) void k_bin(const DevBox* __restrict__ pbox, const uint32_t* __restrict__ node_of_pos, const SNode* __restrict__ nodes,
+                                               const uint32_t* __restrict__ bin_slot, const uint8_t* __restrict__ stamp, Bin* bins, uint32_t n,
+                                               Counters* ctr, uint32_t level, uint32_t replicas)
 {
-    __shared__ Bin sb[3 * kBins];
-    __shared__ uint32_t s_node, s_mixed;
+    // On the upper levels thousands of workgroups flush into the bins of a handful of nodes, and device-scope atomics on one word serialise
+    // at the memory side (~40 ns each): every node of such a level has `replicas` copies of its bins, a workgroup adds to copy
+    // blockIdx.x % replicas, k_split sums the copies.
+    const uint32_t par = level & 1u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_active[par ^ 1u] = 0; // the level before this one is done with it; k_split counts the next level's nodes into it
+    if (ctr->n_active[par] == 0u) return; // a level past the last one with big nodes
+    __shared__ Bin sb[2][3 * kBins];
+    __shared__ uint32_t s_lo, s_hi;
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     uint32_t nd = p < n ? node_of_pos[p] : kNone;
-    if (nd != kNone && !is_big[nd]) nd = kNone;
-    if (threadIdx.x == 0) { s_node = kNone; s_mixed = 0; }
-    __syncthreads();
-    if (nd != kNone) atomicMin(&s_node, nd);
-    __syncthreads();
-    const uint32_t first_node = s_node;
-    if (first_node == kNone) return; // nothing active in this workgroup
-    if (nd != kNone && nd != first_node) s_mixed = 1;
-    if (threadIdx.x < 3 * kBins) {
+    DevBox b;
+    if (p < n) b = pbox[p]; // issued before the node is known to be active: the load overlaps the dependent ones below
+    if (nd != kNone && stamp[nd] != (uint8_t)level) nd = kNone;
+    if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; }
+    if (threadIdx.x < 2 * 3 * kBins) {
         Bin e; e.count = 0;
         for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
-        sb[threadIdx.x] = e;
+        sb[threadIdx.x / (3 * kBins)][threadIdx.x % (3 * kBins)] = e;
     }
     __syncthreads();
-    const bool mixed = s_mixed != 0;
+    if (nd != kNone) { atomicMin(&s_lo, nd); atomicMax(&s_hi, nd); }
+    __syncthreads();
+    const uint32_t node_a = s_lo, node_b = s_hi; // the (at most two) active nodes of this block, by id
+    if (node_a == kNone) return; // nothing active in these 256 positions (uniform)
+    int my_bin[3] = {0, 0, 0};
     if (nd != kNone) {
-        const DevBox b = boxes[order[p]];
         const SNode& node = nodes[nd];
-        Bin* gb = bins + (size_t)bin_slot[nd] * 3 * kBins;
-        for (int a = 0; a < 3; a++) {
-            const int k = a * kBins + bin_of(0.5f * (b.lo[a] + b.hi[a]), f_unorder(node.cb[a]), f_unorder(node.cb[3 + a]));
-            if (mixed) { // several nodes in this workgroup: straight to the node's bins in HBM
-                atomicAdd(&gb[k].count, 1u);
-                for (int c = 0; c < 3; c++) { atomicMin(&gb[k].lo[c], f_order(b.lo[c])); atomicMax(&gb[k].hi[c], f_order(b.hi[c])); }
-            } else {
-                atomicAdd(&sb[k].count, 1u);
-                for (int c = 0; c < 3; c++) { atomicMin(&sb[k].lo[c], f_order(b.lo[c])); atomicMax(&sb[k].hi[c], f_order(b.hi[c])); }
-            }
-        }
+        for (int a = 0; a < 3; a++) my_bin[a] = bin_of(0.5f * (b.lo[a] + b.hi[a]), f_unorder(node.cb[a]), f_unorder(node.cb[3 + a]));
     }
-    if (mixed) return; // several nodes in one workgroup: the lanes went to the global bins directly
+    wave_add_to_bins(sb[0], nd == node_a, my_bin, b.lo, b.hi);
+    if (node_b != node_a) wave_add_to_bins(sb[1], nd == node_b, my_bin, b.lo, b.hi); // (uniform)
     __syncthreads();
-    if (threadIdx.x < 3 * kBins && sb[threadIdx.x].count) {
-        Bin* e = bins + (size_t)bin_slot[first_node] * 3 * kBins + threadIdx.x;
-        atomicAdd(&e->count, sb[threadIdx.x].count);
-        for (int c = 0; c < 3; c++) { atomicMin(&e->lo[c], sb[threadIdx.x].lo[c]); atomicMax(&e->hi[c], sb[threadIdx.x].hi[c]); }
+    if (threadIdx.x < 2 * 3 * kBins) {
+        const uint32_t which = threadIdx.x / (3 * kBins), k = threadIdx.x % (3 * kBins);
+        const Bin v = sb[which][k];
+        if (v.count && (which == 0 || node_b != node_a)) {
+            Bin* e = bins + ((size_t)bin_slot[which ? node_b : node_a] * replicas + blockIdx.x % replicas) * 3 * kBins + k;
+            atomicAdd(&e->count, v.count);
+            for (int c = 0; c < 3; c++) { atomicMin(&e->lo[c], v.lo[c]); atomicMax(&e->hi[c], v.hi[c]); }
+        }
     }
 }
 
-// the SAH sweep over one node's 48 bins: best (axis, plane), the two child boxes and the left count
+// the SAH sweep over one node's 48 bins by 48 lanes of a wavefront (lane = 16 * axis + plane; plane 15 is no split): every lane gathers the
+// boxes left and right of its plane, the cheapest lane wins (ties: the lowest lane, i.e. the order a serial sweep would find them in)
 struct SplitChoice {
     int axis, plane;
     uint32_t left_count;
     float llo[3], lhi[3], rlo[3], rhi[3];
     float cost;
 };
-__device__ inline void grow(float* lo, float* hi, const Bin& b)
+// returns the winning lane (or -1: every centroid in one bin on every axis); `mine` is this lane's own candidate.
+// A row of 16 lanes is one axis: every lane loads ITS bin, an inclusive prefix scan along the row (DPP row shifts: no LDS crossbar) gives the
+// box and the count left of each plane, a suffix scan shifted by one the right side — 7 loads and ~70 row operations per lane instead of a
+// loop over the 16 bins of the axis (112 loads).
+#define RFW_ROW_MIN(v, ctrl) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false)))
+#define RFW_ROW_MAX(v, ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false)))
+#define RFW_ROW_ADD(v, ctrl) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false)
+template <typename BinPtr> __device__ inline int sweep48(BinPtr bins, const uint32_t lane, SplitChoice& mine)
 {
-    for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], f_unorder(b.lo[c])); hi[c] = fmaxf(hi[c], f_unorder(b.hi[c])); }
+    mine.axis = -1; mine.plane = -1; mine.left_count = 0; mine.cost = INFINITY;
+    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t cl = 0;
+    if (lane < 48u) {
+        const Bin e = bins[lane];
+        if (e.count) { cl = e.count; for (int c = 0; c < 3; c++) { llo[c] = f_unorder(e.lo[c]); lhi[c] = f_unorder(e.hi[c]); } }
+    }
+    float rlo[3] = {llo[0], llo[1], llo[2]}, rhi[3] = {lhi[0], lhi[1], lhi[2]};
+    uint32_t cr = cl;
+    // inclusive prefix along the row (row_shr 1, 2, 4, 8) and inclusive suffix (row_shl 1, 2, 4, 8); lanes without a source keep their value
+    for (int c = 0; c < 3; c++) {
+        RFW_ROW_MIN(llo[c], 0x111); RFW_ROW_MIN(llo[c], 0x112); RFW_ROW_MIN(llo[c], 0x114); RFW_ROW_MIN(llo[c], 0x118);
+        RFW_ROW_MAX(lhi[c], 0x111); RFW_ROW_MAX(lhi[c], 0x112); RFW_ROW_MAX(lhi[c], 0x114); RFW_ROW_MAX(lhi[c], 0x118);
+        RFW_ROW_MIN(rlo[c], 0x101); RFW_ROW_MIN(rlo[c], 0x102); RFW_ROW_MIN(rlo[c], 0x104); RFW_ROW_MIN(rlo[c], 0x108);
+        RFW_ROW_MAX(rhi[c], 0x101); RFW_ROW_MAX(rhi[c], 0x102); RFW_ROW_MAX(rhi[c], 0x104); RFW_ROW_MAX(rhi[c], 0x108);
+    }
+    RFW_ROW_ADD(cl, 0x111); RFW_ROW_ADD(cl, 0x112); RFW_ROW_ADD(cl, 0x114); RFW_ROW_ADD(cl, 0x118);
+    RFW_ROW_ADD(cr, 0x101); RFW_ROW_ADD(cr, 0x102); RFW_ROW_ADD(cr, 0x104); RFW_ROW_ADD(cr, 0x108);
+    // the right side of plane b = the suffix of bin b + 1: one more shift (the last lane of a row gets "nothing")
+    for (int c = 0; c < 3; c++) {
+        rlo[c] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INFINITY), __float_as_int(rlo[c]), 0x101, 0xf, 0xf, false));
+        rhi[c] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(rhi[c]), 0x101, 0xf, 0xf, false));
+    }
+    cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cr, 0x101, 0xf, 0xf, false);
+    for (int c = 0; c < 3; c++) { mine.llo[c] = llo[c]; mine.lhi[c] = lhi[c]; mine.rlo[c] = rlo[c]; mine.rhi[c] = rhi[c]; }
+    if (lane < 48u && (lane & 15u) < (uint32_t)kBins - 1u && cl != 0u && cr != 0u) {
+        mine.axis = (int)(lane >> 4); mine.plane = (int)(lane & 15u); mine.left_count = cl;
+        mine.cost = (float)cl * half_area(llo, lhi) + (float)cr * half_area(rlo, rhi);
+    }
+    // arg-min over the wavefront: (cost, lane), lowest lane among equal costs
+    float c = mine.cost;
+    int who = mine.axis >= 0 ? (int)lane : 64;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(c, off);
+        const int ow = __shfl_xor(who, off);
+        if (oc < c || (oc == c && ow < who)) { c = oc; who = ow; }
+    }
+    return who < 64 ? who : -1;
 }
-template <typename BinPtr> __device__ inline SplitChoice sweep_axis(BinPtr bins, const int a)
-{
-    SplitChoice best;
-    best.axis = -1; best.plane = -1; best.left_count = 0; best.cost = INFINITY;
-    float right_area[kBins];
-    uint32_t right_cnt[kBins];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    uint32_t c = 0;
-    for (int b = kBins - 1; b > 0; b--) {
-        const Bin e = bins[a * kBins + b];
-        if (e.count) grow(lo, hi, e);
-        c += e.count;
-        right_area[b] = half_area(lo, hi);
-        right_cnt[b] = c;
-    }
-    for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-    c = 0;
-    for (int b = 0; b < kBins - 1; b++) {
-        const Bin e = bins[a * kBins + b];
-        if (e.count) grow(lo, hi, e);
-        c += e.count;
-        if (c == 0 || right_cnt[b + 1] == 0) continue;
-        const float cost = (float)c * half_area(lo, hi) + (float)right_cnt[b + 1] * right_area[b + 1];
-        if (cost < best.cost) { best.cost = cost; best.axis = a; best.plane = b; best.left_count = c; }
-    }
-    if (best.axis >= 0) { // the two child boxes of the chosen plane
-        for (int k = 0; k < 3; k++) { best.llo[k] = best.rlo[k] = INFINITY; best.lhi[k] = best.rhi[k] = -INFINITY; }
-        for (int b = 0; b < kBins; b++) {
-            const Bin e = bins[a * kBins + b];
-            if (!e.count) continue;
-            if (b <= best.plane) grow(best.llo, best.lhi, e);
-            else grow(best.rlo, best.rhi, e);
-        }
-    }
-    return best;
-}
-template <typename BinPtr> __device__ inline SplitChoice sweep_bins(BinPtr bins)
-{
-    SplitChoice best = sweep_axis(bins, 0);
-    for (int a = 1; a < 3; a++) {
-        const SplitChoice s = sweep_axis(bins, a);
-        if (s.axis >= 0 && (best.axis < 0 || s.cost < best.cost)) best = s;
-    }
-    return best;
-}
+#undef RFW_ROW_MIN
+#undef RFW_ROW_MAX
+#undef RFW_ROW_ADD
 
 __device__ inline void init_child(SNode& c, uint32_t first, uint32_t count, const float* lo, const float* hi, uint32_t parent)
 {
@@ -242,54 +316,117 @@ __device__ inline void init_child(SNode& c, uint32_t first, uint32_t count, cons
     c.first = first; c.count = count; c.left = kNone; c.parent = parent;
 }
 
-__global__ void k_split(const uint32_t* __restrict__ active, uint32_t level_parity, Counters* ctr, SNode* nodes, const Bin* __restrict__ bins,
-                        const uint32_t* __restrict__ bin_slot, Split* splits, uint32_t* fill)
+// one wavefront per active node; the winning lane creates the two children and files each of them: more than kSmall primitives -> the next
+// level's list (its bins cleared by the wavefront), else the queue of phase 2
+__global__ __launch_bounds__(kBlock) void k_split(const uint32_t* __restrict__ active, uint32_t* active_out, uint32_t level, Counters* ctr, SNode* nodes, Bin* bins,
+                                                 uint32_t* bin_slot, uint8_t* stamp, Split* splits, uint32_t* fill, uint32_t* small, uint32_t replicas,
+                                                 uint32_t replicas_next, uint32_t small_cap)
 {
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= ctr->n_active[level_parity]) return;
+    __shared__ Bin s_sum[kBlock / 64][3 * kBins];
+    const uint32_t par = level & 1u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, k = blockIdx.x * (kBlock / 64) + wave;
+    if (k >= ctr->n_active[par]) return; // (wave-uniform; no workgroup barrier below)
     const uint32_t nd = active[k];
-    SNode node = nodes[nd];
-    const Bin* nb = bins + (size_t)bin_slot[nd] * 3 * kBins;
-    SplitChoice s = sweep_bins(nb);
-    const uint32_t li = atomicAdd(&ctr->node_count, 2u);
-    SNode l, r;
-    uint32_t code;
-    if (s.axis >= 0) {
-        init_child(l, node.first, s.left_count, s.llo, s.lhi, nd);
-        init_child(r, node.first + s.left_count, node.count - s.left_count, s.rlo, s.rhi, nd);
-        code = (uint32_t)s.axis | ((uint32_t)s.plane << 2);
-    } else { // every centroid in one bin on every axis: halve the range by position (boxes: the parent's, conservatively)
-        init_child(l, node.first, node.count / 2, node.lo, node.hi, nd);
-        init_child(r, node.first + node.count / 2, node.count - node.count / 2, node.lo, node.hi, nd);
-        code = 1u << 8;
+    if (lane < 3 * kBins) { // the node's bins: the sum of its replicas, into LDS (read 16 times each by the sweep)
+        const Bin* nb = bins + (size_t)bin_slot[nd] * replicas * 3 * kBins + lane;
+        Bin acc = nb[0];
+        for (uint32_t r = 1; r < replicas; r++) {
+            const Bin e = nb[(size_t)r * 3 * kBins];
+            acc.count += e.count;
+            for (int c = 0; c < 3; c++) { acc.lo[c] = e.lo[c] < acc.lo[c] ? e.lo[c] : acc.lo[c]; acc.hi[c] = e.hi[c] > acc.hi[c] ? e.hi[c] : acc.hi[c]; }
+        }
+        s_sum[wave][lane] = acc;
     }
-    nodes[li] = l;
-    nodes[li + 1] = r;
-    nodes[nd].left = li;
-    splits[nd].axis_plane = code;
-    fill[li] = 0;
-    fill[li + 1] = 0;
+    __builtin_amdgcn_wave_barrier(); // (LDS operations of one wavefront complete in order; this only keeps the compiler from moving the reads up)
+    SplitChoice s;
+    const int win = sweep48(s_sum[wave], lane, s);
+    const uint32_t writer = win >= 0 ? (uint32_t)win : 0u; // the winning lane (lane 0 when there is no split) writes the children
+    uint32_t slot_l = kNone, slot_r = kNone;
+    if (lane == writer) {
+        const SNode node = nodes[nd];
+        const uint32_t li = atomicAdd(&ctr->node_count, 2u);
+        SNode l, r;
+        uint32_t code;
+        if (win >= 0) {
+            init_child(l, node.first, s.left_count, s.llo, s.lhi, nd);
+            init_child(r, node.first + s.left_count, node.count - s.left_count, s.rlo, s.rhi, nd);
+            code = (uint32_t)s.axis | ((uint32_t)s.plane << 2);
+        } else { // every centroid in one bin on every axis: halve the range by position (boxes: the parent's, conservatively)
+            init_child(l, node.first, node.count / 2, node.lo, node.hi, nd);
+            init_child(r, node.first + node.count / 2, node.count - node.count / 2, node.lo, node.hi, nd);
+            code = 1u << 8;
+        }
+        nodes[li] = l;
+        nodes[li + 1] = r;
+        nodes[nd].left = li;
+        splits[nd].axis_plane = code;
+        fill[li] = 0;
+        fill[li + 1] = 0;
+        for (uint32_t c = 0; c < 2; c++) {
+            const uint32_t id = li + c, cnt = c ? r.count : l.count;
+            if (cnt > small_cap) {
+                const uint32_t slot = atomicAdd(&ctr->n_active[par ^ 1u], 1u);
+                active_out[slot] = id;
+                bin_slot[id] = slot;
+                stamp[id] = (uint8_t)(level + 1u);
+                (c ? slot_r : slot_l) = slot;
+            } else {
+                small[atomicAdd(&ctr->n_small, 1u)] = id;
+            }
+        }
+    }
+    // the bins of the children that go on: cleared by 48 lanes each
+    slot_l = (uint32_t)__shfl((int)slot_l, (int)writer);
+    slot_r = (uint32_t)__shfl((int)slot_r, (int)writer);
+    {
+        Bin e; e.count = 0;
+        for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
+        for (uint32_t q = lane; q < replicas_next * 3 * kBins; q += 64u) {
+            if (slot_l != kNone) bins[(size_t)slot_l * replicas_next * 3 * kBins + q] = e;
+            if (slot_r != kNone) bins[(size_t)slot_r * replicas_next * 3 * kBins + q] = e;
+        }
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void k_partition(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ nop_in,
-                                                     uint32_t* order_out, uint32_t* nop_out, SNode* nodes, const Split* __restrict__ splits,
-                                                     const uint8_t* __restrict__ is_big, uint32_t* fill, uint32_t n)
+// Where a 256-block of positions lies inside ONE active node (the upper levels, where the atomics of thousands of wavefronts would meet on
+// a handful of words) slots and centroid bounds are aggregated over the workgroup: 2 + 12 atomics per block; blocks that hold several
+// nodes aggregate per wavefront, lanes of mixed wavefronts go alone.
+struct PartShared {
+    uint32_t node, mixed, cnt[kBlock / 64][2], base[2], cb[2][6];
+};
+__device__ inline void partition_block(PartShared& S, const uint32_t vblock, const DevBox* __restrict__ pbox_in, DevBox* __restrict__ pbox_out,
+                                       const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ nop_in, uint32_t* order_out, uint32_t* nop_out, SNode* nodes,
+                                       const Split* __restrict__ splits, const uint8_t* __restrict__ stamp, uint32_t* fill, uint32_t n, uint32_t level)
 {
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t& s_node = S.node; uint32_t& s_mixed = S.mixed;
+    uint32_t (&s_cnt)[kBlock / 64][2] = S.cnt; uint32_t (&s_base)[2] = S.base; uint32_t (&s_cb)[2][6] = S.cb;
+    __syncthreads(); // (a caller that walks several blocks: nobody is still reading the previous block's shared values)
+    const uint32_t p = vblock * kBlock + threadIdx.x;
     const uint32_t nd = p < n ? nop_in[p] : kNone;
     const uint32_t prim = p < n ? order_in[p] : 0u;
-    const bool act = nd != kNone && is_big[nd];
-    if (p < n && !act) { // finished ranges keep their place
+    const bool act = nd != kNone && stamp[nd] == (uint8_t)level;
+    if (p < n && !act) { // finished ranges keep their place (their boxes are not needed again: phase 2 reads the builder's input)
         order_out[p] = prim;
         nop_out[p] = nd;
     }
+    if (threadIdx.x == 0) { s_node = kNone; s_mixed = 0; }
+    if (threadIdx.x < 12) s_cb[threadIdx.x / 6][threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    if (act) atomicMin(&s_node, nd);
+    __syncthreads();
+    const uint32_t block_node = s_node;
+    if (block_node == kNone) return; // nothing active here (uniform)
+    if (act && nd != block_node) s_mixed = 1;
+    __syncthreads();
+    const bool block_single = s_mixed == 0;
     // every lane stays in the kernel: the wave-level reductions below need the whole wavefront
     uint32_t child = kNone;
     float c3[3] = {0.0f, 0.0f, 0.0f};
+    DevBox b;
     if (act) {
         const SNode& node = nodes[nd];
         const uint32_t code = splits[nd].axis_plane;
-        const DevBox b = boxes[prim];
+        b = pbox_in[p];
         for (int a = 0; a < 3; a++) c3[a] = 0.5f * (b.lo[a] + b.hi[a]);
         bool left;
         if (code >> 8) left = (p - node.first) < node.count / 2;
@@ -299,206 +436,456 @@ __global__ __launch_bounds__(kBlock) void k_partition(const DevBox* __restrict__
         }
         child = node.left + (left ? 0u : 1u);
     }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long actmask = __ballot(act);
-    if (actmask == 0ull) return;
-    const int lead = __ffsll((long long)actmask) - 1;
-    const uint32_t lead_node = (uint32_t)__shfl((int)nd, lead);
-    const unsigned long long same = __ballot(act && nd == lead_node);
     uint32_t dest = 0;
-    if (same == actmask) {
-        // the common case: every active lane of the wave belongs to one node -> per child one atomic for the slots and six for
-        // the centroid bounds, however the lanes interleave between the two children
-        const uint32_t li = nodes[lead_node].left;
+    if (block_single) {
+        const uint32_t li = nodes[block_node].left;
         const bool to_right = act && child != li;
         const unsigned long long rmask = __ballot(to_right), lmask = actmask & ~rmask;
         const unsigned long long mine = to_right ? rmask : lmask;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-        uint32_t base = 0;
-        if (act && rank == 0) base = atomicAdd(&fill[child], (uint32_t)__popcll(mine));
-        const int my_lead = __ffsll((long long)mine) - 1;
-        base = (uint32_t)__shfl((int)base, act ? my_lead : 0);
-        dest = base + rank;
-        for (int side = 0; side < 2; side++) {
+        if (lane == 0) { s_cnt[wave][0] = (uint32_t)__popcll(lmask); s_cnt[wave][1] = (uint32_t)__popcll(rmask); }
+        for (int side = 0; side < 2; side++) { // centroid bounds of the two children: wavefront, then workgroup (LDS), then 12 atomics per block
             const unsigned long long m = side ? rmask : lmask;
             if (m == 0ull) continue; // wave-uniform
             const bool in = act && (to_right == (side != 0));
-            float lo[3], hi[3];
-            for (int a = 0; a < 3; a++) { lo[a] = in ? c3[a] : INFINITY; hi[a] = in ? c3[a] : -INFINITY; }
-            for (int off = 32; off > 0; off >>= 1)
-                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
-            if ((int)(threadIdx.x & 63u) == lead)
-                for (int a = 0; a < 3; a++) { atomicMin(&nodes[li + side].cb[a], f_order(lo[a])); atomicMax(&nodes[li + side].cb[3 + a], f_order(hi[a])); }
+            for (int a = 0; a < 3; a++) {
+                const float lo = wave_min(in ? c3[a] : INFINITY), hi = wave_max(in ? c3[a] : -INFINITY);
+                if (lane == 0) { atomicMin(&s_cb[side][a], f_order(lo)); atomicMax(&s_cb[side][3 + a], f_order(hi)); }
+            }
         }
-    } else if (act) {
-        dest = atomicAdd(&fill[child], 1u);
-        for (int a = 0; a < 3; a++) { atomicMin(&nodes[child].cb[a], f_order(c3[a])); atomicMax(&nodes[child].cb[3 + a], f_order(c3[a])); }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            uint32_t tot = 0;
+            for (int w = 0; w < kBlock / 64; w++) tot += s_cnt[w][threadIdx.x];
+            s_base[threadIdx.x] = tot ? atomicAdd(&fill[li + threadIdx.x], tot) : 0u;
+        }
+        if (threadIdx.x >= 64 && threadIdx.x < 76) {
+            const uint32_t k = threadIdx.x - 64, side = k / 6, c = k % 6;
+            uint32_t tot = 0;
+            for (int w = 0; w < kBlock / 64; w++) tot += s_cnt[w][side];
+            if (tot) {
+                if (c < 3) atomicMin(&nodes[li + side].cb[c], s_cb[side][c]);
+                else atomicMax(&nodes[li + side].cb[c], s_cb[side][c]);
+            }
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t side = to_right ? 1u : 0u;
+            uint32_t off = s_base[side];
+            for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][side];
+            dest = off + rank;
+        }
+    } else {
+        if (actmask == 0ull) return;
+        const int lead = __ffsll((long long)actmask) - 1;
+        const uint32_t lead_node = (uint32_t)__shfl((int)nd, lead);
+        const unsigned long long same = __ballot(act && nd == lead_node);
+        if (same == actmask) {
+            // every active lane of the wave belongs to one node -> per child one atomic for the slots and six for the centroid bounds
+            const uint32_t li = nodes[lead_node].left;
+            const bool to_right = act && child != li;
+            const unsigned long long rmask = __ballot(to_right), lmask = actmask & ~rmask;
+            const unsigned long long mine = to_right ? rmask : lmask;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            uint32_t base = 0;
+            if (act && rank == 0) base = atomicAdd(&fill[child], (uint32_t)__popcll(mine));
+            const int my_lead = __ffsll((long long)mine) - 1;
+            base = (uint32_t)__shfl((int)base, act ? my_lead : 0);
+            dest = base + rank;
+            for (int side = 0; side < 2; side++) {
+                const unsigned long long m = side ? rmask : lmask;
+                if (m == 0ull) continue; // wave-uniform
+                const bool in = act && (to_right == (side != 0));
+                for (int a = 0; a < 3; a++) {
+                    const float lo = wave_min(in ? c3[a] : INFINITY), hi = wave_max(in ? c3[a] : -INFINITY);
+                    if ((int)lane == lead) { atomicMin(&nodes[li + side].cb[a], f_order(lo)); atomicMax(&nodes[li + side].cb[3 + a], f_order(hi)); }
+                }
+            }
+        } else if (act) {
+            dest = atomicAdd(&fill[child], 1u);
+            for (int a = 0; a < 3; a++) { atomicMin(&nodes[child].cb[a], f_order(c3[a])); atomicMax(&nodes[child].cb[3 + a], f_order(c3[a])); }
+        }
     }
     if (act) {
         dest += nodes[child].first;
         order_out[dest] = prim;
         nop_out[dest] = child;
+        pbox_out[dest] = b;
     }
 }
 
-__global__ void k_classify(const uint32_t* __restrict__ active_in, uint32_t* active_out, uint32_t level_parity, Counters* ctr, const SNode* __restrict__ nodes,
-                           uint32_t* small, uint32_t* bin_slot, uint8_t* is_big, Bin* bins, uint32_t small_limit)
+__global__ __launch_bounds__(kBlock) void k_partition(const DevBox* __restrict__ pbox_in, DevBox* __restrict__ pbox_out, const uint32_t* __restrict__ order_in,
+                                                     const uint32_t* __restrict__ nop_in, uint32_t* order_out, uint32_t* nop_out, SNode* nodes,
+                                                     const Split* __restrict__ splits, const uint8_t* __restrict__ stamp, uint32_t* fill, uint32_t n, uint32_t level)
 {
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= 2u * ctr->n_active[level_parity]) return;
-    const uint32_t parent = active_in[k >> 1];
-    const uint32_t nd = nodes[parent].left + (k & 1u);
-    if ((k & 1u) == 0u) is_big[parent] = 0; // the parent's range now belongs to its children
-    if (nodes[nd].count > small_limit) {
-        const uint32_t slot = atomicAdd(&ctr->n_active[level_parity ^ 1u], 1u);
-        active_out[slot] = nd;
-        bin_slot[nd] = slot;
-        is_big[nd] = 1;
-        Bin e; e.count = 0;
-        for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
-        for (int b = 0; b < 3 * kBins; b++) bins[(size_t)slot * 3 * kBins + b] = e;
-    } else {
-        is_big[nd] = 0;
-        small[atomicAdd(&ctr->n_small, 1u)] = nd;
-    }
-}
-__global__ void k_next_level(Counters* ctr, uint32_t level_parity)
-{
-    if (threadIdx.x == 0) ctr->n_active[level_parity] = 0; // the level just finished; its slot counts the level after next
+    __shared__ PartShared S;
+    partition_block(S, blockIdx.x, pbox_in, pbox_out, order_in, nop_in, order_out, nop_out, nodes, splits, stamp, fill, n, level);
 }
 
-// ---------------------------------------------------------------- phase 2: one workgroup finishes one node of <= kSmall primitives
-__global__ __launch_bounds__(kBlock) void k_small(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order_in, uint32_t* order_out,
-                                                 const uint32_t* __restrict__ small, Counters* ctr, SNode* nodes, int max_leaf, float trav_cost)
+// The same for the UPPER levels, where thousands of 256-blocks lie inside the same few nodes and their atomics (2 for the slots, 12 for the
+// centroid bounds per block) meet on the same words, ~40 ns apiece at the memory side: a workgroup takes kPartChunk consecutive blocks; when they
+// all lie inside ONE node that is split on this level it counts first (one pass: sides as bits in a register, counts per block and wavefront
+// in LDS, centroid bounds reduced over the whole chunk), takes its slots with ONE atomic per child, and writes in a second pass (the boxes
+// come from L2 then).  A chunk that crosses nodes goes block by block through the generic code.
+constexpr int kPartChunk = 8;
+__global__ __launch_bounds__(kBlock) void k_partition_chunk(const DevBox* __restrict__ pbox_in, DevBox* __restrict__ pbox_out, const uint32_t* __restrict__ order_in,
+                                                           const uint32_t* __restrict__ nop_in, uint32_t* order_out, uint32_t* nop_out, SNode* nodes,
+                                                           const Split* __restrict__ splits, const uint8_t* __restrict__ stamp, uint32_t* fill, uint32_t n, uint32_t level)
 {
-    static_assert(kSmall <= kBlock, "one primitive per thread");
-    __shared__ float s_lo[3][kSmall], s_hi[3][kSmall];
-    __shared__ uint16_t s_perm[2][kSmall];
-    __shared__ Bin s_bins[3 * kBins];
-    __shared__ uint32_t s_cb[6];
-    __shared__ uint32_t s_stack[3 * 16];
-    __shared__ uint32_t s_fill[2];
-    __shared__ SplitChoice s_axis[3];
-    __shared__ SplitChoice s_choice;
-    __shared__ SNode s_node;          // the node being processed (box, ids)
-    __shared__ uint32_t s_decision[2]; // 0: 1 = split; 1: left child node id
-    __shared__ uint32_t s_next;        // next unused node id of this workgroup's reservation
-    const uint32_t tid = threadIdx.x;
-    const uint32_t root = small[blockIdx.x];
-    const uint32_t gfirst = nodes[root].first, gcount = nodes[root].count;
-    if (tid < gcount) {
-        const DevBox b = boxes[order_in[gfirst + tid]];
-        for (int a = 0; a < 3; a++) { s_lo[a][tid] = b.lo[a]; s_hi[a][tid] = b.hi[a]; }
-        s_perm[0][tid] = (uint16_t)tid;
+    __shared__ PartShared S;
+    __shared__ uint32_t s_cnt[kPartChunk][kBlock / 64][2], s_tot[2], s_cbu[2][6];
+    const uint32_t begin = blockIdx.x * kPartChunk * kBlock, end = begin + kPartChunk * kBlock < n ? begin + kPartChunk * kBlock : n;
+    const uint32_t nd0 = nop_in[begin], nd1 = nop_in[end - 1];
+    const bool one_node = nd0 == nd1 && nd0 != kNone && stamp[nd0] == (uint8_t)level; // (uniform; a node's positions are consecutive)
+    if (!one_node) {
+        for (uint32_t vb = begin / kBlock; vb * kBlock < end; vb++)
+            partition_block(S, vb, pbox_in, pbox_out, order_in, nop_in, order_out, nop_out, nodes, splits, stamp, fill, n, level);
+        return;
     }
-    if (tid == 0) {
-        s_next = atomicAdd(&ctr->node_count, 2u * gcount); // a subtree over c primitives has at most 2c - 2 nodes below its root
-        s_node = nodes[root];
+    const SNode node = nodes[nd0];
+    const uint32_t code = splits[nd0].axis_plane, li = node.left;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 12) s_cbu[threadIdx.x / 6][threadIdx.x % 6] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    // ---- pass 1: sides and counts
+    uint32_t right_bits = 0; // bit j: my primitive of block j goes right
+    float clo[2][3], chi[2][3];
+    for (int sd = 0; sd < 2; sd++) for (int a = 0; a < 3; a++) { clo[sd][a] = INFINITY; chi[sd][a] = -INFINITY; }
+    for (int j = 0; j < kPartChunk; j++) {
+        const uint32_t p = begin + (uint32_t)j * kBlock + threadIdx.x;
+        bool in = p < end, right = false;
+        if (in) {
+            const DevBox b = pbox_in[p];
+            float c3[3];
+            for (int a = 0; a < 3; a++) c3[a] = 0.5f * (b.lo[a] + b.hi[a]);
+            bool left;
+            if (code >> 8) left = (p - node.first) < node.count / 2;
+            else {
+                const int a = (int)(code & 3u);
+                left = bin_of(c3[a], f_unorder(node.cb[a]), f_unorder(node.cb[3 + a])) <= (int)((code >> 2) & 63u);
+            }
+            right = !left;
+            const int sd = right ? 1 : 0;
+            for (int a = 0; a < 3; a++) { clo[sd][a] = fminf(clo[sd][a], c3[a]); chi[sd][a] = fmaxf(chi[sd][a], c3[a]); }
+        }
+        const unsigned long long rm = __ballot(in && right), lm = __ballot(in && !right);
+        if (right) right_bits |= 1u << j;
+        if (lane == 0) { s_cnt[j][wave][0] = (uint32_t)__popcll(lm); s_cnt[j][wave][1] = (uint32_t)__popcll(rm); }
     }
-    int sp = 0;
-    uint32_t first = 0, count = gcount, nid = root; // range in s_perm[0], local
+    for (int sd = 0; sd < 2; sd++)
+        for (int a = 0; a < 3; a++) {
+            const float l = wave_min(clo[sd][a]), h = wave_max(chi[sd][a]);
+            if (lane == 0 && l <= h) { atomicMin(&s_cbu[sd][a], f_order(l)); atomicMax(&s_cbu[sd][3 + a], f_order(h)); }
+        }
     __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t tot = 0;
+        for (int j = 0; j < kPartChunk; j++)
+            for (int w = 0; w < kBlock / 64; w++) tot += s_cnt[j][w][threadIdx.x];
+        s_tot[threadIdx.x] = tot ? atomicAdd(&fill[li + threadIdx.x], tot) : 0u; // the chunk's slots in the child's range
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 76) {
+        const uint32_t k = threadIdx.x - 64, sd = k / 6, c = k % 6;
+        const uint32_t v = s_cbu[sd][c];
+        if (c < 3) { if (v != 0xffffffffu) atomicMin(&nodes[li + sd].cb[c], v); }
+        else if (v != 0u) atomicMax(&nodes[li + sd].cb[c], v);
+    }
+    __syncthreads();
+    // ---- pass 2: every primitive to its slot (chunk order is kept on both sides)
+    const uint32_t first_l = nodes[li].first, first_r = nodes[li + 1].first;
+    uint32_t run[2] = {s_tot[0], s_tot[1]}; // slots taken by the blocks and wavefronts before mine
+    for (int j = 0; j < kPartChunk; j++) {
+        const uint32_t p = begin + (uint32_t)j * kBlock + threadIdx.x;
+        const bool in = p < end, right = (right_bits >> j) & 1u;
+        const unsigned long long rm = __ballot(in && right), lm = __ballot(in && !right);
+        uint32_t off[2] = {run[0], run[1]};
+        for (uint32_t w = 0; w < wave; w++) { off[0] += s_cnt[j][w][0]; off[1] += s_cnt[j][w][1]; }
+        if (in) {
+            const unsigned long long m = right ? rm : lm;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t dest = (right ? first_r + off[1] : first_l + off[0]) + rank;
+            order_out[dest] = order_in[p];
+            nop_out[dest] = li + (right ? 1u : 0u);
+            pbox_out[dest] = pbox_in[p];
+        }
+        for (int w = 0; w < kBlock / 64; w++) { run[0] += s_cnt[j][w][0]; run[1] += s_cnt[j][w][1]; }
+    }
+}
+
+// ---------------------------------------------------------------- phase 2: one workgroup finishes one range of <= kSmall primitives
+// Boxes and the permutation of the range stay in LDS (a primitive per thread).  Two stages:
+//   A  the whole workgroup splits, one after the other, the sub-ranges of MORE than kWaveRange (64) primitives: bins by LDS atomics, the same
+//      48-lane sweep as k_split by wavefront 0, partition by ballots + a prefix over the wavefronts; sub-ranges of <= 64 go on a list;
+//   B  every wavefront takes sub-ranges off that list and finishes each alone, wave-synchronously (no workgroup barrier): a primitive per lane,
+//      its own bins, the larger child on a small stack.
+// (Round 2 finished ranges of 256 with one lane per axis sweeping the bins and one split at a time: 12.5 of the builder's 26 ms; the first
+// version of this round handed over at 64 primitives and paid for five more LEVELS of phase 1, ~0.5 ms each at 720 k primitives.)
+constexpr uint32_t kWaveRange = 64;
+constexpr int kListCap = 96;
+
+__device__ inline void wave_sync()
+{
+    // LDS operations of one wavefront are executed in issue order; this only stops the compiler from moving accesses across
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <uint32_t CAP> struct SmallShared {
+    static constexpr int kWaves = (int)(CAP / 64);
+    float lo[3][CAP], hi[3][CAP];
+    uint16_t perm[2][CAP];
+    Bin bins[3 * kBins];               // stage A
+    Bin wbins[kWaves][3 * kBins];      // stage B, per wavefront
+    uint32_t cb[6];
+    SplitChoice choice;
+    SplitChoice wchoice[kWaves];
+    uint32_t next_id;                  // next unused node id of this workgroup's reservation
+    uint32_t wave_cnt[kWaves][2];
+    // stage A's stack of ranges still above kWaveRange, and the list of ranges for stage B: first, count, node id, box
+    uint32_t stack[3 * 12]; float stack_box[6 * 12];
+    uint32_t list[3 * kListCap]; float list_box[6 * kListCap];
+    uint32_t list_n, list_head;
+    uint32_t wstack[kWaves][3 * 8]; float wstack_box[kWaves][6 * 8];
+};
+
+// one wavefront finishes the range [first, first + count) of S.perm[0] (count <= 64) whose node is nid with box nlo / nhi
+template <uint32_t CAP> __device__ inline void finish_range_wave(SmallShared<CAP>& S, const uint32_t wave, const uint32_t lane, uint32_t first, uint32_t count, uint32_t nid, float* nlo, float* nhi,
+                                         const uint32_t gfirst, SNode* nodes, const int max_leaf, const float trav_cost)
+{
+    int sp = 0;
     for (;;) {
-        // ---- centroid bounds and bins of [first, first + count)
-        if (tid < 6) s_cb[tid] = tid < 3 ? 0xffffffffu : 0u;
-        if (tid < 3 * kBins) {
-            Bin e; e.count = 0;
-            for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
-            s_bins[tid] = e;
-        }
-        __syncthreads();
-        const bool mine = tid < count;
-        const uint32_t q = mine ? s_perm[0][first + tid] : 0u;
+        const bool mine = lane < count;
+        const uint32_t q = mine ? S.perm[0][first + lane] : 0u;
         float cen[3] = {0.0f, 0.0f, 0.0f};
-        if (mine) {
-            for (int a = 0; a < 3; a++) {
-                cen[a] = 0.5f * (s_lo[a][q] + s_hi[a][q]);
-                const uint32_t ce = f_order(cen[a]);
-                atomicMin(&s_cb[a], ce);
-                atomicMax(&s_cb[3 + a], ce);
-            }
-        }
-        __syncthreads();
         int my_bin[3] = {0, 0, 0};
-        if (mine) {
+        bool split = false;
+        int win = -1;
+        SplitChoice s;
+        if (count > 1) {
+            if (lane < 3 * kBins) {
+                Bin e; e.count = 0;
+                for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
+                S.wbins[wave][lane] = e;
+            }
+            float clo[3], chi[3];
             for (int a = 0; a < 3; a++) {
-                my_bin[a] = bin_of(cen[a], f_unorder(s_cb[a]), f_unorder(s_cb[3 + a]));
-                Bin* e = &s_bins[a * kBins + my_bin[a]];
-                atomicAdd(&e->count, 1u);
-                for (int c = 0; c < 3; c++) { atomicMin(&e->lo[c], f_order(s_lo[c][q])); atomicMax(&e->hi[c], f_order(s_hi[c][q])); }
+                cen[a] = mine ? 0.5f * (S.lo[a][q] + S.hi[a][q]) : 0.0f;
+                clo[a] = wave_min(mine ? cen[a] : INFINITY);
+                chi[a] = wave_max(mine ? cen[a] : -INFINITY);
+            }
+            wave_sync();
+            {
+                float blo[3] = {0.0f, 0.0f, 0.0f}, bhi[3] = {0.0f, 0.0f, 0.0f};
+                if (mine)
+                    for (int a = 0; a < 3; a++) { my_bin[a] = bin_of(cen[a], clo[a], chi[a]); blo[a] = S.lo[a][q]; bhi[a] = S.hi[a][q]; }
+                wave_add_to_bins(S.wbins[wave], mine, my_bin, blo, bhi);
+            }
+            wave_sync();
+            win = sweep48(S.wbins[wave], lane, s);
+            if ((int)lane == (win >= 0 ? win : 0)) S.wchoice[wave] = s;
+            wave_sync();
+            s = S.wchoice[wave];
+            // ---- decide (uniform): leaf, SAH split, or halve a range whose centroids coincide
+            const float area = half_area(nlo, nhi);
+            const float leaf_cost = (float)count * area;
+            if (win >= 0 && (s.cost + trav_cost * area < leaf_cost || (int)count > max_leaf)) split = true;
+            else if ((int)count > max_leaf) { // coincident centroids: arbitrary halves keep leaves bounded
+                split = true;
+                win = -1;
+                s.left_count = count / 2;
+                for (int a = 0; a < 3; a++) { s.llo[a] = s.rlo[a] = nlo[a]; s.lhi[a] = s.rhi[a] = nhi[a]; }
             }
         }
-        __syncthreads();
-        if (tid < 3) s_axis[tid] = sweep_axis(s_bins, (int)tid); // one lane per axis
-        __syncthreads();
-        // ---- decide (one thread): leaf, SAH split, or halve a range whose centroids coincide
-        if (tid == 0) {
-            SplitChoice s = s_axis[0];
-            for (int a = 1; a < 3; a++)
-                if (s_axis[a].axis >= 0 && (s.axis < 0 || s_axis[a].cost < s.cost)) s = s_axis[a];
-            const float area = half_area(s_node.lo, s_node.hi);
-            const float leaf_cost = (float)count * area;
-            bool split = false;
-            if (count > 1) {
-                if (s.axis >= 0 && (s.cost + trav_cost * area < leaf_cost || (int)count > max_leaf)) split = true;
-                else if ((int)count > max_leaf) { // coincident centroids: arbitrary halves keep leaves bounded
-                    split = true;
-                    s.axis = -1;
-                    s.left_count = count / 2;
-                    for (int a = 0; a < 3; a++) { s.llo[a] = s.rlo[a] = s_node.lo[a]; s.lhi[a] = s.rhi[a] = s_node.hi[a]; }
-                }
-            }
-            s_choice = s;
-            s_decision[0] = split ? 1u : 0u;
-            if (split) {
-                const uint32_t li = s_next;
-                s_next += 2;
-                s_decision[1] = li;
+        if (split) {
+            const uint32_t lc = s.left_count, rc = count - lc;
+            uint32_t li = 0;
+            if (lane == 0) li = atomicAdd(&S.next_id, 2u);
+            li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
+            if (lane == 0) {
                 SNode l, r;
-                init_child(l, gfirst + first, s.left_count, s.llo, s.lhi, nid);
-                init_child(r, gfirst + first + s.left_count, count - s.left_count, s.rlo, s.rhi, nid);
+                init_child(l, gfirst + first, lc, s.llo, s.lhi, nid);
+                init_child(r, gfirst + first + lc, rc, s.rlo, s.rhi, nid);
                 nodes[li] = l;
                 nodes[li + 1] = r;
                 nodes[nid].left = li;
-                // the smaller child is processed next, the larger one waits on the stack: never more than log2(kSmall) entries
-                const bool left_next = s.left_count <= count - s.left_count;
-                s_stack[3 * sp + 0] = left_next ? first + s.left_count : first;
-                s_stack[3 * sp + 1] = left_next ? count - s.left_count : s.left_count;
-                s_stack[3 * sp + 2] = left_next ? li + 1 : li;
-                s_node = left_next ? l : r;
-            } else if (sp > 0) {
-                s_node = nodes[s_stack[3 * (sp - 1) + 2]]; // written by this thread earlier
             }
-            s_fill[0] = 0;
-            s_fill[1] = 0;
-        }
-        __syncthreads();
-        if (s_decision[0] != 0u) {
-            const int axis = s_choice.axis, plane = s_choice.plane;
-            const uint32_t lc = s_choice.left_count;
+            // partition the lanes' primitives: left ones first, in lane order on both sides
+            const bool left = mine && (win < 0 ? lane < lc : my_bin[s.axis] <= s.plane);
+            const unsigned long long lm = __ballot(left), rm = __ballot(mine && !left);
             if (mine) {
-                const bool left = axis < 0 ? tid < lc : my_bin[axis] <= plane;
-                const uint32_t d = left ? atomicAdd(&s_fill[0], 1u) : lc + atomicAdd(&s_fill[1], 1u);
-                s_perm[1][first + d] = (uint16_t)q;
+                const unsigned long long m = left ? lm : rm;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                S.perm[1][first + (left ? rank : lc + rank)] = (uint16_t)q;
             }
-            __syncthreads();
-            if (mine) s_perm[0][first + tid] = s_perm[1][first + tid];
-            const uint32_t li = s_decision[1], rc = count - lc;
+            wave_sync();
+            if (mine) S.perm[0][first + lane] = S.perm[1][first + lane];
+            // the smaller child is processed next, the larger one waits on the stack: never more than log2(64) entries
+            const bool left_next = lc <= rc;
+            if (lane == 0) {
+                S.wstack[wave][3 * sp + 0] = left_next ? first + lc : first;
+                S.wstack[wave][3 * sp + 1] = left_next ? rc : lc;
+                S.wstack[wave][3 * sp + 2] = left_next ? li + 1 : li;
+                for (int a = 0; a < 3; a++) { S.wstack_box[wave][6 * sp + a] = left_next ? s.rlo[a] : s.llo[a]; S.wstack_box[wave][6 * sp + 3 + a] = left_next ? s.rhi[a] : s.lhi[a]; }
+            }
             sp++;
-            if (lc <= rc) { count = lc; nid = li; }
-            else { first = first + lc; count = rc; nid = li + 1; }
-            __syncthreads();
+            if (left_next) { count = lc; nid = li; for (int a = 0; a < 3; a++) { nlo[a] = s.llo[a]; nhi[a] = s.lhi[a]; } }
+            else { first = first + lc; count = rc; nid = li + 1; for (int a = 0; a < 3; a++) { nlo[a] = s.rlo[a]; nhi[a] = s.rhi[a]; } }
+            wave_sync();
             continue;
         }
         // ---- leaf: nodes[nid].left stays kNone; take the next range
         if (sp == 0) break;
         sp--;
-        first = s_stack[3 * sp + 0];
-        count = s_stack[3 * sp + 1];
-        nid = s_stack[3 * sp + 2];
-        __syncthreads();
+        first = S.wstack[wave][3 * sp + 0];
+        count = S.wstack[wave][3 * sp + 1];
+        nid = S.wstack[wave][3 * sp + 2];
+        for (int a = 0; a < 3; a++) { nlo[a] = S.wstack_box[wave][6 * sp + a]; nhi[a] = S.wstack_box[wave][6 * sp + 3 + a]; }
+        wave_sync();
+    }
+}
+
+template <uint32_t CAP> __global__ __launch_bounds__(CAP) void k_small(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order_in, uint32_t* order_out,
+                                                 const uint32_t* __restrict__ small, Counters* ctr, SNode* nodes, int max_leaf, float trav_cost)
+{
+    __shared__ SmallShared<CAP> S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (blockIdx.x >= ctr->n_small) return;
+    const uint32_t root = small[blockIdx.x];
+    const uint32_t gfirst = nodes[root].first, gcount = nodes[root].count;
+    if (tid < gcount) {
+        const DevBox b = boxes[order_in[gfirst + tid]];
+        for (int a = 0; a < 3; a++) { S.lo[a][tid] = b.lo[a]; S.hi[a][tid] = b.hi[a]; }
+        S.perm[0][tid] = (uint16_t)tid;
+    }
+    if (tid == 0) {
+        S.next_id = atomicAdd(&ctr->node_count, 2u * gcount); // a subtree over c primitives has at most 2c - 2 nodes below its root
+        S.list_n = 0; S.list_head = 0;
+        S.stack[0] = 0; S.stack[1] = gcount; S.stack[2] = root;
+        for (int a = 0; a < 3; a++) { S.stack_box[a] = nodes[root].lo[a]; S.stack_box[3 + a] = nodes[root].hi[a]; }
     }
     __syncthreads();
-    if (tid < gcount) order_out[gfirst + tid] = order_in[gfirst + s_perm[0][tid]];
+    // ---- stage A: the workgroup splits ranges above kWaveRange (everything below is uniform over the workgroup)
+    int sp = 1;
+    while (sp > 0) {
+        sp--;
+        uint32_t first = S.stack[3 * sp + 0], count = S.stack[3 * sp + 1], nid = S.stack[3 * sp + 2];
+        float nlo[3], nhi[3];
+        for (int a = 0; a < 3; a++) { nlo[a] = S.stack_box[6 * sp + a]; nhi[a] = S.stack_box[6 * sp + 3 + a]; }
+        __syncthreads(); // everybody has read the entry before somebody overwrites it
+        for (;;) { // this range, then its smaller children, for as long as they are above kWaveRange
+            const bool list_full = S.list_n >= (uint32_t)kListCap; // (uniform: written behind barriers only)
+            if (count <= kWaveRange && !list_full) {
+                if ((int)count > max_leaf || count > 1) { // something to decide: a wavefront will (a single primitive is a leaf as it stands)
+                    if (tid == 0) {
+                        const uint32_t e = S.list_n++;
+                        S.list[3 * e + 0] = first; S.list[3 * e + 1] = count; S.list[3 * e + 2] = nid;
+                        for (int a = 0; a < 3; a++) { S.list_box[6 * e + a] = nlo[a]; S.list_box[6 * e + 3 + a] = nhi[a]; }
+                    }
+                    __syncthreads();
+                }
+                break;
+            }
+            if (count <= 1) break; // (list full and a single primitive: a leaf)
+            // ---- centroid bounds and bins of [first, first + count)
+            if (tid < 6) S.cb[tid] = tid < 3 ? 0xffffffffu : 0u;
+            if (tid < 3 * kBins) {
+                Bin e; e.count = 0;
+                for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
+                S.bins[tid] = e;
+            }
+            __syncthreads();
+            const bool mine = tid < count;
+            const uint32_t q = mine ? S.perm[0][first + tid] : 0u;
+            float cen[3] = {0.0f, 0.0f, 0.0f};
+            for (int a = 0; a < 3; a++) {
+                cen[a] = mine ? 0.5f * (S.lo[a][q] + S.hi[a][q]) : 0.0f;
+                const float l = wave_min(mine ? cen[a] : INFINITY), h = wave_max(mine ? cen[a] : -INFINITY);
+                if (lane == 0 && l <= h) { atomicMin(&S.cb[a], f_order(l)); atomicMax(&S.cb[3 + a], f_order(h)); }
+            }
+            __syncthreads();
+            int my_bin[3] = {0, 0, 0};
+            {
+                float blo[3] = {0.0f, 0.0f, 0.0f}, bhi[3] = {0.0f, 0.0f, 0.0f};
+                if (mine)
+                    for (int a = 0; a < 3; a++) { my_bin[a] = bin_of(cen[a], f_unorder(S.cb[a]), f_unorder(S.cb[3 + a])); blo[a] = S.lo[a][q]; bhi[a] = S.hi[a][q]; }
+                wave_add_to_bins(S.bins, mine, my_bin, blo, bhi);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                SplitChoice s;
+                const int win = sweep48(S.bins, lane, s);
+                if ((int)lane == (win >= 0 ? win : 0)) {
+                    if (win < 0) s.axis = -1;
+                    S.choice = s;
+                }
+            }
+            __syncthreads();
+            SplitChoice s = S.choice;
+            bool split = false;
+            {
+                const float area = half_area(nlo, nhi);
+                const float leaf_cost = (float)count * area;
+                if (s.axis >= 0 && (s.cost + trav_cost * area < leaf_cost || (int)count > max_leaf)) split = true;
+                else if ((int)count > max_leaf) { // coincident centroids: arbitrary halves keep leaves bounded
+                    split = true;
+                    s.axis = -1;
+                    s.left_count = count / 2;
+                    for (int a = 0; a < 3; a++) { s.llo[a] = s.rlo[a] = nlo[a]; s.lhi[a] = s.rhi[a] = nhi[a]; }
+                }
+            }
+            if (!split) break; // a leaf (only when the list was full and the range small)
+            const uint32_t lc = s.left_count, rc = count - lc, li = S.next_id;
+            // partition: left ones first, in thread order on both sides (ballots per wavefront, prefix over the wavefronts)
+            const bool left = mine && (s.axis < 0 ? tid < lc : my_bin[s.axis] <= s.plane);
+            const unsigned long long lm = __ballot(left), rm = __ballot(mine && !left);
+            if (lane == 0) { S.wave_cnt[wave][0] = (uint32_t)__popcll(lm); S.wave_cnt[wave][1] = (uint32_t)__popcll(rm); }
+            __syncthreads();
+            if (mine) {
+                uint32_t off = 0;
+                for (uint32_t w = 0; w < wave; w++) off += S.wave_cnt[w][left ? 0 : 1];
+                const unsigned long long m = left ? lm : rm;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                S.perm[1][first + (left ? off + rank : lc + off + rank)] = (uint16_t)q;
+            }
+            if (tid == 0) {
+                S.next_id = li + 2;
+                SNode l, r;
+                init_child(l, gfirst + first, lc, s.llo, s.lhi, nid);
+                init_child(r, gfirst + first + lc, rc, s.rlo, s.rhi, nid);
+                nodes[li] = l;
+                nodes[li + 1] = r;
+                nodes[nid].left = li;
+                // the larger child waits on the stack
+                const bool left_next = lc <= rc;
+                S.stack[3 * sp + 0] = left_next ? first + lc : first;
+                S.stack[3 * sp + 1] = left_next ? rc : lc;
+                S.stack[3 * sp + 2] = left_next ? li + 1 : li;
+                for (int a = 0; a < 3; a++) { S.stack_box[6 * sp + a] = left_next ? s.rlo[a] : s.llo[a]; S.stack_box[6 * sp + 3 + a] = left_next ? s.rhi[a] : s.lhi[a]; }
+            }
+            __syncthreads();
+            if (mine) S.perm[0][first + tid] = S.perm[1][first + tid];
+            sp++;
+            const bool left_next = lc <= rc;
+            if (left_next) { count = lc; nid = li; for (int a = 0; a < 3; a++) { nlo[a] = s.llo[a]; nhi[a] = s.lhi[a]; } }
+            else { first = first + lc; count = rc; nid = li + 1; for (int a = 0; a < 3; a++) { nlo[a] = s.rlo[a]; nhi[a] = s.rhi[a]; } }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- stage B: every wavefront takes ranges off the list
+    const uint32_t n_list = S.list_n;
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(&S.list_head, 1u);
+        e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+        if (e >= n_list) break;
+        float nlo[3], nhi[3];
+        for (int a = 0; a < 3; a++) { nlo[a] = S.list_box[6 * e + a]; nhi[a] = S.list_box[6 * e + 3 + a]; }
+        finish_range_wave(S, wave, lane, S.list[3 * e + 0], S.list[3 * e + 1], S.list[3 * e + 2], nlo, nhi, gfirst, nodes, max_leaf, trav_cost);
+    }
+    __syncthreads();
+    if (tid < gcount) order_out[gfirst + tid] = order_in[gfirst + S.perm[0][tid]];
 }
 
 // ---------------------------------------------------------------- BVH2 -> Node4
@@ -630,7 +1017,7 @@ __global__ void k_refit_up(Node4* nodes, uint32_t n_nodes, const uint32_t* __res
 }
 
 struct Layout {
-    size_t ctr, nodes, order[2], nop[2], active[2], small, bin_slot, is_big, splits, fill, bins, flag4, idx4, cub, total, cub_bytes;
+    size_t ctr, nodes, order[2], nop[2], pbox[2], active[2], small, bin_slot, stamp, splits, fill, bins, flag4, idx4, cub, total, cub_bytes;
     uint32_t node_cap, big_cap;
 };
 Layout make_layout(uint32_t n)
@@ -640,16 +1027,16 @@ Layout make_layout(uint32_t n)
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t m = n > 0 ? n : 1;
     L.node_cap = (uint32_t)(4 * m + 64); // phase 1 makes < 2 nodes per queued range, phase 2 reserves 2c ids for a range of c primitives
-    L.big_cap = (uint32_t)(2 * m / small_limit_for(n) + 2); // ranges above the hand-over size that can coexist on one level
+    L.big_cap = (uint32_t)(2 * m / small_cap_for(n) + 2); // ranges above the hand-over size that can coexist on one level
     L.ctr = take(sizeof(Counters));
     L.nodes = take((size_t)L.node_cap * sizeof(SNode));
-    for (int k = 0; k < 2; k++) { L.order[k] = take(m * 4); L.nop[k] = take(m * 4); L.active[k] = take((size_t)L.big_cap * 4); }
-    L.small = take(m * 4);
+    for (int k = 0; k < 2; k++) { L.order[k] = take(m * 4); L.nop[k] = take(m * 4); L.pbox[k] = take(m * sizeof(DevBox)); L.active[k] = take((size_t)L.big_cap * 4); }
+    L.small = take((m + 1) * 4);
     L.bin_slot = take((size_t)L.node_cap * 4);
-    L.is_big = take((size_t)L.node_cap);
+    L.stamp = take((size_t)L.node_cap);
     L.splits = take((size_t)L.node_cap * sizeof(Split));
     L.fill = take((size_t)L.node_cap * 4);
-    L.bins = take((size_t)L.big_cap * 3 * kBins * sizeof(Bin));
+    L.bins = take(((size_t)L.big_cap + 512) * 3 * kBins * sizeof(Bin)); // (nodes of a level) x (replicas of that level) <= max(big_cap, 256 + ...)
     L.flag4 = take((size_t)L.node_cap * 4);
     L.idx4 = take((size_t)L.node_cap * 4);
     size_t cb = 0;
@@ -680,56 +1067,77 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     uint32_t* active[2] = {(uint32_t*)(w + L.active[0]), (uint32_t*)(w + L.active[1])};
     uint32_t* small = (uint32_t*)(w + L.small);
     uint32_t* bin_slot = (uint32_t*)(w + L.bin_slot);
-    uint8_t* is_big = (uint8_t*)(w + L.is_big);
+    uint8_t* stamp = (uint8_t*)(w + L.stamp);
+    DevBox* pbox[2] = {(DevBox*)(w + L.pbox[0]), (DevBox*)(w + L.pbox[1])};
     Split* splits = (Split*)(w + L.splits);
     uint32_t* fill = (uint32_t*)(w + L.fill);
     Bin* bins = (Bin*)(w + L.bins);
     uint32_t* flag4 = (uint32_t*)(w + L.flag4);
     uint32_t* idx4 = (uint32_t*)(w + L.idx4);
 
-    {   // ids a workgroup of phase 2 reserves but does not use must read as leaves nobody references: left = kNone
-        const hipError_t me = hipMemsetAsync(nodes, 0xff, (size_t)L.node_cap * sizeof(SNode), s);
+    {   // ids a wavefront of phase 2 reserves but does not use must read as leaves nobody references: left = kNone
+        hipError_t me = hipMemsetAsync(nodes, 0xff, (size_t)L.node_cap * sizeof(SNode), s);
+        if (me == hipSuccess) me = hipMemsetAsync(stamp, 0xff, (size_t)L.node_cap, s);
         if (me != hipSuccess) return me;
     }
     hipLaunchKernelGGL(k_root_init, dim3(1), dim3(64), 0, s, ctr);
-    if (n) hipLaunchKernelGGL(k_root_bounds, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, n, ctr, order[0], nop[0]);
-    const uint32_t small_limit = small_limit_for(n);
-    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, is_big, bins, small_limit);
+    if (n) hipLaunchKernelGGL(k_root_bounds, dim3(std::min(blocks(n), 1024u)), dim3(kBlock), 0, s, boxes, n, ctr, order[0], nop[0]);
+    // upper bound of the big nodes of a level, and the replicas of their bins on that level (so that ~8 workgroups of k_bin share a copy)
+    const uint32_t small_cap = small_cap_for(n);
+    auto level_ub = [&](int l) { return (uint32_t)std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), (uint64_t)n / small_cap + 1); };
+    const uint32_t bin_groups = blocks(n); // workgroups of k_bin
+    auto level_replicas = [&](int l) { return std::max(1u, std::min(32u, bin_groups / (8u * level_ub(l)))); };
+    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, stamp, bins, level_replicas(0), small_cap);
     static const bool dbg = getenv("RFW_SAH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto msf = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
     if (dbg) (void)hipStreamSynchronize(s);
     const auto t_start = now();
-    int levels = 0;
-    // phase 1: level by level while nodes above kSmall remain (the count comes back to the host once per level)
-    int cur = 0;
-    uint32_t n_active = n > small_limit ? 1u : 0u;
-    for (int level = 0; level < kMaxLevels && n_active > 0; level++) {
+    // phase 1: level by level.  The host does not know how many big nodes a level has: it launches for an upper bound (level l has at most
+    // 2^l nodes, and at most n / kSmall of them are big) and for a depth estimated from n; the kernels of a level without big nodes return at
+    // once.  One read-back after the estimated depth tells whether big nodes are left (a very uneven tree) and how many ranges phase 2 has.
+    int cur = 0, level = 0;
+    auto run_level = [&]() {
         const uint32_t par = (uint32_t)(level & 1);
-        hipLaunchKernelGGL(k_bin, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order[cur], nop[cur], nodes, bin_slot, is_big, bins, n);
-        hipLaunchKernelGGL(k_split, dim3(blocks(n_active, 64)), dim3(64), 0, s, active[par], par, ctr, nodes, bins, bin_slot, splits, fill);
-        hipLaunchKernelGGL(k_partition, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1], nodes, splits, is_big, fill, n);
-        hipLaunchKernelGGL(k_classify, dim3(blocks(2 * n_active, 64)), dim3(64), 0, s, active[par], active[par ^ 1], par, ctr, nodes, small, bin_slot, is_big, bins, small_limit);
-        hipLaunchKernelGGL(k_next_level, dim3(1), dim3(64), 0, s, ctr, par);
+        const uint32_t ub = level_ub(level), reps = level_replicas(level), reps_next = level_replicas(level + 1);
+        const DevBox* pin = level == 0 ? boxes : pbox[cur]; // level 0: the order is the identity, the input boxes ARE position-ordered
+        hipLaunchKernelGGL(k_bin, dim3(bin_groups), dim3(kBlock), 0, s, pin, nop[cur], nodes, bin_slot, stamp, bins, n, ctr, (uint32_t)level, reps);
+        hipLaunchKernelGGL(k_split, dim3(blocks(ub, kBlock / 64)), dim3(kBlock), 0, s, active[par], active[par ^ 1], (uint32_t)level, ctr, nodes, bins, bin_slot, stamp, splits, fill,
+                           small, reps, reps_next, small_cap);
+        if (ub * 64u <= blocks(n)) // few nodes, each across many blocks: chunks of blocks take their slots together
+            hipLaunchKernelGGL(k_partition_chunk, dim3(blocks(n, kPartChunk * kBlock)), dim3(kBlock), 0, s, pin, pbox[cur ^ 1], order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1],
+                               nodes, splits, stamp, fill, n, (uint32_t)level);
+        else
+            hipLaunchKernelGGL(k_partition, dim3(blocks(n)), dim3(kBlock), 0, s, pin, pbox[cur ^ 1], order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1], nodes, splits, stamp, fill, n,
+                               (uint32_t)level);
         cur ^= 1;
-        uint32_t next = 0;
-        hipError_t e = hipMemcpyAsync(&next, &ctr->n_active[par ^ 1], 4, hipMemcpyDeviceToHost, s);
+        level++;
+    };
+    uint32_t counts[4] = {0, 0, 0, 0}; // node_count, n_active[0], n_active[1], n_small
+    auto read_counts = [&]() -> hipError_t {
+        hipError_t e = hipMemcpyAsync(counts, ctr, sizeof(counts), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return e;
-        if (next > L.big_cap) return hipErrorInvalidValue;
-        n_active = next;
-        levels++;
-        if (dbg) fprintf(stderr, "sah level %d: next active %u, %.3f ms since start\n", level, next, msf(t_start, now()));
+        return e;
+    };
+    if (n > small_cap) {
+        int expect = n > 65536u ? 8 : 2; // log2(n / kSmall) levels for an even tree, some more for an uneven one (a small mesh is launch-bound: fewer spare levels, look sooner)
+        for (uint32_t v = n / small_cap; v > 1; v >>= 1) expect++;
+        while (level < expect && level < kMaxLevels) run_level();
+    }
+    hipError_t e = read_counts();
+    if (e != hipSuccess) return e;
+    while (counts[1 + (level & 1)] > 0 && level < kMaxLevels) { // (rare) big nodes are left: a few levels more, and look again
+        if (counts[1 + (level & 1)] > L.big_cap) return hipErrorInvalidValue;
+        for (int k = 0; k < 4 && level < kMaxLevels; k++) run_level();
+        if ((e = read_counts()) != hipSuccess) return e;
     }
     const auto t_p1 = now();
-    if (n_active > 0) return hipErrorInvalidValue; // deeper than kMaxLevels above kSmall: not a tree this builder makes
+    if (counts[1 + (level & 1)] > 0) return hipErrorInvalidValue; // deeper than kMaxLevels above kSmall: not a tree this builder makes
     // phase 2
-    uint32_t n_small = 0;
-    hipError_t e = hipMemcpyAsync(&n_small, &ctr->n_small, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return e;
-    if (n_small) hipLaunchKernelGGL(k_small, dim3(n_small), dim3(kBlock), 0, s, boxes, order[cur], order_out, small, ctr, nodes, max_leaf, trav_cost);
-    if (dbg) { (void)hipStreamSynchronize(s); fprintf(stderr, "sah n=%u: phase1 %.3f ms (%d levels), phase2 %.3f ms (%u small nodes)\n", n, msf(t_start, t_p1), levels, msf(t_p1, now()), n_small); }
+    const uint32_t n_small = counts[3];
+    if (n_small && small_cap == kSmall) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_small<kSmall>), dim3(n_small), dim3(kSmall), 0, s, boxes, order[cur], order_out, small, ctr, nodes, max_leaf, trav_cost);
+    else if (n_small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_small<kSmallFew>), dim3(n_small), dim3(kSmallFew), 0, s, boxes, order[cur], order_out, small, ctr, nodes, max_leaf, trav_cost);
+    if (dbg) { (void)hipStreamSynchronize(s); fprintf(stderr, "sah n=%u: phase1 %.3f ms (%d levels), phase2 %.3f ms (%u small ranges)\n", n, msf(t_start, t_p1), level, msf(t_p1, now()), n_small); }
     // BVH2 -> Node4: internal nodes at even depth, children = grandchildren
     hipLaunchKernelGGL(k_flag_nodes, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, ctr, nodes, flag4);
     size_t cub_bytes = L.cub_bytes;
