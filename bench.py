@@ -621,15 +621,17 @@ def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
     """The oracle — a CPU RESTATEMENT of the reference's rtbvh / MBVH path, not rfw-rs measured — timed on this host's cores on the
     bench's own workload at the bench's own resolution: the frames of `check` (view, animation time) first, whose accumulators are
     returned for the comparison with the timed frames, then more frames of the same views until about `budget_s` seconds are spent."""
-    from oracle.bindings import Oracle
+    from oracle.bindings import Oracle, build_timing_library
     cores = os.cpu_count() or 1
-    orc = Oracle(w, h, threads=cores, max_path_length=max_path_length)
+    # the same source, built for speed on THIS machine (-O3 -march=native; -ffp-contract=off stays: its frames are still the checker's frames)
+    timing_lib, timing_flags = build_timing_library()
+    orc = Oracle(w, h, library=timing_lib, threads=cores, max_path_length=max_path_length)
     scene.mark_all_changed()
     t0 = time.time()
     scene.sync(orc)
     build_s = time.time() - t0
     frames = []
-    n, spent, rays = 0, 0.0, 0
+    n, spent, rays, busy = 0, 0.0, 0, 0
     count = lambda s_: s_["primary"] + s_["shadow"] + s_["extension"]
     k = 0
     while True:
@@ -644,15 +646,18 @@ def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
         orc.render(view)
         spent += time.perf_counter() - t1
         rays += count(orc.stats()) - before
+        busy = max(busy, orc.stats().get("busy_threads", 0))
         n += 1
         if k < len(check):
             frames.append(orc.accumulator().copy())
         k += 1
         if k >= len(check) and (spent > budget_s or n >= 64):
             break
-    return ({"value": round(rays / spent / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return ({"value": round(rays / spent / 1e6, 3), "unit": "Mrays/s", "cores": busy or cores, "kind": "port",
              "what": "CPU restatement of the reference's path (oracle/), not the reference binary: rfw-rs cannot be built here (no Rust toolchain, rtbvh un-vendored)",
-             "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {cores} threads, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded"},
+             "build": (f"g++ {timing_flags}, built on this host" if timing_lib else f"oracle/liboracle.so (-O2, portable): {timing_flags}"),
+             "threads": {"started": cores, "rendered_at_least_one_tile": busy, "work_items": "16x16-pixel tiles from one atomic counter, persistent pool"},
+             "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {busy or cores} busy threads of {cores}, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded"},
             frames)
 
 

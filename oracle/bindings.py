@@ -19,15 +19,39 @@ class OrcStats(C.Structure):
                                           "n_tris", "n_instances", "n_mesh_mbvh_nodes", "n_top_mbvh_nodes")] + [("sample_count", C.c_uint32), ("pad", C.c_uint32)]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(ORACLE_LIB):
-            raise RuntimeError(f"{ORACLE_LIB} missing: run `make -C oracle`")
-        l = C.CDLL(ORACLE_LIB)
+def build_timing_library():
+    """The oracle's source compiled again for TIMING on the machine that runs the bench: -O3 -march=native (code for this CPU does not
+    travel, so it is built where it runs, into a temporary directory), still -ffp-contract=off, so its images are the checker's images.
+    Returns (path, flags) or (None, reason)."""
+    import hashlib
+    import subprocess
+    import tempfile
+    src = os.path.join(_HERE, "oracle.cpp")
+    flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-pthread", "-shared"]
+    tag = hashlib.sha1(open(src, "rb").read() + " ".join(flags).encode()).hexdigest()[:12]
+    out_dir = os.path.join(tempfile.gettempdir(), f"rfw_oracle_timing_{os.getuid()}")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"liboracle_timing_{tag}.so")
+    if not os.path.exists(out):
+        try:
+            r = subprocess.run([os.environ.get("CXX", "g++")] + flags + ["-o", out + ".tmp", src], capture_output=True, text=True, timeout=300)
+        except Exception as e:  # no compiler on this machine
+            return None, f"timing build failed ({e})"
+        if r.returncode != 0:
+            return None, "timing build failed: " + r.stderr[-200:]
+        os.replace(out + ".tmp", out)
+    return out, " ".join(flags[:2] + flags[4:5])
+
+
+def lib(path=None):
+    path = path or ORACLE_LIB
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        l = C.CDLL(path)
         l.orc_create.restype = C.c_void_p
         l.orc_create.argtypes = [C.c_uint32, C.c_uint32]
         l.orc_destroy.argtypes = [C.c_void_p]
@@ -60,16 +84,16 @@ def lib():
         l.orc_safe_origin.argtypes = [C.POINTER(C.c_float)] * 4
         l.orc_intersect_triangle.argtypes = [C.POINTER(pod.RTTriangle), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
         l.orc_mat4_inverse.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        _lib = l
-    return _lib
+        _libs[path] = l
+    return _libs[path]
 
 
 HIT_DTYPE = np.dtype([("inst", "<i4"), ("tri", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
 
 class Oracle:
-    def __init__(self, width, height, **options):
-        self._l = lib()
+    def __init__(self, width, height, library=None, **options):
+        self._l = lib(library)
         self.width, self.height = width, height
         self._h = C.c_void_p(self._l.orc_create(width, height))
         for k, v in options.items():
@@ -167,7 +191,9 @@ class Oracle:
     def stats(self):
         s = OrcStats()
         self._l.orc_get_stats(self._h, C.byref(s))
-        return {n: getattr(s, n) for n, _ in OrcStats._fields_ if n != "pad"}
+        d = {n: getattr(s, n) for n, _ in OrcStats._fields_ if n != "pad"}
+        d["busy_threads"] = int(s.pad)  # threads that rendered at least one tile of the last frame
+        return d
 
     def validate_bvh(self):
         e = C.c_uint64(0)

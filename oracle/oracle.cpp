@@ -57,6 +57,9 @@
  */
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -437,6 +440,60 @@ struct Tex {
     std::vector<uint8_t> bytes;
 };
 
+// A persistent pool for orc_render: the workers live as long as the oracle (they used to be spawned per frame), every frame is dealt as
+// 16 x 16-pixel tiles from one atomic counter, so all threads work until the tiles run out (8-row strips of a 1080-row image were 135 work
+// items: at most 135 of 256 threads ever had one).  Pixels are independent (one path per pixel and pass), so the image does not depend on
+// who renders which tile.
+struct Pool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    std::function<void(int)> job; // argument: worker index
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+    void ensure(int n)
+    {
+        if ((int)workers.size() == n) return;
+        shutdown();
+        stop = false;
+        for (int i = 0; i < n; i++)
+            workers.emplace_back([this, i]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_start.wait(lk, [&] { return stop || generation != seen; });
+                    if (stop) return;
+                    seen = generation;
+                    lk.unlock();
+                    job(i);
+                    lk.lock();
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    }
+    void run(const std::function<void(int)>& f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = f;
+        pending = (int)workers.size();
+        generation++;
+        cv_start.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_start.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear();
+    }
+    ~Pool() { shutdown(); }
+};
+
 struct Oracle {
     uint32_t width = 0, height = 0;
     std::vector<Tex> textures;
@@ -469,6 +526,8 @@ struct Oracle {
     bool tie_break = true;
     vec3 sky{0.0f, 0.0f, 0.0f};
     int threads = 1;
+    Pool pool;
+    uint32_t busy_threads = 0; // threads that rendered at least one tile of the last frame
     Counters counters;
     std::string error;
 };
@@ -1244,10 +1303,10 @@ static inline void trace_and_pack(const Oracle& o, PathState& st, Counters& c)
     st.bary = f2u(65535.0f * uvx) + (f2u(65535.0f * uvy) << 16);
 }
 
-static void render_rows(Oracle& o, const rfw_camera_view_3d& cam, uint32_t y0, uint32_t y1, Counters& c)
+static void render_tile(Oracle& o, const rfw_camera_view_3d& cam, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, Counters& c)
 {
     for (uint32_t y = y0; y < y1; y++) {
-        for (uint32_t x = 0; x < o.width; x++) {
+        for (uint32_t x = x0; x < x1; x++) {
             const uint32_t path_id = x + y * o.width;
             vec4& acc = o.acc[path_id];
             if (o.sample_count == 0) acc = vec4{0.0f, 0.0f, 0.0f, 0.0f}; // ray_gen.comp:46-48
@@ -1599,23 +1658,26 @@ ORC_API int orc_render(void* p, const rfw_camera_view_3d* view)
     o.spread_angle = cam.spread_angle;
     const int nt = o.threads;
     std::vector<Counters> cs(nt);
-    if (nt <= 1) {
-        render_rows(o, cam, 0, o.height, cs[0]);
-    } else {
-        std::atomic<uint32_t> next_row{0};
-        std::vector<std::thread> th;
-        for (int i = 0; i < nt; i++) {
-            th.emplace_back([&, i]() {
-                for (;;) {
-                    const uint32_t y0 = next_row.fetch_add(8);
-                    if (y0 >= o.height) break;
-                    const uint32_t y1 = y0 + 8 < o.height ? y0 + 8 : o.height;
-                    render_rows(o, cam, y0, y1, cs[i]);
-                }
-            });
+    std::vector<uint32_t> tiles_done(nt, 0);
+    constexpr uint32_t kTile = 16;
+    const uint32_t tx = (o.width + kTile - 1) / kTile, ty = (o.height + kTile - 1) / kTile;
+    std::atomic<uint32_t> next_tile{0};
+    auto work = [&](int i) {
+        for (;;) {
+            const uint32_t t = next_tile.fetch_add(1);
+            if (t >= tx * ty) break;
+            const uint32_t x0 = (t % tx) * kTile, y0 = (t / tx) * kTile;
+            render_tile(o, cam, x0, x0 + kTile < o.width ? x0 + kTile : o.width, y0, y0 + kTile < o.height ? y0 + kTile : o.height, cs[i]);
+            tiles_done[i]++;
         }
-        for (auto& t : th) t.join();
+    };
+    if (nt <= 1) work(0);
+    else {
+        o.pool.ensure(nt);
+        o.pool.run(work);
     }
+    o.busy_threads = 0;
+    for (uint32_t d : tiles_done) o.busy_threads += d ? 1u : 0u;
     for (auto& c : cs) o.counters.add(c);
     o.sample_count += 1;
     return 0;
@@ -1706,7 +1768,7 @@ ORC_API int orc_get_stats(void* p, orc_stats* s)
     uint64_t mn = 0;
     for (auto& kv : o.meshes) mn += kv.second.mbvh.nodes.size();
     s->n_mesh_mbvh_nodes = mn; s->n_top_mbvh_nodes = o.top_mbvh.nodes.size();
-    s->sample_count = o.sample_count; s->pad = 0;
+    s->sample_count = o.sample_count; s->pad = o.busy_threads; // (pad: threads that rendered at least one tile of the last frame)
     return 0;
 }
 
