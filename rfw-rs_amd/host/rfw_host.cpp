@@ -60,7 +60,13 @@ struct Rng {
 // ------------------------------------------------------------------ materials
 rfw_device_material into_device_material(const Material& mat)
 {
-    auto to_char = [](float f) -> uint32_t { return (uint32_t)(uint8_t)std::min(f * 255.0f, 255.0f); };
+    // `(f * 255.0).min(255.0) as u8` (material/list.rs:756): Rust's float -> integer `as` saturates and maps NaN to 0 (f32::min returns the
+    // other operand for a NaN, so a NaN parameter becomes 255.0 first); a C++ cast of a negative float would wrap instead
+    auto to_char = [](float f) -> uint32_t {
+        float x = f * 255.0f;
+        x = (x != x) ? 255.0f : std::min(x, 255.0f);
+        return x <= 0.0f ? 0u : (uint32_t)(uint8_t)x;
+    };
     auto to_u32 = [&](float a, float b, float c, float d) -> uint32_t { return to_char(a) | (to_char(b) << 8) | (to_char(c) << 16) | (to_char(d) << 24); };
     rfw_device_material d;
     std::memset(&d, 0, sizeof(d));
