@@ -67,9 +67,12 @@ impl HipBackend {
             panic!("rfw-hip: {}", msg);
         }
     }
-    fn words(changed: &BitSlice) -> Vec<u32> {   // BitSlice<Lsb0, usize> -> packed little-endian u32 words
-        let mut w = vec![0u32; (changed.len() + 31) / 32];
-        for (i, b) in changed.iter().enumerate() { if *b { w[i / 32] |= 1 << (i % 32); } }
+    /// BitSlice<Lsb0, usize> -> packed little-endian u32 words covering `n` elements (the library reads exactly n bits).  The trait does not
+    /// promise `changed.len() == n` (rfw-scene builds the two from different ranges): bits past the slice read as CHANGED, so that a short
+    /// slice can never make the library skip an element.
+    fn words(changed: &BitSlice, n: usize) -> Vec<u32> {
+        let mut w = vec![0u32; (n + 31) / 32];
+        for i in 0..n { if changed.get(i).map(|b| *b).unwrap_or(true) { w[i / 32] |= 1 << (i % 32); } }
         w
     }
     /// One process per GPU: rank 0 calls `comm_unique_id()`, hands the 128 bytes to every rank (MPI, a file, a socket), every rank
@@ -124,13 +127,13 @@ impl Backend for HipBackend {
         self.check(unsafe { rfw_hip_set_3d_instances(self.instance, mesh as u32, &d) });
     }
     fn set_materials(&mut self, materials: &[DeviceMaterial], changed: &BitSlice) {
-        let w = Self::words(changed);
+        let w = Self::words(changed, materials.len());
         self.check(unsafe { rfw_hip_set_materials(self.instance, materials.as_ptr(), materials.len() as u32, w.as_ptr()) });
     }
     fn set_textures(&mut self, textures: &[TextureData<'_>], changed: &BitSlice) {
         let t: Vec<TextureDataC> = textures.iter().map(|t| TextureDataC { width: t.width, height: t.height, mip_levels: t.mip_levels,
             bytes: t.bytes.as_ptr(), format: t.format as u32 }).collect();
-        let w = Self::words(changed);
+        let w = Self::words(changed, t.len());
         self.check(unsafe { rfw_hip_set_textures(self.instance, t.as_ptr(), t.len() as u32, w.as_ptr()) });
     }
     fn synchronize(&mut self) { self.check(unsafe { rfw_hip_synchronize(self.instance) }); }
@@ -141,19 +144,19 @@ impl Backend for HipBackend {
         self.check(unsafe { rfw_hip_resize(self.instance, window_size.0, window_size.1, scale_factor) });
     }
     fn set_point_lights(&mut self, lights: &[PointLight], changed: &BitSlice) {
-        let w = Self::words(changed);
+        let w = Self::words(changed, lights.len());
         self.check(unsafe { rfw_hip_set_point_lights(self.instance, lights.as_ptr(), lights.len() as u32, w.as_ptr()) });
     }
     fn set_spot_lights(&mut self, lights: &[SpotLight], changed: &BitSlice) {
-        let w = Self::words(changed);
+        let w = Self::words(changed, lights.len());
         self.check(unsafe { rfw_hip_set_spot_lights(self.instance, lights.as_ptr(), lights.len() as u32, w.as_ptr()) });
     }
     fn set_area_lights(&mut self, lights: &[AreaLight], changed: &BitSlice) {
-        let w = Self::words(changed);
+        let w = Self::words(changed, lights.len());
         self.check(unsafe { rfw_hip_set_area_lights(self.instance, lights.as_ptr(), lights.len() as u32, w.as_ptr()) });
     }
     fn set_directional_lights(&mut self, lights: &[DirectionalLight], changed: &BitSlice) {
-        let w = Self::words(changed);
+        let w = Self::words(changed, lights.len());
         self.check(unsafe { rfw_hip_set_directional_lights(self.instance, lights.as_ptr(), lights.len() as u32, w.as_ptr()) });
     }
     fn set_skybox(&mut self, skybox: TextureData<'_>) {
@@ -164,7 +167,7 @@ impl Backend for HipBackend {
         let c: Vec<SkinDataC> = skins.iter().map(|s| SkinDataC {
             inverse_bind_matrices: s.inverse_bind_matrices.as_ptr(), num_inverse_bind_matrices: s.inverse_bind_matrices.len() as u32,
             joint_matrices: s.joint_matrices.as_ptr(), num_joint_matrices: s.joint_matrices.len() as u32 }).collect();
-        let w = Self::words(changed);
+        let w = Self::words(changed, c.len());
         self.check(unsafe { rfw_hip_set_skins(self.instance, c.as_ptr(), c.len() as u32, w.as_ptr()) });
     }
 }

@@ -150,7 +150,8 @@ RFW_HIP_API int rfw_hip_set_3d_mesh(void* instance, uint32_t id, const rfw_mesh_
 RFW_HIP_API int rfw_hip_unload_3d_meshes(void* instance, const uint32_t* ids, uint32_t num_ids);
 /* :46 set_3d_instances — a zero matrix marks a removed slot (crates/rfw-scene/src/instances_3d.rs:79-86). */
 RFW_HIP_API int rfw_hip_set_3d_instances(void* instance, uint32_t mesh, const rfw_instances_data_3d* data);
-/* :49 set_materials */
+/* :49 set_materials — `changed` (here and in every call below that takes one): bit k of word k / 32 = element k, NULL = everything; the
+ * array must cover all `num` elements ((num + 31) / 32 words) — a clear bit means the element is not looked at. */
 RFW_HIP_API int rfw_hip_set_materials(void* instance, const rfw_device_material* materials, uint32_t num, const uint32_t* changed);
 /* :53 set_textures — sampled by shade for diffuse and normal maps (the two maps shade.comp reads).  `changed` (bit k = texture k, may be NULL =
  * all): with the same number of textures as before, textures whose bit is clear are not read at all, and synchronize() uploads only the

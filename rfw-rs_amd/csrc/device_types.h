@@ -179,7 +179,8 @@ struct BatchViews {
 #ifndef RFW_SHADOW_BUCKETS
 #define RFW_SHADOW_BUCKETS 8
 #endif
-// shadow rays are queued per bucket: light index & 7 (a wavefront's rays aim at one light).  Experiment RFW_SHADOW_BUCKETS = 16: (light & 3)
+// shadow rays are queued per bucket: every directional light's rays in the LAST bucket (they are traced far to near), the positional lights
+// dealt over the other seven (picked light % 7) — a wavefront's rays aim at one light (or one kind of light).  Experiment RFW_SHADOW_BUCKETS = 16: (light & 3)
 // x 4 classes of the surface orientation (dominant axis of the geometric normal), so that a wavefront's rays also leave similar surfaces
 constexpr int kShadowBuckets = RFW_SHADOW_BUCKETS;
 struct QueueCounters {

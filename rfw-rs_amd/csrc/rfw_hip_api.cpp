@@ -4,7 +4,23 @@
 // host read-back.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h> // types and prototypes only: librccl is opened at run time by rfw_hip_comm_* (no link-time dependency for single-GPU hosts)
+// RCCL: types and prototypes only — librccl is opened at run time by rfw_hip_comm_* (no link-time dependency for single-GPU hosts), and a ROCm
+// installation without the rccl development headers can still build this library: the handful of declarations used here are then made locally
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t type, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t r);
+}
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -108,6 +124,15 @@ struct PinnedRing {
             if (c.cap < bytes) continue;
             if (c.pending && hipEventQuery(c.ev) == hipSuccess) c.pending = false;
             if (!c.pending) { b = &c; break; }
+        }
+        if (!b && blocks.size() >= 64) { // the ring is capped: wait for the oldest copy that used a block big enough instead of pinning more memory
+            for (Block& c : blocks) {
+                if (c.cap < bytes) continue;
+                (void)hipEventSynchronize(c.ev);
+                c.pending = false;
+                b = &c;
+                break;
+            }
         }
         if (!b) {
             Block n;
@@ -814,6 +839,12 @@ int build_blas_device(Instance* I)
     for (auto& kv : I->mesh_index) removed = removed || I->meshes.find(kv.first) == I->meshes.end();
     if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed)) {
         const int rc = build_blas_device_incremental(I);
+        I->d_sah_ws.release(); // build scratch is not kept between scene changes (as after a full build)
+        if (rc < 0) { // an error part-way through: records, capacities and dirty flags may be half-updated — the next synchronize() starts over
+            I->layout_valid = false;
+            for (auto& kv : I->meshes) kv.second.dirty = true;
+            I->meshes_dirty = true;
+        }
         if (rc <= 0) return rc;
         for (auto& kv : I->meshes) kv.second.dirty = true; // (only matters for the host builder; the full device build takes every mesh)
     }
@@ -1069,6 +1100,14 @@ template <typename T> int write_table(Instance* I, DevBuf<T>& dst, size_t& dst_n
     }
     std::vector<uint32_t> idx = d.idx;
     std::sort(idx.begin(), idx.end());
+    {   // many scattered elements (every other material of thousands, say): one copy of the whole table beats a pinned block and a copy per run
+        size_t runs = 0;
+        for (size_t a = 0; a < idx.size(); a++) runs += (a == 0 || idx[a] > idx[a - 1] + 1) ? 1 : 0;
+        if (runs > 16 || idx.size() * 4 > n) {
+            HIP_TRY(I, I->pins.upload(dst.ptr, host.data(), n * sizeof(T), s));
+            return RFW_HIP_OK;
+        }
+    }
     for (size_t a = 0; a < idx.size();) {
         size_t b = a + 1;
         while (b < idx.size() && idx[b] <= idx[b - 1] + 1) b++;
@@ -2056,7 +2095,10 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "timing") I->timing = value != 0.0;
     else if (k == "sort_extension_rays") I->sort_extension_rays = std::max(0, std::min(2, (int)value));
     else if (k == "texture_array") { I->texture_array = value != 0.0; I->tex_offsets.clear(); } // applies to textures set from now on (all of them: no partial update across the switch)
-    else if (k == "spill_rows") I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill); // tests: exercise the overflow path
+    else if (k == "spill_rows") { // tests: exercise the overflow path
+        I->spill_rows = std::min<uint32_t>((uint32_t)std::max(0.0, value), (uint32_t)kStackSpill);
+        clear_overflow(I); // an overflow seen with another stack size says nothing about this one
+    }
     else if (k == "sky_r") I->sky[0] = (float)value;
     else if (k == "sky_g") I->sky[1] = (float)value;
     else if (k == "sky_b") I->sky[2] = (float)value;
