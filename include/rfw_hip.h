@@ -200,7 +200,14 @@ RFW_HIP_API int rfw_hip_device_synchronize(void* instance);
  * slabs (RCCL) into a buffer of world * slab_floats and hands it to rfw_hip_assemble_frame, which de-tiles it into the full
  * frame.  Accumulation over samples happens in the instance's own slab, not in the caller's buffer.  The linear accumulator of the
  * assembled frame (rfw_hip_read_accumulator*) is de-tiled on demand from the gathered buffer, which therefore has to stay valid
- * until the next assemble if that call is used. */
+ * until the next assemble if that call is used.
+ * rfw_hip_set_option("gather_format", f) chooses WHAT travels: 0 (default) the accumulator's RGB as floats, as described; 1 the FINISHED frame
+ * sqrt(acc / samples) as three halves per pixel (6 B); 2 the PRESENTED frame, B, G, R, A bytes as rfw_hip_download_frame(what = 2) encodes it
+ * (4 B: what the reference draws onto its swap chain).  `slab_floats` is then the number of 4-byte words per frame in that format.  With 1 and 2
+ * the accumulators stay on the ranks that own the tiles: rfw_hip_read_accumulator* fails on a sharded instance, and with 2 the frame is
+ * available through rfw_hip_download_frame(what = 2) only.
+ * rfw_hip_set_option("present_rank", r): only rank r de-tiles a gathered frame at once (it presents); the other ranks keep the gathered tiles
+ * and de-tile when a frame is read.  Default -1: every rank de-tiles every frame. */
 RFW_HIP_API int rfw_hip_shard_info(void* instance, uint64_t* slab_floats, uint32_t* num_tiles_local, uint32_t* num_tiles_total);
 /* device buffer (slab_floats floats; count * slab_floats for render_batch) render() leaves this rank's slab in; NULL = none */
 RFW_HIP_API int rfw_hip_set_slab_output(void* instance, void* device_ptr);

@@ -63,6 +63,9 @@ void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathere
                      uint32_t samples);
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
+// the FINISHED frame of a slab for the all-gather (format 1: three halves per pixel; 2: presented B, G, R, A bytes) and its de-tiling
+void launch_pack_finished(hipStream_t s, const float4* acc_slab, void* out, uint64_t n, uint32_t samples, uint32_t format, const float* steps255);
+void launch_assemble_finished(hipStream_t s, const CameraParams& cam, const void* gathered, uint64_t slab_elems, uint32_t format, float4* frame, uint32_t* presented);
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);
 void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& cam, int op, uint32_t n, const float* in, float* out);
 void launch_query_closest(hipStream_t s, const SceneDev& sc, const float* origins, const float* directions, float t_min, float t_max, uint64_t n,

@@ -702,6 +702,60 @@ __global__ __launch_bounds__(256) void k_pack_rgb(const float4* __restrict__ acc
     out[3 * i + 1] = a.y;
     out[3 * i + 2] = a.z;
 }
+// What a rank contributes to the all-gather when only the FINISHED frame has to travel (option "gather_format"; the accumulators stay on
+// the rank that owns the tiles, where the next sample is added): blit.comp's sqrt(acc / samples) as three halves (6 B per pixel) ...
+__global__ __launch_bounds__(256) void k_pack_f16(const float4* __restrict__ acc_slab, _Float16* __restrict__ out, const uint64_t n, const uint32_t samples)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = acc_slab[i];
+    const float s = (float)(int)samples;
+    out[3 * i] = (_Float16)__builtin_sqrtf(a.x * 1.0f / s);
+    out[3 * i + 1] = (_Float16)__builtin_sqrtf(a.y * 1.0f / s);
+    out[3 * i + 2] = (_Float16)__builtin_sqrtf(a.z * 1.0f / s);
+}
+// ... or as the swap-chain image itself, B, G, R, A bytes (4 B per pixel): exactly what k_present makes of the de-tiled frame
+struct SrgbSteps { float t[256]; };
+__device__ inline uint32_t srgb_encode(const float* s_t, float x)
+{
+    uint32_t lo = 0; // number of steps <= x (a NaN encodes as 0, like a clamped attachment write)
+    for (uint32_t bit = 128; bit != 0; bit >>= 1)
+        if (x >= s_t[lo + bit - 1]) lo += bit;
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_pack_bgra8(const float4* __restrict__ acc_slab, uint32_t* __restrict__ out, const uint64_t n, const uint32_t samples,
+                                                   const SrgbSteps steps)
+{
+    __shared__ float s_t[256];
+    s_t[threadIdx.x] = steps.t[threadIdx.x];
+    __syncthreads();
+    const float s = (float)(int)samples;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const float4 a = acc_slab[i];
+        const float r = __builtin_sqrtf(a.x * 1.0f / s), g = __builtin_sqrtf(a.y * 1.0f / s), b = __builtin_sqrtf(a.z * 1.0f / s);
+        out[i] = srgb_encode(s_t, b) | (srgb_encode(s_t, g) << 8) | (srgb_encode(s_t, r) << 16) | 0xff000000u;
+    }
+}
+// all-gathered finished slabs [world][frame][slab_elems] -> the frame, de-tiled (halves -> the float frame; bytes -> the presented frame)
+__global__ void k_assemble_f16(const CameraParams cam, const _Float16* __restrict__ gathered, const uint64_t slab_elems, float4* __restrict__ frame)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= cam.width || py >= cam.height) return;
+    uint32_t owner;
+    const uint32_t slot = pixel_to_slab(cam, px, py, owner);
+    const uint32_t f = blockIdx.z;
+    const _Float16* g = gathered + 3 * (((uint64_t)owner * cam.batch + f) * slab_elems + slot);
+    frame[(size_t)f * cam.width * cam.height + px + py * cam.width] = make_float4((float)g[0], (float)g[1], (float)g[2], 0.0f);
+}
+__global__ void k_assemble_bgra8(const CameraParams cam, const uint32_t* __restrict__ gathered, const uint64_t slab_elems, uint32_t* __restrict__ presented)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= cam.width || py >= cam.height) return;
+    uint32_t owner;
+    const uint32_t slot = pixel_to_slab(cam, px, py, owner);
+    const uint32_t f = blockIdx.z;
+    presented[(size_t)f * cam.width * cam.height + px + py * cam.width] = gathered[((uint64_t)owner * cam.batch + f) * slab_elems + slot];
+}
 // rfw_hip_render_samples: the k sample slabs of one image -> slab 0, added in sample order (the same left-to-right sum per pixel whatever
 // the launch geometry: deterministic; it differs from k sequential render() calls only in where the partial sums are rounded)
 __global__ __launch_bounds__(256) void k_sum_batch(float4* __restrict__ acc, const uint64_t n, const uint32_t count)
@@ -718,18 +772,12 @@ __global__ __launch_bounds__(256) void k_sum_batch(float4* __restrict__ acc, con
 // Presentation (gpu-rt/src/lib.rs:373,560-585 + shaders/quad.frag): the RGBA32F output is drawn onto a Bgra8UnormSrgb swap chain, i.e.
 // clamped, sRGB-encoded and quantised to 8 bits per channel by the attachment write.  Encoding by comparison against the 255 linear
 // values at which the encoded byte steps (binary search, 8 compares per channel): exact and identical on every machine.
-struct SrgbSteps { float t[256]; };
 __global__ __launch_bounds__(256) void k_present(const float4* __restrict__ frame, uint32_t* __restrict__ bgra, const uint64_t n, const SrgbSteps steps)
 {
     __shared__ float s_t[256];
     s_t[threadIdx.x] = steps.t[threadIdx.x];
     __syncthreads();
-    auto enc = [&](float x) -> uint32_t { // number of steps <= x (a NaN encodes as 0, like a clamped attachment write)
-        uint32_t lo = 0;
-        for (uint32_t bit = 128; bit != 0; bit >>= 1)
-            if (x >= s_t[lo + bit - 1]) lo += bit;
-        return lo;
-    };
+    auto enc = [&](float x) -> uint32_t { return srgb_encode(s_t, x); };
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
         const float4 c = frame[i];
         bgra[i] = enc(c.z) | (enc(c.y) << 8) | (enc(c.x) << 16) | 0xff000000u; // B, G, R, A in memory order; the surface is opaque
@@ -824,6 +872,13 @@ __global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restric
 
 // ---------------------------------------------------------------- launch wrappers
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+static SrgbSteps make_steps(const float* steps255)
+{
+    SrgbSteps st;
+    for (int k = 0; k < 255; k++) st.t[k] = steps255[k];
+    st.t[255] = __builtin_inff(); // never reached: lo + bit - 1 <= 254
+    return st;
+}
 
 void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n,
                               InstanceXform* xf, InstanceNormal* nm)
@@ -907,14 +962,24 @@ void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathere
 // wave slots the trace kernels of the other frames in flight want
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow)
 {
-    SrgbSteps st;
-    for (int k = 0; k < 255; k++) st.t[k] = steps255[k];
-    st.t[255] = __builtin_inff(); // never reached: lo + bit - 1 <= 254
+    const SrgbSteps st = make_steps(steps255);
     if (n) hipLaunchKernelGGL(k_present, dim3(narrow ? 64u : (unsigned)std::min<uint64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, s, frame, bgra, n, st);
 }
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count)
 {
     if (slab_elems && count > 1) hipLaunchKernelGGL(k_sum_batch, dim3((unsigned)ceil_div(slab_elems, 256)), dim3(256), 0, s, acc_slabs, slab_elems, count);
+}
+void launch_pack_finished(hipStream_t s, const float4* acc_slab, void* out, uint64_t n, uint32_t samples, uint32_t format, const float* steps255)
+{
+    if (!n) return;
+    if (format == 1) hipLaunchKernelGGL(k_pack_f16, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, acc_slab, (_Float16*)out, n, samples);
+    else hipLaunchKernelGGL(k_pack_bgra8, dim3((unsigned)std::min<uint64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, s, acc_slab, (uint32_t*)out, n, samples, make_steps(steps255));
+}
+void launch_assemble_finished(hipStream_t s, const CameraParams& cam, const void* gathered, uint64_t slab_elems, uint32_t format, float4* frame, uint32_t* presented)
+{
+    const dim3 block(16, 4), grid(ceil_div(cam.width, 16), ceil_div(cam.height, 4), cam.batch > 1 ? cam.batch : 1u);
+    if (format == 1) hipLaunchKernelGGL(k_assemble_f16, grid, block, 0, s, cam, (const _Float16*)gathered, slab_elems, frame);
+    else hipLaunchKernelGGL(k_assemble_bgra8, grid, block, 0, s, cam, (const uint32_t*)gathered, slab_elems, presented);
 }
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n)
 {

@@ -339,6 +339,19 @@ struct Instance {
     // multi-GPU inside the library (rfw_hip_comm_init): this rank's RGB slab(s) -> ncclAllGather on the instance's stream -> assemble
     ncclComm_t comm = nullptr;
     DevBuf<float> d_send, d_recv;
+    // WHAT travels in the all-gather (option "gather_format"): 0 = the slab's linear RGB accumulator as floats (12 B per pixel; every rank can
+    // then also hand out the accumulator), 1 = the finished frame sqrt(acc / samples) as halves (6 B), 2 = the presented B, G, R, A bytes
+    // (4 B: what the reference draws onto its swap chain).  With 1 and 2 the accumulators stay on the ranks that own the tiles.
+    uint32_t gather_format = 0;
+    // WHO de-tiles the gathered frame at once (option "present_rank"): -1 = every rank (each render leaves the row-major frame behind
+    // everywhere), r >= 0 = only rank r — the one that presents; the other ranks keep the gathered tiles and de-tile when somebody reads
+    int present_rank = -1;
+    struct Deferred { const void* gathered = nullptr; uint32_t k = 0, samples = 1; } deferred; // a gathered frame not de-tiled yet
+    bool presented_valid = false; // d_present holds the de-tiled presented frame(s) of the latest gather (format 2)
+    // frame slots share the owner's communicator: collectives of ONE communicator must not run side by side, so every all-gather waits (on
+    // the device) for the one issued before it, whichever slot's stream that was on, while the slots' traces overlap freely
+    hipEvent_t comm_chain = nullptr;
+    bool comm_chain_pending = false;
     uint32_t tiles_x = 0, tiles_y = 0, local_tiles = 0, capacity = 0;
     uint64_t local_pixels = 0;
     uint32_t sample_count = 0;
@@ -1318,6 +1331,74 @@ hipEvent_t* ring_events(Instance* I, int slot, uint32_t sub) { return I->ring.da
 // tall virtual frame — every stage is ONE launch over the paths of all k frames.
 // `samples` (rfw_hip_render_samples): the k frames are k consecutive SAMPLES of the one image of views[0] — sample indices sample_count …
 // sample_count + k - 1, each traced into its own slab, then summed into slab 0 in sample order.
+// ---- sharded frame: what a rank sends, and what it does with what it receives
+inline uint64_t slab_words(const Instance* I) // 4-byte words one frame of this rank contributes to the all-gather
+{
+    const uint64_t c = I->capacity;
+    const uint32_t f = scene_of(I)->gather_format;
+    return f == 0 ? c * 3u : (f == 1 ? c * 3u / 2u : c);
+}
+const float* srgb_steps()
+{
+    static float t[255];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int k = 0; k < 255; k++) {
+            const double e = (k + 0.5) / 255.0;
+            const double lin = e <= 0.04045 ? e / 12.92 : std::pow((e + 0.055) / 1.055, 2.4);
+            float f = (float)lin;
+            if ((double)f < lin) f = std::nextafter(f, 2.0f); // smallest float NOT below the exact step
+            t[k] = f;
+        }
+    });
+    return t;
+}
+void pack_slabs(Instance* I, hipStream_t s, void* dst, uint32_t frames)
+{
+    const uint64_t n = (uint64_t)I->capacity * frames;
+    const uint32_t f = scene_of(I)->gather_format;
+    if (f == 0) launch_pack_rgb(s, I->d_acc_slab.ptr, (float*)dst, n);
+    else launch_pack_finished(s, I->d_acc_slab.ptr, dst, n, std::max(1u, I->sample_count), f, srgb_steps());
+}
+// gathered = [rank][frame][slab] in the instance's gather format -> the row-major frame(s)
+int assemble_gathered(Instance* I, hipStream_t s, const void* gathered, uint32_t k, uint32_t samples)
+{
+    CameraParams cam = camera_params(I, I->last_view);
+    cam.batch = k;
+    const uint32_t fmt = scene_of(I)->gather_format;
+    if (fmt == 0) {
+        launch_assemble(s, cam, gathered, true, false, I->cap_v, I->d_frame_out.ptr, samples);
+        I->acc_source = gathered; I->acc_source_rgb = true; I->acc_source_batch = k;
+    } else if (fmt == 1) {
+        launch_assemble_finished(s, cam, gathered, I->cap_v, 1u, I->d_frame_out.ptr, nullptr);
+        I->acc_source = nullptr;
+    } else {
+        HIP_TRY(I, I->d_present.ensure((size_t)I->width * I->height * I->max_batch));
+        launch_assemble_finished(s, cam, gathered, I->cap_v, 2u, nullptr, I->d_present.ptr);
+        I->acc_source = nullptr;
+        I->presented_valid = true;
+    }
+    I->deferred = Instance::Deferred();
+    HIP_TRY(I, hipGetLastError());
+    return RFW_HIP_OK;
+}
+// after a gather: de-tile now (this rank presents, or every rank does), or remember where the tiles are
+int gathered_arrived(Instance* I, hipStream_t s, const void* gathered, uint32_t k)
+{
+    const uint32_t samples = std::max(1u, I->sample_count);
+    const int pr = scene_of(I)->present_rank;
+    if (pr < 0 || (uint32_t)pr == I->rank) return assemble_gathered(I, s, gathered, k, samples);
+    I->deferred.gathered = gathered; I->deferred.k = k; I->deferred.samples = samples;
+    I->acc_source = nullptr;
+    I->presented_valid = false;
+    return RFW_HIP_OK;
+}
+int ensure_assembled(Instance* I)
+{
+    if (!I->deferred.gathered) return RFW_HIP_OK;
+    return assemble_gathered(I, I->stream, I->deferred.gathered, I->deferred.k, I->deferred.samples);
+}
+
 int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool samples = false)
 {
     const rfw_camera_view_3d& view = views[0];
@@ -1443,23 +1524,23 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
     I->sample_count += samples ? k : 1;
     const uint32_t frames_out = samples ? 1u : k; // images this call leaves behind
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
-    if (I->comm) {
-        // the frame's ONE collective, issued by the library itself: RGB of this rank's slab(s) -> all ranks (RCCL over xGMI) -> de-tile
-        const uint64_t n_send = (uint64_t)I->capacity * frames_out * 3u;
-        launch_pack_rgb(main, I->d_acc_slab.ptr, I->d_send.ptr, (uint64_t)I->capacity * frames_out);
-        const ncclResult_t nr = g_rccl.all_gather(I->d_send.ptr, I->d_recv.ptr, n_send, ncclFloat, I->comm, main);
+    if (Instance* C = scene_of(I); C->comm) {
+        // the frame's ONE collective, issued by the library itself: this rank's slab(s) -> all ranks (RCCL over xGMI) -> de-tile
+        const uint64_t n_send = slab_words(I) * frames_out; // 4-byte words, whatever they hold
+        pack_slabs(I, main, I->d_send.ptr, frames_out);
+        if (C->comm_chain && C->comm_chain_pending) HIP_TRY(I, hipStreamWaitEvent(main, C->comm_chain, 0)); // behind the previous slot's collective
+        const ncclResult_t nr = g_rccl.all_gather(I->d_send.ptr, I->d_recv.ptr, n_send, ncclFloat, C->comm, main);
         if (nr != ncclSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("ncclAllGather: ") + g_rccl.error_string(nr));
-        CameraParams ac = cam[0];
-        ac.batch = frames_out;
-        launch_assemble(main, ac, I->d_recv.ptr, true, false, I->cap_v, I->d_frame_out.ptr, std::max(1u, I->sample_count)); // gathered = [rank][frame][slab]
-        I->acc_source = I->d_recv.ptr; I->acc_source_rgb = true; I->acc_source_batch = frames_out;
+        if (C->comm_chain) { HIP_TRY(I, hipEventRecord(C->comm_chain, main)); C->comm_chain_pending = true; }
+        const int arc = gathered_arrived(I, main, I->d_recv.ptr, frames_out); // gathered = [rank][frame][slab]
+        if (arc != RFW_HIP_OK) return arc;
     } else if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
     {
         launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, false, I->cap_v, I->d_frame_out.ptr, I->sample_count);
         I->acc_source = I->d_acc_slab.ptr; I->acc_source_rgb = false; I->acc_source_batch = frames_out;
     }
-    if (I->external_slab) // this rank's contribution to the all-gather: RGB of the slab(s), [frame][sub-shard][slot]
-        launch_pack_rgb(main, I->d_acc_slab.ptr, (float*)I->external_slab, (uint64_t)I->capacity * frames_out);
+    if (I->external_slab) // this rank's contribution to the all-gather, [frame][sub-shard][slot] in the instance's gather format
+        pack_slabs(I, main, I->external_slab, frames_out);
     if (tm) (void)hipEventRecord(I->events[kEvBlit + 1], main);
     if (tm) (void)hipEventRecord(I->events[EV_FRAME1], main);
     HIP_TRY(I, hipGetLastError());
@@ -1548,11 +1629,6 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
         if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 16u);
         if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
-    }
-    if (n_slots > 1 && I->world > 1) {
-        g_create_error = "frames_in_flight > 1 needs world == 1 (a sharded frame is pipelined with one instance per frame in flight)";
-        delete I;
-        return nullptr;
     }
     if (I->max_batch > 1 && I->substreams > 1) {
         g_create_error = "max_batch > 1 needs streams <= 1 (a batch already fills the device with one launch per stage)";
@@ -1661,6 +1737,7 @@ void rfw_hip_destroy(void* inst)
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
+        if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
         I->d_send.release(); I->d_recv.release();
         for (int q = 0; q < 2; q++) { I->d_sort_keys[q].release(); I->d_sort_vals[q].release(); }
         I->d_sort_ws.release();
@@ -1934,7 +2011,7 @@ int rfw_hip_comm_init(void* inst, const void* id128, uint32_t rank, uint32_t wor
     LOCK(inst);
     if (!id128 || world == 0 || rank >= world) return fail(I, RFW_HIP_E_INVALID, "comm_init: bad arguments");
     if (rank != I->rank || world != I->world) return fail(I, RFW_HIP_E_INVALID, "comm_init: rank / world differ from the shard this instance was created with (rfw_hip_options.rank / world)");
-    if (!I->slots.empty() || I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "comm_init: an instance with frame slots or sub-streams cannot own a communicator (use one instance per frame in flight)");
+    if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "comm_init: an instance with sub-streams cannot own a communicator");
     if (I->comm) return fail(I, RFW_HIP_E_STATE, "comm_init: this instance already has a communicator");
     {
         std::lock_guard<std::mutex> g(g_rccl_mu);
@@ -1945,11 +2022,16 @@ int rfw_hip_comm_init(void* inst, const void* id128, uint32_t rank, uint32_t wor
     std::memcpy(&id, id128, 128);
     const ncclResult_t r = g_rccl.comm_init_rank(&I->comm, (int)world, id, (int)rank);
     if (r != ncclSuccess) { I->comm = nullptr; return fail(I, RFW_HIP_E_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.error_string(r)); }
-    const size_t n = (size_t)I->capacity * I->max_batch * 3u;
-    HIP_TRY(I, I->d_send.ensure(n));
-    HIP_TRY(I, I->d_recv.ensure(n * world));
-    HIP_TRY(I, hipMemsetAsync(I->d_recv.ptr, 0, n * world * sizeof(float), I->stream));
-    I->sample_count = 0;
+    const size_t n = (size_t)I->capacity * I->max_batch * 3u; // (room for the widest format: the option may still change)
+    for (uint32_t k = 0; k <= I->slots.size(); k++) { // every frame slot gathers into buffers of its own, on its own stream, through the owner's communicator
+        Instance* c = slot_ptr(I, k);
+        HIP_TRY(I, c->d_send.ensure(n));
+        HIP_TRY(I, c->d_recv.ensure(n * world));
+        HIP_TRY(I, hipMemsetAsync(c->d_recv.ptr, 0, n * world * sizeof(float), c->stream));
+        c->sample_count = 0;
+    }
+    if (!I->slots.empty() && !I->comm_chain) HIP_TRY(I, hipEventCreateWithFlags(&I->comm_chain, hipEventDisableTiming));
+    I->comm_chain_pending = false;
     return RFW_HIP_OK;
 }
 
@@ -1959,6 +2041,7 @@ int rfw_hip_comm_destroy(void* inst)
     if (!I->comm) return RFW_HIP_OK;
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream));
     (void)g_rccl.comm_destroy(I->comm);
     I->comm = nullptr;
     I->acc_source = nullptr;
@@ -2003,7 +2086,7 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     I->width = w;
     I->height = h;
     const int arc = alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
-    if (arc == RFW_HIP_OK && I->comm) { // the gather buffers follow the slab size
+    if (arc == RFW_HIP_OK && scene_of(I)->comm) { // the gather buffers follow the slab size
         const size_t n = (size_t)I->capacity * I->max_batch * 3u;
         HIP_TRY(I, I->d_send.ensure(n));
         HIP_TRY(I, I->d_recv.ensure(n * I->world));
@@ -2092,6 +2175,12 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         else if ((int)value == 2) I->flags |= kFlagFarFirstPositional;
     }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
+    else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)
+        if (value < 0 || value > 2) return fail(I, RFW_HIP_E_INVALID, "set_option: gather_format is 0, 1 or 2");
+        I->gather_format = (uint32_t)value;
+        I->deferred = Instance::Deferred(); I->acc_source = nullptr; I->presented_valid = false;
+    }
+    else if (k == "present_rank") I->present_rank = (int)value;
     else if (k == "timing") I->timing = value != 0.0;
     else if (k == "sort_extension_rays") I->sort_extension_rays = std::max(0, std::min(2, (int)value));
     else if (k == "texture_array") { I->texture_array = value != 0.0; I->tex_offsets.clear(); } // applies to textures set from now on (all of them: no partial update across the switch)
@@ -2112,6 +2201,9 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
 // de-tiles the linear accumulator of the latest frame(s) into d_frame_acc, on the instance's stream (zeros before the first frame)
 static int materialize_accumulator(Instance* I)
 {
+    if (scene_of(I)->gather_format != 0 && (scene_of(I)->comm || I->external_slab))
+        return fail(I, RFW_HIP_E_STATE, "read_accumulator: with gather_format 1 / 2 only the finished frame travels; the accumulators stay on the ranks that own the tiles");
+    { const int rc = ensure_assembled(I); if (rc != RFW_HIP_OK) return rc; }
     const size_t px = (size_t)I->width * I->height * I->max_batch;
     HIP_TRY(I, I->d_frame_acc.ensure(px));
     if (!I->acc_source) {
@@ -2142,6 +2234,11 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
     if (accumulator) {
         const int rc = materialize_accumulator(I);
         if (rc != RFW_HIP_OK) return rc;
+    } else {
+        if (scene_of(I)->gather_format == 2 && (scene_of(I)->comm || I->external_slab))
+            return fail(I, RFW_HIP_E_STATE, "read_framebuffer: gather_format 2 leaves the PRESENTED frame only: rfw_hip_download_frame(what = 2)");
+        const int rc = ensure_assembled(I);
+        if (rc != RFW_HIP_OK) return rc;
     }
     const float4* src = (accumulator ? I->d_frame_acc.ptr : I->d_frame_out.ptr) + (size_t)frame * I->width * I->height;
     HIP_TRY(I, hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
@@ -2151,21 +2248,6 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
 }
 
 // step k = the smallest linear value whose sRGB encoding rounds to byte k + 1: srgb_to_linear((k + 0.5) / 255), IEC 61966-2-1
-static const float* srgb_steps()
-{
-    static float t[255];
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (int k = 0; k < 255; k++) {
-            const double e = (k + 0.5) / 255.0;
-            const double lin = e <= 0.04045 ? e / 12.92 : std::pow((e + 0.055) / 1.055, 2.4);
-            float f = (float)lin;
-            if ((double)f < lin) f = std::nextafter(f, 2.0f); // smallest float NOT below the exact step
-            t[k] = f;
-        }
-    });
-    return t;
-}
 void rfw_hip_srgb_steps(float* out255)
 {
     if (out255) std::memcpy(out255, srgb_steps(), 255 * sizeof(float));
@@ -2196,6 +2278,18 @@ int rfw_hip_download_frame(void* inst, uint32_t what, uint32_t frame, float* hos
     if (what == 1) {
         const int rc = materialize_accumulator(c);
         if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
+    } else {
+        const int rc = ensure_assembled(c);
+        if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
+    }
+    const bool sharded_presented = scene_of(c)->gather_format == 2 && (scene_of(c)->comm || c->external_slab);
+    if (sharded_presented) { // the gathered frame IS the presented frame: de-tiled into d_present already, nothing to encode
+        if (what != 2) return fail(I, RFW_HIP_E_STATE, "download_frame: gather_format 2 leaves the PRESENTED frame only (what = 2)");
+        if (!c->presented_valid) return fail(I, RFW_HIP_E_STATE, "download_frame: no gathered frame yet");
+        HIP_TRY(I, hipMemcpyAsync(host_rgba, c->d_present.ptr + (size_t)frame * px, px * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(I, hipEventRecord(c->download_done, c->stream));
+        c->download_dst.push_back(host_rgba);
+        return RFW_HIP_OK;
     }
     const float4* src = (what == 1 ? c->d_frame_acc.ptr : c->d_frame_out.ptr) + (size_t)frame * px;
     // Presented frame into a pinned destination (rfw_hip_host_alloc, or registered by the caller): the encoding kernel stores straight
@@ -2237,42 +2331,9 @@ int rfw_hip_wait_download(void* inst, const void* host_ptr)
 }
 int rfw_hip_wait_downloads(void* inst) { return rfw_hip_wait_download(inst, nullptr); }
 
-int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n)
-{
-    LOCK(inst);
-    if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_framebuffer: size mismatch");
-    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest frame lives in a slot
-        Instance* c = slot_ptr(I, I->cur_slot);
-        const int rc = rfw_hip_read_framebuffer(c, rgba, n);
-        if (rc != RFW_HIP_OK) I->err = c->err;
-        return rc;
-    }
-    HIP_TRY(I, hipSetDevice(I->device));
-    HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_out.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
-    HIP_TRY(I, hipStreamSynchronize(I->stream));
-    CHECK_OVERFLOW(I);
-    return RFW_HIP_OK;
-}
-int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n)
-{
-    LOCK(inst);
-    if (!rgba || n != (uint64_t)I->width * I->height * 4) return fail(I, RFW_HIP_E_INVALID, "read_accumulator: size mismatch");
-    if (!I->slots.empty() && I->cur_slot != 0) { // frames in flight: the latest frame lives in a slot
-        Instance* c = slot_ptr(I, I->cur_slot);
-        const int rc = rfw_hip_read_accumulator(c, rgba, n);
-        if (rc != RFW_HIP_OK) I->err = c->err;
-        return rc;
-    }
-    HIP_TRY(I, hipSetDevice(I->device));
-    {
-        const int rc = materialize_accumulator(I);
-        if (rc != RFW_HIP_OK) return rc;
-    }
-    HIP_TRY(I, hipMemcpyAsync(rgba, I->d_frame_acc.ptr, n * sizeof(float), hipMemcpyDeviceToHost, I->stream));
-    HIP_TRY(I, hipStreamSynchronize(I->stream));
-    CHECK_OVERFLOW(I);
-    return RFW_HIP_OK;
-}
+// the latest frame (frame 0 of a batch)
+int rfw_hip_read_framebuffer(void* inst, float* rgba, uint64_t n) { return read_frame_impl(inst, 0, false, rgba, n); }
+int rfw_hip_read_accumulator(void* inst, float* rgba, uint64_t n) { return read_frame_impl(inst, 0, true, rgba, n); }
 
 static void add_frame_timing(Instance* I, int slot, uint32_t nb, bool nee, rfw_hip_frame_stats* out)
 {
@@ -2429,7 +2490,7 @@ int rfw_hip_device_synchronize(void* inst)
 int rfw_hip_shard_info(void* inst, uint64_t* slab_floats, uint32_t* local, uint32_t* total)
 {
     LOCK(inst);
-    if (slab_floats) *slab_floats = (uint64_t)I->capacity * 3; // RGB of the accumulator per slab element
+    if (slab_floats) *slab_floats = slab_words(I); // 4-byte words per frame in the instance's gather format (format 0: RGB of the accumulator as floats)
     if (local) *local = I->local_tiles;
     if (total) *total = I->tiles_x * I->tiles_y;
     return RFW_HIP_OK;
@@ -2448,13 +2509,8 @@ static int assemble_impl(void* inst, const void* gathered, uint32_t k)
     if (!gathered) return fail(I, RFW_HIP_E_INVALID, "assemble_frame: null buffer");
     if (k == 0 || k > I->max_batch || (k > 1 && I->substreams > 1)) return fail(I, RFW_HIP_E_INVALID, "assemble_batch: bad frame count");
     HIP_TRY(I, hipSetDevice(I->device));
-    CameraParams cam = camera_params(I, I->last_view);
-    cam.batch = k;
     // gathered = [world][substreams][cap_v] = [virtual rank][cap_v]; for a batch (one sub-stream): [rank][frame][cap_v]
-    launch_assemble(I->stream, cam, gathered, true, false, I->cap_v, I->d_frame_out.ptr, std::max(1u, I->sample_count));
-    I->acc_source = gathered; I->acc_source_rgb = true; I->acc_source_batch = k;
-    HIP_TRY(I, hipGetLastError());
-    return RFW_HIP_OK;
+    return gathered_arrived(I, I->stream, gathered, k);
 }
 int rfw_hip_assemble_frame(void* inst, const void* gathered) { return assemble_impl(inst, gathered, 1); }
 int rfw_hip_assemble_batch(void* inst, const void* gathered, uint32_t count) { return assemble_impl(inst, gathered, count); }

@@ -355,6 +355,49 @@ def test_library_owned_collective_with_a_one_rank_communicator():
     be.close(); plain.close()
 
 
+def test_frame_slots_share_one_communicator():
+    """VERDICT r02 #6d: frames in flight of a sharded frame without a scene copy per frame.  One instance, three frame slots, ONE
+    communicator: every slot gathers into buffers of its own on its own stream, the collectives are chained on the device.  Frames rendered
+    round-robin over the slots equal the frames of a plain instance, for every gather format."""
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 200, 136
+    scene = Scene().build("soup", 1500, 5, 0.0, 4)
+    scene.set_aspect(w / h)
+    views = []
+    for i in range(7):
+        scene.set_camera([0.2 * i - 0.6, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    plain = HipBackend.init(w, h, 1.0, max_path_length=3)
+    scene.sync(plain)
+    want = []
+    for v in views:
+        plain.reset_accumulation(); plain.render(v)
+        pres = plain.host_frame(presented=True)
+        plain.download_frame(pres); plain.wait_downloads()
+        want.append((plain.framebuffer().copy(), pres.copy()))
+        plain.free_host_frame(pres)
+    for fmt in (0, 1, 2):
+        be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=3)
+        scene.mark_all_changed(); scene.sync(be)
+        be.set_option("gather_format", fmt)
+        be.comm_init(HipBackend.comm_unique_id(), 0, 1)
+        host = [be.host_frame(presented=(fmt == 2)) for _ in views]
+        for v, dst in zip(views, host):     # nothing waits between the frames: three are in flight
+            be.render(v)
+            be.download_frame(dst)
+        be.wait_downloads()
+        for i, dst in enumerate(host):
+            if fmt == 0:
+                assert np.array_equal(dst.view(np.uint32), want[i][0].view(np.uint32)), (fmt, i)
+            elif fmt == 1:
+                assert np.array_equal(dst[..., :3].astype(np.float16).view(np.uint16), want[i][0][..., :3].astype(np.float16).view(np.uint16)), (fmt, i)
+            else:
+                assert np.array_equal(dst, want[i][1]), (fmt, i)
+        be.comm_destroy()
+        be.close()
+    plain.close()
+
+
 def test_packet_queries_are_four_single_ray_queries():
     """TIntersector::intersect4 / occludes4 (intersector.rs:129-166) in rtbvh's SoA packet layout."""
     from oracle.bindings import Oracle

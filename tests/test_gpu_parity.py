@@ -186,6 +186,63 @@ def test_tile_sharding_is_bit_exact(tile_size):
         assert np.array_equal(gathered[r].cpu().numpy().reshape(-1, 3).view(np.uint32), want.view(np.uint32)), r
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_finished_frame_gather_formats_equal_the_single_gpu_frame(fmt):
+    """VERDICT r02 #6a/b: only the FINISHED frame has to travel — halves (option gather_format = 1, 6 B per pixel) or the presented B, G, R, A
+    bytes (2, 4 B per pixel) instead of the accumulator's floats (12 B) — and only the rank that presents has to de-tile it at once
+    (present_rank).  Three shards on one device: what every rank ends up with equals the single-GPU frame in the same format, bit for bit."""
+    import torch
+    from rfw_rs_amd import BackendError, HipBackend, Scene
+    w, h = 200, 136
+    scene = Scene().build("soup", 1500, 5, 0.0, 4)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    full = HipBackend.init(w, h, 1.0)
+    scene.sync(full)
+    for _ in range(2):
+        full.render(view)
+    ref_frame = full.framebuffer()
+    ref_presented = full.host_frame(presented=True)
+    full.download_frame(ref_presented)
+    full.wait_downloads()
+    world = 3
+    ranks = []
+    for r in range(world):
+        be = HipBackend.init(w, h, 1.0, rank=r, world=world, tile_size=32)
+        be.set_option("gather_format", fmt)
+        be.set_option("present_rank", 0)
+        scene.mark_all_changed()
+        scene.sync(be)
+        ranks.append(be)
+    words = ranks[0].shard_info()["slab_floats"]
+    px_per_slab = ranks[0].shard_info()["tiles_local"] * 32 * 32
+    assert words == (px_per_slab * 3 // 2 if fmt == 1 else px_per_slab)          # 6 / 4 bytes per pixel instead of 12
+    gathered = torch.zeros(world, words, dtype=torch.float32, device="cuda")     # opaque 4-byte words
+    for r, be in enumerate(ranks):
+        be.set_slab_output(gathered[r].data_ptr())
+        for _ in range(2):
+            be.render(view)
+        be.device_synchronize()
+    for be in ranks:                                                              # rank 0 de-tiles now, ranks 1 and 2 when somebody reads
+        be.assemble_frame(gathered.data_ptr())
+    for r, be in enumerate(ranks):
+        if fmt == 1:
+            got = be.framebuffer()[..., :3]
+            want = ref_frame[..., :3].astype(np.float16).astype(np.float32)       # the device's conversion rounds to nearest even, as numpy's
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), r
+        else:
+            dst = be.host_frame(presented=True)
+            be.download_frame(dst)
+            be.wait_downloads()
+            assert np.array_equal(dst, ref_presented), r
+            with pytest.raises(BackendError):
+                be.framebuffer()                                                  # only the presented frame exists
+        with pytest.raises(BackendError):
+            be.accumulator()                                                      # the accumulators stayed on their ranks
+    for be in ranks + [full]:
+        be.close()
+
+
 def test_full_size_properties():
     """BASELINE config C2 at full size (1920x1080, ~262k triangles): properties that need no oracle run."""
     from rfw_rs_amd import HipBackend, Scene
