@@ -78,6 +78,11 @@ def main():
                          "gathered buffer), without any collective; the value then counts this shard's rays only")
     ap.add_argument("--collective", default="torch", choices=["torch", "native"],
                     help="N > 1: who issues the all-gather — torch.distributed (RCCL through PyTorch) or the library itself (rfw_hip_comm_*: librccl on the instance's stream)")
+    ap.add_argument("--gather-format", default="bgra8", choices=["f32", "f16", "bgra8"],
+                    help="N > 1: what a rank's tiles travel as — the accumulator's RGB floats (12 B per pixel), the finished frame as halves (6 B) or the "
+                         "presented B, G, R, A bytes (4 B: the swap-chain image Backend::render ends with; default).  Accumulation stays in f32 on the "
+                         "rank that owns the tiles in every format")
+    ap.add_argument("--present-rank", type=int, default=0, help="N > 1: the rank that de-tiles every gathered frame at once (-1: all ranks do)")
     ap.add_argument("--readback", nargs="?", const="float", default=None, choices=["float", "presented"],
                     help="copy every finished frame to (pinned) host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -137,8 +142,10 @@ def main():
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.
-    use_slots = single and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
     native = args.collective == "native" and world > 1 and dist_backend == "nccl"
+    # (with the library's own communicator the frame slots of ONE instance share it: one scene copy per rank at N > 1 too)
+    use_slots = (single or native) and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
+    gather_format = {"f32": 0, "f16": 1, "bgra8": 2}[args.gather_format] if (world > 1 or args.emulate_shard) else 0
 
     def make_instances(n_slots_or_inst, batch, slots):
         n_inst = 1 if slots else n_slots_or_inst
@@ -153,11 +160,14 @@ def main():
             for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays"):  # builder / queue-order experiments
                 if os.environ.get("RFW_" + key.upper()):
                     be.set_option(key, float(os.environ["RFW_" + key.upper()]))
+            if world > 1 or args.emulate_shard:
+                be.set_option("gather_format", gather_format)
+                be.set_option("present_rank", args.present_rank)
             scene.mark_all_changed()
             scene.sync(be)
             g = None
             if (world > 1 and not native) or args.emulate_shard:
-                nslab = be.shard_info()["slab_floats"]
+                nslab = be.shard_info()["slab_floats"]  # 4-byte words of one frame's slab in the gather format
                 wn = world if not args.emulate_shard else args.emulate_shard
                 send = torch.zeros(batch * nslab, dtype=torch.float32, device="cuda")           # this rank's tiles of `batch` frames (written by render())
                 g = (send, torch.zeros(wn * batch * nslab, dtype=torch.float32, device="cuda"), nslab, wn)  # (send buffer, all ranks' slabs)
@@ -323,10 +333,19 @@ def main():
         scene.mark_all_changed()
         scene.sync(whole)
         shard_check = True
+        pres = [whole.host_frame(presented=True), lb.host_frame(presented=True)] if gather_format == 2 else None
         for f, vi in enumerate(lframes):
             whole.reset_accumulation()
             whole.render(views[vi % N_VIEWS])
-            shard_check = shard_check and bool(np.array_equal(lb.accumulator_at(f).view(np.uint32), whole.accumulator().view(np.uint32)))
+            if gather_format == 0:    # the accumulators themselves
+                same = np.array_equal(lb.accumulator_at(f).view(np.uint32), whole.accumulator().view(np.uint32))
+            elif gather_format == 1:  # the finished frame in halves: what one GPU's finished frame rounds to
+                same = np.array_equal(lb.framebuffer_at(f)[..., :3].astype(np.float16).view(np.uint16), whole.framebuffer()[..., :3].astype(np.float16).view(np.uint16))
+            else:                     # the presented frame, byte for byte
+                whole.download_frame(pres[0]); whole.wait_downloads()
+                lb.download_frame(pres[1], frame=f); lb.wait_downloads()
+                same = np.array_equal(pres[0], pres[1])
+            shard_check = shard_check and bool(same)
         whole.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
@@ -472,6 +491,8 @@ def main():
                        "modes": modes,
                        "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check,
                        "tile_shard": "64x64 round-robin" if world > 1 else "none", "collective": (args.collective if world > 1 else None),
+                       "gather_format": (args.gather_format if (world > 1 or args.emulate_shard) else None), "present_rank": (args.present_rank if world > 1 else None),
+                       "gather_bytes_per_frame": ({"f32": 12, "f16": 6, "bgra8": 4}[args.gather_format] * w * h if world > 1 else None),
                        "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],

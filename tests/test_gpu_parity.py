@@ -268,9 +268,10 @@ def test_full_size_properties():
     assert (be.occludes(po, pd, tm * np.float32(0.99)) == 0).sum() >= 0.999 * len(po)
 
 
-def test_bench_two_ranks_on_one_gpu_gloo_hook():
+@pytest.mark.parametrize("gather_format", ["f32", "f16", "bgra8"])
+def test_bench_two_ranks_on_one_gpu_gloo_hook(gather_format):
     """bench.py's N > 1 code path (tile shard, all-gather, assemble, max-over-ranks timing) with two processes sharing this GPU
-    through the gloo test hook (RCCL itself refuses two ranks on one device)."""
+    through the gloo test hook (RCCL itself refuses two ranks on one device), for every format the tiles can travel in."""
     import json
     import os
     import subprocess
@@ -279,13 +280,15 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook():
     env = dict(os.environ, RFW_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "cornell", "--width", "320", "--height", "200", "--no-cpu-baseline"]
+           "--workload", "cornell", "--width", "320", "--height", "200", "--no-cpu-baseline", "--gather-format", gather_format]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rays_per_frame"] >= 320 * 200
     assert out["config"]["frames_per_batch"] == 8 and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
+    assert out["config"]["gather_format"] == gather_format
+    assert out["config"]["gather_bytes_per_frame"] == {"f32": 12, "f16": 6, "bgra8": 4}[gather_format] * 320 * 200
     assert "distinct" in out["config"]["views"] or "cycled" in out["config"]["views"]
 
 
