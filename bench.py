@@ -76,8 +76,9 @@ def main():
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU study of multi-GPU scaling: render only rank 0's tiles of an N-way tile shard (and de-tile a stand-in "
                          "gathered buffer), without any collective; the value then counts this shard's rays only")
-    ap.add_argument("--collective", default="torch", choices=["torch", "native"],
-                    help="N > 1: who issues the all-gather — torch.distributed (RCCL through PyTorch) or the library itself (rfw_hip_comm_*: librccl on the instance's stream)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "native", "p2p"],
+                    help="N > 1: who exchanges the tiles — torch.distributed's all-gather (RCCL through PyTorch), the library's own (rfw_hip_comm_*: librccl on the "
+                         "instance's stream), or no collective at all: p2p = every rank stores its tiles into the destinations' buffers over xGMI (rfw_hip_p2p_*)")
     ap.add_argument("--gather-format", default="bgra8", choices=["f32", "f16", "bgra8"],
                     help="N > 1: what a rank's tiles travel as — the accumulator's RGB floats (12 B per pixel), the finished frame as halves (6 B) or the "
                          "presented B, G, R, A bytes (4 B: the swap-chain image Backend::render ends with; default).  Accumulation stays in f32 on the "
@@ -142,8 +143,9 @@ def main():
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.
-    native = args.collective == "native" and world > 1 and dist_backend == "nccl"
-    # (with the library's own communicator the frame slots of ONE instance share it: one scene copy per rank at N > 1 too)
+    p2p = args.collective == "p2p" and world > 1
+    native = (args.collective == "native" and world > 1 and dist_backend == "nccl") or p2p  # the exchange happens inside render()
+    # (with the library's own exchange the frame slots of ONE instance share it: one scene copy per rank at N > 1 too)
     use_slots = (single or native) and F > 1 and os.environ.get("RFW_BENCH_INSTANCES") is None
     gather_format = {"f32": 0, "f16": 1, "bgra8": 2}[args.gather_format] if (world > 1 or args.emulate_shard) else 0
 
@@ -178,7 +180,14 @@ def main():
     t0 = time.time()
     inst = make_instances(F, B, use_slots)
     sync_s = (time.time() - t0) / len(inst)
-    if native:
+    if p2p:
+        # every rank's 256-byte handle to every rank, once; after that the ranks only meet in their peers' flag words
+        for be_, _, _ in inst:
+            hds = [None] * world
+            dist.all_gather_object(hds, be_.p2p_export())
+            be_.p2p_connect(hds)
+        dist.barrier()
+    elif native:
         # the communicators live inside the library (librccl; one per instance, i.e. per frame / batch in flight): rank 0's unique ids
         # travel through torch's store once, after that torch.distributed is only used for the barrier around the timed region
         uids = [[HipBackend.comm_unique_id() for _ in inst] if rank == 0 else None]

@@ -220,10 +220,31 @@ RFW_HIP_API int rfw_hip_assemble_frame(void* instance, const void* gathered_devi
  * its slab is packed, ONE ncclAllGather per call runs on the instance's own stream (RCCL over xGMI) and the gathered slabs are de-tiled —
  * no buffer, stream or collective on the host's side (rfw_hip_set_slab_output / rfw_hip_assemble_* stay for hosts that bring their own
  * collective, e.g. torch.distributed).  world = 1 is allowed (a one-rank communicator).  librccl is opened at run time, on first use.
- * Not available on instances with frame slots or sub-streams: pipeline sharded frames over several instances, each with its communicator. */
+ * Frame slots (options.frames_in_flight) share the instance's communicator: every slot gathers into buffers of its own on its own stream and the
+ * collectives are chained on the device, so a rank pipelines sharded frames with ONE scene copy.  Not available with sub-streams. */
 RFW_HIP_API int rfw_hip_comm_unique_id(void* out128);
 RFW_HIP_API int rfw_hip_comm_init(void* instance, const void* id128, uint32_t rank, uint32_t world);
 RFW_HIP_API int rfw_hip_comm_destroy(void* instance);
+
+/* The same exchange WITHOUT a collective library (SURVEY.md §8e's alternative): every rank stores its tiles straight into its peers'
+ * receive buffers over xGMI.  xGMI is point to point, so the 7 links of a GPU carry the 7 peers' tiles side by side, where a ring
+ * all-gather is bound by one link; and with present_rank = r the tiles travel to rank r ONLY (1 / world of the all-gather's bytes).
+ *   rfw_hip_p2p_export   allocates this instance's receive buffers (per frame slot, per rank) and its flag words and writes a
+ *                        RFW_HIP_P2P_HANDLE_BYTES handle: process id, device, the buffers' addresses and their hipIpcMemHandles
+ *   (the host hands every rank's handle to every rank: one all-gather of 256 bytes, by whatever means it has)
+ *   rfw_hip_p2p_connect  handles = world x RFW_HIP_P2P_HANDLE_BYTES in rank order.  A peer of this process is reached through its address
+ *                        (hipDeviceEnablePeerAccess when it is on another device), a peer of another process through hipIpcOpenMemHandle
+ *   (a host barrier: nobody renders before every rank has connected)
+ * From then on rfw_hip_render / rfw_hip_render_batch pack this rank's slab(s) in the gather format DIRECTLY into the destinations'
+ * buffers, raise the destinations' arrival flags (system-scope release stores), and a destination waits (one wavefront polling its OWN
+ * memory) for all world flags before it de-tiles; afterwards it returns a credit to every sender, which a sender waits for before it
+ * overwrites that slot's buffer.  All remote traffic is stores.  A wait gives up after option "p2p_timeout_ms" (default 5000): the
+ * next read then fails instead of the device hanging.  On a rank that is not a destination the frame does not exist: reads fail.
+ * rfw_hip_p2p_disconnect (after a host barrier) unmaps and frees.  The instance's size cannot change while connected. */
+#define RFW_HIP_P2P_HANDLE_BYTES 256
+RFW_HIP_API int rfw_hip_p2p_export(void* instance, void* handle_out);
+RFW_HIP_API int rfw_hip_p2p_connect(void* instance, const void* handles);
+RFW_HIP_API int rfw_hip_p2p_disconnect(void* instance);
 
 /* Ray queries against the synchronized scene — the C form of the reference's CPU query
  * interface TIntersector::{intersect, occludes} (crates/rfw-scene/src/intersector.rs:45-75,

@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes", "rfw_hip_debug_occludes_depth",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_intersect4", "rfw_hip_occludes4",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_p2p_export", "rfw_hip_p2p_connect", "rfw_hip_p2p_disconnect", "rfw_hip_intersect4", "rfw_hip_occludes4",
 ]
 
 _lib = None
@@ -93,6 +93,9 @@ def hip_lib():
         l.rfw_hip_comm_unique_id.argtypes = [vp]
         l.rfw_hip_comm_init.argtypes = [vp, vp, u32, u32]
         l.rfw_hip_comm_destroy.argtypes = [vp]
+        l.rfw_hip_p2p_export.argtypes = [vp, vp]
+        l.rfw_hip_p2p_connect.argtypes = [vp, vp]
+        l.rfw_hip_p2p_disconnect.argtypes = [vp]
         l.rfw_hip_intersect4.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         l.rfw_hip_occludes4.argtypes = [vp, vp, vp, vp, vp, vp]
         l.rfw_hip_read_framebuffer_at.argtypes = [vp, C.c_uint32, vp, u64]
@@ -279,6 +282,23 @@ class HipBackend:
 
     def comm_destroy(self):
         self._check(self._l.rfw_hip_comm_destroy(self._h))
+
+    P2P_HANDLE_BYTES = 256
+
+    def p2p_export(self):
+        """This rank's 256-byte handle for the exchange by peer stores (every rank hands its handle to every rank)."""
+        buf = (C.c_uint8 * self.P2P_HANDLE_BYTES)()
+        self._check(self._l.rfw_hip_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_connect(self, handles):
+        """handles: every rank's handle in rank order.  render() then stores this rank's tiles straight into the destinations' buffers."""
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._check(self._l.rfw_hip_p2p_connect(self._h, buf))
+
+    def p2p_disconnect(self):
+        self._check(self._l.rfw_hip_p2p_disconnect(self._h))
 
     def assemble_batch(self, gathered_ptr, count):
         self._check(self._l.rfw_hip_assemble_batch(self._h, C.c_void_p(gathered_ptr), count))

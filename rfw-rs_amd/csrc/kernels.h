@@ -65,6 +65,11 @@ void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uin
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n);
 // the FINISHED frame of a slab for the all-gather (format 1: three halves per pixel; 2: presented B, G, R, A bytes) and its de-tiling
 void launch_pack_finished(hipStream_t s, const float4* acc_slab, void* out, uint64_t n, uint32_t samples, uint32_t format, const float* steps255);
+// peer-to-peer exchange: flag words in uncached memory.  wait: lanes first .. first + count - 1 of ONE wavefront poll flags[lane] until it has
+// reached `want` (wrap-safe), at most `limit_ticks` of the 100 MHz wall clock, then *timeout_flag = 1.  signal: *targets.p[i] = value.
+struct P2PTargets { uint32_t* p[16]; };
+void launch_p2p_wait(hipStream_t s, const uint32_t* flags, uint32_t first, uint32_t count, uint32_t want, uint64_t limit_ticks, uint32_t* timeout_flag);
+void launch_p2p_signal(hipStream_t s, const P2PTargets& targets, uint32_t count, uint32_t value);
 void launch_assemble_finished(hipStream_t s, const CameraParams& cam, const void* gathered, uint64_t slab_elems, uint32_t format, float4* frame, uint32_t* presented);
 void launch_present(hipStream_t s, const float4* frame, uint32_t* bgra, uint64_t n, const float* steps255, bool narrow);
 void launch_eval_shading(hipStream_t s, const SceneDev& sc, const CameraParams& cam, int op, uint32_t n, const float* in, float* out);

@@ -981,6 +981,39 @@ void launch_assemble_finished(hipStream_t s, const CameraParams& cam, const void
     if (format == 1) hipLaunchKernelGGL(k_assemble_f16, grid, block, 0, s, cam, (const _Float16*)gathered, slab_elems, frame);
     else hipLaunchKernelGGL(k_assemble_bgra8, grid, block, 0, s, cam, (const uint32_t*)gathered, slab_elems, presented);
 }
+// ---------------------------------------------------------------- peer-to-peer exchange (rfw_hip_p2p_*)
+// The data travels as ordinary stores of the pack kernels into a peer's buffer; these two order it.  A kernel boundary on the sender's
+// stream makes the packed tiles visible before the flag (the end of a kernel releases at system scope), the flag itself lives in uncached
+// memory and is written / read with system-scope atomics, and the de-tiling kernel starts after the wait kernel has ended.
+__global__ __launch_bounds__(64) void k_p2p_wait(const uint32_t* flags, const uint32_t first, const uint32_t count, const uint32_t want, const uint64_t limit_ticks,
+                                                 uint32_t* timeout_flag)
+{
+    const uint32_t lane = threadIdx.x;
+    if (lane >= count) return;
+    const uint32_t* f = flags + first + lane;
+    const uint64_t t0 = wall_clock64();
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - want) >= 0) return;
+        if (wall_clock64() - t0 > limit_ticks) {
+            __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__global__ __launch_bounds__(64) void k_p2p_signal(const P2PTargets targets, const uint32_t count, const uint32_t value)
+{
+    if (threadIdx.x < count) __hip_atomic_store(targets.p[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_p2p_wait(hipStream_t s, const uint32_t* flags, uint32_t first, uint32_t count, uint32_t want, uint64_t limit_ticks, uint32_t* timeout_flag)
+{
+    if (count) hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, s, flags, first, count, want, limit_ticks, timeout_flag);
+}
+void launch_p2p_signal(hipStream_t s, const P2PTargets& targets, uint32_t count, uint32_t value)
+{
+    if (count) hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, s, targets, count, value);
+}
 void launch_pack_rgb(hipStream_t s, const float4* acc_slab, float* out, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_pack_rgb, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, acc_slab, out, n);

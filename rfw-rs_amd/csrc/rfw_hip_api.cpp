@@ -4,6 +4,7 @@
 // host read-back.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 // RCCL: types and prototypes only — librccl is opened at run time by rfw_hip_comm_* (no link-time dependency for single-GPU hosts), and a ROCm
 // installation without the rccl development headers can still build this library: the handful of declarations used here are then made locally
 #if __has_include(<rccl/rccl.h>)
@@ -352,6 +353,21 @@ struct Instance {
     // the device) for the one issued before it, whichever slot's stream that was on, while the slots' traces overlap freely
     hipEvent_t comm_chain = nullptr;
     bool comm_chain_pending = false;
+    // the exchange without a collective library (rfw_hip_p2p_*): receive buffers [slot][rank][frame][slab] and flag words
+    // [slot][arrived | credit][rank] of THIS rank, and where the peers' are mapped.  Lives in the owner; a slot knows its index.
+    struct P2P {
+        bool connected = false;
+        uint32_t* data = nullptr;   // hipMalloc: 4-byte words
+        uint32_t* flags = nullptr;  // uncached device memory
+        size_t slot_words = 0;      // words per frame slot: world x max_batch x capacity x 3 (room for the widest format)
+        uint32_t n_slots = 0;
+        std::vector<uint32_t*> peer_data, peer_flags;
+        std::vector<uint8_t> opened; // bit 0: data, bit 1: flags came from hipIpcOpenMemHandle
+        uint64_t timeout_ticks = 500000000ull; // 5 s of the 100 MHz wall clock
+    } p2p;
+    uint32_t slot_index = 0;
+    uint32_t p2p_seq = 0;           // frames this slot has exchanged
+    bool frame_elsewhere = false;   // the latest frame was sent to the presenting rank and does not exist here
     uint32_t tiles_x = 0, tiles_y = 0, local_tiles = 0, capacity = 0;
     uint64_t local_pixels = 0;
     uint32_t sample_count = 0;
@@ -388,6 +404,7 @@ struct Instance {
 
 inline Instance* scene_of(Instance* I) { return I->scene ? I->scene : I; }
 inline const Instance* scene_of(const Instance* I) { return I->scene ? I->scene : I; }
+void p2p_release(Instance* I);
 inline Instance* slot_ptr(Instance* I, uint32_t k) { return k == 0 ? I : I->slots[k - 1]; }
 // Whose TLAS and instance descriptors a frame reads.  With frame slots every slot keeps its OWN (rebuilt lazily from the owner's
 // instance lists when stale), so a scene whose instances move every frame still pipelines; skinned copies live in the owner's
@@ -1382,6 +1399,47 @@ int assemble_gathered(Instance* I, hipStream_t s, const void* gathered, uint32_t
     HIP_TRY(I, hipGetLastError());
     return RFW_HIP_OK;
 }
+// does this instance receive other ranks' tiles in the gather format (whoever moves them)?
+bool gathers_tiles(const Instance* I) { return scene_of(I)->comm != nullptr || I->external_slab != nullptr || scene_of(I)->p2p.connected; }
+bool p2p_timed_out(const Instance* I) { return I->overflow_host && ((volatile const uint32_t*)I->overflow_host)[1] != 0u; }
+// The frame's exchange by stores into the peers' buffers (include/rfw_hip.h, rfw_hip_p2p_*).  Destinations: the presenting rank, or all.
+int p2p_exchange(Instance* I, hipStream_t s, uint32_t frames)
+{
+    Instance* C = scene_of(I);
+    Instance::P2P& P = C->p2p;
+    const uint32_t W = I->world, me = I->rank, slot = I->slot_index;
+    const int pr = C->present_rank;
+    if (pr >= (int)W) return fail(I, RFW_HIP_E_INVALID, "present_rank is not a rank of this world");
+    const uint32_t d0 = pr >= 0 ? (uint32_t)pr : 0u, nd = pr >= 0 ? 1u : W;
+    const bool receiver = pr < 0 || (uint32_t)pr == me;
+    const uint32_t seq = ++I->p2p_seq;
+    uint32_t* timeout_flag = I->overflow_dev + 1;
+    uint32_t* my_flags = P.flags + (size_t)slot * 2u * W; // arrived[W], credit[W]
+    // 1. the destinations are done with what this slot sent last time
+    launch_p2p_wait(s, my_flags + W, d0, nd, seq - 1u, P.timeout_ticks, timeout_flag);
+    // 2. this rank's slab(s), packed where the destination's de-tiling reads them: [slot][rank][frame][slab], densely
+    const size_t at = (size_t)slot * P.slot_words + (size_t)me * frames * slab_words(I);
+    P2PTargets t;
+    for (uint32_t d = d0; d < d0 + nd; d++) {
+        pack_slabs(I, s, P.peer_data[d] + at, frames);
+        t.p[d - d0] = P.peer_flags[d] + (size_t)slot * 2u * W + me;
+    }
+    // 3. ... and say so (behind the pack kernels on this stream)
+    launch_p2p_signal(s, t, nd, seq);
+    I->frame_elsewhere = !receiver;
+    I->acc_source = nullptr;
+    I->presented_valid = false;
+    I->deferred = Instance::Deferred();
+    if (receiver) {
+        launch_p2p_wait(s, my_flags, 0u, W, seq, P.timeout_ticks, timeout_flag);
+        const int arc = assemble_gathered(I, s, P.data + (size_t)slot * P.slot_words, frames, std::max(1u, I->sample_count));
+        if (arc != RFW_HIP_OK) return arc;
+        for (uint32_t q = 0; q < W; q++) t.p[q] = P.peer_flags[q] + (size_t)slot * 2u * W + W + me; // credit[me] at every sender
+        launch_p2p_signal(s, t, W, seq);
+    }
+    HIP_TRY(I, hipGetLastError());
+    return RFW_HIP_OK;
+}
 // after a gather: de-tile now (this rank presents, or every rank does), or remember where the tiles are
 int gathered_arrived(Instance* I, hipStream_t s, const void* gathered, uint32_t k)
 {
@@ -1395,6 +1453,8 @@ int gathered_arrived(Instance* I, hipStream_t s, const void* gathered, uint32_t 
 }
 int ensure_assembled(Instance* I)
 {
+    if (I->frame_elsewhere) return fail(I, RFW_HIP_E_STATE, "this rank sent its tiles to the presenting rank (present_rank): the frame exists there only");
+    if (p2p_timed_out(I)) return fail(I, RFW_HIP_E_DEVICE, "p2p exchange: a peer's flag did not arrive within p2p_timeout_ms (the frame is incomplete)");
     if (!I->deferred.gathered) return RFW_HIP_OK;
     return assemble_gathered(I, I->stream, I->deferred.gathered, I->deferred.k, I->deferred.samples);
 }
@@ -1534,6 +1594,9 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
         if (C->comm_chain) { HIP_TRY(I, hipEventRecord(C->comm_chain, main)); C->comm_chain_pending = true; }
         const int arc = gathered_arrived(I, main, I->d_recv.ptr, frames_out); // gathered = [rank][frame][slab]
         if (arc != RFW_HIP_OK) return arc;
+    } else if (C->p2p.connected) {
+        const int prc = p2p_exchange(I, main, frames_out);
+        if (prc != RFW_HIP_OK) return prc;
     } else if (I->world <= 1) // de-tile the sub-slabs into the linear accumulator / tonemapped frame (blit.comp:15-23)
     {
         launch_assemble(main, cam[0], I->d_acc_slab.ptr, false, false, I->cap_v, I->d_frame_out.ptr, I->sample_count);
@@ -1699,6 +1762,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
                 return nullptr;
             }
             c->scene = I;
+            c->slot_index = k;
             if (hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming) != hipSuccess) {
                 g_create_error = "hipEventCreate (frame slot)";
                 rfw_hip_destroy(c);
@@ -1738,6 +1802,7 @@ void rfw_hip_destroy(void* inst)
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
+        p2p_release(I);
         I->d_send.release(); I->d_recv.release();
         for (int q = 0; q < 2; q++) { I->d_sort_keys[q].release(); I->d_sort_vals[q].release(); }
         I->d_sort_ws.release();
@@ -2013,6 +2078,7 @@ int rfw_hip_comm_init(void* inst, const void* id128, uint32_t rank, uint32_t wor
     if (rank != I->rank || world != I->world) return fail(I, RFW_HIP_E_INVALID, "comm_init: rank / world differ from the shard this instance was created with (rfw_hip_options.rank / world)");
     if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "comm_init: an instance with sub-streams cannot own a communicator");
     if (I->comm) return fail(I, RFW_HIP_E_STATE, "comm_init: this instance already has a communicator");
+    if (I->p2p.data) return fail(I, RFW_HIP_E_STATE, "comm_init: this instance already exchanges by peer stores (rfw_hip_p2p_*)");
     {
         std::lock_guard<std::mutex> g(g_rccl_mu);
         if (!g_rccl.load()) return fail(I, RFW_HIP_E_DEVICE, g_rccl.error);
@@ -2048,6 +2114,133 @@ int rfw_hip_comm_destroy(void* inst)
     return RFW_HIP_OK;
 }
 
+// ---- the exchange by peer stores
+namespace {
+struct P2PHandle { // RFW_HIP_P2P_HANDLE_BYTES on the wire
+    uint32_t magic, rank, world, n_slots;
+    int64_t pid;
+    int32_t device, pad;
+    uint64_t data, flags, slot_words, flags_bytes;
+    hipIpcMemHandle_t data_ipc, flags_ipc;
+};
+static_assert(sizeof(P2PHandle) <= RFW_HIP_P2P_HANDLE_BYTES, "P2P handle grew beyond its wire size");
+constexpr uint32_t kP2PMagic = 0x70325032u;
+void p2p_release(Instance* I)
+{
+    Instance::P2P& P = I->p2p;
+    for (size_t q = 0; q < P.opened.size(); q++) {
+        if (P.opened[q] & 1u) (void)hipIpcCloseMemHandle(P.peer_data[q]);
+        if (P.opened[q] & 2u) (void)hipIpcCloseMemHandle(P.peer_flags[q]);
+    }
+    P.peer_data.clear(); P.peer_flags.clear(); P.opened.clear();
+    if (P.data) (void)hipFree(P.data);
+    if (P.flags) (void)hipFree(P.flags);
+    P.data = nullptr; P.flags = nullptr; P.connected = false; P.slot_words = 0; P.n_slots = 0;
+}
+} // namespace
+
+int rfw_hip_p2p_export(void* inst, void* handle_out)
+{
+    LOCK(inst);
+    if (!handle_out) return fail(I, RFW_HIP_E_INVALID, "p2p_export: null handle");
+    if (I->scene) return fail(I, RFW_HIP_E_INVALID, "p2p_export: call it on the instance, not on a frame slot");
+    if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "p2p_export: not available with sub-streams");
+    if (I->comm) return fail(I, RFW_HIP_E_STATE, "p2p_export: this instance already gathers through a communicator");
+    if (I->world > 16) return fail(I, RFW_HIP_E_INVALID, "p2p_export: at most 16 ranks");
+    if (I->p2p.connected) return fail(I, RFW_HIP_E_STATE, "p2p_export: already connected");
+    HIP_TRY(I, hipSetDevice(I->device));
+    Instance::P2P& P = I->p2p;
+    p2p_release(I);
+    P.n_slots = 1u + (uint32_t)I->slots.size();
+    P.slot_words = (size_t)I->world * I->max_batch * I->capacity * 3u;
+    const size_t flag_bytes = std::max<size_t>((size_t)P.n_slots * 2u * I->world * sizeof(uint32_t), 4096);
+    HIP_TRY(I, hipMalloc((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t)));
+    // flag words are polled while peers write them: uncached, so that a poll never reads a stale line of this device's L2
+    if (hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            p2p_release(I);
+            return fail(I, RFW_HIP_E_DEVICE, "p2p_export: no uncached / fine-grained device memory for the flag words");
+        }
+    }
+    HIP_TRY(I, hipMemsetAsync(P.data, 0, P.n_slots * P.slot_words * sizeof(uint32_t), I->stream));
+    HIP_TRY(I, hipMemsetAsync(P.flags, 0, flag_bytes, I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    P2PHandle hd;
+    std::memset(&hd, 0, sizeof(hd));
+    hd.magic = kP2PMagic; hd.rank = I->rank; hd.world = I->world; hd.n_slots = P.n_slots;
+    hd.pid = (int64_t)getpid(); hd.device = I->device;
+    hd.data = (uint64_t)(uintptr_t)P.data; hd.flags = (uint64_t)(uintptr_t)P.flags; hd.slot_words = P.slot_words; hd.flags_bytes = flag_bytes;
+    // (a peer of this very process uses the addresses; the IPC handles are for the other processes — a failure to make them only matters there)
+    if (hipIpcGetMemHandle(&hd.data_ipc, P.data) != hipSuccess || hipIpcGetMemHandle(&hd.flags_ipc, P.flags) != hipSuccess) {
+        (void)hipGetLastError();
+        hd.pad = 1; // no IPC handles in this blob
+    }
+    std::memset(handle_out, 0, RFW_HIP_P2P_HANDLE_BYTES);
+    std::memcpy(handle_out, &hd, sizeof(hd));
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_p2p_connect(void* inst, const void* handles)
+{
+    LOCK(inst);
+    if (!handles) return fail(I, RFW_HIP_E_INVALID, "p2p_connect: null handles");
+    Instance::P2P& P = I->p2p;
+    if (!P.data || !P.flags) return fail(I, RFW_HIP_E_STATE, "p2p_connect: rfw_hip_p2p_export first");
+    if (P.connected) return fail(I, RFW_HIP_E_STATE, "p2p_connect: already connected");
+    HIP_TRY(I, hipSetDevice(I->device));
+    const uint32_t W = I->world;
+    P.peer_data.assign(W, nullptr); P.peer_flags.assign(W, nullptr); P.opened.assign(W, 0);
+    for (uint32_t q = 0; q < W; q++) {
+        P2PHandle hd;
+        std::memcpy(&hd, (const uint8_t*)handles + (size_t)q * RFW_HIP_P2P_HANDLE_BYTES, sizeof(hd));
+        if (hd.magic != kP2PMagic || hd.rank != q || hd.world != W || hd.n_slots != P.n_slots || hd.slot_words != P.slot_words) {
+            p2p_release(I);
+            return fail(I, RFW_HIP_E_INVALID, "p2p_connect: handle " + std::to_string(q) + " is not rank " + std::to_string(q) + "'s handle of an instance of this size, world and number of frame slots");
+        }
+        if (q == I->rank) {
+            P.peer_data[q] = P.data; P.peer_flags[q] = P.flags;
+        } else if (hd.pid == (int64_t)getpid()) { // one process driving several devices (or several ranks of one device: the tests)
+            if (hd.device != I->device) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, I->device, hd.device);
+                if (!can) { p2p_release(I); return fail(I, RFW_HIP_E_DEVICE, "p2p_connect: device " + std::to_string(I->device) + " cannot access device " + std::to_string(hd.device)); }
+                const hipError_t pe = hipDeviceEnablePeerAccess(hd.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { p2p_release(I); return fail(I, RFW_HIP_E_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe)); }
+                (void)hipGetLastError();
+            }
+            P.peer_data[q] = (uint32_t*)(uintptr_t)hd.data; P.peer_flags[q] = (uint32_t*)(uintptr_t)hd.flags;
+        } else {
+            if (hd.pad) { p2p_release(I); return fail(I, RFW_HIP_E_DEVICE, "p2p_connect: rank " + std::to_string(q) + " could not export IPC handles (hipIpcGetMemHandle)"); }
+            void* pd = nullptr; void* pf = nullptr;
+            hipError_t e1 = hipIpcOpenMemHandle(&pd, hd.data_ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e1 == hipSuccess) { P.peer_data[q] = (uint32_t*)pd; P.opened[q] |= 1u; }
+            hipError_t e2 = e1 == hipSuccess ? hipIpcOpenMemHandle(&pf, hd.flags_ipc, hipIpcMemLazyEnablePeerAccess) : e1;
+            if (e2 == hipSuccess) { P.peer_flags[q] = (uint32_t*)pf; P.opened[q] |= 2u; }
+            if (e2 != hipSuccess) { (void)hipGetLastError(); p2p_release(I); return fail(I, RFW_HIP_E_DEVICE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e2)); }
+        }
+    }
+    for (uint32_t k = 0; k <= I->slots.size(); k++) {
+        Instance* c = slot_ptr(I, k);
+        c->p2p_seq = 0; c->sample_count = 0; c->frame_elsewhere = false;
+        if (c->overflow_host) ((volatile uint32_t*)c->overflow_host)[1] = 0u;
+    }
+    P.connected = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_p2p_disconnect(void* inst)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream));
+    p2p_release(I);
+    for (uint32_t k = 0; k <= I->slots.size(); k++) { Instance* c = slot_ptr(I, k); c->frame_elsewhere = false; c->acc_source = nullptr; c->sample_count = 0; }
+    return RFW_HIP_OK;
+}
+
 int rfw_hip_set_blue_noise(void* inst, const uint32_t* table, uint32_t n_words)
 {
     LOCK(inst);
@@ -2076,6 +2269,7 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
 {
     LOCK(inst);
     if (w == 0 || h == 0) return fail(I, RFW_HIP_E_INVALID, "resize: zero size");
+    if (scene_of(I)->p2p.data && (w != I->width || h != I->height)) return fail(I, RFW_HIP_E_STATE, "resize: disconnect the p2p exchange first (its buffers are sized for the frame)");
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     for (Instance* c : I->slots) {
@@ -2193,6 +2387,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "sky_b") I->sky[2] = (float)value;
     else if (k == "sah_max_leaf") I->sah_max_leaf = std::max(1, std::min((int)value, kMaxLeafTris));
     else if (k == "sah_trav_cost") I->sah_trav_cost = (float)value;
+    else if (k == "p2p_timeout_ms") I->p2p.timeout_ticks = (uint64_t)std::max(1.0, value) * 100000ull;
     else if (k == "build_threads") I->build_threads = std::max(1, (int)value);
     else return fail(I, RFW_HIP_E_INVALID, "set_option: unknown key " + k);
     return RFW_HIP_OK;
@@ -2201,7 +2396,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
 // de-tiles the linear accumulator of the latest frame(s) into d_frame_acc, on the instance's stream (zeros before the first frame)
 static int materialize_accumulator(Instance* I)
 {
-    if (scene_of(I)->gather_format != 0 && (scene_of(I)->comm || I->external_slab))
+    if (scene_of(I)->gather_format != 0 && gathers_tiles(I))
         return fail(I, RFW_HIP_E_STATE, "read_accumulator: with gather_format 1 / 2 only the finished frame travels; the accumulators stay on the ranks that own the tiles");
     { const int rc = ensure_assembled(I); if (rc != RFW_HIP_OK) return rc; }
     const size_t px = (size_t)I->width * I->height * I->max_batch;
@@ -2235,7 +2430,7 @@ static int read_frame_impl(void* inst, uint32_t frame, bool accumulator, float* 
         const int rc = materialize_accumulator(I);
         if (rc != RFW_HIP_OK) return rc;
     } else {
-        if (scene_of(I)->gather_format == 2 && (scene_of(I)->comm || I->external_slab))
+        if (scene_of(I)->gather_format == 2 && gathers_tiles(I))
             return fail(I, RFW_HIP_E_STATE, "read_framebuffer: gather_format 2 leaves the PRESENTED frame only: rfw_hip_download_frame(what = 2)");
         const int rc = ensure_assembled(I);
         if (rc != RFW_HIP_OK) return rc;
@@ -2282,7 +2477,7 @@ int rfw_hip_download_frame(void* inst, uint32_t what, uint32_t frame, float* hos
         const int rc = ensure_assembled(c);
         if (rc != RFW_HIP_OK) return fail(I, rc, c->err);
     }
-    const bool sharded_presented = scene_of(c)->gather_format == 2 && (scene_of(c)->comm || c->external_slab);
+    const bool sharded_presented = scene_of(c)->gather_format == 2 && gathers_tiles(c);
     if (sharded_presented) { // the gathered frame IS the presented frame: de-tiled into d_present already, nothing to encode
         if (what != 2) return fail(I, RFW_HIP_E_STATE, "download_frame: gather_format 2 leaves the PRESENTED frame only (what = 2)");
         if (!c->presented_valid) return fail(I, RFW_HIP_E_STATE, "download_frame: no gathered frame yet");

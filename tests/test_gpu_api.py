@@ -398,6 +398,101 @@ def test_frame_slots_share_one_communicator():
     plain.close()
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_exchange_by_peer_stores(fmt, present_rank=0):
+    """VERDICT r02 #6c / SURVEY §8e's alternative to the all-gather: every rank packs its tiles straight into the destinations' receive buffers
+    and raises their arrival flags; a destination polls its own flags, de-tiles, and returns credits.  One GPU holds one rank per instance
+    here (three ranks of one process: peers are reached through their addresses, the multi-process mapping through hipIpcOpenMemHandle is
+    what tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu_p2p runs), with two frame slots each so that the credit of frame k
+    gates frame k + 2.  The presenting rank ends up with the single-GPU frame; a rank that only sends has no frame.  (Every rank a
+    destination, present_rank = -1, needs streams that wait for LATER launches of other streams: on one device that deadlocks as soon as
+    two of them share a hardware queue, so that case runs with one process per rank in the bench test.)"""
+    from rfw_rs_amd import BackendError, HipBackend, Scene
+    w, h = 200, 136
+    scene = Scene().build("soup", 1500, 5, 0.0, 4)
+    scene.set_aspect(w / h)
+    views = []
+    for i in range(5):
+        scene.set_camera([0.2 * i - 0.4, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    plain = HipBackend.init(w, h, 1.0, max_path_length=3)
+    scene.sync(plain)
+    world = 3
+    ranks = []
+    for r in range(world):
+        be = HipBackend.init(w, h, 1.0, max_path_length=3, rank=r, world=world, tile_size=32, frames_in_flight=2)
+        be.set_option("gather_format", fmt)
+        be.set_option("present_rank", present_rank)
+        be.set_option("p2p_timeout_ms", 3000)
+        scene.mark_all_changed(); scene.sync(be)
+        ranks.append(be)
+    handles = [be.p2p_export() for be in ranks]
+    assert all(len(hd) == 256 for hd in handles)
+    with pytest.raises(BackendError):
+        ranks[0].p2p_connect(handles[::-1])           # not in rank order
+    handles = [be.p2p_export() for be in ranks]       # (the failed connect released rank 0's buffers)
+    for be in ranks:
+        be.p2p_connect(handles)
+    with pytest.raises(BackendError):
+        ranks[0].resize((96, 64))                     # the buffers are sized for the frame
+    with pytest.raises(BackendError):
+        ranks[0].comm_init(HipBackend.comm_unique_id(), 0, world)
+    dests = range(world) if present_rank < 0 else [present_rank]
+    host = {r: [ranks[r].host_frame(presented=(fmt == 2)) for _ in views] for r in dests}
+    for i, v in enumerate(views):                     # nothing waits on the host: the streams wait for each other's flags
+        for r in reversed(range(world)):              # (senders first: with one presenting rank nobody ever waits for a later launch)
+            ranks[r].render(v)
+            if r in host:
+                ranks[r].download_frame(host[r][i], accumulator=False)
+    for r in dests:
+        ranks[r].wait_downloads()
+    for i, v in enumerate(views):
+        plain.reset_accumulation(); plain.render(v)
+        if fmt == 2:
+            want = plain.host_frame(presented=True)
+            plain.download_frame(want); plain.wait_downloads()
+        else:
+            want = plain.framebuffer()
+        for r in dests:
+            if fmt == 1:
+                assert np.array_equal(host[r][i][..., :3].astype(np.float16).view(np.uint16), want[..., :3].astype(np.float16).view(np.uint16)), (r, i)
+            else:
+                assert np.array_equal(host[r][i].view(np.uint32), want.view(np.uint32)), (r, i)
+    if present_rank >= 0:
+        with pytest.raises(BackendError):
+            ranks[1].framebuffer()                    # rank 1 only sent its tiles
+    for be in ranks:
+        be.device_synchronize()
+    for be in ranks:
+        be.p2p_disconnect()
+    ranks[0].render(views[0])                         # a sharded instance without an exchange again
+    for be in ranks + [plain]:
+        be.close()
+
+
+def test_exchange_by_peer_stores_times_out_instead_of_hanging():
+    """A peer that never renders: the wait gives up after p2p_timeout_ms and the next read fails."""
+    from rfw_rs_amd import BackendError, HipBackend, Scene
+    w, h = 96, 64
+    scene = Scene().build("cornell")
+    scene.set_aspect(w / h)
+    ranks = []
+    for r in range(2):
+        be = HipBackend.init(w, h, 1.0, rank=r, world=2, tile_size=32)
+        be.set_option("p2p_timeout_ms", 200)
+        scene.mark_all_changed(); scene.sync(be)
+        ranks.append(be)
+    handles = [be.p2p_export() for be in ranks]
+    for be in ranks:
+        be.p2p_connect(handles)
+    ranks[0].render(scene.view(w, h))                 # rank 1 never sends
+    ranks[0].device_synchronize()
+    with pytest.raises(BackendError):
+        ranks[0].framebuffer()
+    for be in ranks:
+        be.p2p_disconnect(); be.close()
+
+
 def test_packet_queries_are_four_single_ray_queries():
     """TIntersector::intersect4 / occludes4 (intersector.rs:129-166) in rtbvh's SoA packet layout."""
     from oracle.bindings import Oracle

@@ -292,6 +292,28 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook(gather_format):
     assert "distinct" in out["config"]["views"] or "cycled" in out["config"]["views"]
 
 
+@pytest.mark.parametrize("present_rank", [0, -1])
+def test_bench_two_ranks_on_one_gpu_p2p(present_rank):
+    """bench.py --collective p2p with one process per rank (both on this GPU): the handles travel through torch.distributed once, the
+    peers' buffers are mapped with hipIpcOpenMemHandle, the tiles travel as stores and the ranks meet in each other's flag words only.
+    With every rank a destination (-1) both ranks de-tile every frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RFW_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--workload", "cornell", "--width", "320", "--height", "200", "--no-cpu-baseline", "--collective", "p2p", "--present-rank", str(present_rank)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["config"]["collective"] == "p2p" and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
+    assert "frame slots" in out["config"]["frames_in_flight_held_by"]
+
+
 def test_animated_instances_match_oracle():
     """C3 in miniature: a grid of icosphere instances moved every frame -> set_3d_instances + synchronize + render."""
     w, h = 96, 64
