@@ -443,6 +443,10 @@ hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* work
     const Layout L = make_layout(n, cub_temp_bytes(n));
     if (L.total > workspace_bytes) return hipErrorInvalidValue;
     char* w = static_cast<char*>(workspace);
+    {   // test hook: nothing may depend on what the workspace held before
+        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
+        if (poison) (void)hipMemsetAsync(workspace, 0xCD, L.total, s);
+    }
     uint32_t* bounds = (uint32_t*)(w + L.bounds);
     uint32_t* keys_in = (uint32_t*)(w + L.keys_in);
     uint32_t* keys_out = (uint32_t*)(w + L.keys_out);

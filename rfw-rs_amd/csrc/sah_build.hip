@@ -318,8 +318,8 @@ __device__ inline void init_child(SNode& c, uint32_t first, uint32_t count, cons
 
 // one wavefront per active node; the winning lane creates the two children and files each of them: more than kSmall primitives -> the next
 // level's list (its bins cleared by the wavefront), else the queue of phase 2
-__global__ __launch_bounds__(kBlock) void k_split(const uint32_t* __restrict__ active, uint32_t* active_out, uint32_t level, Counters* ctr, SNode* nodes, Bin* bins,
-                                                 uint32_t* bin_slot, uint8_t* stamp, Split* splits, uint32_t* fill, uint32_t* small, uint32_t replicas,
+__global__ __launch_bounds__(kBlock) void k_split(const uint32_t* __restrict__ active, uint32_t* active_out, uint32_t level, Counters* ctr, SNode* nodes,
+                                                 const Bin* __restrict__ bins, Bin* bins_next, uint32_t* bin_slot, uint8_t* stamp, Split* splits, uint32_t* fill, uint32_t* small, uint32_t replicas,
                                                  uint32_t replicas_next, uint32_t small_cap)
 {
     __shared__ Bin s_sum[kBlock / 64][3 * kBins];
@@ -375,15 +375,17 @@ __global__ __launch_bounds__(kBlock) void k_split(const uint32_t* __restrict__ a
             }
         }
     }
-    // the bins of the children that go on: cleared by 48 lanes each
+    // the bins of the children that go on: cleared by 48 lanes each.  They live in the OTHER of two bin arrays (by level parity): the
+    // wavefronts of this launch run in any order, and a child's slot on the next level says nothing about whose bins of THIS level it
+    // would overwrite (found as a memory fault / hang with two processes sharing the device: a late wavefront read bins an early one had cleared)
     slot_l = (uint32_t)__shfl((int)slot_l, (int)writer);
     slot_r = (uint32_t)__shfl((int)slot_r, (int)writer);
     {
         Bin e; e.count = 0;
         for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
         for (uint32_t q = lane; q < replicas_next * 3 * kBins; q += 64u) {
-            if (slot_l != kNone) bins[(size_t)slot_l * replicas_next * 3 * kBins + q] = e;
-            if (slot_r != kNone) bins[(size_t)slot_r * replicas_next * 3 * kBins + q] = e;
+            if (slot_l != kNone) bins_next[(size_t)slot_l * replicas_next * 3 * kBins + q] = e;
+            if (slot_r != kNone) bins_next[(size_t)slot_r * replicas_next * 3 * kBins + q] = e;
         }
     }
 }
@@ -1017,7 +1019,7 @@ __global__ void k_refit_up(Node4* nodes, uint32_t n_nodes, const uint32_t* __res
 }
 
 struct Layout {
-    size_t ctr, nodes, order[2], nop[2], pbox[2], active[2], small, bin_slot, stamp, splits, fill, bins, flag4, idx4, cub, total, cub_bytes;
+    size_t ctr, nodes, order[2], nop[2], pbox[2], active[2], small, bin_slot, stamp, splits, fill, bins[2], flag4, idx4, cub, total, cub_bytes;
     uint32_t node_cap, big_cap;
 };
 Layout make_layout(uint32_t n)
@@ -1036,7 +1038,7 @@ Layout make_layout(uint32_t n)
     L.stamp = take((size_t)L.node_cap);
     L.splits = take((size_t)L.node_cap * sizeof(Split));
     L.fill = take((size_t)L.node_cap * 4);
-    L.bins = take(((size_t)L.big_cap + 512) * 3 * kBins * sizeof(Bin)); // (nodes of a level) x (replicas of that level) <= max(big_cap, 256 + ...)
+    for (int k = 0; k < 2; k++) L.bins[k] = take(((size_t)L.big_cap + 512) * 3 * kBins * sizeof(Bin)); // (nodes of a level) x (replicas of that level) <= max(big_cap, 256 + ...); one array per level parity
     L.flag4 = take((size_t)L.node_cap * 4);
     L.idx4 = take((size_t)L.node_cap * 4);
     size_t cb = 0;
@@ -1060,6 +1062,10 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     if (L.total > workspace_bytes) return hipErrorInvalidValue;
     max_leaf = max_leaf < 1 ? 1 : (max_leaf > kMaxLeafTris ? kMaxLeafTris : max_leaf);
     char* w = static_cast<char*>(workspace);
+    {   // test hook: nothing may depend on what the workspace held before (tests/test_gpu_builders.py poisons it)
+        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
+        if (poison) (void)hipMemsetAsync(workspace, 0xCD, L.total, s);
+    }
     Counters* ctr = (Counters*)(w + L.ctr);
     SNode* nodes = (SNode*)(w + L.nodes);
     uint32_t* order[2] = {(uint32_t*)(w + L.order[0]), (uint32_t*)(w + L.order[1])};
@@ -1071,7 +1077,7 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     DevBox* pbox[2] = {(DevBox*)(w + L.pbox[0]), (DevBox*)(w + L.pbox[1])};
     Split* splits = (Split*)(w + L.splits);
     uint32_t* fill = (uint32_t*)(w + L.fill);
-    Bin* bins = (Bin*)(w + L.bins);
+    Bin* bins[2] = {(Bin*)(w + L.bins[0]), (Bin*)(w + L.bins[1])};
     uint32_t* flag4 = (uint32_t*)(w + L.flag4);
     uint32_t* idx4 = (uint32_t*)(w + L.idx4);
 
@@ -1087,7 +1093,7 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     auto level_ub = [&](int l) { return (uint32_t)std::min<uint64_t>(l < 31 ? (1ull << l) : (1ull << 31), (uint64_t)n / small_cap + 1); };
     const uint32_t bin_groups = blocks(n); // workgroups of k_bin
     auto level_replicas = [&](int l) { return std::max(1u, std::min(32u, bin_groups / (8u * level_ub(l)))); };
-    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, stamp, bins, level_replicas(0), small_cap);
+    hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, stamp, bins[0], level_replicas(0), small_cap);
     static const bool dbg = getenv("RFW_SAH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto msf = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
@@ -1101,8 +1107,8 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
         const uint32_t par = (uint32_t)(level & 1);
         const uint32_t ub = level_ub(level), reps = level_replicas(level), reps_next = level_replicas(level + 1);
         const DevBox* pin = level == 0 ? boxes : pbox[cur]; // level 0: the order is the identity, the input boxes ARE position-ordered
-        hipLaunchKernelGGL(k_bin, dim3(bin_groups), dim3(kBlock), 0, s, pin, nop[cur], nodes, bin_slot, stamp, bins, n, ctr, (uint32_t)level, reps);
-        hipLaunchKernelGGL(k_split, dim3(blocks(ub, kBlock / 64)), dim3(kBlock), 0, s, active[par], active[par ^ 1], (uint32_t)level, ctr, nodes, bins, bin_slot, stamp, splits, fill,
+        hipLaunchKernelGGL(k_bin, dim3(bin_groups), dim3(kBlock), 0, s, pin, nop[cur], nodes, bin_slot, stamp, bins[par], n, ctr, (uint32_t)level, reps);
+        hipLaunchKernelGGL(k_split, dim3(blocks(ub, kBlock / 64)), dim3(kBlock), 0, s, active[par], active[par ^ 1], (uint32_t)level, ctr, nodes, bins[par], bins[par ^ 1], bin_slot, stamp, splits, fill,
                            small, reps, reps_next, small_cap);
         if (ub * 64u <= blocks(n)) // few nodes, each across many blocks: chunks of blocks take their slots together
             hipLaunchKernelGGL(k_partition_chunk, dim3(blocks(n, kPartChunk * kBlock)), dim3(kBlock), 0, s, pin, pbox[cur ^ 1], order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1],

@@ -314,6 +314,41 @@ def test_bench_two_ranks_on_one_gpu_p2p(present_rank):
     assert "frame slots" in out["config"]["frames_in_flight_held_by"]
 
 
+_CONTENDED_BUILDS = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1])
+from rfw_rs_amd import HipBackend, Scene
+w, h = 256, 144
+scene = Scene().build("atrium", 1048576, 0, 0.0, 0xC0FFEE)
+scene.set_aspect(w / h)
+view = scene.view(w, h)
+for k in range(int(sys.argv[2])):
+    be = HipBackend.init(w, h, 1.0, builder=int(sys.argv[3]))
+    scene.mark_all_changed(); scene.sync(be)
+    be.render(view)
+    print(hashlib.sha1(be.accumulator().tobytes()).hexdigest(), flush=True)
+    be.close()
+"""
+
+
+def test_device_builder_while_another_process_uses_the_device():
+    """Regression (round 3): the level kernels of the binned-SAH builder run their wavefronts in any order, and one of them cleared the
+    NEXT level's bins in the array another was still reading THIS level's bins from — invisible while a launch's wavefronts start together,
+    a memory fault or a hang (one build in five) as soon as a second process time-slices the device, which is how two ranks share a GPU.
+    Two processes build the 1 M-triangle scene six times each, side by side; every build must give the image of the host builder's tree."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    ref = subprocess.run([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "1", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    want = ref.stdout.split()[-1]
+    procs = [subprocess.Popen([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "6", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        assert out.split() == [want] * 6
+
+
 def test_animated_instances_match_oracle():
     """C3 in miniature: a grid of icosphere instances moved every frame -> set_3d_instances + synchronize + render."""
     w, h = 96, 64
