@@ -156,7 +156,9 @@ struct CameraParams {
     float sky[3]; float pad2;
     // a batch of independent frames traced as ONE tall virtual frame (rfw_hip_render_batch): frame f owns paths
     // [f * frame_capacity, (f + 1) * frame_capacity); a path carries f in the top byte of its path-id word
-    uint32_t batch, frame_capacity, pad3, pad4;
+    // streaming trace kernels (traverse.h, traverse_stream): a wavefront owns stream_run x 64 consecutive queue entries and hands a new ray to its idle
+    // lanes whenever stream_refill of them are idle; stream_run = 0: one ray per lane, the wavefront lasts as long as its longest ray
+    uint32_t batch, frame_capacity, stream_run, stream_refill;
     // sample index of every frame of a batch (seeds the RNG / indexes the blue-noise sequence): 0 for rfw_hip_render_batch's new images,
     // first_sample + f for rfw_hip_render_samples
     uint32_t batch_sample[16];

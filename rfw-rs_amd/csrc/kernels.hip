@@ -17,6 +17,12 @@
 #ifndef RFW_TRACE_WAVES
 #define RFW_TRACE_WAVES 6
 #endif
+#ifndef RFW_STREAM_WAVES
+#define RFW_STREAM_WAVES 6      // waves per SIMD the streaming closest-hit kernel is compiled for
+#endif
+#ifndef RFW_STREAM_WAVES_ANY
+#define RFW_STREAM_WAVES_ANY 8  // the same for the streaming any-hit kernel
+#endif
 #ifndef RFW_TRACE_WAVES_ANY
 #define RFW_TRACE_WAVES_ANY 8
 #endif
@@ -237,6 +243,13 @@ RFW_DI uint32_t xcd_block(const uint32_t b)
     return (((b >> 9) << 3) + (b & 7u)) * 64u + ((b & 511u) >> 3);
 }
 
+// the same for the streaming kernels, whose wavefronts own runs of 64 x run entries: a 64x64-pixel tile is 64 / run wavefronts
+RFW_DI uint32_t xcd_run(const uint32_t b, const uint32_t per_tile)
+{
+    const uint32_t group = 8u * per_tile;
+    return ((b / group) * 8u + (b & 7u)) * per_tile + ((b % group) >> 3);
+}
+
 // ---------------------------------------------------------------- ray_gen.comp:39-70
 template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
@@ -366,6 +379,49 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
     flush_counters<COUNT>(sc.counters, tc, 1);
 }
 
+// The streaming flavour (traverse.h, traverse_stream): a wavefront owns cam.stream_run x 64 consecutive entries of the extension queue
+struct ExtendStream {
+    const PathDev& p;
+    const uint32_t* order;
+    uint32_t half;
+    uint32_t next, end; // wave-uniform: the run's entries not handed out yet
+    uint32_t j;         // the lane's entry
+    RFW_DI bool more() const { return next < end; }
+    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t_min, float& t)
+    {
+        const uint32_t i = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        if (i >= end) return false;
+        j = order ? order[i] : i;
+        const float4 o4 = p.ray_o[half][j], d4 = p.ray_d[half][j];
+        O = mk3(o4.x, o4.y, o4.z);
+        D = mk3(d4.x, d4.y, d4.z);
+        t_min = 1e-4f;
+        t = 1e26f;
+        return true;
+    }
+    RFW_DI void advance(const uint64_t idle) { next += (uint32_t)__popcll(idle); }
+    RFW_DI void commit(bool, const float t, const float hu, const float hv, const int32_t hi, const int32_t ht)
+    {
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.hit[half][j] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    }
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES) void k_extend_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce,
+                                                                                const uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    const uint32_t run = cam.stream_run * kTraceBlock;
+    const uint32_t block = xcd_run(blockIdx.x, 64u / cam.stream_run);
+    const uint32_t count = sc.counters->ext[bounce - 1];
+    if (block * run >= count) return;
+    TravCounters tc{0, 0, 0};
+    ExtendStream st{p, order, bounce & 1u, block * run, min(count, (block + 1u) * run), 0u};
+    const SceneView sv = scene_view(sc);
+    traverse_stream<false, COUNT, false>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, tc);
+    flush_counters<COUNT>(sc.counters, tc, 1);
+}
+
 // ---------------------------------------------------------------- ray_shadow.comp:245-268
 // Buckets are walked from the LAST light index down (directional lights come last in the reference's light order, shade.comp:471-527): a
 // measured choice — k_shadow alone 0.364 -> 0.336 ms when it was made, 0.382 -> 0.329 ms with the far-to-near order of the directional
@@ -431,6 +487,67 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
             p.acc[slot] = a;
         }
     }
+    flush_counters<COUNT>(sc.counters, tc, 2);
+}
+
+struct ShadowStream {
+    const PathDev& p;
+    uint32_t base;      // the bucket's first queue entry
+    uint32_t next, end; // wave-uniform: the run's entries (bucket-local) not handed out yet
+    uint32_t idx;       // the lane's entry
+    RFW_DI bool more() const { return next < end; }
+    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t_min, float& t)
+    {
+        const uint32_t i = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        if (i >= end) return false;
+        idx = base + i;
+        const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
+        O = mk3(o4.x, o4.y, o4.z);
+        D = mk3(d4.x, d4.y, d4.z);
+        t_min = 0.001f;
+        t = d4.w - 0.0001f;
+        if (t > 3.0e38f) t = 3.0e38f;
+        return true;
+    }
+    RFW_DI void advance(const uint64_t idle) { next += (uint32_t)__popcll(idle); }
+    RFW_DI void commit(const bool occluded, float, float, float, int32_t, int32_t)
+    {
+        if (occluded) return;
+        const float4 e = p.sh_e[idx];
+        const uint32_t slot = fbits(e.w);
+        float4 a = p.acc[slot]; // single writer per pixel per pass, whichever lane traces the ray
+        a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
+        p.acc[slot] = a;
+    }
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+{
+    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
+    const uint32_t run = cam.stream_run * kTraceBlock;
+    uint32_t block = xcd_run(blockIdx.x, 64u / cam.stream_run);
+    uint32_t bucket = 0, count = 0;
+    {
+        bool found = false;
+        for (int kk = 0; kk < kShadowBuckets; kk++) {
+            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            const uint32_t c = sc.counters->shadow[bounce][k];
+            const uint32_t nb = (c + run - 1u) / run;
+            if (!found) {
+                if (block < nb) { found = true; bucket = (uint32_t)k; count = c; }
+                else block -= nb;
+            }
+        }
+        if (!found) return;
+    }
+    TravCounters tc{0, 0, 0};
+    ShadowStream st{p, bucket * p.capacity, block * run, min(count, (block + 1u) * run), 0u};
+    const SceneView sv = scene_view(sc);
+    const uint32_t spill_slot = blockIdx.x * kTraceBlock + threadIdx.x;
+    const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional)
+                                                                                             : (cam.flags & kFlagFarFirstPositional) != 0u);
+    if (far_first) traverse_stream<true, COUNT, true>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
+    else traverse_stream<true, COUNT, false>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
     flush_counters<COUNT>(sc.counters, tc, 2);
 }
 
@@ -900,7 +1017,14 @@ void launch_primary_batch(hipStream_t s, const CameraParams& cam, const BatchVie
 }
 void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count, const uint32_t* order)
 {
-    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
+    const dim3 block(kTraceBlock);
+    if (cam.stream_run) {
+        const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + 511u) & ~511u);
+        if (count) hipLaunchKernelGGL(k_extend_stream<true>, grid, block, 0, s, cam, sc, p, bounce, order);
+        else hipLaunchKernelGGL(k_extend_stream<false>, grid, block, 0, s, cam, sc, p, bounce, order);
+        return;
+    }
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u);
     if (count) hipLaunchKernelGGL(k_extend<true>, grid, block, 0, s, cam, sc, p, bounce, order);
     else hipLaunchKernelGGL(k_extend<false>, grid, block, 0, s, cam, sc, p, bounce, order);
 }
@@ -911,7 +1035,16 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
-    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + kShadowBuckets + 511u) & ~511u), block(kTraceBlock);
+    const dim3 block(kTraceBlock);
+    // streaming pays where a wavefront's rays differ in length and direction: the shadow rays of the bounces.  The camera paths' own shadow rays
+    // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too)
+    if (cam.stream_run && bounce >= 1u) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
+        const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + kShadowBuckets + 511u) & ~511u);
+        if (count) hipLaunchKernelGGL(k_shadow_stream<true>, grid, block, 0, s, cam, sc, p, bounce);
+        else hipLaunchKernelGGL(k_shadow_stream<false>, grid, block, 0, s, cam, sc, p, bounce);
+        return;
+    }
+    const dim3 grid((ceil_div(p.capacity, kTraceBlock) + kShadowBuckets + 511u) & ~511u);
     if (cam.batch > 1) {
         if (count) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, s, cam, sc, p, bounce);
         else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, s, cam, sc, p, bounce);

@@ -180,6 +180,47 @@ def test_sorted_extension_rays_give_the_same_image():
     be.close()
 
 
+@pytest.mark.parametrize("run,refill", [(1, 16), (4, 1), (4, 16), (16, 48), (64, 64)])
+def test_streaming_trace_kernels_give_the_same_image(run, refill):
+    """Options stream_run / stream_refill: a wavefront of the shadow and extension kernels owns run x 64 consecutive queue entries and hands
+    new rays to its idle lanes whenever `refill` of them are idle.  Which LANE traces a ray is no part of the answer: image, ray counts and
+    node visits equal the oracle's and the one-ray-per-lane kernels', with the sorted extension order, frame slots and batches too."""
+    w, h = 200, 136
+    scene, be, orc = make("soup", w, h, 2500, 6, seed=13, max_path_length=4, frames_in_flight=2, max_batch=3)
+    orc.set_option("max_path_length", 4)
+    view = scene.view(w, h)
+    be.set_option("count_traversal", 1)
+    be.set_option("stream_run", 0)              # one ray per lane
+    be.render(view)
+    plain = be.frame_stats()
+    be.reset_accumulation()
+    be.set_option("stream_run", run)
+    be.set_option("stream_refill", refill)
+    for k in range(2):
+        be.render(view); orc.render(view)
+        if k == 0:
+            s = be.frame_stats()
+            for key in ("primary_rays", "shadow_rays", "extension_rays", "tris_tested", "instances_entered"):
+                assert s[key] == plain[key], key   # every ray does what it did, whichever lane it ran on
+            # (a closest-hit lane that waits at a leaf for company meets its later nodes with the SAME ray interval — the order of its own
+            # steps does not change — so the node visits are the same too)
+            assert s["nodes_visited"] == plain["nodes_visited"]
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    be.set_option("count_traversal", 0)
+    be.set_option("sort_extension_rays", 1)
+    views = []
+    for i in range(3):
+        scene.set_camera([0.3 * i - 0.3, 0.3, -4.0], [0.0, 0.0, 1.0], fov=45.0, aspect=w / h)
+        views.append(scene.view(w, h))
+    be.render_batch(views)
+    for f, v in enumerate(views):
+        orc.reset(); orc.render(v)
+        assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+    with pytest.raises(Exception):
+        be.set_option("stream_run", 3)          # runs are powers of two (a 64x64-pixel tile is a whole number of them)
+    be.close()
+
+
 @pytest.mark.parametrize("kind,a,b", [("atrium", 30000, 0), ("soup", 2000, 4)])
 def test_shadow_order_option_never_changes_the_image(kind, a, b):
     """Option shadow_order: which end of a shadow ray the any-hit traversal starts from (default: directional lights far to near, positional
