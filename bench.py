@@ -37,6 +37,31 @@ CLOCK_GHZ = 2.4              # peak engine clock (the busy-cycle fractions below
 N_VIEWS = 16                 # distinct camera views the frames cycle through
 
 
+def kernel_source_hash():
+    """sha1 over the sources the device code is built from (rfw-rs_amd/csrc: *.hip, *.h, *.inc, *.cpp, Makefile), in name order.  Counter
+    summaries under profiles/ carry the hash of the sources they were measured on (tools/summarize_profile.py); instruction and request
+    counts are properties of (scene, view, kernel code), so they may only be divided by THIS run's durations when the code is the same."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "rfw-rs_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+def config_key(args):
+    """The configuration of BASELINE.json this run is (the tag of its counter summaries under profiles/), or None."""
+    if args.width != 1920 or args.height != 1080 or args.identical_frames or args.emulate_shard:
+        return None
+    if args.workload == "atrium1m":
+        return {1: "c4", 3: "c4path"}.get(args.max_path_length)
+    if args.max_path_length != 1:
+        return None
+    return {"atrium262k": "c2", "spheres10k": "c3"}.get(args.workload)
+
+
 def dolly_views(base, n, step):
     """n camera views: `base` translated k * step along its viewing direction (pos and the virtual screen's corner move together)."""
     from rfw_rs_amd import pod
@@ -198,6 +223,28 @@ def main():
     be = bes[0]
     sstats = be.scene_stats()
     torch.cuda.synchronize()
+    # the acceleration-structure build, warm: everything changed -> synchronize(), three times; the device's share by events
+    build_report = None
+    if rank == 0 and single and not animated:
+        warm = []
+        for _ in range(3):
+            scene.mark_all_changed()
+            t_b = time.perf_counter()
+            scene.sync(be)
+            be.device_synchronize()
+            warm.append((time.perf_counter() - t_b) * 1e3)
+        bs = be.scene_stats()
+        up_ms, k_ms = bs["ms_blas_upload"], bs["ms_blas_kernels"]
+        build_report = {
+            "synchronize_warm_ms": [round(x, 2) for x in warm],
+            "note": "synchronize() after every mesh changed: host copies of the meshes, host -> device copy of the triangles (176 B each), then on the device boxes, "
+                    "binned-SAH builder, leaf-ordered packets, quantised nodes; the last two figures by HIP events on the instance's stream",
+            "triangle_upload": {"ms": round(up_ms, 3), "bytes": bs["blas_upload_bytes"], "GBps": round(bs["blas_upload_bytes"] / max(up_ms, 1e-6) / 1e6, 1)},
+            "device_kernels": {"ms": round(k_ms, 3), "algorithmic_bytes": bs["blas_kernel_bytes"],
+                               "algorithmic_GBps": round(bs["blas_kernel_bytes"] / max(k_ms, 1e-6) / 1e6, 1),
+                               "frac_of_hbm_peak": round(bs["blas_kernel_bytes"] / max(k_ms, 1e-6) / 1e6 / HBM_PEAK_GBS, 4),
+                               "bound": "kernel launches and device-scope atomics on the upper levels (few nodes, each across thousands of workgroups), not bandwidth"},
+        }
 
     frame_no = [0]
     sync_ms = [0.0]
@@ -471,10 +518,20 @@ def main():
             # per path: hit 16 + ray 32 read; per hit: RTTriangle 176 + material 96 + normal matrix 48; shadow-queue push 48 per shadow ray
             "k_shade": n_prim * (16 + 32) + n_prim * (176 + 96 + 48) + n_shad * 48,
         }
+        n_ext = mean("extension_rays")
+        if n_ext:
+            # the extension rays of ALL bounces of a frame: 32 B of ray read and 16 B of hit record written per ray
+            alg["k_extend"] = mean("nodes_visited", 1) * node_b + mean("tris_tested", 1) * tri_b + mean("instances_entered", 1) * 64 + n_ext * (32 + 16)
         kms = None
         if iso and iso[1] > 0:
             kms = {"k_primary": iso[0]["ms_trace_primary"] / iso[1], "k_shadow": iso[0]["ms_trace_shadow"] / iso[1], "k_shade": iso[0]["ms_shade"] / iso[1]}
-        roofline = build_roofline(alg, kms, ms_step, sum(alg.values()), bw_measured, args, single)
+            if "k_extend" in alg:
+                kms["k_extend"] = iso[0]["ms_trace_extend"] / iso[1]
+            # launches of a kernel per frame: the ms above are sums over them, the counters of profiles/ are means per launch
+            # (shadow rays: bounce 0 is traced one ray per lane by k_shadow, the bounces by the streaming flavour k_shadow_stream)
+            launches = {"k_primary": 1, "k_shade": args.max_path_length, "k_shadow": 1, "k_shadow_stream": max(args.max_path_length - 1, 0),
+                        "k_extend": max(args.max_path_length - 1, 1)}
+        roofline = build_roofline(alg, kms, ms_step, sum(alg.values()), bw_measured, args, single, launches if kms else None)
         roofline["nodes_per_ray"] = {"primary": round(mean("nodes_visited", 0) / max(n_prim, 1), 2), "shadow": round(mean("nodes_visited", 2) / max(n_shad, 1), 2)}
         roofline["tris_per_ray"] = {"primary": round(mean("tris_tested", 0) / max(n_prim, 1), 2), "shadow": round(mean("tris_tested", 2) / max(n_shad, 1), 2)}
         # SIMD efficiency of the traversal, from the instrumented frames: active lanes / 64 per execution of the node test and of the
@@ -502,7 +559,7 @@ def main():
                        "tile_shard": "64x64 round-robin" if world > 1 else "none", "collective": (args.collective if world > 1 else None),
                        "gather_format": (args.gather_format if (world > 1 or args.emulate_shard) else None), "present_rank": (args.present_rank if world > 1 else None),
                        "gather_bytes_per_frame": ({"f32": 12, "f16": 6, "bgra8": 4}[args.gather_format] * w * h if world > 1 else None),
-                       "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1)},
+                       "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1), "build": build_report},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
                        "per_frame_synchronize_ms": round(host_sync_ms, 3) if animated else None,
@@ -543,14 +600,16 @@ def latest_profile(pattern):
 
 
 def profile_kernel(kernels, name):
-    """The entry of kernel `name` in a committed PMC summary: the non-counting, single-frame instantiation as the profiler prints it."""
-    for n in (name + "<false, false>", name + "<false,false>", name + "<false>", name):
+    """The entry of kernel `name` in a committed PMC summary: the non-counting, single-frame instantiation as the profiler prints it.
+    (k_extend: the streaming flavour when that is what ran.  k_shadow of a path-traced frame: bounce 0 only — the bounces' streaming
+    launches are listed as k_shadow_stream and are not folded in.)"""
+    for n in ((name + "_stream<false>",) if name == "k_extend" else ()) + (name + "<false, false>", name + "<false,false>", name + "<false>", name):
         if n in kernels:
             return kernels[n]
     return None
 
 
-def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
+def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, launches=None):
     """Which ceiling bounds the dominant kernel: every candidate as a fraction <= 1 of its own peak, the highest one is `bound`.
 
     Live in this run: the kernels' mean launch durations (HIP events on the launch stream, one frame at a time) and the algorithmic
@@ -558,9 +617,19 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
     counters cannot be read from inside the process): wave64 VALU instructions, vector-memory read instructions, L2 requests and
     HBM-side bytes per launch.  Instruction counts are properties of (scene, view, kernel code), so dividing them by the live
     duration is legitimate as long as the profile is of the same code; the profile's tag is named in `counters_from`."""
-    pv, pm, pc = latest_profile("*_pmc_valu.json"), latest_profile("*_pmc.json"), latest_profile("*_pmc_cache.json")
-    usable = args.workload == "atrium1m" and args.max_path_length == 1 and single and args.width == 1920 and args.height == 1080
+    cfg = config_key(args) if single else None
+    pv, pm, pc = (latest_profile(f"*_{cfg}_pmc_valu.json"), latest_profile(f"*_{cfg}_pmc.json"), latest_profile(f"*_{cfg}_pmc_cache.json")) if cfg else (None, None, None)
+    usable = bool(cfg) and any((pv, pm, pc))
     r = {"unit": "GB/s", "counters_from": [p[1] for p in (pv, pm, pc) if p] if usable else None}
+    if usable:
+        # counters measured on other kernel sources say nothing about this build: refuse them rather than print ceilings of another program
+        here = kernel_source_hash()
+        stale = [p[1] for p in (pv, pm, pc) if p and p[0].get("source_hash") != here]
+        if stale:
+            usable = False
+            r["counters_from"] = None
+            r["stale_counters"] = {"files": stale, "note": "measured on other kernel sources than this checkout's (source_hash differs): not used; re-run tools/measure.sh"}
+    launches = launches or {}
     if not kms or not any(kms.values()):
         r.update({"bound": None, "kernel": None, "achieved": None, "peak": None, "frac": None, "traffic": None,
                   "note": "no isolated per-kernel durations in this configuration (kernels of frames in flight overlap)"})
@@ -580,22 +649,23 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
             kv = profile_kernel(pv[0]["kernels"], n) if pv else None
             km = profile_kernel(pm[0]["kernels"], n) if pm else None
             kc = profile_kernel(pc[0]["kernels"], n) if pc else None
+            nl = launches.get(n, 1)  # launches of this kernel per frame (the summaries hold means per launch)
             if kv and kv.get("SQ_INSTS_VALU"):
-                tot["valu"] += kv["SQ_INSTS_VALU"]; tot["vmem"] += kv.get("SQ_INSTS_VMEM_RD", 0)
+                tot["valu"] += nl * kv["SQ_INSTS_VALU"]; tot["vmem"] += nl * kv.get("SQ_INSTS_VMEM_RD", 0)
             else:
                 have["valu"] = False
             if kc and kc.get("TA_BUSY_avr"):
-                tot["ta_busy"] += kc["TA_BUSY_avr"]
+                tot["ta_busy"] += nl * kc["TA_BUSY_avr"]
                 if kc.get("l1_hit_rate") is not None:
                     tot["l1_hit"].append(kc["l1_hit_rate"])
             else:
                 have["ta"] = False
             if kc and kc.get("l2_request_bytes_per_launch"):
-                tot["l2"] += kc["l2_request_bytes_per_launch"]; tot["l2_hit"].append(kc.get("l2_hit_rate"))
+                tot["l2"] += nl * kc["l2_request_bytes_per_launch"]; tot["l2_hit"].append(kc.get("l2_hit_rate"))
             else:
                 have["l2"] = False
             if km:
-                tot["hbm"] += km["hbm_bytes_per_launch_corrected"]
+                tot["hbm"] += nl * km["hbm_bytes_per_launch_corrected"]
             else:
                 have["hbm"] = False
         if have["valu"] and tot["valu"]:
@@ -617,15 +687,16 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single):
             c["hbm"] = {"achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "per_launch_bytes": int(tot["hbm"]),
                         "note": "L2 fabric-side requests (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits are included, so true HBM bytes are lower still"}
             if len(names) == 1:
-                traffic = int(tot["hbm"])
+                traffic = int(tot["hbm"] / max(launches.get(names[0], 1), 1))  # per launch, like `achieved`
         return c
 
     dur = kms[dom] * 1e-3
     ceilings = ceilings_of([dom], dur)
     # the timed region as a whole: one launch of every kernel of a frame over the wall time per frame (frames in flight overlap, so this is
     # the utilisation the chip actually runs at, where the per-kernel figures above are launches with the machine to themselves)
-    steady = ceilings_of(["k_primary", "k_shade", "k_shadow", "k_assemble"], ms_step * 1e-3)
-    contract = {"algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
+    steady = ceilings_of(["k_primary", "k_shade", "k_shadow", "k_assemble"] + (["k_extend", "k_shadow_stream"] if "k_extend" in kms else []), ms_step * 1e-3)
+    nl_dom = max(launches.get(dom, 1), 1)
+    contract = {"algorithmic_bytes_per_launch": int(alg[dom] / nl_dom), "avg_launch_ms": round(kms[dom] / nl_dom, 4), "launches_per_frame": nl_dom,
                 "algorithmic_GBps": round(alg[dom] / dur / 1e9, 1), "hbm_peak_GBps": HBM_PEAK_GBS,
                 "measured_copy_GBps": round(bw_measured, 1) if bw_measured else None,
                 "note": "SURVEY §8(d)'s figure: bytes the rays of one launch ask for, lane by lane.  64 coherent lanes share most node fetches, so this is an UPPER bound on traffic, "

@@ -118,6 +118,12 @@ typedef struct {
     uint32_t tri_bytes;
     float ms_blas_build;  /* last synchronize */
     float ms_tlas_build;
+    /* the last device build of (all, or the changed) meshes, by HIP events on the instance's stream: the host -> device copy of their
+     * triangles, and the kernels behind it (boxes, builder, leaf-ordered packets, quantised nodes); 0 when the host built */
+    float ms_blas_upload;
+    float ms_blas_kernels;
+    uint64_t blas_upload_bytes;   /* triangles x 176 B */
+    uint64_t blas_kernel_bytes;   /* ALGORITHMIC bytes of those kernels (what each pass reads and writes per primitive) */
 } rfw_hip_scene_stats;
 
 /* Hit record of the ray-query extension: what ray_gen/ray_extend store per path

@@ -327,6 +327,10 @@ struct Instance {
     PinnedRing pins;
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
+    float ms_blas_upload = 0, ms_blas_kernels = 0; // the last full device build, by events
+    uint64_t blas_upload_bytes = 0, blas_kernel_bytes = 0;
+    hipEvent_t ev_build[3] = {nullptr, nullptr, nullptr};
+    bool build_events_pending = false; // recorded, not read yet (rfw_hip_get_scene_stats reads them: no synchronisation for them in synchronize())
 
     // device path state
     DevBuf<float4> d_ray_o[2], d_ray_d[2], d_thr[2], d_sh_o, d_sh_d, d_sh_e, d_acc_slab, d_frame_acc, d_frame_out;
@@ -669,6 +673,16 @@ int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
     return upload(I, I->d_skin_data, skin_all.data(), skin_all.size());
 }
 
+// ALGORITHMIC bytes of the device passes over one mesh of n triangles (rfw_hip_scene_stats.blas_kernel_bytes), per primitive: boxes (176 in,
+// 32 out); per builder level above the hand-over size bin (32 + 4 in) and partition (32 + 4 + 4 in, the same out) = 116; the workgroup phase
+// (32 + 4 in, 4 out); packets (176 + 4 in, 48 out); and per wide node (~ n / 4) 128 B written by the emitter, 128 read and 64 written by the quantiser
+uint64_t build_pass_bytes(uint64_t n)
+{
+    uint32_t levels = 0;
+    for (uint64_t v = n / 512u; v > 0; v >>= 1) levels++;
+    return n * (208u + 116u * levels + 40u + 228u) + (n / 4u) * 320u;
+}
+
 // One static mesh on the device, into the region its record names: boxes -> BVH (binned SAH, or LBVH) -> leaf-ordered packets ->
 // quantised nodes.  The triangles are already in d_triangles.  `quantise_count` nodes of the region are quantised (the region is sized for
 // the worst case, one node per primitive; nodes behind the tree's own are never referenced).
@@ -744,6 +758,9 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
     HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
+    for (auto& ev : I->ev_build)
+        if (!ev) HIP_TRY(I, hipEventCreate(&ev));
+    HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
     uint32_t max_n = 0;
     size_t k = 0;
     for (auto& kv : I->meshes) {
@@ -756,13 +773,21 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
     HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
-    for (size_t q = 0; q < n_static; q++)
+    HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
+    uint64_t kernel_bytes = 0;
+    for (size_t q = 0; q < n_static; q++) {
         if ((rc = build_mesh_device(I, (uint32_t)q, 0u))) return rc;
+        kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count);
+    }
     launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
+    HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    I->build_events_pending = true;
+    I->blas_upload_bytes = (uint64_t)static_tris * sizeof(rfw_rt_triangle);
+    I->blas_kernel_bytes = kernel_bytes;
     // nodes actually in use (the regions are sized for the worst case, one node per primitive); skinned copies count at their worst case
     std::vector<uint32_t> counts(n_static, 0u);
     if (n_static) HIP_TRY(I, hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
@@ -838,12 +863,17 @@ int build_blas_device_incremental(Instance* I)
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, 1u)));
     int rc;
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
-    for (const uint32_t q : todo) {
+    for (auto& ev : I->ev_build)
+        if (!ev) HIP_TRY(I, hipEventCreate(&ev));
+    HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    uint64_t upload_bytes = 0, kernel_bytes = 0;
+    for (const uint32_t q : todo) { // the changed meshes' triangles first (their regions are disjoint) ...
         const MeshRecord& r = I->mesh_records[q];
         const MeshHost* mh = nullptr;
         for (auto& kv : I->mesh_index)
             if (kv.second == q) mh = &I->meshes[kv.first];
         if (r.tri_count && mh) {
+            upload_bytes += (uint64_t)r.tri_count * sizeof(rfw_rt_triangle);
             // through the pinned ring when small (the host copy may be replaced by the next set_3d_mesh before a pageable copy has run)
             if ((size_t)r.tri_count * sizeof(rfw_rt_triangle) <= (8u << 20))
                 HIP_TRY(I, I->pins.upload(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), I->stream));
@@ -852,8 +882,17 @@ int build_blas_device_incremental(Instance* I)
                 HIP_TRY(I, hipStreamSynchronize(I->stream));
             }
         }
-        if ((rc = build_mesh_device(I, q, std::max(r.tri_count, 1u)))) return rc;
     }
+    HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
+    for (const uint32_t q : todo) { // ... then their trees
+        const MeshRecord& r = I->mesh_records[q];
+        if ((rc = build_mesh_device(I, q, std::max(r.tri_count, 1u)))) return rc;
+        kernel_bytes += build_pass_bytes(r.tri_count);
+    }
+    HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
+    I->build_events_pending = true;
+    I->blas_upload_bytes = upload_bytes;
+    I->blas_kernel_bytes = kernel_bytes;
     HIP_TRY(I, hipGetLastError());
     HIP_TRY(I, I->pins.upload(I->d_mesh_records.ptr, I->mesh_records.data(), I->mesh_records.size() * sizeof(MeshRecord), I->stream));
     uint64_t live = 0;
@@ -1806,6 +1845,8 @@ void rfw_hip_destroy(void* inst)
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
+        for (auto& ev : I->ev_build)
+            if (ev) (void)hipEventDestroy(ev);
         p2p_release(I);
         I->d_send.release(); I->d_recv.release();
         for (int q = 0; q < 2; q++) { I->d_sort_keys[q].release(); I->d_sort_vals[q].release(); }
@@ -2662,6 +2703,18 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
     out->tri_bytes = sizeof(TriPacket);
     out->ms_blas_build = I->ms_blas_build;
     out->ms_tlas_build = I->ms_tlas_build;
+    if (I->build_events_pending) {
+        (void)hipSetDevice(I->device);
+        if (hipEventSynchronize(I->ev_build[2]) == hipSuccess) {
+            (void)hipEventElapsedTime(&I->ms_blas_upload, I->ev_build[0], I->ev_build[1]);
+            (void)hipEventElapsedTime(&I->ms_blas_kernels, I->ev_build[1], I->ev_build[2]);
+        }
+        I->build_events_pending = false;
+    }
+    out->ms_blas_upload = I->ms_blas_upload;
+    out->ms_blas_kernels = I->ms_blas_kernels;
+    out->blas_upload_bytes = I->blas_upload_bytes;
+    out->blas_kernel_bytes = I->blas_kernel_bytes;
     return RFW_HIP_OK;
 }
 

@@ -3,7 +3,7 @@
 
 usage: tools/summarize_profile.py <round-tag> <kernel-trace-dir> [<pmc-fetch-dir> <pmc-write-dir> [<pmc-inst-dir> <pmc-valu-dir> [<more pmc dirs> ...]]]
 Writes
-  profiles/<tag>_kernel_stats.csv  copy of rocprofv3 --stats
+  profiles/<tag>_kernel_stats_one_at_a_time.csv  copy of rocprofv3 --stats of the trace directory given (tools/measure.sh: one frame at a time)
   profiles/<tag>_pmc.json          mean FETCH_SIZE / WRITE_SIZE per kernel (KB as rocprofv3 reports them) + bytes per launch with the gfx950
                                    correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane loads => x2
   profiles/<tag>_pmc_valu.json     instruction mix and VALU activity per launch
@@ -55,7 +55,10 @@ def main():
     tag, kt = sys.argv[1], sys.argv[2]
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
-    shutil.copy(find(kt, "*_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+    shutil.copy(find(kt, "*_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats_one_at_a_time.csv"))
+    sys.path.insert(0, os.path.dirname(out))
+    from bench import kernel_source_hash
+    stamp = {"source_hash": kernel_source_hash(), "source_hash_note": "sha1 of rfw-rs_amd/csrc sources at measurement time (bench.kernel_source_hash): bench.py ignores this file when its checkout differs"}
     if len(sys.argv) >= 5:
         fetch, nf = pmc_means(sys.argv[3], "FETCH_SIZE")
         write, _ = pmc_means(sys.argv[4], "WRITE_SIZE")
@@ -66,7 +69,7 @@ def main():
             f, w = fetch.get(k, 0.0), write.get(k, 0.0)
             res[short_name(k)] = {"launches_sampled": nf.get(k, 0), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                                   "hbm_bytes_per_launch_raw": int((f + w) * 1024), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
-        json.dump({"note": "means per launch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a "
+        json.dump({**stamp, "note": "means per launch; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a "
                            "16-B-per-lane stream; uncalibrated for divergent gathers, so treat as an upper bound there).  These are the L2's "
                            "fabric-side requests: Infinity-Cache hits are included (MI355X_MICROARCH.md §HBM), so true HBM bytes are lower still",
                    "kernels": res}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
@@ -88,7 +91,7 @@ def main():
                 # chip, so this per-launch figure then overstates what ONE kernel would need alone
                 e["cycles_per_valu_inst_per_simd"] = round((gui / 8.0 * 1024.0) / max(valu, 1.0), 2)
             res[k] = e
-        json.dump({"note": "means per launch from two rocprofv3 --pmc passes (instruction counts; VALU activity). cycles_per_valu_inst_per_simd = "
+        json.dump({**stamp, "note": "means per launch from two rocprofv3 --pmc passes (instruction counts; VALU activity). cycles_per_valu_inst_per_simd = "
                            "kernel cycles * 1024 SIMDs / SQ_INSTS_VALU (an FP32 instruction occupies its SIMD for 2 cycles); valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
                    "kernels": res}, open(os.path.join(out, f"{tag}_pmc_valu.json"), "w"), indent=1)
     if len(sys.argv) >= 8:
@@ -105,7 +108,7 @@ def main():
             if acc and tcc_rd is not None:
                 e["l1_hit_rate"] = round(1.0 - tcc_rd / acc, 4)  # share of the L1's line accesses that did not become an L2 read
             res[k] = e
-        json.dump({"note": "means per launch, one rocprofv3 --pmc pass per pair of counters.  l1_hit_rate = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES; "
+        json.dump({**stamp, "note": "means per launch, one rocprofv3 --pmc pass per pair of counters.  l1_hit_rate = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES; "
                            "l2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS) (MI355X_MICROARCH.md §L2); l2_request_bytes = (TCC_HIT + TCC_MISS) x 128 B",
                    "kernels": res}, open(os.path.join(out, f"{tag}_pmc_cache.json"), "w"), indent=1)
     print("wrote profiles/", tag)
