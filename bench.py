@@ -81,8 +81,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell", "spheres10k"],
-                    help="atrium1m = headline (C4 geometry, primary+shadow); atrium262k = C2; spheres10k = C3 (atrium262k + 10 000 "
+    ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell", "spheres10k", "atrium32m"],
+                    help="atrium32m = the same atrium at 33.5 M triangles (2 GB of nodes, 1.6 GB of packets: far outside every cache; use --procedural); "
+                         "atrium1m = headline (C4 geometry, primary+shadow); atrium262k = C2; spheres10k = C3 (atrium262k + 10 000 "
                          "animated icosphere instances, synchronize() every frame); cornell = C1 geometry")
     ap.add_argument("--max-path-length", type=int, default=1, help="1 = primary+shadow (the metric); 3 = the reference's path tracer (C4)")
     ap.add_argument("--width", type=int, default=1920)
@@ -138,7 +139,7 @@ def main():
     from rfw_rs_amd import HipBackend, Scene
 
     w, h = args.width, args.height
-    tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267}[args.workload]
+    tris = {"atrium1m": 1048576, "atrium262k": 262267, "cornell": 0, "spheres10k": 262267, "atrium32m": 33554432}[args.workload]
     scene = Scene().build("cornell") if args.workload == "cornell" else Scene().build("atrium", tris, int(os.environ.get("RFW_SPHERE_MESHES", "1" if args.separate_spheres else "0")), 0.0, 0xC0FFEE)
     scene_source = "procedural"
     if not args.procedural:

@@ -387,7 +387,8 @@ struct ExtendStream {
     uint32_t next, end; // wave-uniform: the run's entries not handed out yet
     uint32_t j;         // the lane's entry
     RFW_DI bool more() const { return next < end; }
-    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t_min, float& t)
+    static constexpr float kTMin = 1e-4f;
+    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t)
     {
         const uint32_t i = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         if (i >= end) return false;
@@ -395,7 +396,6 @@ struct ExtendStream {
         const float4 o4 = p.ray_o[half][j], d4 = p.ray_d[half][j];
         O = mk3(o4.x, o4.y, o4.z);
         D = mk3(d4.x, d4.y, d4.z);
-        t_min = 1e-4f;
         t = 1e26f;
         return true;
     }
@@ -496,7 +496,8 @@ struct ShadowStream {
     uint32_t next, end; // wave-uniform: the run's entries (bucket-local) not handed out yet
     uint32_t idx;       // the lane's entry
     RFW_DI bool more() const { return next < end; }
-    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t_min, float& t)
+    static constexpr float kTMin = 0.001f;
+    RFW_DI bool fetch(const uint64_t idle, f3& O, f3& D, float& t)
     {
         const uint32_t i = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         if (i >= end) return false;
@@ -504,7 +505,6 @@ struct ShadowStream {
         const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
         O = mk3(o4.x, o4.y, o4.z);
         D = mk3(d4.x, d4.y, d4.z);
-        t_min = 0.001f;
         t = d4.w - 0.0001f;
         if (t > 3.0e38f) t = 3.0e38f;
         return true;
@@ -520,7 +520,13 @@ struct ShadowStream {
         p.acc[slot] = a;
     }
 };
-template <bool COUNT>
+// One instantiation per visiting order (FAR: hit children by decreasing exit distance): a kernel that holds both traversals spills ~50 scalar
+// registers into vector lanes.  Each launch walks the buckets of its own order only.
+RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket)
+{
+    return RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional) : (cam.flags & kFlagFarFirstPositional) != 0u);
+}
+template <bool COUNT, bool FAR>
 __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_st
         bool found = false;
         for (int kk = 0; kk < kShadowBuckets; kk++) {
             const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            if (bucket_far_first(cam, (uint32_t)k) != FAR) continue;
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + run - 1u) / run;
             if (!found) {
@@ -544,10 +551,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_st
     ShadowStream st{p, bucket * p.capacity, block * run, min(count, (block + 1u) * run), 0u};
     const SceneView sv = scene_view(sc);
     const uint32_t spill_slot = blockIdx.x * kTraceBlock + threadIdx.x;
-    const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional)
-                                                                                             : (cam.flags & kFlagFarFirstPositional) != 0u);
-    if (far_first) traverse_stream<true, COUNT, true>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
-    else traverse_stream<true, COUNT, false>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
+    traverse_stream<true, COUNT, FAR>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
     flush_counters<COUNT>(sc.counters, tc, 2);
 }
 
@@ -1040,8 +1044,14 @@ void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
     // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too)
     if (cam.stream_run && bounce >= 1u) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
         const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + kShadowBuckets + 511u) & ~511u);
-        if (count) hipLaunchKernelGGL(k_shadow_stream<true>, grid, block, 0, s, cam, sc, p, bounce);
-        else hipLaunchKernelGGL(k_shadow_stream<false>, grid, block, 0, s, cam, sc, p, bounce);
+        // the two orders' launches follow each other on the stream (no rays of the other kind: the blocks return at once)
+        if (count) {
+            hipLaunchKernelGGL((k_shadow_stream<true, true>), grid, block, 0, s, cam, sc, p, bounce);
+            hipLaunchKernelGGL((k_shadow_stream<true, false>), grid, block, 0, s, cam, sc, p, bounce);
+        } else {
+            hipLaunchKernelGGL((k_shadow_stream<false, true>), grid, block, 0, s, cam, sc, p, bounce);
+            hipLaunchKernelGGL((k_shadow_stream<false, false>), grid, block, 0, s, cam, sc, p, bounce);
+        }
         return;
     }
     const dim3 grid((ceil_div(p.capacity, kTraceBlock) + kShadowBuckets + 511u) & ~511u);

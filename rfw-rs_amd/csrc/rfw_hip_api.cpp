@@ -371,6 +371,7 @@ struct Instance {
     } p2p;
     uint32_t slot_index = 0;
     uint32_t stream_leaf_gate = 16; // ... and a lane that holds a leaf waits until this many do (or nobody has a node to test)
+    bool stream_auto = true; // stream_run applies where it was measured to pay (see camera_params); set_option("stream_run") switches this off
     uint32_t stream_run = 8, stream_refill = 12; // measured on C4 path traced (max path length 3, 8 frame slots): 2880 -> 3180 Mrays/s; 0 = off // streaming shadow / extension kernels: wavefront-runs of stream_run x 64 rays (0: one ray per lane)
     uint32_t p2p_seq = 0;           // frames this slot has exchanged
     bool frame_elsewhere = false;   // the latest frame was sent to the presenting rank and does not exist here
@@ -1358,7 +1359,12 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
     c.batch = 1;
-    c.stream_run = scene_of(I)->stream_run;
+    // streaming trades the tail of every wavefront for fewer, longer wavefronts: it pays when other frames fill the chip meanwhile (measured on
+    // C4 path traced: 8 frame slots 2880 -> 3190 Mrays/s, 4 slots 2840 -> 3100; but 2 slots 2770 -> 2610, one frame at a time 2270 -> 1670,
+    // and batches, whose extension rays are traced in sorted order, 3480 -> 3360).  Unless the option was set by hand it is on for single
+    // frames of an instance with four or more frame slots
+    const Instance* S_ = scene_of(I);
+    c.stream_run = (S_->stream_auto && !(S_->slots.size() + 1 >= 4)) ? 0u : S_->stream_run;
     c.stream_refill = std::max(1u, std::min(64u, scene_of(I)->stream_refill)) | (std::max(1u, std::min(64u, scene_of(I)->stream_leaf_gate)) << 8);
     c.frame_capacity = I->cap_v;
     return c;
@@ -1565,6 +1571,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
     BatchViews bv;
     if (k > 1) {
         cam[0].batch = k;
+        if (scene_of(I)->stream_auto) cam[0].stream_run = 0u; // a batch's extension rays are traced in sorted order: one ray per lane (see camera_params)
         p[0].capacity = I->cap_v * k;
         for (uint32_t f = 0; f < k; f++) {
             cam[0].batch_sample[f] = samples ? I->sample_count + f : 0u;
@@ -2436,6 +2443,8 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         const uint32_t r = (uint32_t)value;
         if (r != 0 && (r > 64 || (r & (r - 1)) != 0)) return fail(I, RFW_HIP_E_INVALID, "set_option: stream_run must be 0 or a power of two up to 64");
         I->stream_run = r;
+        I->stream_auto = false;
+    } else if (k == "stream_auto") { I->stream_auto = value != 0.0;
     } else if (k == "stream_leaf_gate") I->stream_leaf_gate = (uint32_t)std::max(1.0, std::min(64.0, value));
     else if (k == "stream_refill") I->stream_refill = (uint32_t)std::max(1.0, std::min(64.0, value));
     else if (k == "p2p_timeout_ms") I->p2p.timeout_ticks = (uint64_t)std::max(1.0, value) * 100000ull;

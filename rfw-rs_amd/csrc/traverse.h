@@ -163,7 +163,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 // once per 64 rays, and the rays of a wavefront still come from one neighbourhood of the queue (no atomics, no global cursor: the
 // assignment of rays to wavefronts is static, the assignment to LANES is not, and no result depends on either).
 //   st.more()                 wave-uniform: the run has entries left
-//   st.fetch(idle, O, D, t_min, t)   the calling lanes (all idle) take the next entries; false for a lane that gets none
+//   st.fetch(idle, O, D, t)   the calling lanes (all idle) take the next entries; false for a lane that gets none (Stream::kTMin: the queue's t_min)
 //   st.commit(occluded, t, hu, hv, hit_inst, hit_tri)   the calling lane's finished ray
 template <bool ANY_HIT, bool COUNT, bool FAR_FIRST, class Stream>
 RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refill, const uint32_t leaf_gate, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot,
@@ -172,7 +172,8 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
     constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds;
     constexpr bool kPark = RFW_RAY_IN_LDS && (!ANY_HIT || RFW_ANY_PARK);
     f3 O = mk3(0.0f), D = mk3(0.0f), o = O, d = D;
-    float t_min = 0.0f, t = 0.0f, hu = 0.0f, hv = 0.0f;
+    const float t_min = Stream::kTMin; // (the same for every ray of a queue: not a register per lane)
+    float t = 0.0f, hu = 0.0f, hv = 0.0f;
     int32_t hit_inst = -1, hit_tri = -1;
     auto world_o = [&]() -> f3 {
         if (!kPark) return O;
@@ -233,7 +234,7 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
                 if (!have) {                                                                                                          \
                     if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);                                                   \
                     pending = false;                                                                                                  \
-                    have = st.fetch(idle, O, D, t_min, t);                                                                            \
+                    have = st.fetch(idle, O, D, t);                                                                            \
                     if (have) {                                                                                                       \
                         o = O; d = D; inv = slab_inv(d);                                                                              \
                         sp = 0; blas_sp = -1; cur_inst = -1; tri_base = 0; cur = 0; nodes = sc.tlas_nodes;                            \

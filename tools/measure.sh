@@ -74,9 +74,11 @@ rocprofv3 -L > $OUT/counters_available.txt 2>&1
 # the counters are in: the bench lines of the round, now WITH the ceilings of their configuration (bench.py reads profiles/<tag>_<cfg>_pmc*.json)
 python3 bench.py > $OUT/bench_c4_final.json 2> $OUT/bench_c4_final.err && cp $OUT/bench_c4_final.json profiles/${TAG}_c4_bench.json
 if [ -z "$QUICK" ]; then
-  python3 bench.py --workload atrium262k --no-cpu-baseline > $OUT/b.json 2>> $OUT/bench_c4_final.err && cp $OUT/b.json profiles/${TAG}_c2_bench.json
-  python3 bench.py --workload spheres10k > $OUT/b.json 2>> $OUT/bench_c4_final.err && cp $OUT/b.json profiles/${TAG}_c3_bench.json
-  python3 bench.py --max-path-length 3 > $OUT/b.json 2>> $OUT/bench_c4_final.err && cp $OUT/b.json profiles/${TAG}_c4path_bench.json
+  python3 bench.py --workload atrium262k --no-cpu-baseline > $OUT/bench_c2_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c2_final.json profiles/${TAG}_c2_bench.json
+  python3 bench.py --workload spheres10k > $OUT/bench_c3_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c3_final.json profiles/${TAG}_c3_bench.json
+  python3 bench.py --max-path-length 3 > $OUT/bench_c4path_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c4path_final.json profiles/${TAG}_c4path_bench.json
 fi
+# gpurun only brings gpurun_out/ back: the condensed files ride along in it (copy them into profiles/ of the checkout afterwards)
+mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/
 ls -la profiles/ | tail -40
 head -c 400 $OUT/bench_c4_final.json; echo
