@@ -484,11 +484,14 @@ def main():
     elif F == 1 and B == 1 and single:
         ms, n = bes[0].drain_timing()
         iso = (ms, n)
-    elif single and not animated:
+    elif single:
         # no separate strict mode requested: a short one-frame-at-a-time pass on the instance at hand gives the per-kernel durations
+        # (C3: with its scene update before every frame, as in the timed region)
         bes[0].set_option("timing", 1)
         bes[0].drain_timing()
         for i in range(24):
+            if animated:
+                animate_and_sync(bes[0])
             bes[0].reset_accumulation()
             bes[0].render(views[i % N_VIEWS])
             bes[0].device_synchronize()
@@ -631,6 +634,15 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
             r["counters_from"] = None
             r["stale_counters"] = {"files": stale, "note": "measured on other kernel sources than this checkout's (source_hash differs): not used; re-run tools/measure.sh"}
     launches = launches or {}
+    # a path-traced frame with frames in flight runs the STREAMING flavour of k_extend / k_shadow for the bounces (one frame at a time: one ray
+    # per lane): the timed region's ceilings come from the counter set measured with streaming forced (profiles/*_<cfg>S_*), the isolated
+    # kernel's from the plain set
+    sets = {"isolated": (pv, pm, pc), "timed": (pv, pm, pc)}
+    if usable and cfg == "c4path":
+        sv, sm, sc_ = latest_profile(f"*_{cfg}S_pmc_valu.json"), latest_profile(f"*_{cfg}S_pmc.json"), latest_profile(f"*_{cfg}S_pmc_cache.json")
+        if all((sv, sm, sc_)) and all(p[0].get("source_hash") == here for p in (sv, sm, sc_)):
+            sets["timed"] = (sv, sm, sc_)
+            r["counters_from"] += [p[1] for p in (sv, sm, sc_)]
     if not kms or not any(kms.values()):
         r.update({"bound": None, "kernel": None, "achieved": None, "peak": None, "frac": None, "traffic": None,
                   "note": "no isolated per-kernel durations in this configuration (kernels of frames in flight overlap)"})
@@ -638,12 +650,13 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
     dom = max(kms, key=lambda k: kms[k])
     traffic = None
 
-    def ceilings_of(names, seconds):
+    def ceilings_of(names, seconds, which="isolated"):
         """Every ceiling as a fraction <= 1 for the launches `names` (one launch each) taking `seconds` together."""
         nonlocal traffic
         c = {}
         if not usable:
             return c
+        pv, pm, pc = sets[which]
         tot = {"valu": 0.0, "vmem": 0.0, "ta_busy": 0.0, "l2": 0.0, "l2_hit": [], "hbm": 0.0, "l1_hit": []}
         have = {"valu": True, "ta": True, "l2": True, "hbm": True}
         for n in names:
@@ -695,7 +708,7 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
     ceilings = ceilings_of([dom], dur)
     # the timed region as a whole: one launch of every kernel of a frame over the wall time per frame (frames in flight overlap, so this is
     # the utilisation the chip actually runs at, where the per-kernel figures above are launches with the machine to themselves)
-    steady = ceilings_of(["k_primary", "k_shade", "k_shadow", "k_assemble"] + (["k_extend", "k_shadow_stream"] if "k_extend" in kms else []), ms_step * 1e-3)
+    steady = ceilings_of(["k_primary", "k_shade", "k_shadow", "k_assemble"] + (["k_extend", "k_shadow_stream"] if "k_extend" in kms else []), ms_step * 1e-3, "timed")
     nl_dom = max(launches.get(dom, 1), 1)
     contract = {"algorithmic_bytes_per_launch": int(alg[dom] / nl_dom), "avg_launch_ms": round(kms[dom] / nl_dom, 4), "launches_per_frame": nl_dom,
                 "algorithmic_GBps": round(alg[dom] / dur / 1e9, 1), "hbm_peak_GBps": HBM_PEAK_GBS,

@@ -65,6 +65,9 @@ if [ -z "$QUICK" ]; then
   profile_config c2 --workload atrium262k
   profile_config c3 --workload spheres10k
   profile_config c4path --max-path-length 3
+  # with frames in flight the bounces run the streaming kernels (one frame at a time — which is how counters are taken — they do not): the
+  # same passes with streaming forced, for the timed region's ceilings
+  RFW_STREAM_RUN=8 profile_config c4pathS --max-path-length 3
   cd $R
   python3 bench.py --identical-frames --no-cpu-baseline > $OUT/bench_atrium1m_identical_frames.json 2> $OUT/bench_identical.err
   [ -s $OUT/bench_atrium1m_identical_frames.json ] && cp $OUT/bench_atrium1m_identical_frames.json profiles/${TAG}_c4_bench_identical_frames.json
