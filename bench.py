@@ -59,7 +59,7 @@ def config_key(args):
         return {1: "c4", 3: "c4path"}.get(args.max_path_length)
     if args.max_path_length != 1:
         return None
-    return {"atrium262k": "c2", "spheres10k": "c3"}.get(args.workload)
+    return {"atrium262k": "c2", "spheres10k": "c3", "atrium32m": "c32m"}.get(args.workload)
 
 
 def dolly_views(base, n, step):
