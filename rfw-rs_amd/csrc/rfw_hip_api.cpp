@@ -24,6 +24,7 @@ const char* ncclGetErrorString(ncclResult_t r);
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -329,6 +330,10 @@ struct Instance {
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
     float ms_blas_upload = 0, ms_blas_kernels = 0; // the last full device build, by events
     uint64_t blas_upload_bytes = 0, blas_kernel_bytes = 0;
+    // small meshes are built side by side: one worker thread per auxiliary stream, each with scratch of its own (build_meshes)
+    struct BuildLane { hipStream_t s = nullptr; hipEvent_t done = nullptr; DevBuf<char> ws; DevBuf<DevBox> boxes; };
+    static constexpr int kBuildLanes = 8;
+    BuildLane lanes[kBuildLanes];
     hipEvent_t ev_build[3] = {nullptr, nullptr, nullptr};
     bool build_events_pending = false; // recorded, not read yet (rfw_hip_get_scene_stats reads them: no synchronisation for them in synchronize())
 
@@ -711,6 +716,65 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
     return RFW_HIP_OK;
 }
 
+// Several meshes: the large ones one after the other on the instance's stream (each fills the device by itself), the small ones side by
+// side — a 5120-triangle mesh is ~30 dependent launches of a few microseconds and one 16-byte read-back, i.e. all latency: kBuildLanes host
+// threads, each with a stream and scratch of its own, take them from one counter.  The lanes start behind what the instance's stream holds
+// (the triangle uploads) and the stream continues behind the lanes.  A builder failure falls back to the one-by-one path for that mesh.
+int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
+{
+    constexpr uint32_t kSmallMesh = 131072;
+    std::vector<uint32_t> small, large;
+    for (const uint32_t q : qs) (I->blas_sah_on_device && I->mesh_records[q].tri_count && I->mesh_records[q].tri_count <= kSmallMesh ? small : large).push_back(q);
+    if (small.size() < 2) { large = qs; small.clear(); }
+    int rc = RFW_HIP_OK;
+    const int n_lanes = (int)std::min<size_t>(Instance::kBuildLanes, small.size());
+    std::vector<std::thread> workers;
+    std::vector<hipError_t> lane_err((size_t)std::max(n_lanes, 1), hipSuccess);
+    std::vector<uint8_t> redo(I->mesh_records.size(), 0);
+    std::atomic<size_t> next{0};
+    if (n_lanes) {
+        uint32_t max_n = 0;
+        for (const uint32_t q : small) max_n = std::max(max_n, I->mesh_records[q].tri_count);
+        hipEvent_t start = I->ev_build[1]; // recorded by the caller behind the uploads
+        for (int k = 0; k < n_lanes; k++) {
+            Instance::BuildLane& L = I->lanes[k];
+            if (!L.s) HIP_TRY(I, hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+            if (!L.done) HIP_TRY(I, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            HIP_TRY(I, L.ws.ensure(sah_workspace_bytes(max_n)));
+            HIP_TRY(I, L.boxes.ensure(max_n));
+            HIP_TRY(I, hipStreamWaitEvent(L.s, start, 0));
+        }
+        for (int k = 0; k < n_lanes; k++)
+            workers.emplace_back([I, k, &small, &next, &lane_err, &redo, incremental] {
+                Instance::BuildLane& L = I->lanes[k];
+                if (hipSetDevice(I->device) != hipSuccess) { lane_err[k] = hipErrorInvalidDevice; return; }
+                for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) {
+                    const uint32_t q = small[i];
+                    const MeshRecord& r = I->mesh_records[q];
+                    launch_triangle_boxes(L.s, I->d_triangles.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
+                    const hipError_t e = sah_build(L.s, L.boxes.ptr, r.tri_count, L.ws.ptr, L.ws.cap, I->d_blas_raw.ptr + r.node_base, I->d_blas_order.ptr + r.tri_base,
+                                                   I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
+                    if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
+                    if (e != hipSuccess) { lane_err[k] = e; return; }
+                    launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, std::max(r.tri_count, 1u));
+                }
+                (void)hipEventRecord(L.done, L.s);
+            });
+    }
+    for (const uint32_t q : large) // meanwhile, on the instance's own stream
+        if (rc == RFW_HIP_OK) rc = build_mesh_device(I, q, incremental ? std::max(I->mesh_records[q].tri_count, 1u) : 0u);
+    for (auto& t : workers) t.join();
+    for (int k = 0; k < n_lanes; k++) {
+        if (lane_err[k] != hipSuccess && rc == RFW_HIP_OK) rc = fail(I, RFW_HIP_E_DEVICE, std::string("build lane: ") + hipGetErrorString(lane_err[k]));
+        (void)hipStreamWaitEvent(I->stream, I->lanes[k].done, 0);
+    }
+    if (rc != RFW_HIP_OK) return rc;
+    for (const uint32_t q : small)
+        if (redo[q] && (rc = build_mesh_device(I, q, incremental ? std::max(I->mesh_records[q].tri_count, 1u) : 0u))) return rc;
+    return RFW_HIP_OK;
+}
+
 // The triangle-id offsets the boundary reports: meshes in mesh-id order, then the skinned copies (= the order of a full build)
 void assign_logical_ids(Instance* I)
 {
@@ -776,9 +840,10 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
     HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
     uint64_t kernel_bytes = 0;
-    for (size_t q = 0; q < n_static; q++) {
-        if ((rc = build_mesh_device(I, (uint32_t)q, 0u))) return rc;
-        kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count);
+    {
+        std::vector<uint32_t> all(n_static);
+        for (size_t q = 0; q < n_static; q++) { all[q] = (uint32_t)q; kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count); }
+        if ((rc = build_meshes(I, all, false))) return rc;
     }
     launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
@@ -796,6 +861,7 @@ int build_blas_device_full(Instance* I)
     for (uint32_t c : counts) I->n_blas_nodes += c;
     I->node_counts_stale = false;
     I->d_sah_ws.release(); // ~350 B per triangle of build scratch: not kept between scene changes
+    for (auto& L : I->lanes) { L.ws.release(); L.boxes.release(); }
     I->tri_end = static_tris;
     I->node_end = static_nodes;
     I->hole_tris = 0;
@@ -885,11 +951,8 @@ int build_blas_device_incremental(Instance* I)
         }
     }
     HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
-    for (const uint32_t q : todo) { // ... then their trees
-        const MeshRecord& r = I->mesh_records[q];
-        if ((rc = build_mesh_device(I, q, std::max(r.tri_count, 1u)))) return rc;
-        kernel_bytes += build_pass_bytes(r.tri_count);
-    }
+    for (const uint32_t q : todo) kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count);
+    if ((rc = build_meshes(I, todo, true))) return rc; // ... then their trees
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     I->build_events_pending = true;
     I->blas_upload_bytes = upload_bytes;
@@ -911,7 +974,11 @@ int build_blas_device(Instance* I)
     for (auto& kv : I->mesh_index) removed = removed || I->meshes.find(kv.first) == I->meshes.end();
     if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed)) {
         const int rc = build_blas_device_incremental(I);
-        I->d_sah_ws.release(); // build scratch is not kept between scene changes (as after a full build)
+        // build scratch is not kept between scene changes when it is large (as after a full build: ~350 B per triangle); the scratch of small
+        // edits stays — hipFree waits for the device, and an edit of one 5120-triangle mesh would pay its own build time on the host for it
+        if (I->d_sah_ws.cap > (64u << 20)) I->d_sah_ws.release();
+        for (auto& L : I->lanes)
+            if (L.ws.cap > (64u << 20)) { L.ws.release(); L.boxes.release(); }
         if (rc < 0) { // an error part-way through: records, capacities and dirty flags may be half-updated — the next synchronize() starts over
             I->layout_valid = false;
             for (auto& kv : I->meshes) kv.second.dirty = true;
@@ -1854,6 +1921,11 @@ void rfw_hip_destroy(void* inst)
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
         for (auto& ev : I->ev_build)
             if (ev) (void)hipEventDestroy(ev);
+        for (auto& L : I->lanes) {
+            if (L.s) (void)hipStreamDestroy(L.s);
+            if (L.done) (void)hipEventDestroy(L.done);
+            L.ws.release(); L.boxes.release();
+        }
         p2p_release(I);
         I->d_send.release(); I->d_recv.release();
         for (int q = 0; q < 2; q++) { I->d_sort_keys[q].release(); I->d_sort_vals[q].release(); }
