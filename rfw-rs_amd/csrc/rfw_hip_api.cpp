@@ -303,6 +303,7 @@ struct Instance {
     bool tlas_on_device = true, blas_on_device = false, blas_sah_on_device = false;
     DevBuf<char> d_sah_ws;
     DevBuf<uint32_t> d_mesh_node_counts;
+    DevBuf<ForestTree> d_forest; // (first, count, node region) of every mesh of a full build: sah_build_forest
     DevBuf<uint32_t> d_refit_parent, d_refit_nint, d_refit_arrive; // per raw node of the skinned copies
     DevBuf<QueueCounters> d_counters;
     // traversal stack overflow: a word of pinned host memory the kernels set (device-visible mapping), so every later call can report
@@ -843,7 +844,29 @@ int build_blas_device_full(Instance* I)
     {
         std::vector<uint32_t> all(n_static);
         for (size_t q = 0; q < n_static; q++) { all[q] = (uint32_t)q; kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count); }
-        if ((rc = build_meshes(I, all, false))) return rc;
+        // several meshes: ONE build for all of them (sah_build_forest: the meshes lie one after the other in the buffers of a full build, every
+        // mesh is a root of the same level-by-level pass) — ~45 launches for the scene instead of ~30 per mesh
+        bool forest_done = false;
+        // (measured: two meshes of 720 k + 330 k triangles 5.4 ms together, 4.4 ms one after the other; 65 meshes 5.5 ms against 10.4 on lanes, 38 one by one)
+        if (I->blas_sah_on_device && n_static >= 4 && static_tris > 0 && !getenv("RFW_NO_FOREST")) {
+            std::vector<ForestTree> trees(n_static);
+            for (size_t q = 0; q < n_static; q++) trees[q] = ForestTree{I->mesh_records[q].tri_base, I->mesh_records[q].tri_count, I->mesh_records[q].node_base, 0u};
+            HIP_TRY(I, I->d_forest.ensure(n_static));
+            HIP_TRY(I, I->pins.upload(I->d_forest.ptr, trees.data(), n_static * sizeof(ForestTree), I->stream));
+            HIP_TRY(I, I->d_tri_boxes.ensure(std::max(static_tris, I->max_derived_tris)));
+            HIP_TRY(I, I->d_sah_ws.ensure(sah_forest_workspace_bytes(static_tris, (uint32_t)n_static)));
+            launch_triangle_boxes(I->stream, I->d_triangles.ptr, static_tris, I->d_tri_boxes.ptr);
+            const hipError_t fe = sah_build_forest(I->stream, I->d_tri_boxes.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static, max_n, I->d_sah_ws.ptr, I->d_sah_ws.cap,
+                                                   I->d_blas_raw.ptr, I->d_blas_order.ptr, I->d_mesh_node_counts.ptr, I->sah_max_leaf, I->sah_trav_cost);
+            if (fe == hipSuccess) {
+                launch_make_packets(I->stream, I->d_triangles.ptr, I->d_blas_order.ptr, static_tris, 0u, I->d_packets.ptr); // global positions: one launch
+                launch_forest_relative_order(I->stream, I->d_blas_order.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static);
+                forest_done = true;
+            } else if (fe != hipErrorInvalidValue) {
+                HIP_TRY(I, fe);
+            } // else: some tree is deeper than the builder's level budget: mesh by mesh, where LBVH can take over for that one
+        }
+        if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
     }
     launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
@@ -969,10 +992,11 @@ int build_blas_device_incremental(Instance* I)
 
 int build_blas_device(Instance* I)
 {
-    bool any_dirty = false, removed = false;
-    for (auto& kv : I->meshes) any_dirty = any_dirty || kv.second.dirty;
+    bool any_dirty = false, removed = false, all_dirty = !I->meshes.empty();
+    for (auto& kv : I->meshes) { any_dirty = any_dirty || kv.second.dirty; all_dirty = all_dirty && kv.second.dirty; }
     for (auto& kv : I->mesh_index) removed = removed || I->meshes.find(kv.first) == I->meshes.end();
-    if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed)) {
+    // (every mesh changed: nothing to keep — the full build lays the buffers out afresh and builds all meshes in one pass)
+    if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed) && !(all_dirty && I->meshes.size() >= 2)) {
         const int rc = build_blas_device_incremental(I);
         // build scratch is not kept between scene changes when it is large (as after a full build: ~350 B per triangle); the scratch of small
         // edits stays — hipFree waits for the device, and an edit of one 5120-triangle mesh would pay its own build time on the host for it
@@ -1932,7 +1956,7 @@ void rfw_hip_destroy(void* inst)
         I->d_sort_ws.release();
         if (I->overflow_host) (void)hipHostFree(I->overflow_host);
         I->pins.release();
-        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
+        I->d_skin_data.release(); I->d_joints.release(); I->d_bounds_scratch.release(); I->d_sah_ws.release(); I->d_mesh_node_counts.release(); I->d_forest.release(); I->d_refit_parent.release(); I->d_refit_nint.release(); I->d_refit_arrive.release();
         for (int k = 0; k < Instance::kStages; k++) {
             if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
             if (I->stage_event[k]) (void)hipEventDestroy(I->stage_event[k]);

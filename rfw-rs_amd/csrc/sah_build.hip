@@ -950,6 +950,166 @@ __global__ void k_emit_nodes(uint32_t n_nodes_cap, const Counters* __restrict__ 
     out_nodes[idx4[i]] = o;
 }
 
+// ---------------------------------------------------------------- a FOREST: many meshes in one build
+// A scene of many small meshes is all launch latency when every mesh is built by itself (~30 dependent launches and a read-back each).  The
+// level kernels above never cared how many nodes a level has, so the meshes of a scene are built TOGETHER: their primitives lie one mesh
+// after the other in one position space, every mesh is a root (node ids 0 .. M - 1), and the levels, the workgroup phase and the emission
+// run once for all of them.  Per tree: its own node region in the output (root = index 0), leaf ranges relative to the tree's first primitive.
+__global__ void k_forest_init(Counters* ctr, uint32_t n_trees)
+{
+    if (threadIdx.x == 0) { ctr->node_count = n_trees; ctr->n_active[0] = 0; ctr->n_active[1] = 0; ctr->n_small = 0; }
+}
+// one workgroup per tree: bounds and centroid bounds of its range, identity order, the root node, and where the root goes next
+__global__ __launch_bounds__(kBlock) void k_forest_roots(const DevBox* __restrict__ boxes, const ForestTree* __restrict__ trees, Counters* ctr, SNode* nodes,
+                                                        uint32_t* order, uint32_t* node_of_pos, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* stamp,
+                                                        Bin* bins, uint32_t replicas, uint32_t small_cap)
+{
+    __shared__ uint32_t s_b[12];
+    __shared__ uint32_t s_slot;
+    const uint32_t m = blockIdx.x;
+    const ForestTree t = trees[m];
+    if (threadIdx.x < 12) s_b[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    if (threadIdx.x == 0) s_slot = kNone;
+    __syncthreads();
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = t.first + threadIdx.x; i < t.first + t.count; i += kBlock) {
+        order[i] = i;
+        node_of_pos[i] = m;
+        for (int a = 0; a < 3; a++) {
+            const float l = boxes[i].lo[a], h = boxes[i].hi[a], c = 0.5f * (l + h);
+            lo[a] = fminf(lo[a], l); hi[a] = fmaxf(hi[a], h);
+            clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
+        }
+    }
+    for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); clo[a] = wave_min(clo[a]); chi[a] = wave_max(chi[a]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&s_b[a], f_order(lo[a])); atomicMax(&s_b[3 + a], f_order(hi[a]));
+            atomicMin(&s_b[6 + a], f_order(clo[a])); atomicMax(&s_b[9 + a], f_order(chi[a]));
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SNode r;
+        for (int a = 0; a < 3; a++) {
+            r.lo[a] = f_unorder(s_b[a]); r.hi[a] = f_unorder(s_b[3 + a]);
+            r.cb[a] = s_b[6 + a]; r.cb[3 + a] = s_b[9 + a];
+        }
+        r.first = t.first; r.count = t.count; r.left = kNone; r.parent = kNone;
+        nodes[m] = r;
+        if (t.count > small_cap) {
+            const uint32_t slot = atomicAdd(&ctr->n_active[0], 1u);
+            active[slot] = m; bin_slot[m] = slot; stamp[m] = 0;
+            s_slot = slot;
+        } else if (t.count) {
+            small[atomicAdd(&ctr->n_small, 1u)] = m;
+        }
+    }
+    __syncthreads();
+    if (s_slot != kNone) { // the root's bins on level 0 (every replica)
+        Bin e; e.count = 0;
+        for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
+        for (uint32_t k = threadIdx.x; k < replicas * 3 * kBins; k += kBlock) bins[(size_t)s_slot * replicas * 3 * kBins + k] = e;
+    }
+}
+// even-depth interior nodes become wide nodes; every node learns its tree (= the id of its root)
+__global__ void k_flag_forest(uint32_t n_nodes_cap, const Counters* __restrict__ ctr, const SNode* __restrict__ nodes, uint32_t* flag4, uint32_t* tree_of)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes_cap) return;
+    uint32_t f = 0, root = kNone;
+    if (i < ctr->node_count) {
+        uint32_t depth = 0, r = i, p = nodes[i].parent;
+        while (p != kNone) { depth++; r = p; p = nodes[p].parent; }
+        root = r;
+        if (nodes[i].left != kNone) f = (depth & 1u) ? 0u : 1u;
+    }
+    flag4[i] = f;
+    tree_of[i] = root;
+}
+// a wide node's index inside its tree's region: the root is 0, the others take the next free one (any order will do: parents look them up)
+__global__ void k_index_forest(uint32_t n_nodes_cap, const Counters* __restrict__ ctr, const SNode* __restrict__ nodes, const uint32_t* __restrict__ flag4,
+                               const uint32_t* __restrict__ tree_of, uint32_t* idx4, uint32_t* tree_nodes)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool wide = i < n_nodes_cap && i < ctr->node_count && flag4[i] != 0u;
+    const bool is_root = wide && nodes[i].parent == kNone;
+    if (is_root) idx4[i] = 0u;
+    // one atomic per wavefront and tree (a scene of two big meshes would otherwise send every wide node to one of two words)
+    const uint32_t t = wide ? tree_of[i] : kNone;
+    bool todo = wide && !is_root;
+    while (__ballot(todo) != 0ull) {
+        const unsigned long long pending = __ballot(todo);
+        const uint32_t lead_tree = (uint32_t)__shfl((int)t, __ffsll((long long)pending) - 1);
+        const unsigned long long mine = __ballot(todo && t == lead_tree);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        uint32_t base = 0;
+        if (todo && t == lead_tree && rank == 0u) base = atomicAdd(&tree_nodes[lead_tree], (uint32_t)__popcll(mine));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)mine) - 1);
+        if (todo && t == lead_tree) { idx4[i] = 1u + base + rank; todo = false; }
+    }
+}
+__global__ void k_emit_forest(uint32_t n_nodes_cap, uint32_t n_trees, const Counters* __restrict__ ctr, const SNode* __restrict__ nodes, const uint32_t* __restrict__ flag4,
+                              const uint32_t* __restrict__ idx4, const uint32_t* __restrict__ tree_of, const ForestTree* __restrict__ trees,
+                              const uint32_t* __restrict__ tree_nodes, Node4* out_base, uint32_t* node_counts_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes_cap) return;
+    const uint32_t total = ctr->node_count;
+    if (i < n_trees) { // a root: its tree's node count; a tree that is one leaf (or empty) is one wide node with one (or no) child
+        if (nodes[i].left == kNone) {
+            Node4 o;
+            for (int k = 0; k < 4; k++) {
+                o.lox[k] = o.loy[k] = o.loz[k] = INFINITY; o.hix[k] = o.hiy[k] = o.hiz[k] = -INFINITY;
+                o.child[k] = kInvalidRef; o.pad[k] = 0;
+            }
+            if (nodes[i].count) {
+                o.lox[0] = nodes[i].lo[0]; o.loy[0] = nodes[i].lo[1]; o.loz[0] = nodes[i].lo[2];
+                o.hix[0] = nodes[i].hi[0]; o.hiy[0] = nodes[i].hi[1]; o.hiz[0] = nodes[i].hi[2];
+                o.child[0] = make_leaf(0u, nodes[i].count);
+            }
+            out_base[trees[i].node_base] = o;
+            if (node_counts_out) node_counts_out[i] = 1;
+            return;
+        }
+        if (node_counts_out) node_counts_out[i] = tree_nodes[i] + 1u;
+    }
+    if (i >= total || !flag4[i]) return;
+    const ForestTree t = trees[tree_of[i]];
+    uint32_t kids[4];
+    int nk = 0;
+    for (uint32_t c = nodes[i].left; c < nodes[i].left + 2; c++) {
+        if (nodes[c].left == kNone) kids[nk++] = c;
+        else { kids[nk++] = nodes[c].left; kids[nk++] = nodes[c].left + 1; }
+    }
+    Node4 o;
+    for (int k = 0; k < 4; k++) {
+        if (k < nk) {
+            const SNode& c = nodes[kids[k]];
+            o.lox[k] = c.lo[0]; o.loy[k] = c.lo[1]; o.loz[k] = c.lo[2];
+            o.hix[k] = c.hi[0]; o.hiy[k] = c.hi[1]; o.hiz[k] = c.hi[2];
+            o.child[k] = c.left == kNone ? make_leaf(c.first - t.first, c.count) : idx4[kids[k]];
+        } else {
+            o.lox[k] = o.loy[k] = o.loz[k] = INFINITY; o.hix[k] = o.hiy[k] = o.hiz[k] = -INFINITY;
+            o.child[k] = kInvalidRef;
+        }
+        o.pad[k] = 0;
+    }
+    out_base[t.node_base + idx4[i]] = o;
+}
+// the primitive order holds positions of the whole forest: make every tree's part relative to the tree's first primitive
+__global__ void k_forest_relative_order(uint32_t* order, uint32_t n, const ForestTree* __restrict__ trees, uint32_t n_trees)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    uint32_t lo = 0, hi = n_trees; // the last tree with first <= p (trees are sorted by first, ranges are disjoint and cover [0, n))
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (trees[mid].first <= p) lo = mid; else hi = mid;
+    }
+    order[p] -= trees[lo].first;
+}
+
 // ---------------------------------------------------------------- refit
 __global__ void k_refit_setup(const Node4* __restrict__ nodes, uint32_t n_nodes, uint32_t* parent_slot, uint32_t* n_internal)
 {
@@ -1151,6 +1311,100 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_nodes, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, ctr, nodes, flag4, idx4, nodes_out, node_count_out);
     return hipGetLastError();
+}
+
+size_t sah_forest_workspace_bytes(uint32_t n, uint32_t n_trees)
+{
+    return make_layout(n + n_trees).total + align_up((size_t)(4 * ((size_t)n + n_trees) + 64 + n_trees) * 4, 256) + align_up((size_t)n_trees * 4, 256);
+}
+
+hipError_t sah_build_forest(hipStream_t s, const DevBox* boxes, uint32_t n, const ForestTree* trees, uint32_t n_trees, uint32_t largest_tree, void* workspace,
+                            size_t workspace_bytes, Node4* nodes_base, uint32_t* order_out, uint32_t* node_counts_out, int max_leaf, float trav_cost)
+{
+    if (n == 0 || n_trees == 0) return hipErrorInvalidValue;
+    // the single-tree layout for n + M primitives has room for the M extra roots everywhere a per-node array is sized from n
+    const Layout L = make_layout(n + n_trees);
+    const size_t tree_of_off = L.total, tree_nodes_off = tree_of_off + align_up((size_t)L.node_cap * 4, 256);
+    if (sah_forest_workspace_bytes(n, n_trees) > workspace_bytes) return hipErrorInvalidValue;
+    max_leaf = max_leaf < 1 ? 1 : (max_leaf > kMaxLeafTris ? kMaxLeafTris : max_leaf);
+    char* w = static_cast<char*>(workspace);
+    {
+        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
+        if (poison) (void)hipMemsetAsync(workspace, 0xCD, sah_forest_workspace_bytes(n, n_trees), s);
+    }
+    Counters* ctr = (Counters*)(w + L.ctr);
+    SNode* nodes = (SNode*)(w + L.nodes);
+    uint32_t* order[2] = {(uint32_t*)(w + L.order[0]), (uint32_t*)(w + L.order[1])};
+    uint32_t* nop[2] = {(uint32_t*)(w + L.nop[0]), (uint32_t*)(w + L.nop[1])};
+    uint32_t* active[2] = {(uint32_t*)(w + L.active[0]), (uint32_t*)(w + L.active[1])};
+    uint32_t* small = (uint32_t*)(w + L.small);
+    uint32_t* bin_slot = (uint32_t*)(w + L.bin_slot);
+    uint8_t* stamp = (uint8_t*)(w + L.stamp);
+    DevBox* pbox[2] = {(DevBox*)(w + L.pbox[0]), (DevBox*)(w + L.pbox[1])};
+    Split* splits = (Split*)(w + L.splits);
+    uint32_t* fill = (uint32_t*)(w + L.fill);
+    Bin* bins[2] = {(Bin*)(w + L.bins[0]), (Bin*)(w + L.bins[1])};
+    uint32_t* flag4 = (uint32_t*)(w + L.flag4);
+    uint32_t* idx4 = (uint32_t*)(w + L.idx4);
+    uint32_t* tree_of = (uint32_t*)(w + tree_of_off);
+    uint32_t* tree_nodes = (uint32_t*)(w + tree_nodes_off);
+    hipError_t e = hipMemsetAsync(nodes, 0xff, (size_t)L.node_cap * sizeof(SNode), s);
+    if (e == hipSuccess) e = hipMemsetAsync(stamp, 0xff, (size_t)L.node_cap, s);
+    if (e == hipSuccess) e = hipMemsetAsync(tree_nodes, 0, (size_t)n_trees * 4, s);
+    if (e != hipSuccess) return e;
+    const uint32_t small_cap = small_cap_for(n);
+    // big nodes of level l: at most 2^l per tree, and at most n / small_cap altogether
+    auto level_ub = [&](int l) { return (uint32_t)std::min<uint64_t>(l < 20 ? ((uint64_t)n_trees << l) : ~0ull >> 1, (uint64_t)n / small_cap + 1); };
+    const uint32_t bin_groups = blocks(n);
+    auto level_replicas = [&](int l) { return std::max(1u, std::min(32u, bin_groups / (8u * level_ub(l)))); };
+    hipLaunchKernelGGL(k_forest_init, dim3(1), dim3(64), 0, s, ctr, n_trees);
+    hipLaunchKernelGGL(k_forest_roots, dim3(n_trees), dim3(kBlock), 0, s, boxes, trees, ctr, nodes, order[0], nop[0], active[0], small, bin_slot, stamp, bins[0], level_replicas(0), small_cap);
+    int cur = 0, level = 0;
+    auto run_level = [&]() {
+        const uint32_t par = (uint32_t)(level & 1);
+        const uint32_t ub = level_ub(level), reps = level_replicas(level), reps_next = level_replicas(level + 1);
+        const DevBox* pin = level == 0 ? boxes : pbox[cur];
+        hipLaunchKernelGGL(k_bin, dim3(bin_groups), dim3(kBlock), 0, s, pin, nop[cur], nodes, bin_slot, stamp, bins[par], n, ctr, (uint32_t)level, reps);
+        hipLaunchKernelGGL(k_split, dim3(blocks(ub, kBlock / 64)), dim3(kBlock), 0, s, active[par], active[par ^ 1], (uint32_t)level, ctr, nodes, bins[par], bins[par ^ 1], bin_slot, stamp, splits, fill,
+                           small, reps, reps_next, small_cap);
+        if ((largest_tree >> std::min(level, 31)) >= 64u * kBlock) // the largest tree's nodes still span many blocks: chunks of blocks take their slots together
+            hipLaunchKernelGGL(k_partition_chunk, dim3(blocks(n, kPartChunk * kBlock)), dim3(kBlock), 0, s, pin, pbox[cur ^ 1], order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1],
+                               nodes, splits, stamp, fill, n, (uint32_t)level);
+        else
+            hipLaunchKernelGGL(k_partition, dim3(blocks(n)), dim3(kBlock), 0, s, pin, pbox[cur ^ 1], order[cur], nop[cur], order[cur ^ 1], nop[cur ^ 1], nodes, splits, stamp, fill, n,
+                               (uint32_t)level);
+        cur ^= 1;
+        level++;
+    };
+    uint32_t counts[4] = {0, 0, 0, 0};
+    auto read_counts = [&]() -> hipError_t {
+        hipError_t e2 = hipMemcpyAsync(counts, ctr, sizeof(counts), hipMemcpyDeviceToHost, s);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+        return e2;
+    };
+    if (largest_tree > small_cap) {
+        int expect = largest_tree > 65536u ? 8 : 3;
+        for (uint32_t v = largest_tree / small_cap; v > 1; v >>= 1) expect++;
+        while (level < expect && level < kMaxLevels) run_level();
+    }
+    if ((e = read_counts()) != hipSuccess) return e;
+    while (counts[1 + (level & 1)] > 0 && level < kMaxLevels) {
+        if (counts[1 + (level & 1)] > L.big_cap) return hipErrorInvalidValue;
+        for (int k = 0; k < 4 && level < kMaxLevels; k++) run_level();
+        if ((e = read_counts()) != hipSuccess) return e;
+    }
+    if (counts[1 + (level & 1)] > 0) return hipErrorInvalidValue;
+    const uint32_t n_small = counts[3];
+    if (n_small && small_cap == kSmall) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_small<kSmall>), dim3(n_small), dim3(kSmall), 0, s, boxes, order[cur], order_out, small, ctr, nodes, max_leaf, trav_cost);
+    else if (n_small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_small<kSmallFew>), dim3(n_small), dim3(kSmallFew), 0, s, boxes, order[cur], order_out, small, ctr, nodes, max_leaf, trav_cost);
+    hipLaunchKernelGGL(k_flag_forest, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, ctr, nodes, flag4, tree_of);
+    hipLaunchKernelGGL(k_index_forest, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, ctr, nodes, flag4, tree_of, idx4, tree_nodes);
+    hipLaunchKernelGGL(k_emit_forest, dim3(blocks(L.node_cap)), dim3(kBlock), 0, s, L.node_cap, n_trees, ctr, nodes, flag4, idx4, tree_of, trees, tree_nodes, nodes_base, node_counts_out);
+    return hipGetLastError();
+}
+void launch_forest_relative_order(hipStream_t s, uint32_t* order, uint32_t n, const ForestTree* trees, uint32_t n_trees)
+{
+    if (n && n_trees) hipLaunchKernelGGL(k_forest_relative_order, dim3(blocks(n)), dim3(kBlock), 0, s, order, n, trees, n_trees);
 }
 
 void launch_refit_setup(hipStream_t s, const Node4* nodes, uint32_t n_nodes, uint32_t* parent_slot, uint32_t* n_internal)

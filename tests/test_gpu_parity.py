@@ -388,6 +388,39 @@ def test_builders_give_identical_answers(builder):
     assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
 
 
+@pytest.mark.parametrize("forest", [True, False])
+def test_many_meshes_are_built_in_one_pass(forest, monkeypatch):
+    """A scene of many meshes of very different sizes (2-triangle walls, boxes, an icosphere mesh with 30 instances, a 30 000-triangle soup,
+    the 65 meshes of C4's atrium in miniature): the full device build takes all meshes as roots of ONE level-by-level pass
+    (sah_build_forest) — or, with RFW_NO_FOREST, mesh by mesh on parallel lanes.  Ray queries equal the tree-free definition, the image
+    equals the oracle's, and one mesh edited afterwards (the per-mesh path, in place) still does."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    if not forest:
+        monkeypatch.setenv("RFW_NO_FOREST", "1")
+    w, h = 160, 104
+    scene = Scene().build("cornell").build("spheres", 6, 5, 0.3).build("soup", 30000, 3, 0.0, 5)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=3)
+    scene.sync(be)
+    orc = Oracle(w, h, threads=8, max_path_length=3)
+    scene.mark_all_changed(); scene.sync(orc)
+    o, d = random_rays(8000, 5)
+    assert_hits_equal(be.intersect(o, d), orc.intersect(o, d, brute=True))
+    for _ in range(2):
+        be.render(view); orc.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    st = be.scene_stats()
+    assert st["triangles"] == orc.stats()["n_tris"] and st["blas_nodes"] > 0
+    # everything changed again (the full build once more), then render: same image
+    scene.mark_all_changed(); scene.sync(be)
+    be.reset_accumulation(); orc.reset()
+    be.render(view); orc.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    be.close()
+
+
 def test_device_builders_on_large_mesh_match_host_sah():
     from rfw_rs_amd import HipBackend, Scene
     w, h = 480, 270
