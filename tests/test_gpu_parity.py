@@ -319,7 +319,7 @@ import hashlib, sys
 sys.path.insert(0, sys.argv[1])
 from rfw_rs_amd import HipBackend, Scene
 w, h = 256, 144
-scene = Scene().build("atrium", 1048576, 0, 0.0, 0xC0FFEE)
+scene = Scene().build("atrium", 1048576, int(sys.argv[4]), 0.0, 0xC0FFEE)   # 0: two meshes (built one after the other); 1: 65 meshes (one forest)
 scene.set_aspect(w / h)
 view = scene.view(w, h)
 for k in range(int(sys.argv[2])):
@@ -335,18 +335,20 @@ def test_device_builder_while_another_process_uses_the_device():
     """Regression (round 3): the level kernels of the binned-SAH builder run their wavefronts in any order, and one of them cleared the
     NEXT level's bins in the array another was still reading THIS level's bins from — invisible while a launch's wavefronts start together,
     a memory fault or a hang (one build in five) as soon as a second process time-slices the device, which is how two ranks share a GPU.
-    Two processes build the 1 M-triangle scene six times each, side by side; every build must give the image of the host builder's tree."""
+    Two processes build the 1 M-triangle scene six times each, side by side — as two meshes and as 65 (one forest) —; every build must give
+    the image of the host builder's tree."""
     import subprocess
     import sys
     from conftest import ROOT
-    ref = subprocess.run([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "1", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert ref.returncode == 0, ref.stderr[-2000:]
-    want = ref.stdout.split()[-1]
-    procs = [subprocess.Popen([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "6", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
-    for p in procs:
-        out, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-2000:]
-        assert out.split() == [want] * 6
+    for meshes in ("0", "1"):       # the scene as two meshes, and as 65 (the forest build)
+        ref = subprocess.run([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "1", "1", meshes], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert ref.returncode == 0, ref.stderr[-2000:]
+        want = ref.stdout.split()[-1]
+        procs = [subprocess.Popen([sys.executable, "-c", _CONTENDED_BUILDS, ROOT, "6", "3", meshes], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-2000:]
+            assert out.split() == [want] * 6, meshes
 
 
 def test_animated_instances_match_oracle():

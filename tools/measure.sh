@@ -54,10 +54,9 @@ profile_config() { # name, bench arguments...
   python3 tools/summarize_profile.py ${TAG}_$cfg $O/trace_one $O/pmc_fetch $O/pmc_write $O/pmc_inst $O/pmc_valu $O/pmc_tcp $O/pmc_tcc $O/pmc_ta $O/pmc_tcp2 $O/pmc_tcp3 $O/pmc_tcc2 $O/pmc_ta2 $O/pmc_wait
   cp $(find $O/trace -name '*_kernel_stats.csv' | head -1) profiles/${TAG}_${cfg}_kernel_stats_frames_in_flight.csv 2>/dev/null
   for f in bench bench_under_rocprof bench_one_at_a_time; do [ -s $O/$f.json ] && cp $O/$f.json profiles/${TAG}_${cfg}_$f.json; done
-  # only the small condensed files travel back: drop the raw traces beyond the csv summaries
-  find $O -name '*.db' -delete 2>/dev/null
-  find $O -name '*_counter_collection.csv' -size +20M -delete 2>/dev/null
-  find $O -name '*_kernel_trace.csv' -size +20M -delete 2>/dev/null
+  # only the condensed files travel back (gpurun brings at most 64 MiB home, and nothing at all beyond that): the raw traces and counter
+  # collections have been summarised above
+  rm -rf $O/trace $O/trace_one $O/pmc_*/
 }
 
 profile_config c4
