@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
 {
     __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
 #if RFW_STAGE_PRIO
-    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO); // experiment: the later stages of a frame win the issue arbitration over younger frames' primary rays
+    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO); // experiment (EXPERIMENTS.md): the later stages of a frame win the issue arbitration over younger frames' primary rays
 #endif
     // the queue is bucketed by light (shade pushes directional lights into the last region, positional lights into region light % 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light

@@ -1453,7 +1453,7 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     // streaming trades the tail of every wavefront for fewer, longer wavefronts: it pays when other frames fill the chip meanwhile (measured on
     // C4 path traced: 8 frame slots 2880 -> 3190 Mrays/s, 4 slots 2840 -> 3100; but 2 slots 2770 -> 2610, one frame at a time 2270 -> 1670,
     // and batches, whose extension rays are traced in sorted order, 3480 -> 3360).  Unless the option was set by hand it is on for single
-    // frames of an instance with four or more frame slots
+    // frames of an instance with four or more frame slots (and for batches, which fill the chip by themselves: do_render)
     const Instance* S_ = scene_of(I);
     c.stream_run = (S_->stream_auto && !(S_->slots.size() + 1 >= 4)) ? 0u : S_->stream_run;
     c.stream_refill = std::max(1u, std::min(64u, scene_of(I)->stream_refill)) | (std::max(1u, std::min(64u, scene_of(I)->stream_leaf_gate)) << 8);
@@ -1662,7 +1662,8 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
     BatchViews bv;
     if (k > 1) {
         cam[0].batch = k;
-        if (scene_of(I)->stream_auto) cam[0].stream_run = 0u; // a batch's extension rays are traced in sorted order: one ray per lane (see camera_params)
+        // a batch fills the chip by itself: its bounces stream whatever the number of frame slots (and are then NOT sorted, see below)
+        if (scene_of(I)->stream_auto) cam[0].stream_run = scene_of(I)->stream_run;
         p[0].capacity = I->cap_v * k;
         for (uint32_t f = 0; f < k; f++) {
             cam[0].batch_sample[f] = samples ? I->sample_count + f : 0u;
@@ -1682,11 +1683,14 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool
             else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
             else {
                 const uint32_t* order = nullptr;
-                // Measured on C4, max path length 3: a single 1-spp frame has too few rays per cell and direction for the sort
+                // Measured on C4, max path length 3 (EXPERIMENTS.md): a single 1-spp frame has too few rays per cell and direction for the sort
                 // to form coherent wavefronts (+1.5 % with frames in flight, -2.7 % alone: it costs a 2 M-pair sort per bounce); a batch of 8
                 // frames — or k samples of one image — sorts 8 x / k x as many rays of the same surfaces together: +17 %
+                // Round 3: streaming (traverse_stream) does for a batch what the sort does, without the sort — batches of 8: 3480 sorted, 3490
+                // streaming, 3300 both; 4 samples of one image per call: 3070 sorted, 3415 streaming, 3130 both — so "only where it pays"
+                // (mode 2) now means: batches whose bounces do NOT stream
                 const int mode = scene_of(I)->sort_extension_rays;
-                if ((mode == 1 || (mode == 2 && k > 1)) && S == 1) { // (sub-shards keep the queue order: one sort buffer per instance)
+                if ((mode == 1 || (mode == 2 && k > 1 && cam[s].stream_run == 0u)) && S == 1) { // (sub-shards keep the queue order: one sort buffer per instance)
                     const size_t n = p[s].capacity;
                     for (int q = 0; q < 2; q++) { HIP_TRY(I, I->d_sort_keys[q].ensure(n)); HIP_TRY(I, I->d_sort_vals[q].ensure(n)); }
                     HIP_TRY(I, I->d_sort_ws.ensure(sort_pairs_workspace_bytes((uint32_t)n)));
