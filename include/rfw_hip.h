@@ -182,7 +182,18 @@ RFW_HIP_API int rfw_hip_set_skins(void* instance, const rfw_skin_data* skins, ui
 /* ---- extensions: the trait presents to a swap chain and has no read-back, options or queries ---- */
 /* gpu-rt's RenderMode::Reset (gpu-rt/src/lib.rs:1690-1692): restart accumulation. */
 RFW_HIP_API int rfw_hip_reset_accumulation(void* instance);
-/* keys: "max_path_length", "clamp_value", "nee", "count_traversal", "sample_count" */
+/* Options (unknown keys are an error).  The trait has none: these are the knobs a host outside the trait may turn.
+ *   rendering      "max_path_length" (1 = primary + shadow), "clamp_value", "nee" (0 / 1), "sample_count", "sky_r" / "sky_g" / "sky_b",
+ *                  "texture_array" (gpu-rt's 1024^2 x 5 texture array, default 1)
+ *   measurement    "count_traversal" (node / triangle / instance counters of the next frames), "timing" (HIP events per kernel)
+ *   ray order      "shadow_order" 0 | 1 | 2 (which end any-hit traversals start from; the image is the same under every order),
+ *                  "sort_extension_rays" 0 never | 1 always | 2 batches whose bounces do not stream (default),
+ *                  "stream_run" r (0 or a power of two <= 64: a wavefront of the bounces' trace kernels owns r x 64 queue entries and refills
+ *                  its idle lanes; setting it forces, the default 8 applies by "stream_auto" = 1 to single frames of an instance with >= 4 frame
+ *                  slots and to batches), "stream_refill" (idle lanes that trigger a refill, 12), "stream_leaf_gate" (lanes at a leaf that
+ *                  start the packet loop, 16) — images never depend on any of these
+ *   builders       "sah_max_leaf", "sah_trav_cost", "build_threads" (host builder), "spill_rows" (test hook: rows of the HBM stack spill)
+ *   multi-GPU      "gather_format" 0 | 1 | 2, "present_rank" r (see rfw_hip_shard_info), "p2p_timeout_ms" (see rfw_hip_p2p_*) */
 RFW_HIP_API int rfw_hip_set_option(void* instance, const char* key, double value);
 /* tonemapped frame, RGBA32F, sqrt(acc/samples) (backends/gpu-rt/shaders/blit.comp:15-23); n_floats = w*h*4 */
 RFW_HIP_API int rfw_hip_read_framebuffer(void* instance, float* rgba, uint64_t n_floats);
