@@ -734,12 +734,41 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
     return r
 
 
+def usable_cpus():
+    """Threads this process may actually run at once: the scheduler affinity mask capped by the cgroup CPU quota (cpu.max) — os.cpu_count()
+    reports the machine, and a pool sized from it on a quota-limited box only adds context switches."""
+    limits = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        limits["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        limits["sched_affinity"] = limits["os_cpu_count"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    limits["cgroup_cpu_quota"] = round(quota, 2) if quota else None
+    n = limits["sched_affinity"]
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, limits
+
+
 def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
     """The oracle — a CPU RESTATEMENT of the reference's rtbvh / MBVH path, not rfw-rs measured — timed on this host's cores on the
     bench's own workload at the bench's own resolution: the frames of `check` (view, animation time) first, whose accumulators are
     returned for the comparison with the timed frames, then more frames of the same views until about `budget_s` seconds are spent."""
     from oracle.bindings import Oracle, build_timing_library
-    cores = os.cpu_count() or 1
+    cores, limits = usable_cpus()
     # the same source, built for speed on THIS machine (-O3 -march=native; -ffp-contract=off stays: its frames are still the checker's frames)
     timing_lib, timing_flags = build_timing_library()
     orc = Oracle(w, h, library=timing_lib, threads=cores, max_path_length=max_path_length)
@@ -770,11 +799,41 @@ def cpu_baseline(scene, check, w, h, budget_s, max_path_length, animated):
         k += 1
         if k >= len(check) and (spent > budget_s or n >= 64):
             break
-    return ({"value": round(rays / spent / 1e6, 3), "unit": "Mrays/s", "cores": busy or cores, "kind": "port",
+    # thread scaling of the same frame (view 0), one frame per point: says whether the full pool is limited by the cores or by something
+    # else (quota, NUMA, memory) — per-thread rate at `all` within 2x of the single-thread rate = the pool scales
+    scaling = []
+    rate_all = rays / spent / 1e6
+    for nt in sorted({1, min(8, cores), min(64, cores)}):
+        if nt >= cores:
+            continue
+        orc.set_option("threads", nt)
+        orc.set_option("tile_stride", max(1, 16 // nt))  # a bounded sample: every 16th tile of the frame for one thread, every 2nd for eight
+        orc.reset()
+        before = count(orc.stats())
+        t1 = time.perf_counter()
+        orc.render(check[0][0])
+        dt = time.perf_counter() - t1
+        r_ = (count(orc.stats()) - before) / dt / 1e6
+        scaling.append({"threads": nt, "Mrays_per_s": round(r_, 3), "krays_per_s_per_thread": round(1e3 * r_ / nt, 1), "seconds": round(dt, 2)})
+    orc.set_option("threads", cores)
+    orc.set_option("tile_stride", 1)
+    scaling.append({"threads": busy or cores, "Mrays_per_s": round(rate_all, 3), "krays_per_s_per_thread": round(1e3 * rate_all / (busy or cores), 1)})
+    single = scaling[0]["krays_per_s_per_thread"] if scaling and scaling[0]["threads"] == 1 else None
+    per_thread = scaling[-1]["krays_per_s_per_thread"]
+    verdict = None
+    if single:
+        ratio = single / max(per_thread, 1e-9)
+        verdict = (f"per-thread rate with all threads is {ratio:.2f}x below the single-thread rate: " +
+                   ("the pool scales with the cores" if ratio <= 2.0 else
+                    ("limited by the cgroup CPU quota" if limits.get("cgroup_cpu_quota") and limits["cgroup_cpu_quota"] < limits["sched_affinity"] else
+                     "limited by something other than core count (SMT siblings, NUMA / memory bandwidth: BVH and triangles are shared by all threads)")))
+    return ({"value": round(rate_all, 3), "unit": "Mrays/s", "cores": busy or cores, "kind": "port",
              "what": "CPU restatement of the reference's path (oracle/), not the reference binary: rfw-rs cannot be built here (no Rust toolchain, rtbvh un-vendored)",
              "build": (f"g++ {timing_flags}, built on this host" if timing_lib else f"oracle/liboracle.so (-O2, portable): {timing_flags}"),
-             "threads": {"started": cores, "rendered_at_least_one_tile": busy, "work_items": "16x16-pixel tiles from one atomic counter, persistent pool"},
-             "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {busy or cores} busy threads of {cores}, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded"},
+             "threads": {"started": cores, "rendered_at_least_one_tile": busy, "work_items": "16x16-pixel tiles from one atomic counter, persistent pool; per-thread counters on cache lines of their own",
+                         "limits": limits, "scaling": scaling, "scaling_verdict": verdict},
+             "sample": f"{n} frame(s) of the bench's own scene and views at {w}x{h}, 1 spp, max path length {max_path_length}, {busy or cores} busy threads of {cores}, {spent:.1f} s of rendering; BVH build {build_s:.1f} s excluded",
+             },
             frames)
 
 

@@ -293,6 +293,12 @@ RFW_HIP_API int rfw_hip_debug_read(void* instance, const char* what, void* dst, 
  * the planning probes under tools/probes (wave-occupancy models from real per-ray traversal lengths); not part of the trait. */
 RFW_HIP_API int rfw_hip_debug_occludes_depth(void* instance, const float* origins, const float* directions, float t_min, const float* t_max,
                                              uint64_t num_rays, uint8_t* occluded, uint32_t* depth);
+/* Test-only: stress test of the device LBVH builder that rebuilds the TLAS every frame (its bottom-up fit hands a subtree's box from one
+ * thread to another without fences: csrc/lbvh.hip, k_fit).  `iterations` times: num_boxes jittered boxes -> tree -> exact structural check
+ * on the device (every child box equals the union of what lies below it; every box in exactly one leaf), all queued on the instance's
+ * stream; *errors = mismatches found, *checked = child boxes compared.  Environment RFW_LBVH_FENCED=1 selects the fenced fit. */
+RFW_HIP_API int rfw_hip_debug_lbvh_stress(void* instance, uint32_t num_boxes, uint32_t iterations, uint32_t seed, uint64_t* errors, uint64_t* checked);
+
 /* Test-only: the device functions the shade kernel is made of, evaluated one by one on caller-supplied inputs, so that each can be held
  * against an independent formulation (tests/test_shading_kat.py compares with numpy float64).  Host pointers; per case 48 input floats:
  *   [0,24) one rfw_device_material (its 96 bytes)  [24,27) N  [27,30) wo (op 3: D; op 4: the shaded point I)  [30,33) wi  [33,36) T

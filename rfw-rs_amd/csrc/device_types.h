@@ -95,6 +95,30 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
     return q;
 }
 
+// The boxes a Node4Q encodes, as floats again (plane = origin + q * scale: exact in binary32 up to the rounding of the one add, which the
+// per-lane kernels' own decoding shares in spirit but not in bits — both are conservative supersets of the builder's boxes, and no result
+// depends on the boxes).  The packet kernels (traverse_packet.h) read these 128-B nodes through the scalar cache.
+// An empty slot keeps its inverted box and kInvalidRef.
+inline __host__ __device__ Node4 dequantize_node(const Node4Q& q)
+{
+    Node4 n;
+    const float o[3] = {q.ox, q.oy, q.oz}, sc[3] = {q.sx, q.sy, q.sz};
+    float* lo[3] = {n.lox, n.loy, n.loz};
+    float* hi[3] = {n.hix, n.hiy, n.hiz};
+    for (int i = 0; i < 4; i++) {
+        for (int a = 0; a < 3; a++) {
+            // rounding of the add: push the decoded plane outwards by one ulp-sized step of the result so that the float box still encloses
+            // the exact decoded box (lo towards -inf, hi towards +inf)
+            const float l = o[a] + (float)((q.qlo[a] >> (8 * i)) & 0xffu) * sc[a], h = o[a] + (float)((q.qhi[a] >> (8 * i)) & 0xffu) * sc[a];
+            lo[a][i] = l - 1.1920929e-7f * (l < 0.0f ? -l : l);
+            hi[a][i] = h + 1.1920929e-7f * (h < 0.0f ? -h : h);
+        }
+        n.child[i] = q.child[i];
+        n.pad[i] = 0u;
+    }
+    return n;
+}
+
 // Triangle packet for traversal, 48 B, stored in BLAS leaf order (no index indirection in the leaf loop):
 //   p0 = (v0.xyz, bits(global triangle id)), p1 = (edge1.xyz, 1/dot(gn,gn)), p2 = (edge2.xyz, 0)
 // edge1 = v1 - v0 and edge2 = v2 - v0 are the very subtractions intersection.glsl:7-8 performs per test, done once.
@@ -198,7 +222,9 @@ struct QueueCounters {
     unsigned long long pad3;
 };
 
-enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u, kFlagNearFirstDirectional = 4u, kFlagFarFirstPositional = 8u }; // the last two: option "shadow_order"
+enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u, kFlagNearFirstDirectional = 4u, kFlagFarFirstPositional = 8u,
+                  kFlagPacketPrimary = 16u, kFlagPacketShadow = 32u }; // option "packet_trace": which rays walk the tree as wavefront packets (traverse_packet.h)
+// (kFlagNearFirstDirectional, kFlagFarFirstPositional: option "shadow_order")
 
 
 } // namespace rfwhip

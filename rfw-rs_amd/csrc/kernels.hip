@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "shade_device.h"
 #include "traverse.h"
+#include "traverse_packet.h"
 
 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves), chosen by measurement with frames in flight:
 // closest hit (k_primary, k_extend) 6 (5: -6 %, 7: -2 %, 8: -11 %); any hit (k_shadow: fewer live values) 8 (7: -1.4 %, 6: -2.8 %)
@@ -275,6 +276,41 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     } else if (idx < p.capacity) {
         p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u); // a slab slot without a pixel (ragged edge tile): k_shade skips it without redoing the index arithmetic
+    }
+    flush_counters<COUNT>(sc.counters, tc, 0);
+}
+
+// The packet flavour (traverse_packet.h): the 64 camera rays of an 8x8-pixel block walk the tree together on one shared stack.  Same rays,
+// same triangle tests, same image; no LDS.
+#ifndef RFW_PACKET_WAVES
+#define RFW_PACKET_WAVES 6
+#endif
+template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_primary_packet(const CameraParams cam, const SceneDev sc, const PathDev p)
+{
+    const uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
+    TravCounters tc{0, 0, 0};
+    uint32_t px = 0, py = 0;
+    const bool valid = idx < p.capacity && slab_to_pixel(cam, idx, px, py);
+    f3 O = mk3(0.0f), D = mk3(0.0f);
+    if (valid) {
+        if (cam.sample_count == 0) p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t path_id = px + py * cam.width;
+        uint32_t seed = wang_hash(path_id * 16789u + cam.sample_count * 1791u + 0u * 720898027u);
+        generate_eye_ray(cam, O, D, px, py, seed, sc.blue_noise, cam.sample_count);
+        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id));
+        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
+    }
+    float t = 1e26f, hu = 0.0f, hv = 0.0f;
+    int32_t hi = -1, ht = -1;
+    bool occluded;
+    const SceneView sv = scene_view(sc);
+    traverse_packet<false, COUNT>(sv, sc.tlas_wide, sc.blas_wide, valid, O, D, 1e-4f, t, hu, hv, hi, ht, occluded, tc);
+    if (valid) {
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    } else if (idx < p.capacity) {
+        p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u);
     }
     flush_counters<COUNT>(sc.counters, tc, 0);
 }
@@ -985,10 +1021,18 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes visited until the first occluder / the end of the traversal
 }
 
-__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n)
+__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, Node4* __restrict__ wide, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = quantize_node(in[i]);
+    if (i >= n) return;
+    const Node4Q q = quantize_node(in[i]);
+    out[i] = q;
+    if (wide) wide[i] = dequantize_node(q); // the same boxes as floats, for the packet kernels
+}
+__global__ void k_expand_nodes(const Node4Q* __restrict__ in, Node4* __restrict__ wide, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wide[i] = dequantize_node(in[i]);
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -1010,6 +1054,11 @@ void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uin
 void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count)
 {
     const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
+    if ((cam.flags & kFlagPacketPrimary) && sc.tlas_wide && sc.blas_wide) {
+        if (count) hipLaunchKernelGGL(k_primary_packet<true>, grid, block, 0, s, cam, sc, p);
+        else hipLaunchKernelGGL(k_primary_packet<false>, grid, block, 0, s, cam, sc, p);
+        return;
+    }
     if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, s, cam, sc, p);
     else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, s, cam, sc, p);
 }
@@ -1088,9 +1137,13 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
 }
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, uint32_t n)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, Node4* wide, uint32_t n)
 {
-    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);
+    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, wide, n);
+}
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, Node4* wide, uint32_t n)
+{
+    if (n) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, wide, n);
 }
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)

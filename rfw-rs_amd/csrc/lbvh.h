@@ -30,6 +30,12 @@ size_t lbvh_workspace_bytes(uint32_t n);
 hipError_t lbvh_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
                       uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */);
 
+// Stress test of lbvh_build's fence-free bottom-up fit: `iterations` times n jittered boxes -> tree -> exact structural check, all on the
+// stream (no host round trip).  nodes / order / seen: room for n; node_count: 1 word; result: 2 words, zeroed by the caller
+// ([0] += mismatches, [1] += child boxes checked).
+hipError_t lbvh_stress(hipStream_t s, uint32_t n, uint32_t iterations, uint32_t seed, void* workspace, size_t workspace_bytes, DevBox* boxes, Node4* nodes,
+                       uint32_t* order, uint32_t* node_count, uint32_t* seen, unsigned long long* result);
+
 // world-space boxes of instances: box k = local_aabb(mesh of gid[k]) through matrix gid[k], padded
 void launch_instance_boxes(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const DevBox* mesh_local_boxes,
                            const uint32_t* valid_gids, uint32_t n_valid, DevBox* out);

@@ -157,6 +157,11 @@ __device__ inline uint32_t node_slot(int32_t child, uint32_t n) { return child <
 // drained before the arrival counter is bumped, and the second arrival reads its sibling's box with sc1 loads (past the vector L1, which
 // another CU's stores never refresh).  Round 2 fenced twice per step (__threadfence = L2 write-back + L1 invalidate, ~3.5 us, for every
 // thread on every level): 12 ms for 1 M primitives.
+// FENCED (environment RFW_LBVH_FENCED=1, read once): the textbook hand-off instead — plain stores, __threadfence(), the arrival counter,
+// __threadfence(), plain loads — i.e. a release / acquire pair at device scope around the counter (an L2 write-back and an L1 invalidate per
+// step: 9.4 instead of 4.8 ms for 1 M primitives).  The known-good fallback should the fence-free form ever fail
+// rfw_hip_debug_lbvh_stress (tests/test_gpu_api.py::test_fence_free_tlas_fit_survives_ten_thousand_rebuilds) on some driver or firmware.
+template <bool FENCED>
 __global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n, const int32_t* __restrict__ left,
                       const int32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* flags, DevBox* nbox)
 {
@@ -166,19 +171,30 @@ __global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restri
     uint32_t me = n - 1 + i;
     uint32_t node = parent[me];
     for (;;) {
-        for (int a = 0; a < 3; a++) {
-            __hip_atomic_store(&nbox[me].lo[a], b.lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&nbox[me].hi[a], b.hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FENCED) {
+            for (int a = 0; a < 3; a++) { nbox[me].lo[a] = b.lo[a]; nbox[me].hi[a] = b.hi[a]; }
+        } else {
+            for (int a = 0; a < 3; a++) {
+                __hip_atomic_store(&nbox[me].lo[a], b.lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&nbox[me].hi[a], b.hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (node == 0xffffffffu) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the box is out before the arrival counts
+        if (FENCED) __threadfence();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the box is out before the arrival counts
         const uint32_t old = atomicAdd(&flags[node], 1u);
         if (old == 0u) return; // the second arrival at a node owns it
+        if (FENCED) __threadfence();
         const uint32_t ls = node_slot(left[node], n), rs = node_slot(right[node], n);
         const uint32_t sib = ls == me ? rs : ls;
-        for (int a = 0; a < 3; a++) {
-            b.lo[a] = fminf(b.lo[a], __hip_atomic_load(&nbox[sib].lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            b.hi[a] = fmaxf(b.hi[a], __hip_atomic_load(&nbox[sib].hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (FENCED) {
+            const volatile DevBox* sb = nbox + sib;
+            for (int a = 0; a < 3; a++) { b.lo[a] = fminf(b.lo[a], sb->lo[a]); b.hi[a] = fmaxf(b.hi[a], sb->hi[a]); }
+        } else {
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] = fminf(b.lo[a], __hip_atomic_load(&nbox[sib].lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b.hi[a] = fmaxf(b.hi[a], __hip_atomic_load(&nbox[sib].hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
         }
         me = node;
         node = parent[node];
@@ -469,12 +485,96 @@ hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* work
     e = hipMemsetAsync(flags, 0, (size_t)n * 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks(n - 1)), dim3(kBlock), 0, s, keys_out, n, left, right, parent);
-    hipLaunchKernelGGL(k_fit, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
+    static const bool fenced = getenv("RFW_LBVH_FENCED") != nullptr && atoi(getenv("RFW_LBVH_FENCED")) != 0;
+    if (fenced) hipLaunchKernelGGL(k_fit<true>, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
+    else hipLaunchKernelGGL(k_fit<false>, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
     hipLaunchKernelGGL(k_flag_even_depth, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n - 1, parent, flag4);
     cub_bytes = L.cub_bytes;
     e = hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag4, idx4, (int)(n - 1), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit4, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n, left, right, flag4, idx4, nbox, nodes_out, node_count_out);
+    return hipGetLastError();
+}
+
+// ---- stress test of the builder (rfw_hip_debug_lbvh_stress): n jittered boxes -> tree -> exact structural check, `iterations` times, all
+// on the stream.  Box k sits near cell k of a cube grid and moves and changes size with (seed, iteration): neighbouring keys, deep
+// common prefixes and coincident centres all occur.
+__global__ void k_stress_boxes(DevBox* out, uint32_t n, uint32_t side, uint32_t seed, uint32_t iteration)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (i * 2654435761u) ^ (seed * 40503u) ^ (iteration * 2246822519u);
+    auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (float)(h & 0xffffu) * (1.0f / 65536.0f); };
+    const bool twin = (h & 0x30000u) == 0u; // a quarter of the boxes sit exactly on the corner of their group of four's cell: equal Morton keys
+    const uint32_t j = twin ? (i & ~3u) : i;
+    const float cx = (float)(j % side), cy = (float)((j / side) % side), cz = (float)(j / (side * side));
+    DevBox b;
+    const float c[3] = {cx + (twin ? 0.0f : 2.0f * rnd()), cy + (twin ? 0.0f : 2.0f * rnd()), cz + (twin ? 0.0f : 2.0f * rnd())};
+    for (int a = 0; a < 3; a++) {
+        const float e = 0.05f + 0.6f * rnd();
+        b.lo[a] = c[a] - e; b.hi[a] = c[a] + e;
+    }
+    b.lo[3] = 0.0f; b.hi[3] = 0.0f;
+    out[i] = b;
+}
+// every child box of every wide node must EQUAL the union of what lies below it (the fit is min / max only: exact), every primitive must be
+// in exactly one leaf: a sibling's box read too early shows up as a mismatch one level up
+__global__ void k_stress_validate(const Node4* __restrict__ nodes, const uint32_t* __restrict__ node_count, const DevBox* __restrict__ boxes,
+                                  const uint32_t* __restrict__ order, uint32_t n, uint32_t* seen, unsigned long long* result)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *node_count) return;
+    const Node4 nd = nodes[i];
+    unsigned long long errors = 0, checked = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = nd.child[k];
+        if (c == kInvalidRef) continue;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (c & kLeafBit) {
+            const uint32_t first = c & kLeafFirstMask, count = ((c >> 27) & 15u) + 1u;
+            for (uint32_t q = 0; q < count; q++) {
+                if (first + q >= n) { errors++; continue; }
+                atomicAdd(&seen[order[first + q]], 1u);
+                const DevBox b = boxes[order[first + q]];
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], b.lo[a]); hi[a] = fmaxf(hi[a], b.hi[a]); }
+            }
+        } else {
+            if (c >= *node_count) { errors++; continue; }
+            const Node4 ch = nodes[c];
+            const float* clo[3] = {ch.lox, ch.loy, ch.loz};
+            const float* chi[3] = {ch.hix, ch.hiy, ch.hiz};
+            for (int kk = 0; kk < 4; kk++) {
+                if (ch.child[kk] == kInvalidRef) continue;
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], clo[a][kk]); hi[a] = fmaxf(hi[a], chi[a][kk]); }
+            }
+        }
+        const float mlo[3] = {nd.lox[k], nd.loy[k], nd.loz[k]}, mhi[3] = {nd.hix[k], nd.hiy[k], nd.hiz[k]};
+        for (int a = 0; a < 3; a++)
+            if (!(mlo[a] == lo[a]) || !(mhi[a] == hi[a])) errors++;
+        checked++;
+    }
+    if (errors) atomicAdd(&result[0], errors);
+    atomicAdd(&result[1], checked);
+}
+__global__ void k_stress_seen(const uint32_t* __restrict__ seen, uint32_t n, unsigned long long* result)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n && seen[i] != 1u) atomicAdd(&result[0], 1ull);
+}
+hipError_t lbvh_stress(hipStream_t s, uint32_t n, uint32_t iterations, uint32_t seed, void* workspace, size_t workspace_bytes, DevBox* boxes, Node4* nodes,
+                       uint32_t* order, uint32_t* node_count, uint32_t* seen, unsigned long long* result /* [0] errors, [1] child boxes checked */)
+{
+    uint32_t side = 1;
+    while (side * side * side < n) side++;
+    for (uint32_t it = 0; it < iterations; it++) {
+        hipLaunchKernelGGL(k_stress_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, n, side, seed, it);
+        hipError_t e = lbvh_build(s, boxes, n, workspace, workspace_bytes, nodes, order, node_count);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(seen, 0, (size_t)n * 4, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_stress_validate, dim3(blocks(n)), dim3(kBlock), 0, s, nodes, node_count, boxes, order, n, seen, result);
+        hipLaunchKernelGGL(k_stress_seen, dim3(blocks(n)), dim3(kBlock), 0, s, seen, n, result);
+    }
     return hipGetLastError();
 }
 

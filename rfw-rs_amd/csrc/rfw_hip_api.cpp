@@ -188,6 +188,7 @@ struct InstList {
     std::vector<int32_t> skin_ids; // per slot, -1 = none
 };
 
+constexpr int kDefaultPacketTrace = 0; // option "packet_trace" when nobody sets it
 enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
@@ -249,6 +250,7 @@ struct Instance {
     // device scene
     DevBuf<Node4Q> d_blas_nodes, d_tlas_nodes;   // what the kernels traverse
     DevBuf<Node4> d_blas_raw, d_tlas_raw;        // device-built trees before quantisation
+    DevBuf<Node4> d_blas_wide, d_tlas_wide;      // what the PACKET kernels traverse: the boxes of d_*_nodes as floats, same index (traverse_packet.h)
     DevBuf<TriPacket> d_packets;
     DevBuf<rfw_rt_triangle> d_triangles;
     DevBuf<MeshRecord> d_mesh_records;
@@ -535,6 +537,8 @@ SceneDev scene_dev(Instance* I)
     s.instance_normals = TL->d_normals.ptr;
     s.meshes = S->d_mesh_records.ptr;
     s.blas_nodes = S->d_blas_nodes.ptr;
+    s.tlas_wide = TL->d_tlas_wide.ptr;
+    s.blas_wide = S->d_blas_wide.ptr;
     s.tri_packets = S->d_packets.ptr;
     s.triangles = S->d_triangles.ptr;
     const Instance::Tables& tb = S->tables[S->tables_version % Instance::kTableVersions];
@@ -713,7 +717,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
     launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, quantise_count);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, quantise_count);
     return RFW_HIP_OK;
 }
 
@@ -758,7 +762,7 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
                     launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, std::max(r.tri_count, 1u));
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, std::max(r.tri_count, 1u));
                 }
                 (void)hipEventRecord(L.done, L.s);
             });
@@ -822,6 +826,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
+    HIP_TRY(I, I->d_blas_wide.ensure(node_total));
     HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
     for (auto& ev : I->ev_build)
@@ -868,7 +873,7 @@ int build_blas_device_full(Instance* I)
         }
         if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
     }
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, static_nodes); // all static regions in one launch
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
@@ -947,6 +952,7 @@ int build_blas_device_incremental(Instance* I)
     HIP_TRY(I, I->d_packets.grow_keep(I->tri_end, I->d_packets.cap, I->stream));
     HIP_TRY(I, I->d_blas_order.grow_keep(I->tri_end, I->d_blas_order.cap, I->stream));
     HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
+    HIP_TRY(I, I->d_blas_wide.grow_keep(I->node_end, I->d_blas_wide.cap, I->stream));
     HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
     HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
     HIP_TRY(I, I->d_mesh_records.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), 0, I->stream));
@@ -1048,11 +1054,13 @@ int build_blas_host(Instance* I)
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
+    HIP_TRY(I, I->d_blas_wide.ensure(node_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     std::vector<Node4Q> qnodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
     if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
+    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, (uint32_t)qnodes.size());
     if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
     if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
@@ -1125,6 +1133,7 @@ int build_instances(Instance* I, Instance* T)
     HIP_TRY(I, T->d_normals.ensure(n_all));
     HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
     HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, T->d_tlas_wide.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_node_count.ensure(1));
     hipStream_t s = T->stream;
@@ -1184,7 +1193,7 @@ int build_instances(Instance* I, Instance* T)
                 quantise_count = d.node_count;
             }
             launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, quantise_count);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, quantise_count);
             launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, T->d_mesh_local.ptr + d.record);
         }
         HIP_TRY(I, hipGetLastError());
@@ -1202,7 +1211,7 @@ int build_instances(Instance* I, Instance* T)
         launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
         HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
                               T->d_node_count.ptr));
-        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, std::max<uint32_t>(n_valid, 1u));
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, std::max<uint32_t>(n_valid, 1u));
         launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
@@ -1239,6 +1248,8 @@ int build_instances(Instance* I, Instance* T)
         std::vector<Node4Q> qn(tlas.nodes.size());
         for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
         if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
+        HIP_TRY(I, T->d_tlas_wide.ensure(std::max<size_t>(qn.size(), 1)));
+        launch_expand_nodes(s, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, (uint32_t)qn.size());
         if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));
@@ -1541,7 +1552,7 @@ int assemble_gathered(Instance* I, hipStream_t s, const void* gathered, uint32_t
 }
 // does this instance receive other ranks' tiles in the gather format (whoever moves them)?
 bool gathers_tiles(const Instance* I) { return scene_of(I)->comm != nullptr || I->external_slab != nullptr || scene_of(I)->p2p.connected; }
-bool p2p_timed_out(const Instance* I) { return I->overflow_host && ((volatile const uint32_t*)I->overflow_host)[1] != 0u; }
+bool p2p_timed_out(const Instance* I) { return scene_of(I)->p2p.connected && I->overflow_host && ((volatile const uint32_t*)I->overflow_host)[1] != 0u; }
 // The frame's exchange by stores into the peers' buffers (include/rfw_hip.h, rfw_hip_p2p_*).  Destinations: the presenting rank, or all.
 int p2p_exchange(Instance* I, hipStream_t s, uint32_t frames)
 {
@@ -1833,10 +1844,16 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         I->rank = o->rank;
         if (o->tile_size) I->tile_size = o->tile_size;
         if (o->builder) I->builder = o->builder;
-        I->flags = o->flags;
+        I->flags = o->flags & 15u; // the public RFW_HIP_FLAG_* bits; the others are internal (set_option)
         if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
         if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 16u);
         if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
+    }
+    {
+        const char* e = getenv("RFW_PACKET_TRACE"); // A/B runs: the default of option "packet_trace"
+        const int pt = e ? atoi(e) : kDefaultPacketTrace;
+        if (pt & 1) I->flags |= kFlagPacketPrimary;
+        if (pt & 2) I->flags |= kFlagPacketShadow;
     }
     if (I->max_batch > 1 && I->substreams > 1) {
         g_create_error = "max_batch > 1 needs streams <= 1 (a batch already fills the device with one launch per stage)";
@@ -1880,7 +1897,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     for (int k = 0; k < Instance::kStages; k++)
         if ((e = hipEventCreateWithFlags(&I->stage_event[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&I->overflow_host, 64, hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc (overflow flag)", e);
-    *I->overflow_host = 0u;
+    std::memset(I->overflow_host, 0, 64); // word 0: traversal stack overflow, word 1: p2p timeout; hipHostMalloc does not zero, and a block may be recycled
     if ((e = hipHostGetDevicePointer((void**)&I->overflow_dev, I->overflow_host, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     if (alloc_paths(I) != RFW_HIP_OK) {
         g_create_error = I->err;
@@ -1935,7 +1952,7 @@ void rfw_hip_destroy(void* inst)
         if (I->scene_ready) (void)hipEventDestroy(I->scene_ready);
         if (I->frame_done) (void)hipEventDestroy(I->frame_done);
         if (I->download_done) (void)hipEventDestroy(I->download_done);
-        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
+        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_wide.release(); I->d_tlas_wide.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release();
         for (auto& tb : I->tables) { tb.materials.release(); tb.area.release(); tb.point.release(); tb.spot.release(); tb.dir.release(); }
@@ -2288,6 +2305,8 @@ void p2p_release(Instance* I)
     if (P.data) (void)hipFree(P.data);
     if (P.flags) (void)hipFree(P.flags);
     P.data = nullptr; P.flags = nullptr; P.connected = false; P.slot_words = 0; P.n_slots = 0;
+    for (uint32_t k = 0; k <= I->slots.size(); k++) // a timeout seen by the old connection says nothing about the next one
+        if (slot_ptr(I, k)->overflow_host) ((volatile uint32_t*)slot_ptr(I, k)->overflow_host)[1] = 0u;
 }
 } // namespace
 
@@ -2306,10 +2325,20 @@ int rfw_hip_p2p_export(void* inst, void* handle_out)
     P.n_slots = 1u + (uint32_t)I->slots.size();
     P.slot_words = (size_t)I->world * I->max_batch * I->capacity * 3u;
     const size_t flag_bytes = std::max<size_t>((size_t)P.n_slots * 2u * I->world * sizeof(uint32_t), 4096);
-    HIP_TRY(I, hipMalloc((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t)));
-    // flag words are polled while peers write them: uncached, so that a poll never reads a stale line of this device's L2
-    if (hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    // The receive buffer is written by the PEERS (stores over xGMI) and read by this device's de-tiling kernel.  Ordinary hipMalloc memory is
+    // cached in this device's L2, which a remote store does not invalidate: fine-grained (system-scope coherent) memory instead, so that a
+    // frame never de-tiles a stale line whatever the kernel-boundary cache policy is.  RFW_P2P_DATA_CACHED=1 keeps round 3's
+    // plain allocation (A/B on a multi-GPU node); a device without fine-grained memory falls back to it as well.
+    if (getenv("RFW_P2P_DATA_CACHED") || hipExtMallocWithFlags((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
+        P.data = nullptr;
+        HIP_TRY(I, hipMalloc((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t)));
+    }
+    // flag words are polled while peers write them: uncached, so that a poll never reads a stale line of this device's L2
+    // (RFW_P2P_FLAGS_FINEGRAINED=1 forces the fall-back kind of memory, so that tests can take that path)
+    if (getenv("RFW_P2P_FLAGS_FINEGRAINED") || hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        P.flags = nullptr;
         if (hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             p2p_release(I);
@@ -2431,6 +2460,8 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     I->restart = true;
     I->width = w;
     I->height = h;
+    // a gathered frame not de-tiled yet belongs to the old size (and d_recv may move below): forget it (each slot passes here for itself)
+    I->deferred = Instance::Deferred(); I->acc_source = nullptr; I->presented_valid = false;
     const int arc = alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
     if (arc == RFW_HIP_OK && scene_of(I)->comm) { // the gather buffers follow the slab size
         const size_t n = (size_t)I->capacity * I->max_batch * 3u;
@@ -2520,11 +2551,19 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         if ((int)value == 1) I->flags |= kFlagNearFirstDirectional;
         else if ((int)value == 2) I->flags |= kFlagFarFirstPositional;
     }
+    else if (k == "packet_trace") { // which rays walk the tree as wavefront packets (traverse_packet.h): bit 0 camera rays, bit 1 the camera paths' shadow rays
+        I->flags &= ~(kFlagPacketPrimary | kFlagPacketShadow);
+        if ((int)value & 1) I->flags |= kFlagPacketPrimary;
+        if ((int)value & 2) I->flags |= kFlagPacketShadow;
+    }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)
         if (value < 0 || value > 2) return fail(I, RFW_HIP_E_INVALID, "set_option: gather_format is 0, 1 or 2");
         I->gather_format = (uint32_t)value;
-        I->deferred = Instance::Deferred(); I->acc_source = nullptr; I->presented_valid = false;
+        for (uint32_t q = 0; q <= I->slots.size(); q++) { // every slot: a frame gathered in the old format must not be de-tiled in the new one
+            Instance* c = slot_ptr(I, q);
+            c->deferred = Instance::Deferred(); c->acc_source = nullptr; c->presented_valid = false;
+        }
     }
     else if (k == "present_rank") I->present_rank = (int)value;
     else if (k == "timing") I->timing = value != 0.0;
@@ -3005,6 +3044,32 @@ int rfw_hip_occludes4(void* inst, const float* origin_xyz4, const float* directi
         const int rc = rfw_hip_occludes(inst, o, d, t_min4[k], t_max4 + k, 1, occluded4 + k);
         if (rc != RFW_HIP_OK) return rc;
     }
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_debug_lbvh_stress(void* inst, uint32_t n, uint32_t iterations, uint32_t seed, uint64_t* errors, uint64_t* checked)
+{
+    LOCK(inst);
+    if (!errors || !checked || n < 2) return fail(I, RFW_HIP_E_INVALID, "debug_lbvh_stress: needs two or more boxes and both result pointers");
+    HIP_TRY(I, hipSetDevice(I->device));
+    DevBuf<char> ws; DevBuf<DevBox> boxes; DevBuf<Node4> nodes; DevBuf<uint32_t> order, count, seen; DevBuf<unsigned long long> result;
+    auto release = [&]() { ws.release(); boxes.release(); nodes.release(); order.release(); count.release(); seen.release(); result.release(); };
+    hipError_t e = ws.ensure(lbvh_workspace_bytes(n));
+    if (e == hipSuccess) e = boxes.ensure(n);
+    if (e == hipSuccess) e = nodes.ensure(n);
+    if (e == hipSuccess) e = order.ensure(n);
+    if (e == hipSuccess) e = count.ensure(1);
+    if (e == hipSuccess) e = seen.ensure(n);
+    if (e == hipSuccess) e = result.ensure(2);
+    if (e == hipSuccess) e = hipMemsetAsync(result.ptr, 0, 16, I->stream);
+    if (e == hipSuccess) e = lbvh_stress(I->stream, n, iterations, seed, ws.ptr, ws.cap, boxes.ptr, nodes.ptr, order.ptr, count.ptr, seen.ptr, result.ptr);
+    unsigned long long host[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, result.ptr, 16, hipMemcpyDeviceToHost, I->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(I->stream);
+    release();
+    if (e != hipSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("debug_lbvh_stress: ") + hipGetErrorString(e));
+    *errors = host[0];
+    *checked = host[1];
     return RFW_HIP_OK;
 }
 

@@ -177,6 +177,33 @@ def test_device_built_trees_are_structurally_valid(builder):
     be.close()
 
 
+def test_fence_free_tlas_fit_survives_ten_thousand_rebuilds():
+    """The per-frame TLAS builder hands a subtree's box from the first child to arrive at a node to the second WITHOUT fences (csrc/lbvh.hip,
+    k_fit: write-through stores, s_waitcnt, a relaxed counter, sc1 loads).  10 000 rebuilds of a tree over 10 000 jittered boxes — every tree
+    checked on the device, exactly: each child box equals the union of what lies below it, each box sits in one leaf — while a second process
+    keeps the device busy, so that the wavefronts of a launch do NOT all start together.  RFW_LBVH_FENCED=1 is the known-good fallback."""
+    import subprocess, sys, os
+    from rfw_rs_amd import HipBackend
+    hog = subprocess.Popen([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r)\nfrom rfw_rs_amd import HipBackend\nbe = HipBackend.init(64, 64, 1.0)\n"
+                            "import time\nt = time.time()\nwhile time.time() - t < 60: be.bandwidth_probe(1 << 28, 20)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))])
+    try:
+        be = HipBackend.init(32, 32, 1.0)
+        total_checked = 0
+        for k in range(10):
+            errors, checked = be.lbvh_stress(10_000, 1_000, seed=1 + k)
+            assert errors == 0, (k, errors, checked)
+            total_checked += checked
+        assert total_checked > 10_000 * 10_000  # every primitive's leaf box and every interior child box, every rebuild
+        # a few large trees too (1 M boxes: the BLAS-sized case of builder = DEVICE_LBVH)
+        errors, checked = be.lbvh_stress(1_000_000, 5, seed=99)
+        assert errors == 0 and checked > 5_000_000, (errors, checked)
+        be.close()
+    finally:
+        hog.kill()
+        hog.wait()
+
+
 def test_depth_test_returns_the_closest_hit_and_a_node_count():
     from oracle.bindings import Oracle
     from rfw_rs_amd import HipBackend, Scene
