@@ -606,12 +606,34 @@ def latest_profile(pattern):
 
 
 def profile_kernel(kernels, name):
-    """The entry of kernel `name` in a committed PMC summary: the non-counting, single-frame instantiation as the profiler prints it.
-    (k_extend: the streaming flavour when that is what ran.  k_shadow of a path-traced frame: bounce 0 only — the bounces' streaming
-    launches are listed as k_shadow_stream and are not folded in.)"""
-    for n in ((name + "_stream<false>",) if name == "k_extend" else ()) + (name + "<false, false>", name + "<false,false>", name + "<false>", name):
-        if n in kernels:
-            return kernels[n]
+    """The entry of kernel `name` in a committed PMC summary: the non-counting, single-frame instantiation(s) as the profiler prints them,
+    counters SUMMED over the instantiations one launch of the stage consists of (the summaries hold means per launch):
+      k_primary        the packet flavour when that is what ran (option packet_trace), else the one-ray-per-lane kernel
+      k_shadow         bounce 0: the packet flavour = one launch per visiting order (<false, true> + <false, false>), else k_shadow<false, false>
+      k_shadow_stream  the bounces' streaming launches: one per visiting order as well (both are counted)
+      k_extend         the streaming flavour when that is what ran"""
+    def pick(*names):
+        found = [kernels[n] for n in names if n in kernels]
+        return found
+    cands = {
+        "k_primary": [("k_primary_packet<false>",), ("k_primary<false>",)],
+        "k_shadow": [("k_shadow_packet<false, true>", "k_shadow_packet<false, false>"), ("k_shadow<false, false>",), ("k_shadow<false,false>",)],
+        "k_shadow_stream": [("k_shadow_stream<false, true>", "k_shadow_stream<false, false>")],
+        "k_extend": [("k_extend_stream<false>",), ("k_extend<false>",)],
+    }.get(name, [(name + "<false, false>",), (name + "<false,false>",), (name + "<false>",), (name,)])
+    for group in cands:
+        found = pick(*group)
+        if not found:
+            continue
+        if len(found) == 1:
+            return found[0]
+        merged = {}
+        for k in set().union(*found):
+            vals = [f[k] for f in found if isinstance(f.get(k), (int, float))]
+            if not vals:
+                continue
+            merged[k] = sum(vals) / len(vals) if "rate" in k else sum(vals)
+        return merged
     return None
 
 

@@ -459,9 +459,10 @@ struct Pool {
         if ((int)workers.size() == n) return;
         shutdown();
         stop = false;
+        const uint64_t born = generation; // a pool re-made with another size must not take the last job of the old one for a new one
         for (int i = 0; i < n; i++)
-            workers.emplace_back([this, i]() {
-                uint64_t seen = 0;
+            workers.emplace_back([this, i, born]() {
+                uint64_t seen = born;
                 for (;;) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv_start.wait(lk, [&] { return stop || generation != seen; });

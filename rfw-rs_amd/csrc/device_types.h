@@ -95,26 +95,51 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
     return q;
 }
 
-// The boxes a Node4Q encodes, as floats again (plane = origin + q * scale: exact in binary32 up to the rounding of the one add, which the
-// per-lane kernels' own decoding shares in spirit but not in bits — both are conservative supersets of the builder's boxes, and no result
-// depends on the boxes).  The packet kernels (traverse_packet.h) read these 128-B nodes through the scalar cache.
-// An empty slot keeps its inverted box and kInvalidRef.
-inline __host__ __device__ Node4 dequantize_node(const Node4Q& q)
+// A BVH4 node as the PACKET kernels read it (traverse_packet.h): ONE OF EIGHT copies, the one for a ray octant (bit a: direction component
+// a negative) — the near and far plane of every axis already picked by the octant's signs, the children sorted front to back along the
+// octant's diagonal (the order every packet of that octant visits them in: no per-node sorting at run time).  Copy `oct` of node i lives at
+// [oct * stride + i] of the array.  Made from the quantised node: the boxes are the ones the 64-B node encodes, as floats (plane = origin +
+// q * scale, pushed outwards by an ulp for the rounding of the add): conservative like those, and no result depends on the boxes.
+// An empty slot gets the box (+inf, -inf) — every ray's entry distance is +inf, so it needs no test of its own — and keeps kInvalidRef.
+struct PacketNode {
+    float nx[4], ny[4], nz[4], fx[4];
+    float fy[4], fz[4];
+    uint32_t child[4], pad[4];
+};
+static_assert(sizeof(PacketNode) == 128, "PacketNode");
+constexpr uint64_t kPacketNodeCopies = 8;
+
+inline __host__ __device__ PacketNode make_packet_node(const Node4Q& q, const uint32_t oct)
 {
-    Node4 n;
     const float o[3] = {q.ox, q.oy, q.oz}, sc[3] = {q.sx, q.sy, q.sz};
-    float* lo[3] = {n.lox, n.loy, n.loz};
-    float* hi[3] = {n.hix, n.hiy, n.hiz};
+    float lo[3][4], hi[3][4], key[4];
     for (int i = 0; i < 4; i++) {
+        key[i] = 0.0f;
         for (int a = 0; a < 3; a++) {
-            // rounding of the add: push the decoded plane outwards by one ulp-sized step of the result so that the float box still encloses
-            // the exact decoded box (lo towards -inf, hi towards +inf)
+            if (q.child[i] == 0xffffffffu) {
+                lo[a][i] = INFINITY;
+                hi[a][i] = -INFINITY;
+                continue;
+            }
             const float l = o[a] + (float)((q.qlo[a] >> (8 * i)) & 0xffu) * sc[a], h = o[a] + (float)((q.qhi[a] >> (8 * i)) & 0xffu) * sc[a];
             lo[a][i] = l - 1.1920929e-7f * (l < 0.0f ? -l : l);
             hi[a][i] = h + 1.1920929e-7f * (h < 0.0f ? -h : h);
+            key[i] += ((oct >> a) & 1u) ? -hi[a][i] : lo[a][i]; // where a plane swept along the octant's diagonal meets the box first
         }
-        n.child[i] = q.child[i];
-        n.pad[i] = 0u;
+        if (q.child[i] == 0xffffffffu) key[i] = INFINITY;
+    }
+    // order of the four slots by key (stable: equal keys keep slot order), empty slots last
+    int ord[4] = {0, 1, 2, 3};
+    for (int i = 1; i < 4; i++)
+        for (int j = i; j > 0 && key[ord[j]] < key[ord[j - 1]]; j--) { const int t_ = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t_; }
+    PacketNode n;
+    for (int k = 0; k < 4; k++) {
+        const int i = ord[k];
+        n.nx[k] = (oct & 1u) ? hi[0][i] : lo[0][i]; n.fx[k] = (oct & 1u) ? lo[0][i] : hi[0][i];
+        n.ny[k] = (oct & 2u) ? hi[1][i] : lo[1][i]; n.fy[k] = (oct & 2u) ? lo[1][i] : hi[1][i];
+        n.nz[k] = (oct & 4u) ? hi[2][i] : lo[2][i]; n.fz[k] = (oct & 4u) ? lo[2][i] : hi[2][i];
+        n.child[k] = q.child[i];
+        n.pad[k] = 0u;
     }
     return n;
 }

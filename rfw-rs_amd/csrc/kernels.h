@@ -14,10 +14,12 @@ struct SceneDev {
     const InstanceNormal* instance_normals;
     const MeshRecord* meshes;         // per mesh record: where it lives, and the triangle-id offset the boundary reports
     const Node4Q* blas_nodes;
-    // the same trees with the child boxes as floats (de-quantised: the very boxes the 64-B nodes encode), 128 B per node, for the packet
-    // kernels (traverse_packet.h), which fetch a node once per wavefront through the scalar cache; nullptr = not available
-    const Node4* tlas_wide;
-    const Node4* blas_wide;
+    // the same trees as the packet kernels read them (traverse_packet.h: a node is fetched once per wavefront through the scalar cache):
+    // eight copies, one per ray octant, child boxes as floats, near / far planes picked and children sorted for the octant (PacketNode);
+    // nullptr = not available
+    const PacketNode* tlas_wide;
+    const PacketNode* blas_wide;
+    uint32_t tlas_wide_stride, blas_wide_stride; // nodes per octant copy
     const TriPacket* tri_packets;
     const rfw_rt_triangle* triangles; // shading attributes, global triangle id order
     const rfw_device_material* materials;
@@ -62,8 +64,9 @@ void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, 
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, Node4* wide /* nullable: the de-quantised float nodes of the packet kernels, same index */, uint32_t n);
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, Node4* wide, uint32_t n); // wide[i] = the boxes in[i] encodes, as floats
+// out[i] = quantised in[i]; with `wide` (nullable) also its eight packet-kernel copies: wide[oct * wide_stride + i]
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n);
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n); // the eight copies of already quantised nodes
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples);
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order

@@ -305,7 +305,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES
     int32_t hi = -1, ht = -1;
     bool occluded;
     const SceneView sv = scene_view(sc);
-    traverse_packet<false, COUNT>(sv, sc.tlas_wide, sc.blas_wide, valid, O, D, 1e-4f, t, hu, hv, hi, ht, occluded, tc);
+    traverse_packet<false, COUNT>(sv, sc.tlas_wide, sc.tlas_wide_stride, sc.blas_wide, sc.blas_wide_stride, valid, O, D, 1e-4f, t, hu, hv, hi, ht, occluded, tc);
     if (valid) {
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
@@ -522,6 +522,55 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
             a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
             p.acc[slot] = a;
         }
+    }
+    flush_counters<COUNT>(sc.counters, tc, 2);
+}
+
+// The packet flavour for the camera paths' shadow rays (bounce 0): the 64 rays of a wavefront start on neighbouring pixels and aim at one
+// light.  One instantiation per visiting order, each launch walking the buckets of its order (as the streaming flavour below).
+RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket);
+template <bool COUNT, bool FAR>
+__global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_shadow_packet(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+{
+    uint32_t block = xcd_block(blockIdx.x);
+    uint32_t bucket = 0, count = 0;
+    {
+        bool found = false;
+        for (int kk = 0; kk < kShadowBuckets; kk++) {
+            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            if (bucket_far_first(cam, (uint32_t)k) != FAR) continue;
+            const uint32_t c = sc.counters->shadow[bounce][k];
+            const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
+            if (!found) {
+                if (block < nb) { found = true; bucket = (uint32_t)k; count = c; }
+                else block -= nb;
+            }
+        }
+        if (!found) return;
+    }
+    const uint32_t local = block * kTraceBlock + threadIdx.x;
+    const uint32_t idx = bucket * p.capacity + local;
+    TravCounters tc{0, 0, 0};
+    const bool valid = local < count;
+    f3 O = mk3(0.0f), D = mk3(0.0f);
+    float t = 1.0f, hu, hv;
+    if (valid) {
+        const float4 o4 = p.sh_o[idx], d4 = p.sh_d[idx];
+        O = mk3(o4.x, o4.y, o4.z);
+        D = mk3(d4.x, d4.y, d4.z);
+        t = d4.w - 0.0001f;
+        if (t > 3.0e38f) t = 3.0e38f;
+    }
+    int32_t hi = -1, ht = -1;
+    bool occluded;
+    const SceneView sv = scene_view(sc);
+    traverse_packet<true, COUNT, FAR>(sv, sc.tlas_wide, sc.tlas_wide_stride, sc.blas_wide, sc.blas_wide_stride, valid, O, D, 0.001f, t, hu, hv, hi, ht, occluded, tc);
+    if (valid && !occluded) {
+        const float4 e = p.sh_e[idx];
+        const uint32_t slot = fbits(e.w);
+        float4 a = p.acc[slot]; // single writer per pixel per pass, as ray_shadow.comp:268
+        a.x += e.x; a.y += e.y; a.z += e.z; a.w += 0.0f;
+        p.acc[slot] = a;
     }
     flush_counters<COUNT>(sc.counters, tc, 2);
 }
@@ -1021,18 +1070,17 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes visited until the first occluder / the end of the traversal
 }
 
-__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, Node4* __restrict__ wide, uint32_t n)
+// one thread per (node, octant copy) for the packet nodes: the 1 KB of copies per node is the larger part of the traffic
+__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Node4Q q = quantize_node(in[i]);
-    out[i] = q;
-    if (wide) wide[i] = dequantize_node(q); // the same boxes as floats, for the packet kernels
+    if (i < n) out[i] = quantize_node(in[i]);
 }
-__global__ void k_expand_nodes(const Node4Q* __restrict__ in, Node4* __restrict__ wide, uint32_t n)
+__global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) wide[i] = dequantize_node(in[i]);
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = g >> 3, oct = g & 7u;
+    if (i < n) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -1088,6 +1136,19 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
+    if (bounce == 0 && (cam.flags & kFlagPacketShadow) && sc.tlas_wide && sc.blas_wide && cam.batch <= 1) {
+        // worst case: every path pushed a shadow ray, every bucket padded to whole wavefronts; one launch per visiting order
+        const uint32_t blocks_ = (p.capacity + kTraceBlock - 1) / kTraceBlock + kShadowBuckets;
+        const dim3 grid_(((blocks_ + 511u) / 512u) * 512u), block_(kTraceBlock);
+        if (count) {
+            hipLaunchKernelGGL((k_shadow_packet<true, true>), grid_, block_, 0, s, cam, sc, p, bounce);
+            hipLaunchKernelGGL((k_shadow_packet<true, false>), grid_, block_, 0, s, cam, sc, p, bounce);
+        } else {
+            hipLaunchKernelGGL((k_shadow_packet<false, true>), grid_, block_, 0, s, cam, sc, p, bounce);
+            hipLaunchKernelGGL((k_shadow_packet<false, false>), grid_, block_, 0, s, cam, sc, p, bounce);
+        }
+        return;
+    }
     const dim3 block(kTraceBlock);
     // streaming pays where a wavefront's rays differ in length and direction: the shadow rays of the bounces.  The camera paths' own shadow rays
     // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too)
@@ -1137,13 +1198,14 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
 }
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, Node4* wide, uint32_t n)
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n)
 {
-    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, wide, n);
+    if (n && wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, wide, wide_stride, n);
 }
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, Node4* wide, uint32_t n)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n)
 {
-    if (n) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, wide, n);
+    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);
+    launch_expand_nodes(s, out, wide, wide_stride, n);
 }
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)

@@ -188,7 +188,9 @@ struct InstList {
     std::vector<int32_t> skin_ids; // per slot, -1 = none
 };
 
-constexpr int kDefaultPacketTrace = 0; // option "packet_trace" when nobody sets it
+// option "packet_trace" when nobody sets it: camera rays as packets (C4 5920 -> 7040 Mrays/s, C2 6980 -> 7780, C3 5160 -> 5850; the camera paths'
+// shadow rays are not coherent enough for it: k_shadow 0.32 -> 1.09 ms, EXPERIMENTS.md)
+constexpr int kDefaultPacketTrace = 1;
 enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
@@ -250,7 +252,9 @@ struct Instance {
     // device scene
     DevBuf<Node4Q> d_blas_nodes, d_tlas_nodes;   // what the kernels traverse
     DevBuf<Node4> d_blas_raw, d_tlas_raw;        // device-built trees before quantisation
-    DevBuf<Node4> d_blas_wide, d_tlas_wide;      // what the PACKET kernels traverse: the boxes of d_*_nodes as floats, same index (traverse_packet.h)
+    // what the PACKET kernels traverse (traverse_packet.h): eight copies of d_*_nodes, one per ray octant, copy `oct` of node i at
+    // [oct * stride + i] with stride = the capacity of the quantised array; nullptr when the copies would not fit kMaxPacketNodeBytes
+    DevBuf<PacketNode> d_blas_wide, d_tlas_wide;
     DevBuf<TriPacket> d_packets;
     DevBuf<rfw_rt_triangle> d_triangles;
     DevBuf<MeshRecord> d_mesh_records;
@@ -526,6 +530,26 @@ int alloc_paths(Instance* I)
 
 uint32_t spill_stride(const Instance* I) { return (uint32_t)(I->d_spill.cap / kStackSpill); }
 
+// The packet kernels' node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity.  (Re)allocates when that
+// capacity changed — the stride with it, so every node in use (`keep` of them) is expanded again — and returns the stride; a tree whose
+// copies would exceed kMaxPacketNodeBytes does without (the packet kernels are then not used: scene_dev hands out nullptr).
+constexpr size_t kMaxPacketNodeBytes = size_t(16) << 30;
+hipError_t follow_wide(DevBuf<PacketNode>& wide, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s)
+{
+    const size_t want = nodes.cap * kPacketNodeCopies;
+    if (want * sizeof(PacketNode) > kMaxPacketNodeBytes) { wide.release(); return hipSuccess; }
+    if (wide.cap == want) return hipSuccess;
+    wide.release();
+    if (want == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&wide.ptr, want * sizeof(PacketNode));
+    if (e != hipSuccess) { wide.ptr = nullptr; (void)hipGetLastError(); return hipSuccess; } // no room: the packet kernels are not used
+    wide.cap = want;
+    launch_expand_nodes(s, nodes.ptr, wide.ptr, (uint32_t)nodes.cap, (uint32_t)std::min(keep, nodes.cap));
+    return hipGetLastError();
+}
+inline uint32_t wide_stride(const DevBuf<PacketNode>& wide) { return (uint32_t)(wide.cap / kPacketNodeCopies); }
+inline PacketNode* wide_at(const DevBuf<PacketNode>& wide, size_t first) { return wide.ptr ? wide.ptr + first : nullptr; }
+
 SceneDev scene_dev(Instance* I)
 {
     SceneDev s;
@@ -539,6 +563,8 @@ SceneDev scene_dev(Instance* I)
     s.blas_nodes = S->d_blas_nodes.ptr;
     s.tlas_wide = TL->d_tlas_wide.ptr;
     s.blas_wide = S->d_blas_wide.ptr;
+    s.tlas_wide_stride = (uint32_t)(TL->d_tlas_wide.cap / kPacketNodeCopies);
+    s.blas_wide_stride = (uint32_t)(S->d_blas_wide.cap / kPacketNodeCopies);
     s.tri_packets = S->d_packets.ptr;
     s.triangles = S->d_triangles.ptr;
     const Instance::Tables& tb = S->tables[S->tables_version % Instance::kTableVersions];
@@ -717,7 +743,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
     launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, quantise_count);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count);
     return RFW_HIP_OK;
 }
 
@@ -762,7 +788,7 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
                     launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, std::max(r.tri_count, 1u));
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), std::max(r.tri_count, 1u));
                 }
                 (void)hipEventRecord(L.done, L.s);
             });
@@ -826,7 +852,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
-    HIP_TRY(I, I->d_blas_wide.ensure(node_total));
+    HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, 0, I->stream));
     HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
     for (auto& ev : I->ev_build)
@@ -873,7 +899,7 @@ int build_blas_device_full(Instance* I)
         }
         if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
     }
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, static_nodes); // all static regions in one launch
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, wide_at(I->d_blas_wide, 0), wide_stride(I->d_blas_wide), static_nodes); // all static regions in one launch
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
@@ -951,8 +977,11 @@ int build_blas_device_incremental(Instance* I)
     HIP_TRY(I, I->d_triangles.grow_keep(I->tri_end, I->d_triangles.cap, I->stream));
     HIP_TRY(I, I->d_packets.grow_keep(I->tri_end, I->d_packets.cap, I->stream));
     HIP_TRY(I, I->d_blas_order.grow_keep(I->tri_end, I->d_blas_order.cap, I->stream));
-    HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
-    HIP_TRY(I, I->d_blas_wide.grow_keep(I->node_end, I->d_blas_wide.cap, I->stream));
+    {
+        const size_t nodes_before = I->d_blas_nodes.cap; // (the regions in use end below the old capacity)
+        HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
+        HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, nodes_before, I->stream));
+    }
     HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
     HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
     HIP_TRY(I, I->d_mesh_records.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), 0, I->stream));
@@ -1054,13 +1083,13 @@ int build_blas_host(Instance* I)
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
-    HIP_TRY(I, I->d_blas_wide.ensure(node_total));
+    HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, 0, I->stream));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     std::vector<Node4Q> qnodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
     if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
-    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, (uint32_t)qnodes.size());
+    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, wide_stride(I->d_blas_wide), (uint32_t)qnodes.size());
     if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
     if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
@@ -1133,7 +1162,7 @@ int build_instances(Instance* I, Instance* T)
     HIP_TRY(I, T->d_normals.ensure(n_all));
     HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
     HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(I, T->d_tlas_wide.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, follow_wide(T->d_tlas_wide, T->d_tlas_nodes, 0, T->stream));
     HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_node_count.ensure(1));
     hipStream_t s = T->stream;
@@ -1193,7 +1222,7 @@ int build_instances(Instance* I, Instance* T)
                 quantise_count = d.node_count;
             }
             launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, I->d_blas_wide.ptr + r.node_base, quantise_count);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count);
             launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, T->d_mesh_local.ptr + d.record);
         }
         HIP_TRY(I, hipGetLastError());
@@ -1211,7 +1240,7 @@ int build_instances(Instance* I, Instance* T)
         launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
         HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
                               T->d_node_count.ptr));
-        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, std::max<uint32_t>(n_valid, 1u));
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), std::max<uint32_t>(n_valid, 1u));
         launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
@@ -1248,8 +1277,8 @@ int build_instances(Instance* I, Instance* T)
         std::vector<Node4Q> qn(tlas.nodes.size());
         for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
         if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
-        HIP_TRY(I, T->d_tlas_wide.ensure(std::max<size_t>(qn.size(), 1)));
-        launch_expand_nodes(s, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, (uint32_t)qn.size());
+        HIP_TRY(I, follow_wide(T->d_tlas_wide, T->d_tlas_nodes, 0, s));
+        launch_expand_nodes(s, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), (uint32_t)qn.size());
         if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));

@@ -221,6 +221,39 @@ def test_streaming_trace_kernels_give_the_same_image(run, refill):
     be.close()
 
 
+@pytest.mark.parametrize("kind,a,b", [("atrium", 30000, 0), ("soup", 2000, 6), ("gallery", 0, 0)])
+def test_packet_trace_option_never_changes_the_image(kind, a, b):
+    """Option packet_trace (csrc/traverse_packet.h): camera rays (bit 0, the default) and the camera paths' shadow rays (bit 1) walk the tree as
+    wavefront packets on one shared stack, through the eight octant copies of the nodes, instead of one ray per lane.  Which nodes are
+    visited, by whom and in which order differs; hits, images and ray counts do not — with rotated instances (the soup: lanes of one packet
+    fall into different object-space octants), with and without the traversal counters, for single frames and over frame slots."""
+    w, h = 200, 120
+    scene, be, orc = make(kind, w, h, a, b, seed=33, max_path_length=3, frames_in_flight=2)
+    views = []
+    for i in range(2):
+        scene.translate_relative([0.05 * i, 0.02 * i, 0.0])
+        views.append(scene.view(w, h))
+    refs = []
+    for v in views:
+        orc.reset(); orc.render(v)
+        refs.append((orc.accumulator().copy(), orc.stats()["shadow"]))   # (orc.reset() clears the ray counters)
+    visits = {}
+    for count in (0, 1):
+        be.set_option("count_traversal", count)
+        for mode in (0, 1, 2, 3):
+            be.set_option("packet_trace", mode)
+            for k, v in enumerate(views):   # a new view each: the two frame slots alternate
+                be.reset_accumulation()
+                be.render(v)
+                assert np.array_equal(be.accumulator().view(np.uint32), refs[k][0].view(np.uint32)), (count, mode, k)
+                s = be.frame_stats()
+                assert s["shadow_rays"] == refs[k][1], (count, mode, k)
+                if count:
+                    visits[(mode, k)] = tuple(s["nodes_visited"])
+    assert visits[(0, 0)] != visits[(1, 0)] and visits[(1, 0)] != visits[(3, 0)]   # they really are different traversals
+    be.close()
+
+
 @pytest.mark.parametrize("kind,a,b", [("atrium", 30000, 0), ("soup", 2000, 4)])
 def test_shadow_order_option_never_changes_the_image(kind, a, b):
     """Option shadow_order: which end of a shadow ray the any-hit traversal starts from (default: directional lights far to near, positional
