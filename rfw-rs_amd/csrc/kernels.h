@@ -64,9 +64,13 @@ void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, 
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
-// out[i] = quantised in[i]; with `wide` (nullable) also its eight packet-kernel copies: wide[oct * wide_stride + i]
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n);
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n); // the eight copies of already quantised nodes
+// out[i] = quantised in[i]; with `wide` (nullable) also its eight packet-kernel copies: wide[oct * wide_stride + i].  `live` (nullable): the
+// tree's node count ON THE DEVICE — slots behind it are skipped (regions are sized for the worst case, one node per primitive)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live = nullptr);
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live = nullptr); // the eight copies of already quantised nodes
+// the same for slots [0, n) holding SEVERAL trees: record k's tree lives at recs[k].node_base and has counts[k] nodes (both on the device)
+void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const MeshRecord* recs,
+                             const uint32_t* counts, uint32_t n_recs);
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples);
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order

@@ -283,7 +283,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
 // The packet flavour (traverse_packet.h): the 64 camera rays of an 8x8-pixel block walk the tree together on one shared stack.  Same rays,
 // same triangle tests, same image; no LDS.
 #ifndef RFW_PACKET_WAVES
-#define RFW_PACKET_WAVES 6
+#define RFW_PACKET_WAVES 8 // measured: 6 -> 6755, 7 -> 6785, 8 -> 6855 Mrays/s (16 spilled registers at 8 cost less than the two extra waves hide)
 #endif
 template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_primary_packet(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
@@ -1070,17 +1070,42 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes visited until the first occluder / the end of the traversal
 }
 
-// one thread per (node, octant copy) for the packet nodes: the 1 KB of copies per node is the larger part of the traffic
-__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n)
+// Node regions are sized for the worst case (one node per primitive); a tree uses a quarter of its region or less, and the packet kernels'
+// copies are 1 KB per node: the slots behind a tree's last node are skipped.  `live` (nullable) points at the tree's node count on the device
+// (the builders write it; no read-back); the *_regions flavour covers several trees in one launch and finds a slot's tree by bisection.
+__global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restrict__ out, uint32_t n, const uint32_t* __restrict__ live)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = quantize_node(in[i]);
+    if (i < n && (!live || i < *live)) out[i] = quantize_node(in[i]);
 }
-__global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n)
+// one thread per (node, octant copy): the 1 KB of copies per node is the larger part of the traffic
+__global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n, const uint32_t* __restrict__ live)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = g >> 3, oct = g & 7u;
-    if (i < n) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
+    if (i < n && (!live || i < *live)) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
+}
+RFW_DI bool slot_is_live(const MeshRecord* __restrict__ recs, const uint32_t* __restrict__ counts, const uint32_t n_recs, const uint32_t slot)
+{
+    uint32_t lo = 0, hi = n_recs; // the record with the largest node_base <= slot (records are laid out in order)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (recs[mid].node_base <= slot) lo = mid; else hi = mid;
+    }
+    return slot - recs[lo].node_base < counts[lo];
+}
+__global__ void k_quantize_regions(const Node4* __restrict__ in, Node4Q* __restrict__ out, const uint32_t n, const MeshRecord* __restrict__ recs,
+                                   const uint32_t* __restrict__ counts, const uint32_t n_recs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && slot_is_live(recs, counts, n_recs, i)) out[i] = quantize_node(in[i]);
+}
+__global__ void k_expand_regions(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n,
+                                 const MeshRecord* __restrict__ recs, const uint32_t* __restrict__ counts, const uint32_t n_recs)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = g >> 3, oct = g & 7u;
+    if (i < n && slot_is_live(recs, counts, n_recs, i)) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -1198,14 +1223,21 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
 }
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n)
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live)
 {
-    if (n && wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, wide, wide_stride, n);
+    if (n && wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, wide, wide_stride, n, live);
 }
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live)
 {
-    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n);
-    launch_expand_nodes(s, out, wide, wide_stride, n);
+    if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, live);
+    launch_expand_nodes(s, out, wide, wide_stride, n, live);
+}
+void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const MeshRecord* recs,
+                             const uint32_t* counts, uint32_t n_recs)
+{
+    if (!n || !n_recs) return;
+    hipLaunchKernelGGL(k_quantize_regions, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, recs, counts, n_recs);
+    if (wide) hipLaunchKernelGGL(k_expand_regions, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, out, wide, wide_stride, n, recs, counts, n_recs);
 }
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)

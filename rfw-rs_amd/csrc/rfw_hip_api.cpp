@@ -743,7 +743,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
     launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count, I->d_mesh_node_counts.ptr + q);
     return RFW_HIP_OK;
 }
 
@@ -788,7 +788,7 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
                     launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), std::max(r.tri_count, 1u));
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
                 }
                 (void)hipEventRecord(L.done, L.s);
             });
@@ -870,6 +870,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
     HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
+    HIP_TRY(I, hipMemsetAsync(I->d_mesh_node_counts.ptr, 0, std::max<size_t>(n_static, 1) * 4, I->stream)); // (an empty mesh is not built: its count stays 0)
     HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
     uint64_t kernel_bytes = 0;
     {
@@ -899,11 +900,13 @@ int build_blas_device_full(Instance* I)
         }
         if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
     }
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, wide_at(I->d_blas_wide, 0), wide_stride(I->d_blas_wide), static_nodes); // all static regions in one launch
+    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+    // all static regions in one launch; the slots behind a tree's last node are skipped (the builders left the node counts on the device)
+    launch_quantize_regions(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, wide_at(I->d_blas_wide, 0), wide_stride(I->d_blas_wide), static_nodes, I->d_mesh_records.ptr,
+                            I->d_mesh_node_counts.ptr, (uint32_t)n_static);
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
-    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     I->build_events_pending = true;
     I->blas_upload_bytes = (uint64_t)static_tris * sizeof(rfw_rt_triangle);
@@ -1240,7 +1243,7 @@ int build_instances(Instance* I, Instance* T)
         launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
         HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
                               T->d_node_count.ptr));
-        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), std::max<uint32_t>(n_valid, 1u));
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), std::max<uint32_t>(n_valid, 1u), T->d_node_count.ptr);
         launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)

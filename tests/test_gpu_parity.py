@@ -314,6 +314,18 @@ def test_bench_two_ranks_on_one_gpu_p2p(present_rank):
     assert "frame slots" in out["config"]["frames_in_flight_held_by"]
 
 
+def test_scale_script_dry_run_covers_every_exchange_and_format():
+    """tools/scale.sh --dry: the rehearsal of the 1 / 2 / 4 / 8 GPU table on one device — two ranks per (exchange, format) pair, torch's
+    collective and the peer-store exchange (IPC handles; also with fine-grained flag words and with the cached receive buffer), every
+    sharded frame compared with the single-GPU frame.  The first multi-GPU run must not fail for boring reasons."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale.sh"), "--dry"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert r.stdout.count("ok   ") == 10, r.stdout[-2000:]
+
+
 _CONTENDED_BUILDS = r"""
 import hashlib, sys
 sys.path.insert(0, sys.argv[1])

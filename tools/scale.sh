@@ -7,10 +7,35 @@
 # GPU and compares in the format that travelled).  Raw lines: gpurun_out/<tag>/scale_*.json; table: gpurun_out/<tag>/scale.md.
 # On a 1-GPU box only the N = 1 row runs (RCCL refuses two ranks on one device); RFW_BENCH_DIST_BACKEND=gloo lets 2 ranks share a GPU for a
 # functional check of the other rows (tests/test_gpu_parity.py does that).
+# `bash tools/scale.sh --dry` is the rehearsal for a box WITHOUT the GPUs: every (exchange, format) pair that can run with two ranks on ONE
+# device (torch's collective through the gloo hook, the peer-store exchange through real IPC handles — also with the fall-back kind of flag
+# memory forced, RFW_P2P_FLAGS_FINEGRAINED=1) on a small frame, and it FAILS LOUDLY (exit 1, the failing pairs named) unless every run exits 0
+# with config.sharded_frame_equals_single_gpu_frame true.  `native` (RCCL inside the library) cannot be rehearsed this way — RCCL refuses two
+# ranks on one device; tests/test_gpu_api.py runs it with a one-rank communicator.
+if [ "$1" = "--dry" ]; then
+  R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/scale_dry; mkdir -p "$OUT"; cd "$R" || exit 1
+  export HSA_ENABLE_IPC_MODE_LEGACY=0 RFW_BENCH_DIST_BACKEND=gloo
+  PORT=29710; FAILED=""
+  for v in torch:bgra8 torch:f16 torch:f32 p2p:bgra8 p2p:f16 p2p:f32 p2p:bgra8:finegrained-flags p2p:f32:cached-data torch:bgra8:latency p2p:bgra8:latency; do
+    coll=${v%%:*}; rest=${v#*:}; fmt=${rest%%:*}; extra=""
+    case "$v" in *finegrained-flags) extra="RFW_P2P_FLAGS_FINEGRAINED=1";; *cached-data) extra="RFW_P2P_DATA_CACHED=1";; esac
+    barg=""; case "$v" in *latency) barg="--batch 1";; esac
+    PORT=$((PORT + 1)); f=$OUT/dry_${v//:/_}.json
+    env $extra timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 2 \
+      --steps 12 --warmup 4 --workload cornell --width 320 --height 200 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $barg > "$f" 2> "${f%.json}.err"
+    rc=$?
+    ok=$(python3 -c "import json,sys; l=[x for x in open('$f') if x.startswith('{')]; d=json.loads(l[-1]) if l else {}; print(int(d.get('config',{}).get('sharded_frame_equals_single_gpu_frame') is True and d.get('n_gpus')==2))" 2>/dev/null)
+    if [ "$rc" -ne 0 ] || [ "$ok" != "1" ]; then FAILED="$FAILED $v(rc=$rc)"; echo "FAIL $v"; tail -5 "${f%.json}.err"; else echo "ok   $v"; fi
+  done
+  if [ -n "$FAILED" ]; then echo "scale.sh --dry: FAILED:$FAILED"; exit 1; fi
+  echo "scale.sh --dry: every pair ran and reproduced the single-GPU frame"; exit 0
+fi
 TAG=${1:-scale}
 STEPS=${2:-240}
 GPUS=${GPUS:-"1 2 4 8"}
-VARIANTS=${VARIANTS:-"torch:bgra8 torch:f16 torch:f32 native:bgra8 p2p:bgra8 p2p:f32"}
+VARIANTS=${VARIANTS:-"torch:bgra8 torch:f16 torch:f32 native:bgra8 native:f32 p2p:bgra8 p2p:f16 p2p:f32"}
+# the same exchange per FRAME instead of per batch of 8 (bench.py --batch 1): what an interactive render() loop sees
+LATENCY_VARIANTS=${LATENCY_VARIANTS:-"native:bgra8 p2p:bgra8"}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -20,21 +45,24 @@ HAVE=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 PORT=29610
 ROWS=$OUT/rows.txt
 : > "$ROWS"
-run() { # n collective format
-  local n=$1 coll=$2 fmt=$3 f=$OUT/scale_n${1}_${2}_${3}.json
+run() { # n collective format [latency]
+  local n=$1 coll=$2 fmt=$3 lat=$4 f=$OUT/scale_n${1}_${2}_${3}${4:+_latency}.json
+  local extra=""
+  [ -n "$lat" ] && extra="--batch 1"   # latency mode: one render() per frame over frame slots, one exchange per FRAME (an interactive caller cannot batch 8 frames)
   if [ "$n" -eq 1 ]; then
     python3 bench.py --gpus 1 --steps "$STEPS" --warmup 24 --no-cpu-baseline --no-modes > "$f" 2> "${f%.json}.err"
   else
     PORT=$((PORT + 1))
     python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$n" \
-      --steps "$STEPS" --warmup 24 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" > "$f" 2> "${f%.json}.err"
+      --steps "$STEPS" --warmup 24 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $extra > "$f" 2> "${f%.json}.err"
   fi
-  echo "$n $coll $fmt $f" >> "$ROWS"
+  echo "$n $coll ${fmt}${lat:+(one-frame-per-exchange)} $f" >> "$ROWS"
 }
 for n in $GPUS; do
   if [ "$n" -gt "$HAVE" ] && [ -z "$RFW_BENCH_DIST_BACKEND" ]; then echo "skipping N = $n: this box has $HAVE GPU(s)"; continue; fi
   if [ "$n" -eq 1 ]; then run 1 - -; continue; fi
   for v in $VARIANTS; do run "$n" "${v%%:*}" "${v##*:}"; done
+  for v in $LATENCY_VARIANTS; do run "$n" "${v%%:*}" "${v##*:}" latency; done
 done
 python3 - "$ROWS" > "$OUT/scale.md" <<'PY'
 import json, sys
