@@ -1529,6 +1529,87 @@ ORC_API int orc_eval_shading(void* p, int op, uint64_t n, const float* in, float
     return 0;
 }
 
+// Test-only: the oracle's twins of the reference's pure shader functions one by one, in the call shape of oracle/glsl_ref_wrap.cpp (the
+// build of the reference's own GLSL text as C++), so that tests/test_glsl_differential.py can hold the two against each other bit for bit.
+// Per case 32 input floats and 24 output floats:
+//   10 intersect / 11 intersect_occludes   v0 v1 v2 gn O D t_min t                    -> hit, t, u, v   /   occluded
+//   12 intersect_mnode                     min_x[4] max_x[4] min_y[4] max_y[4] min_z[4] max_z[4] origin dir_inverse t -> any, result[4], sorted tmin[4]
+//   13 safe_origin   O R N epsilon -> P       14 PackNormal   N -> bits       16 DiffuseReflectionCosWeighted / Uniform   r0 r1 -> 3 + 3
+//   17 CLAMPINTENSITY   c clamp -> c          18 wang_hash / randi / randf   seed bits -> hash bits, randi bits, randf, state bits
+//   20 Fr, SchlickFresnel, GTR1, GTR2, SmithGGX of (a, b); Refract(wi, n, eta) -> ok, wt        21 extractParameters -> the 16 unpacked parameters
+ORC_API int orc_glsl_twin(int op, uint64_t n, const float* in, float* out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        const float* q = in + 32 * i;
+        float* r = out + 24 * i;
+        for (int k = 0; k < 24; k++) r[k] = 0.0f;
+        switch (op) {
+        case 10: case 11: {
+            rfw_rt_triangle tr;
+            std::memset(&tr, 0, sizeof(tr));
+            tr.vertex0 = rfw_vec3{q[0], q[1], q[2]}; tr.vertex1 = rfw_vec3{q[3], q[4], q[5]}; tr.vertex2 = rfw_vec3{q[6], q[7], q[8]};
+            tr.normal = rfw_vec3{q[9], q[10], q[11]};
+            const vec3 O = V3(q[12], q[13], q[14]), D = V3(q[15], q[16], q[17]);
+            if (op == 10) {
+                float t = q[19], u = 0.0f, v = 0.0f;
+                const bool h = intersect_tri(tr, O, D, q[18], t, u, v, false, false); // the literal rule (no tie extension)
+                r[0] = h ? 1.0f : 0.0f; r[1] = t; r[2] = u; r[3] = v;
+            } else {
+                r[0] = intersect_occludes(tr, O, D, q[18], q[19]) ? 1.0f : 0.0f;
+            }
+            break;
+        }
+        case 12: {
+            MBVHNode nd;
+            std::memset(&nd, 0, sizeof(nd));
+            for (int k = 0; k < 4; k++) {
+                nd.min_x[k] = q[k]; nd.max_x[k] = q[4 + k]; nd.min_y[k] = q[8 + k]; nd.max_y[k] = q[12 + k]; nd.min_z[k] = q[16 + k]; nd.max_z[k] = q[20 + k];
+            }
+            float tmin[4] = {0, 0, 0, 0};
+            bool res[4] = {false, false, false, false};
+            const bool any_ = intersect_mnode(nd, V3(q[24], q[25], q[26]), V3(q[27], q[28], q[29]), q[30], tmin, res, false);
+            r[0] = any_ ? 1.0f : 0.0f;
+            for (int k = 0; k < 4; k++) { r[1 + k] = res[k] ? 1.0f : 0.0f; r[5 + k] = any_ ? tmin[k] : 0.0f; }
+            break;
+        }
+        case 13: { const vec3 p = safe_origin(V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5]), V3(q[6], q[7], q[8]), q[9]); r[0] = p.x; r[1] = p.y; r[2] = p.z; break; }
+        case 14: r[0] = bitsf(PackNormal(V3(q[0], q[1], q[2]))); break;
+        case 16: {
+            const vec3 a = DiffuseReflectionCosWeighted(q[0], q[1]), b = DiffuseReflectionUniform(q[0], q[1]);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z; break;
+        }
+        case 17: { vec3 c = V3(q[0], q[1], q[2]); CLAMPINTENSITY(c, q[3]); r[0] = c.x; r[1] = c.y; r[2] = c.z; break; }
+        case 18: {
+            uint32_t s = fbits(q[0]);
+            r[0] = bitsf(wang_hash(s));
+            r[1] = bitsf(randi(s)); r[2] = randf(s); r[3] = bitsf(s);
+            break;
+        }
+        case 20: {
+            r[0] = Fr(q[0], q[1]); r[1] = SchlickFresnel(q[0]); r[2] = GTR1(q[0], q[1]); r[3] = GTR2(q[0], q[1]); r[4] = SmithGGX(q[0], q[1]);
+            vec3 wt = V3(0.0f);
+            const bool ok = Refract(V3(q[2], q[3], q[4]), V3(q[5], q[6], q[7]), q[8], wt);
+            r[5] = ok ? 1.0f : 0.0f; r[6] = wt.x; r[7] = wt.y; r[8] = wt.z;
+            break;
+        }
+        case 21: {
+            rfw_device_material m;
+            std::memset(&m, 0, sizeof(m));
+            float* mf = reinterpret_cast<float*>(&m);
+            mf[0] = q[0]; mf[1] = q[1]; mf[2] = q[2]; mf[4] = q[3]; mf[5] = q[4]; mf[6] = q[5]; mf[8] = q[6]; mf[9] = q[7]; mf[10] = q[8];
+            std::memcpy(mf + 12, q + 9, 16);
+            const ShadingData d = extractParameters(m);
+            const float v[] = {d.metallic, d.subsurface, d.specular_f, d.roughness, d.specular_tint, d.anisotropic, d.sheen, d.sheen_tint, d.clearcoat, d.clearcoat_gloss,
+                               d.transmission, d.eta, d.custom0, d.custom1, d.custom2, d.custom3};
+            for (int k = 0; k < 16; k++) r[k] = v[k];
+            break;
+        }
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
 ORC_API int orc_set_option(void* p, const char* key, double value)
 {
     Oracle& o = *(Oracle*)p;

@@ -109,10 +109,12 @@ struct PacketNode {
 static_assert(sizeof(PacketNode) == 128, "PacketNode");
 constexpr uint64_t kPacketNodeCopies = 8;
 
-inline __host__ __device__ PacketNode make_packet_node(const Node4Q& q, const uint32_t oct)
+// The decoded child boxes of a quantised node (floats; empty slots (+inf, -inf)) and the order of its four slots for ray octant `oct`:
+// front to back along the octant's diagonal — by where a plane swept along (+-1, +-1, +-1) meets each box first — stable, empty slots last.
+inline __host__ __device__ void octant_order(const Node4Q& q, const uint32_t oct, float (&lo)[3][4], float (&hi)[3][4], int (&ord)[4])
 {
     const float o[3] = {q.ox, q.oy, q.oz}, sc[3] = {q.sx, q.sy, q.sz};
-    float lo[3][4], hi[3][4], key[4];
+    float key[4];
     for (int i = 0; i < 4; i++) {
         key[i] = 0.0f;
         for (int a = 0; a < 3; a++) {
@@ -122,16 +124,21 @@ inline __host__ __device__ PacketNode make_packet_node(const Node4Q& q, const ui
                 continue;
             }
             const float l = o[a] + (float)((q.qlo[a] >> (8 * i)) & 0xffu) * sc[a], h = o[a] + (float)((q.qhi[a] >> (8 * i)) & 0xffu) * sc[a];
-            lo[a][i] = l - 1.1920929e-7f * (l < 0.0f ? -l : l);
+            lo[a][i] = l - 1.1920929e-7f * (l < 0.0f ? -l : l); // (the rounding of the add: the float box must enclose the exact decoded box)
             hi[a][i] = h + 1.1920929e-7f * (h < 0.0f ? -h : h);
-            key[i] += ((oct >> a) & 1u) ? -hi[a][i] : lo[a][i]; // where a plane swept along the octant's diagonal meets the box first
+            key[i] += ((oct >> a) & 1u) ? -hi[a][i] : lo[a][i];
         }
         if (q.child[i] == 0xffffffffu) key[i] = INFINITY;
     }
-    // order of the four slots by key (stable: equal keys keep slot order), empty slots last
-    int ord[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; i++) ord[i] = i;
     for (int i = 1; i < 4; i++)
         for (int j = i; j > 0 && key[ord[j]] < key[ord[j - 1]]; j--) { const int t_ = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t_; }
+}
+inline __host__ __device__ PacketNode make_packet_node(const Node4Q& q, const uint32_t oct)
+{
+    float lo[3][4], hi[3][4];
+    int ord[4];
+    octant_order(q, oct, lo, hi, ord);
     PacketNode n;
     for (int k = 0; k < 4; k++) {
         const int i = ord[k];
@@ -140,6 +147,29 @@ inline __host__ __device__ PacketNode make_packet_node(const Node4Q& q, const ui
         n.nz[k] = (oct & 4u) ? hi[2][i] : lo[2][i]; n.fz[k] = (oct & 4u) ? lo[2][i] : hi[2][i];
         n.child[k] = q.child[i];
         n.pad[k] = 0u;
+    }
+    return n;
+}
+// The same copy for the ONE-RAY-PER-LANE kernels (traverse.h), still quantised (64 B: a lane fetches its own node): in copy `oct`, qlo[a]
+// holds the planes a ray of that octant ENTERS through (the upper ones where its direction component is negative), qhi[a] the ones it
+// leaves through, and the children are in the octant's front-to-back order — so a visit needs neither the six per-plane selects nor the
+// sorting network: hit children go on the lane's stack in the stored order.  Origin and scales are the node's own.
+inline __host__ __device__ Node4Q make_octant_node(const Node4Q& q, const uint32_t oct)
+{
+    float lo[3][4], hi[3][4];
+    int ord[4];
+    octant_order(q, oct, lo, hi, ord);
+    Node4Q n = q;
+    for (int a = 0; a < 3; a++) { n.qlo[a] = 0u; n.qhi[a] = 0u; }
+    for (int k = 0; k < 4; k++) {
+        const int i = ord[k];
+        n.child[k] = q.child[i];
+        for (int a = 0; a < 3; a++) {
+            const uint32_t l = (q.qlo[a] >> (8 * i)) & 0xffu, h = (q.qhi[a] >> (8 * i)) & 0xffu;
+            const bool neg = ((oct >> a) & 1u) != 0u;
+            n.qlo[a] |= (neg ? h : l) << (8 * k);
+            n.qhi[a] |= (neg ? l : h) << (8 * k);
+        }
     }
     return n;
 }

@@ -20,6 +20,9 @@ struct SceneDev {
     const PacketNode* tlas_wide;
     const PacketNode* blas_wide;
     uint32_t tlas_wide_stride, blas_wide_stride; // nodes per octant copy
+    // ... and as the one-ray-per-lane kernels read them (traverse.h): the same eight copies, still quantised (make_octant_node), same strides
+    const Node4Q* tlas_oct;
+    const Node4Q* blas_oct;
     const TriPacket* tri_packets;
     const rfw_rt_triangle* triangles; // shading attributes, global triangle id order
     const rfw_device_material* materials;
@@ -64,13 +67,19 @@ void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, 
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
-// out[i] = quantised in[i]; with `wide` (nullable) also its eight packet-kernel copies: wide[oct * wide_stride + i].  `live` (nullable): the
-// tree's node count ON THE DEVICE — slots behind it are skipped (regions are sized for the worst case, one node per primitive)
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live = nullptr);
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live = nullptr); // the eight copies of already quantised nodes
+// The eight per-octant copies of a node array (PacketNode for the packet kernels, Node4Q for the one-ray-per-lane kernels): copy `oct` of
+// node i at [oct * stride + i] of both
+struct OctantCopies {
+    PacketNode* wide = nullptr;
+    Node4Q* quant = nullptr;
+    uint32_t stride = 0;
+};
+// out[i] = quantised in[i] and its octant copies at oc[first + i], i < n.  `live` (nullable): the tree's node count ON THE DEVICE — slots behind
+// it are skipped (regions are sized for the worst case, one node per primitive)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live = nullptr);
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live = nullptr); // the copies of already quantised nodes
 // the same for slots [0, n) holding SEVERAL trees: record k's tree lives at recs[k].node_base and has counts[k] nodes (both on the device)
-void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const MeshRecord* recs,
-                             const uint32_t* counts, uint32_t n_recs);
+void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t n, const MeshRecord* recs, const uint32_t* counts, uint32_t n_recs);
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples);
 void launch_sum_batch(hipStream_t s, float4* acc_slabs, uint64_t slab_elems, uint32_t count); // slab 0 += slabs 1 .. count - 1, in order

@@ -78,6 +78,10 @@ RFW_DI SceneView scene_view(const SceneDev& sc)
     v.tlas_prims = sc.tlas_prims;
     v.instances = sc.instances;
     v.blas_nodes = sc.blas_nodes;
+    v.tlas_oct = sc.tlas_oct;
+    v.blas_oct = sc.blas_oct;
+    v.tlas_oct_stride = sc.tlas_wide_stride;
+    v.blas_oct_stride = sc.blas_wide_stride;
     v.tri_packets = sc.tri_packets;
     v.spill = sc.spill;
     v.spill_stride = sc.spill_stride;
@@ -1079,11 +1083,16 @@ __global__ void k_quantize_nodes(const Node4* __restrict__ in, Node4Q* __restric
     if (i < n && (!live || i < *live)) out[i] = quantize_node(in[i]);
 }
 // one thread per (node, octant copy): the 1 KB of copies per node is the larger part of the traffic
-__global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n, const uint32_t* __restrict__ live)
+__global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, Node4Q* __restrict__ octq, const uint32_t wide_stride, const uint32_t n,
+                               const uint32_t* __restrict__ live)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = g >> 3, oct = g & 7u;
-    if (i < n && (!live || i < *live)) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
+    if (i < n && (!live || i < *live)) {
+        const Node4Q q = in[i];
+        wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct);
+        octq[(size_t)oct * wide_stride + i] = make_octant_node(q, oct);
+    }
 }
 RFW_DI bool slot_is_live(const MeshRecord* __restrict__ recs, const uint32_t* __restrict__ counts, const uint32_t n_recs, const uint32_t slot)
 {
@@ -1100,12 +1109,16 @@ __global__ void k_quantize_regions(const Node4* __restrict__ in, Node4Q* __restr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && slot_is_live(recs, counts, n_recs, i)) out[i] = quantize_node(in[i]);
 }
-__global__ void k_expand_regions(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, const uint32_t wide_stride, const uint32_t n,
+__global__ void k_expand_regions(const Node4Q* __restrict__ in, PacketNode* __restrict__ wide, Node4Q* __restrict__ octq, const uint32_t wide_stride, const uint32_t n,
                                  const MeshRecord* __restrict__ recs, const uint32_t* __restrict__ counts, const uint32_t n_recs)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = g >> 3, oct = g & 7u;
-    if (i < n && slot_is_live(recs, counts, n_recs, i)) wide[(size_t)oct * wide_stride + i] = make_packet_node(in[i], oct);
+    if (i < n && slot_is_live(recs, counts, n_recs, i)) {
+        const Node4Q q = in[i];
+        wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct);
+        octq[(size_t)oct * wide_stride + i] = make_octant_node(q, oct);
+    }
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -1223,21 +1236,20 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
 }
-void launch_expand_nodes(hipStream_t s, const Node4Q* in, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live)
+void launch_expand_nodes(hipStream_t s, const Node4Q* in, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {
-    if (n && wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, wide, wide_stride, n, live);
+    if (n && oc.wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, oc.wide + first, oc.quant + first, oc.stride, n, live);
 }
-void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const uint32_t* live)
+void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {
     if (n) hipLaunchKernelGGL(k_quantize_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, live);
-    launch_expand_nodes(s, out, wide, wide_stride, n, live);
+    launch_expand_nodes(s, out, oc, first, n, live);
 }
-void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, PacketNode* wide, uint32_t wide_stride, uint32_t n, const MeshRecord* recs,
-                             const uint32_t* counts, uint32_t n_recs)
+void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t n, const MeshRecord* recs, const uint32_t* counts, uint32_t n_recs)
 {
     if (!n || !n_recs) return;
     hipLaunchKernelGGL(k_quantize_regions, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, recs, counts, n_recs);
-    if (wide) hipLaunchKernelGGL(k_expand_regions, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, out, wide, wide_stride, n, recs, counts, n_recs);
+    if (oc.wide) hipLaunchKernelGGL(k_expand_regions, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, out, oc.wide, oc.quant, oc.stride, n, recs, counts, n_recs);
 }
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)

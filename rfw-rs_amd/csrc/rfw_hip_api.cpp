@@ -255,6 +255,7 @@ struct Instance {
     // what the PACKET kernels traverse (traverse_packet.h): eight copies of d_*_nodes, one per ray octant, copy `oct` of node i at
     // [oct * stride + i] with stride = the capacity of the quantised array; nullptr when the copies would not fit kMaxPacketNodeBytes
     DevBuf<PacketNode> d_blas_wide, d_tlas_wide;
+    DevBuf<Node4Q> d_blas_oct, d_tlas_oct; // the same copies as the one-ray-per-lane kernels read them (make_octant_node), same stride
     DevBuf<TriPacket> d_packets;
     DevBuf<rfw_rt_triangle> d_triangles;
     DevBuf<MeshRecord> d_mesh_records;
@@ -530,25 +531,33 @@ int alloc_paths(Instance* I)
 
 uint32_t spill_stride(const Instance* I) { return (uint32_t)(I->d_spill.cap / kStackSpill); }
 
-// The packet kernels' node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity.  (Re)allocates when that
-// capacity changed — the stride with it, so every node in use (`keep` of them) is expanded again — and returns the stride; a tree whose
-// copies would exceed kMaxPacketNodeBytes does without (the packet kernels are then not used: scene_dev hands out nullptr).
-constexpr size_t kMaxPacketNodeBytes = size_t(16) << 30;
-hipError_t follow_wide(DevBuf<PacketNode>& wide, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s)
+// The per-octant node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity, in both forms (PacketNode
+// for the packet kernels, Node4Q for the one-ray-per-lane kernels).  (Re)allocates when that capacity changed — the stride with it, so every
+// node in use (`keep` of them) is expanded again.
+hipError_t follow_copies(DevBuf<PacketNode>& wide, DevBuf<Node4Q>& oct, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s)
 {
     const size_t want = nodes.cap * kPacketNodeCopies;
-    if (want * sizeof(PacketNode) > kMaxPacketNodeBytes) { wide.release(); return hipSuccess; }
-    if (wide.cap == want) return hipSuccess;
+    if (wide.cap == want && oct.cap == want) return hipSuccess;
     wide.release();
+    oct.release();
     if (want == 0) return hipSuccess;
     hipError_t e = hipMalloc((void**)&wide.ptr, want * sizeof(PacketNode));
-    if (e != hipSuccess) { wide.ptr = nullptr; (void)hipGetLastError(); return hipSuccess; } // no room: the packet kernels are not used
+    if (e != hipSuccess) { wide.ptr = nullptr; return e; }
     wide.cap = want;
-    launch_expand_nodes(s, nodes.ptr, wide.ptr, (uint32_t)nodes.cap, (uint32_t)std::min(keep, nodes.cap));
+    e = hipMalloc((void**)&oct.ptr, want * sizeof(Node4Q));
+    if (e != hipSuccess) { oct.ptr = nullptr; return e; }
+    oct.cap = want;
+    OctantCopies oc;
+    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)nodes.cap;
+    launch_expand_nodes(s, nodes.ptr, oc, 0u, (uint32_t)std::min(keep, nodes.cap));
     return hipGetLastError();
 }
-inline uint32_t wide_stride(const DevBuf<PacketNode>& wide) { return (uint32_t)(wide.cap / kPacketNodeCopies); }
-inline PacketNode* wide_at(const DevBuf<PacketNode>& wide, size_t first) { return wide.ptr ? wide.ptr + first : nullptr; }
+inline OctantCopies copies_of(const DevBuf<PacketNode>& wide, const DevBuf<Node4Q>& oct)
+{
+    OctantCopies oc;
+    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)(wide.cap / kPacketNodeCopies);
+    return oc;
+}
 
 SceneDev scene_dev(Instance* I)
 {
@@ -565,6 +574,8 @@ SceneDev scene_dev(Instance* I)
     s.blas_wide = S->d_blas_wide.ptr;
     s.tlas_wide_stride = (uint32_t)(TL->d_tlas_wide.cap / kPacketNodeCopies);
     s.blas_wide_stride = (uint32_t)(S->d_blas_wide.cap / kPacketNodeCopies);
+    s.tlas_oct = TL->d_tlas_oct.ptr;
+    s.blas_oct = S->d_blas_oct.ptr;
     s.tri_packets = S->d_packets.ptr;
     s.triangles = S->d_triangles.ptr;
     const Instance::Tables& tb = S->tables[S->tables_version % Instance::kTableVersions];
@@ -743,7 +754,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
     launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count, I->d_mesh_node_counts.ptr + q);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count, I->d_mesh_node_counts.ptr + q);
     return RFW_HIP_OK;
 }
 
@@ -788,7 +799,7 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
                     launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
                 }
                 (void)hipEventRecord(L.done, L.s);
             });
@@ -852,7 +863,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
-    HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
     HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
     for (auto& ev : I->ev_build)
@@ -902,7 +913,7 @@ int build_blas_device_full(Instance* I)
     }
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     // all static regions in one launch; the slots behind a tree's last node are skipped (the builders left the node counts on the device)
-    launch_quantize_regions(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, wide_at(I->d_blas_wide, 0), wide_stride(I->d_blas_wide), static_nodes, I->d_mesh_records.ptr,
+    launch_quantize_regions(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, copies_of(I->d_blas_wide, I->d_blas_oct), static_nodes, I->d_mesh_records.ptr,
                             I->d_mesh_node_counts.ptr, (uint32_t)n_static);
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
@@ -983,7 +994,7 @@ int build_blas_device_incremental(Instance* I)
     {
         const size_t nodes_before = I->d_blas_nodes.cap; // (the regions in use end below the old capacity)
         HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
-        HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, nodes_before, I->stream));
+        HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, nodes_before, I->stream));
     }
     HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
     HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
@@ -1086,13 +1097,13 @@ int build_blas_host(Instance* I)
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
-    HIP_TRY(I, follow_wide(I->d_blas_wide, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     std::vector<Node4Q> qnodes(nodes.size());
     for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
     if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
-    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, I->d_blas_wide.ptr, wide_stride(I->d_blas_wide), (uint32_t)qnodes.size());
+    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, copies_of(I->d_blas_wide, I->d_blas_oct), 0u, (uint32_t)qnodes.size());
     if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
     if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
@@ -1165,7 +1176,7 @@ int build_instances(Instance* I, Instance* T)
     HIP_TRY(I, T->d_normals.ensure(n_all));
     HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
     HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(I, follow_wide(T->d_tlas_wide, T->d_tlas_nodes, 0, T->stream));
+    HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, T->stream));
     HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_node_count.ensure(1));
     hipStream_t s = T->stream;
@@ -1225,7 +1236,7 @@ int build_instances(Instance* I, Instance* T)
                 quantise_count = d.node_count;
             }
             launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
-            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, wide_at(I->d_blas_wide, r.node_base), wide_stride(I->d_blas_wide), quantise_count);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count);
             launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, T->d_mesh_local.ptr + d.record);
         }
         HIP_TRY(I, hipGetLastError());
@@ -1243,7 +1254,7 @@ int build_instances(Instance* I, Instance* T)
         launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
         HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
                               T->d_node_count.ptr));
-        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), std::max<uint32_t>(n_valid, 1u), T->d_node_count.ptr);
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, std::max<uint32_t>(n_valid, 1u), T->d_node_count.ptr);
         launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
         HIP_TRY(I, hipGetLastError());
         T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
@@ -1280,8 +1291,8 @@ int build_instances(Instance* I, Instance* T)
         std::vector<Node4Q> qn(tlas.nodes.size());
         for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
         if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
-        HIP_TRY(I, follow_wide(T->d_tlas_wide, T->d_tlas_nodes, 0, s));
-        launch_expand_nodes(s, T->d_tlas_nodes.ptr, T->d_tlas_wide.ptr, wide_stride(T->d_tlas_wide), (uint32_t)qn.size());
+        HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, s));
+        launch_expand_nodes(s, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, (uint32_t)qn.size());
         if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));
@@ -1984,7 +1995,7 @@ void rfw_hip_destroy(void* inst)
         if (I->scene_ready) (void)hipEventDestroy(I->scene_ready);
         if (I->frame_done) (void)hipEventDestroy(I->frame_done);
         if (I->download_done) (void)hipEventDestroy(I->download_done);
-        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_wide.release(); I->d_tlas_wide.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
+        I->d_blas_nodes.release(); I->d_tlas_nodes.release(); I->d_blas_wide.release(); I->d_tlas_wide.release(); I->d_blas_oct.release(); I->d_tlas_oct.release(); I->d_blas_raw.release(); I->d_tlas_raw.release(); I->d_packets.release(); I->d_triangles.release();
         I->d_mesh_records.release(); I->d_matrices.release(); I->d_mesh_of_instance.release(); I->d_tlas_prims.release();
         I->d_xforms.release(); I->d_normals.release();
         for (auto& tb : I->tables) { tb.materials.release(); tb.area.release(); tb.point.release(); tb.spot.release(); tb.dir.release(); }

@@ -69,10 +69,20 @@ static inline void leaf_test(uint32_t ref, const Ray& r, float& t, uint32_t& tes
 }
 
 // children of `cur` a lane goes on with, nearest first
-static inline int ordered_children(const Node4Q& n, const SlabOut& s, uint32_t out[4])
+static bool g_static_order = false; // children in the order of the ray octant's copy of the node (make_packet_node) instead of by entry distance
+static inline int ordered_children(const Node4Q& n, const SlabOut& s, uint32_t out[4], const Ray* ray = nullptr)
 {
     int idx[4], k = 0;
     for (int i = 0; i < 4; i++) if (s.hit[i]) idx[k++] = i;
+    if (g_static_order && ray) {
+        const uint32_t oct = (ray->inv[0] < 0 ? 1u : 0u) | (ray->inv[1] < 0 ? 2u : 0u) | (ray->inv[2] < 0 ? 4u : 0u);
+        const PacketNode pn = make_packet_node(n, oct);
+        int kk = 0;
+        for (int j = 0; j < 4; j++)
+            for (int i = 0; i < 4; i++)
+                if (s.hit[i] && n.child[i] == pn.child[j] && n.child[i] != kInvalidRef) { bool dup = false; for (int q = 0; q < kk; q++) dup |= out[q] == n.child[i]; if (!dup) out[kk++] = n.child[i]; }
+        return kk;
+    }
     std::sort(idx, idx + k, [&](int a, int b) { return s.tn[a] < s.tn[b] || (s.tn[a] == s.tn[b] && a < b); });
     for (int i = 0; i < k; i++) out[i] = n.child[idx[i]];
     return k;
@@ -107,7 +117,7 @@ static void per_lane_loop(std::vector<Lane>& L, WaveCost& c)
                 if (first_node == 0xffffffffu) first_node = l.cur; else if (first_node != l.cur) uni = false;
                 const Node4Q& n = g_nodes[l.cur];
                 const SlabOut s = slab(n, l.r, l.t);
-                uint32_t ch[4]; const int k = ordered_children(n, s, ch);
+                uint32_t ch[4]; const int k = ordered_children(n, s, ch, &l.r);
                 l.nodes++;
                 if (k == 0) l.cur = kInvalidRef;
                 else { l.cur = ch[0]; for (int j = k - 1; j >= 1; j--) l.stack.push_back(ch[j]); }
@@ -247,6 +257,20 @@ int main(int argc, char** argv)
                c.handover_sp / nblocks);
     };
     rep("per-lane", base);
+    {   // the same one-ray-per-lane loop with the STATIC child order of the octant copies
+        g_static_order = true;
+        WaveCost st;
+        srand(12345);
+        for (int b = 0; b < nblocks; b++) {
+            const uint32_t bx = (uint32_t)rand() % (W / 8), by = (uint32_t)rand() % (H / 8);
+            std::vector<Lane> L(64);
+            for (int l = 0; l < 64; l++) L[l].r = make_ray(bx * 8 + (l & 7), by * 8 + (l >> 3));
+            per_lane_loop(L, st);
+            for (auto& l : L) { st.lane_nodes += l.nodes; st.lane_tris += l.tris; }
+        }
+        g_static_order = false;
+        rep("static", st);
+    }
     rep("strict", strict);
     rep("masked", masked);
     return 0;
