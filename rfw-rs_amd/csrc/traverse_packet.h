@@ -65,17 +65,17 @@ RFW_DI uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv
 // lanes that are not part of the packet from the votes.  An empty slot holds the box (+inf, -inf): its entry distance is +inf for every
 // ray, so it needs no test of its own.
 // a: nx[4] ny[4] nz[4] fx[4]   b: fy[4] fz[4] child[4] pad[4]  (the 128-B node, in scalar registers)
-// m[i] = lanes whose ray enters child i before t
+// m[i] = lanes whose ray enters child i before t (6 fma + max3 + min3 + min + 2 compares per child)
 RFW_DI void slab4(const su16 a, const su16 b, const SlabRay& r, const float t, const uint64_t packet, uint64_t (&m)[4])
 {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        // tf >= tn && tn <= t && tf >= 0   <=>   min(tf, t) >= max(tn, 0)   (t > 0)
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(bitsf(a[i]), r.inv.x, r.bn.x), __builtin_fmaf(bitsf(a[4 + i]), r.inv.y, r.bn.y)),
-                                                         __builtin_fmaf(bitsf(a[8 + i]), r.inv.z, r.bn.z)), 0.0f);
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(bitsf(a[12 + i]), r.inv.x, r.bf.x), __builtin_fmaf(bitsf(b[i]), r.inv.y, r.bf.y)),
-                                                         __builtin_fmaf(bitsf(b[4 + i]), r.inv.z, r.bf.z)), t);
-        m[i] = ballot64(tf >= tn) & packet;
+        // tf >= tn && tn <= t  <=>  min(tf, t) >= tn; a direction of exact zeros makes tn NaN on every axis and fails the compare
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(bitsf(a[i]), r.inv.x, r.bn.x), __builtin_fmaf(bitsf(a[4 + i]), r.inv.y, r.bn.y)),
+                                         __builtin_fmaf(bitsf(a[8 + i]), r.inv.z, r.bn.z));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bitsf(a[12 + i]), r.inv.x, r.bf.x), __builtin_fmaf(bitsf(b[i]), r.inv.y, r.bf.y)),
+                                         __builtin_fmaf(bitsf(b[4 + i]), r.inv.z, r.bf.z));
+        m[i] = ballot64(__builtin_fminf(tf, t) >= tn) & ballot64(tf >= 0.0f) & packet;
     }
 }
 
