@@ -538,6 +538,14 @@ def main():
             launches = {"k_primary": 1, "k_shade": args.max_path_length, "k_shadow": 1, "k_shadow_stream": max(args.max_path_length - 1, 0),
                         "k_extend": max(args.max_path_length - 1, 1)}
         roofline = build_roofline(alg, kms, ms_step, sum(alg.values()), bw_measured, args, single, launches if kms else None)
+        if os.environ.get("RFW_PACKET_TRACE", "1") not in ("0", "2"):
+            # camera rays walk the tree as wavefront packets (csrc/traverse_packet.h): a node (128 B, the octant copy) and a triangle packet (48 B)
+            # are fetched ONCE per wavefront through the scalar cache — what the launch actually asks the memory system for, next to §8(d)'s
+            # per-ray figure above (which prices every ray's own visits at 64 B per node)
+            waves = max(n_prim / 64.0, 1.0)
+            roofline["primary_packets"] = {"node_steps_per_wavefront": round(mean("node_test_executions", 0) / waves, 2),
+                                           "triangle_steps_per_wavefront": round(mean("tri_test_executions", 0) / waves, 2),
+                                           "bytes_fetched_per_launch": int(mean("node_test_executions", 0) * 128 + mean("tri_test_executions", 0) * 48 + n_prim * (48 + 16))}
         roofline["nodes_per_ray"] = {"primary": round(mean("nodes_visited", 0) / max(n_prim, 1), 2), "shadow": round(mean("nodes_visited", 2) / max(n_shad, 1), 2)}
         roofline["tris_per_ray"] = {"primary": round(mean("tris_tested", 0) / max(n_prim, 1), 2), "shadow": round(mean("tris_tested", 2) / max(n_shad, 1), 2)}
         # SIMD efficiency of the traversal, from the instrumented frames: active lanes / 64 per execution of the node test and of the

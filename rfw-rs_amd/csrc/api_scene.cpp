@@ -1,0 +1,1242 @@
+// api_scene.cpp — the scene side of the C ABI: set_* calls and synchronize().  Host-side counterpart of backends/gpu-rt/src/lib.rs:1309-1683:
+// BLAS builds per changed mesh (device binned SAH / LBVH, host SAH), skinned copies, the per-frame TLAS, versioned material / light tables, textures.
+#include "api_internal.h"
+
+using namespace rfwapi;
+
+namespace rfwapi {
+// The per-octant node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity, in both forms (PacketNode
+// for the packet kernels, Node4Q for the one-ray-per-lane kernels).  (Re)allocates when that capacity changed — the stride with it, so every
+// node in use (`keep` of them) is expanded again.
+hipError_t follow_copies(DevBuf<PacketNode>& wide, DevBuf<Node4Q>& oct, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s)
+{
+    const size_t want = nodes.cap * kPacketNodeCopies;
+    if (wide.cap == want && oct.cap == want) return hipSuccess;
+    wide.release();
+    oct.release();
+    if (want == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&wide.ptr, want * sizeof(PacketNode));
+    if (e != hipSuccess) { wide.ptr = nullptr; return e; }
+    wide.cap = want;
+    e = hipMalloc((void**)&oct.ptr, want * sizeof(Node4Q));
+    if (e != hipSuccess) { oct.ptr = nullptr; return e; }
+    oct.cap = want;
+    OctantCopies oc;
+    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)nodes.cap;
+    launch_expand_nodes(s, nodes.ptr, oc, 0u, (uint32_t)std::min(keep, nodes.cap));
+    return hipGetLastError();
+}
+inline OctantCopies copies_of(const DevBuf<PacketNode>& wide, const DevBuf<Node4Q>& oct)
+{
+    OctantCopies oc;
+    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)(wide.cap / kPacketNodeCopies);
+    return oc;
+}
+
+// pad so that the slab test is conservative w.r.t. the rounding of the Moeller-Trumbore arithmetic
+inline void pad_box(PrimBox& b)
+{
+    for (int a = 0; a < 3; a++) {
+        const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+        const float e = 1e-4f + 4e-6f * m;
+        b.lo[a] -= e;
+        b.hi[a] += e;
+    }
+}
+
+void build_mesh(Instance* I, MeshHost& m)
+{
+    const size_t n = m.tris.size();
+    std::vector<PrimBox> boxes(n);
+    for (size_t i = 0; i < n; i++) {
+        const rfw_rt_triangle& t = m.tris[i];
+        const float* v[3] = {&t.vertex0.x, &t.vertex1.x, &t.vertex2.x};
+        for (int a = 0; a < 3; a++) {
+            boxes[i].lo[a] = std::min(v[0][a], std::min(v[1][a], v[2][a]));
+            boxes[i].hi[a] = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+        }
+        pad_box(boxes[i]);
+    }
+    build_bvh4_host(boxes, I->sah_max_leaf, I->build_threads, m.bvh, I->sah_trav_cost);
+    m.packets.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t id = m.bvh.prim_order[k];
+        const rfw_rt_triangle& t = m.tris[id];
+        TriPacket p;
+        p.v0x = t.vertex0.x; p.v0y = t.vertex0.y; p.v0z = t.vertex0.z;
+        p.tri_id = id; // mesh-local; the global offset is added when the mega-buffer is assembled
+        // edge1 = v1 - v0, edge2 = v2 - v0 (intersection.glsl:7-8), single IEEE subtractions
+        p.e1x = t.vertex1.x - t.vertex0.x; p.e1y = t.vertex1.y - t.vertex0.y; p.e1z = t.vertex1.z - t.vertex0.z;
+        p.e2x = t.vertex2.x - t.vertex0.x; p.e2y = t.vertex2.y - t.vertex0.y; p.e2z = t.vertex2.z - t.vertex0.z;
+        // denom = 1 / dot(gn, gn) (intersection.glsl:32)
+        p.inv_gn2 = 1.0f / (t.normal.x * t.normal.x + t.normal.y * t.normal.y + t.normal.z * t.normal.z);
+        p.pad = 0.0f;
+        m.packets[k] = p;
+    }
+    m.dirty = false;
+}
+
+int ensure_stage(Instance* I, size_t bytes)
+{
+    const int k = I->stage_next;
+    I->stage = I->stage_buf[k];
+    if (bytes <= I->stage_cap[k]) return RFW_HIP_OK;
+    if (I->stage_buf[k]) (void)hipHostFree(I->stage_buf[k]);
+    I->stage_buf[k] = nullptr;
+    I->stage = nullptr;
+    I->stage_cap[k] = 0;
+    const size_t want = std::max<size_t>(bytes * 2, 1 << 20);
+    HIP_TRY(I, hipHostMalloc(&I->stage_buf[k], want, hipHostMallocDefault));
+    I->stage_cap[k] = want;
+    I->stage = I->stage_buf[k];
+    return RFW_HIP_OK;
+}
+
+int ensure_lbvh_ws(Instance* I, uint32_t n)
+{
+    const size_t need = lbvh_workspace_bytes(n);
+    HIP_TRY(I, I->d_lbvh_ws.ensure(need));
+    return RFW_HIP_OK;
+}
+
+// the (mesh id, skin id) pairs that need a skinned copy: the mesh carries joint data, the skin exists and the slot is live
+std::map<std::pair<uint32_t, int32_t>, DerivedMesh> wanted_derived(const Instance* I)
+{
+    std::map<std::pair<uint32_t, int32_t>, DerivedMesh> out;
+    for (const auto& kv : I->inst_lists) {
+        const auto mit = I->meshes.find(kv.first);
+        if (mit == I->meshes.end() || mit->second.skin.empty()) continue;
+        for (size_t s = 0; s < kv.second.matrices.size(); s++) {
+            const int32_t sk = s < kv.second.skin_ids.size() ? kv.second.skin_ids[s] : -1;
+            if (sk < 0 || (size_t)sk >= I->skins.size() || I->skins[sk].empty() || is_zero_matrix(kv.second.matrices[s])) continue;
+            out[std::make_pair(kv.first, sk)];
+        }
+    }
+    return out;
+}
+
+// Appends one record per skinned copy after the static meshes, reserves their regions of the mega-buffers and uploads the joint
+// data of the source meshes.  The triangles, BVH and packets of these records are (re)built on the device by build_instances.
+int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
+{
+    const uint32_t static_nodes = node_total;
+    I->derived = wanted_derived(I);
+    I->max_derived_tris = 0;
+    std::vector<rfw_joint_data> skin_all;
+    std::map<uint32_t, size_t> skin_off;
+    for (auto& kv : I->derived) {
+        DerivedMesh& d = kv.second;
+        d.src_record = I->mesh_index[kv.first.first];
+        const MeshHost& src = I->meshes[kv.first.first];
+        auto so = skin_off.find(kv.first.first);
+        if (so == skin_off.end()) {
+            so = skin_off.emplace(kv.first.first, skin_all.size()).first;
+            skin_all.insert(skin_all.end(), src.skin.begin(), src.skin.end());
+        }
+        d.skin_offset = so->second;
+        MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
+        r.tri_base = tri_total;
+        r.tri_count = (uint32_t)src.tris.size();
+        r.node_base = node_total;
+        r.node_count = std::max<uint32_t>(r.tri_count, 1u);
+        tri_total += r.tri_count;
+        node_total += r.node_count;
+        d.record = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        I->max_derived_tris = std::max(I->max_derived_tris, r.tri_count);
+    }
+    if (I->derived.empty()) return RFW_HIP_OK;
+    if (!I->blas_on_device) { // the host path has no raw-node buffer of its own: keep one for the skinned records only
+        I->raw_node_origin = static_nodes;
+        HIP_TRY(I, I->d_blas_raw.ensure(node_total - static_nodes));
+    }
+    HIP_TRY(I, I->d_blas_order.ensure(tri_total));
+    HIP_TRY(I, I->d_tri_boxes.ensure(I->max_derived_tris));
+    HIP_TRY(I, I->d_bounds_scratch.ensure(8));
+    return upload(I, I->d_skin_data, skin_all.data(), skin_all.size());
+}
+
+// ALGORITHMIC bytes of the device passes over one mesh of n triangles (rfw_hip_scene_stats.blas_kernel_bytes), per primitive: boxes (176 in,
+// 32 out); per builder level above the hand-over size bin (32 + 4 in) and partition (32 + 4 + 4 in, the same out) = 116; the workgroup phase
+// (32 + 4 in, 4 out); packets (176 + 4 in, 48 out); and per wide node (~ n / 4) 128 B written by the emitter, 128 read and 64 written by the quantiser
+uint64_t build_pass_bytes(uint64_t n)
+{
+    uint32_t levels = 0;
+    for (uint64_t v = n / 512u; v > 0; v >>= 1) levels++;
+    return n * (208u + 116u * levels + 40u + 228u) + (n / 4u) * 320u;
+}
+
+// One static mesh on the device, into the region its record names: boxes -> BVH (binned SAH, or LBVH) -> leaf-ordered packets ->
+// quantised nodes.  The triangles are already in d_triangles.  `quantise_count` nodes of the region are quantised (the region is sized for
+// the worst case, one node per primitive; nodes behind the tree's own are never referenced).
+int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
+{
+    const MeshRecord& r = I->mesh_records[q];
+    if (r.tri_count == 0) return RFW_HIP_OK;
+    launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+    if (I->blas_sah_on_device) {
+        HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
+        const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                        I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
+        if (se == hipErrorInvalidValue) { // a tree deeper than the SAH builder's level budget above its LDS phase: LBVH always terminates
+            HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                                  I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+        } else {
+            HIP_TRY(I, se);
+        }
+    } else {
+        HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
+                              I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
+    }
+    launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count, I->d_mesh_node_counts.ptr + q);
+    return RFW_HIP_OK;
+}
+
+// Several meshes: the large ones one after the other on the instance's stream (each fills the device by itself), the small ones side by
+// side — a 5120-triangle mesh is ~30 dependent launches of a few microseconds and one 16-byte read-back, i.e. all latency: kBuildLanes host
+// threads, each with a stream and scratch of its own, take them from one counter.  The lanes start behind what the instance's stream holds
+// (the triangle uploads) and the stream continues behind the lanes.  A builder failure falls back to the one-by-one path for that mesh.
+int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
+{
+    constexpr uint32_t kSmallMesh = 131072;
+    std::vector<uint32_t> small, large;
+    for (const uint32_t q : qs) (I->blas_sah_on_device && I->mesh_records[q].tri_count && I->mesh_records[q].tri_count <= kSmallMesh ? small : large).push_back(q);
+    if (small.size() < 2) { large = qs; small.clear(); }
+    int rc = RFW_HIP_OK;
+    const int n_lanes = (int)std::min<size_t>(Instance::kBuildLanes, small.size());
+    std::vector<std::thread> workers;
+    std::vector<hipError_t> lane_err((size_t)std::max(n_lanes, 1), hipSuccess);
+    std::vector<uint8_t> redo(I->mesh_records.size(), 0);
+    std::atomic<size_t> next{0};
+    if (n_lanes) {
+        uint32_t max_n = 0;
+        for (const uint32_t q : small) max_n = std::max(max_n, I->mesh_records[q].tri_count);
+        hipEvent_t start = I->ev_build[1]; // recorded by the caller behind the uploads
+        for (int k = 0; k < n_lanes; k++) {
+            Instance::BuildLane& L = I->lanes[k];
+            if (!L.s) HIP_TRY(I, hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+            if (!L.done) HIP_TRY(I, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            HIP_TRY(I, L.ws.ensure(sah_workspace_bytes(max_n)));
+            HIP_TRY(I, L.boxes.ensure(max_n));
+            HIP_TRY(I, hipStreamWaitEvent(L.s, start, 0));
+        }
+        for (int k = 0; k < n_lanes; k++)
+            workers.emplace_back([I, k, &small, &next, &lane_err, &redo, incremental] {
+                Instance::BuildLane& L = I->lanes[k];
+                if (hipSetDevice(I->device) != hipSuccess) { lane_err[k] = hipErrorInvalidDevice; return; }
+                for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) {
+                    const uint32_t q = small[i];
+                    const MeshRecord& r = I->mesh_records[q];
+                    launch_triangle_boxes(L.s, I->d_triangles.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
+                    const hipError_t e = sah_build(L.s, L.boxes.ptr, r.tri_count, L.ws.ptr, L.ws.cap, I->d_blas_raw.ptr + r.node_base, I->d_blas_order.ptr + r.tri_base,
+                                                   I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
+                    if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
+                    if (e != hipSuccess) { lane_err[k] = e; return; }
+                    launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+                    if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
+                }
+                (void)hipEventRecord(L.done, L.s);
+            });
+    }
+    for (const uint32_t q : large) // meanwhile, on the instance's own stream
+        if (rc == RFW_HIP_OK) rc = build_mesh_device(I, q, incremental ? std::max(I->mesh_records[q].tri_count, 1u) : 0u);
+    for (auto& t : workers) t.join();
+    for (int k = 0; k < n_lanes; k++) {
+        if (lane_err[k] != hipSuccess && rc == RFW_HIP_OK) rc = fail(I, RFW_HIP_E_DEVICE, std::string("build lane: ") + hipGetErrorString(lane_err[k]));
+        (void)hipStreamWaitEvent(I->stream, I->lanes[k].done, 0);
+    }
+    if (rc != RFW_HIP_OK) return rc;
+    for (const uint32_t q : small)
+        if (redo[q] && (rc = build_mesh_device(I, q, incremental ? std::max(I->mesh_records[q].tri_count, 1u) : 0u))) return rc;
+    return RFW_HIP_OK;
+}
+
+// The triangle-id offsets the boundary reports: meshes in mesh-id order, then the skinned copies (= the order of a full build)
+void assign_logical_ids(Instance* I)
+{
+    uint32_t logical = 0;
+    for (auto& kv : I->meshes) {
+        const auto it = I->mesh_index.find(kv.first);
+        if (it == I->mesh_index.end()) continue;
+        I->mesh_records[it->second].tri_logical = logical;
+        logical += I->mesh_records[it->second].tri_count;
+    }
+    for (auto& kv : I->derived) {
+        I->mesh_records[kv.second.record].tri_logical = logical;
+        logical += I->mesh_records[kv.second.record].tri_count;
+    }
+}
+
+// BLAS for every mesh on the device: lay the mega-buffers out afresh, upload all triangles, build every mesh
+int build_blas_device_full(Instance* I)
+{
+    I->mesh_records.clear();
+    I->mesh_index.clear();
+    I->record_tri_cap.clear();
+    uint32_t tri_total = 0, node_total = 0;
+    for (auto& kv : I->meshes) {
+        MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
+        r.tri_base = tri_total;
+        r.tri_count = (uint32_t)kv.second.tris.size();
+        r.node_base = node_total;
+        r.node_count = std::max<uint32_t>(r.tri_count, 1u); // worst case (one primitive per leaf => at most n - 1 wide nodes)
+        tri_total += r.tri_count;
+        node_total += r.node_count;
+        I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        I->record_tri_cap.push_back(r.tri_count);
+        kv.second.dirty = false;
+    }
+    const uint32_t static_nodes = node_total, static_tris = tri_total;
+    const size_t n_static = I->mesh_records.size();
+    I->raw_node_origin = 0;
+    int rc;
+    if ((rc = layout_derived(I, tri_total, node_total))) return rc;
+    assign_logical_ids(I);
+    HIP_TRY(I, I->d_triangles.ensure(tri_total));
+    HIP_TRY(I, I->d_packets.ensure(tri_total));
+    HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, I->d_blas_raw.ensure(node_total));
+    HIP_TRY(I, I->d_blas_order.ensure(tri_total));
+    for (auto& ev : I->ev_build)
+        if (!ev) HIP_TRY(I, hipEventCreate(&ev));
+    HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    uint32_t max_n = 0;
+    size_t k = 0;
+    for (auto& kv : I->meshes) {
+        const MeshRecord& r = I->mesh_records[k++];
+        max_n = std::max(max_n, r.tri_count);
+        if (r.tri_count)
+            HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle),
+                                      hipMemcpyHostToDevice, I->stream));
+    }
+    HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
+    if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
+    HIP_TRY(I, I->d_mesh_node_counts.ensure(std::max<size_t>(n_static, 1)));
+    HIP_TRY(I, hipMemsetAsync(I->d_mesh_node_counts.ptr, 0, std::max<size_t>(n_static, 1) * 4, I->stream)); // (an empty mesh is not built: its count stays 0)
+    HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
+    uint64_t kernel_bytes = 0;
+    {
+        std::vector<uint32_t> all(n_static);
+        for (size_t q = 0; q < n_static; q++) { all[q] = (uint32_t)q; kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count); }
+        // several meshes: ONE build for all of them (sah_build_forest: the meshes lie one after the other in the buffers of a full build, every
+        // mesh is a root of the same level-by-level pass) — ~45 launches for the scene instead of ~30 per mesh
+        bool forest_done = false;
+        // (measured: two meshes of 720 k + 330 k triangles 5.4 ms together, 4.4 ms one after the other; 65 meshes 5.5 ms against 10.4 on lanes, 38 one by one)
+        if (I->blas_sah_on_device && n_static >= 4 && static_tris > 0 && !getenv("RFW_NO_FOREST")) {
+            std::vector<ForestTree> trees(n_static);
+            for (size_t q = 0; q < n_static; q++) trees[q] = ForestTree{I->mesh_records[q].tri_base, I->mesh_records[q].tri_count, I->mesh_records[q].node_base, 0u};
+            HIP_TRY(I, I->d_forest.ensure(n_static));
+            HIP_TRY(I, I->pins.upload(I->d_forest.ptr, trees.data(), n_static * sizeof(ForestTree), I->stream));
+            HIP_TRY(I, I->d_tri_boxes.ensure(std::max(static_tris, I->max_derived_tris)));
+            HIP_TRY(I, I->d_sah_ws.ensure(sah_forest_workspace_bytes(static_tris, (uint32_t)n_static)));
+            launch_triangle_boxes(I->stream, I->d_triangles.ptr, static_tris, I->d_tri_boxes.ptr);
+            const hipError_t fe = sah_build_forest(I->stream, I->d_tri_boxes.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static, max_n, I->d_sah_ws.ptr, I->d_sah_ws.cap,
+                                                   I->d_blas_raw.ptr, I->d_blas_order.ptr, I->d_mesh_node_counts.ptr, I->sah_max_leaf, I->sah_trav_cost);
+            if (fe == hipSuccess) {
+                launch_make_packets(I->stream, I->d_triangles.ptr, I->d_blas_order.ptr, static_tris, 0u, I->d_packets.ptr); // global positions: one launch
+                launch_forest_relative_order(I->stream, I->d_blas_order.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static);
+                forest_done = true;
+            } else if (fe != hipErrorInvalidValue) {
+                HIP_TRY(I, fe);
+            } // else: some tree is deeper than the builder's level budget: mesh by mesh, where LBVH can take over for that one
+        }
+        if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
+    }
+    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+    // all static regions in one launch; the slots behind a tree's last node are skipped (the builders left the node counts on the device)
+    launch_quantize_regions(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, copies_of(I->d_blas_wide, I->d_blas_oct), static_nodes, I->d_mesh_records.ptr,
+                            I->d_mesh_node_counts.ptr, (uint32_t)n_static);
+    HIP_TRY(I, hipGetLastError());
+    I->n_tris = tri_total;
+    HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    I->build_events_pending = true;
+    I->blas_upload_bytes = (uint64_t)static_tris * sizeof(rfw_rt_triangle);
+    I->blas_kernel_bytes = kernel_bytes;
+    // nodes actually in use (the regions are sized for the worst case, one node per primitive); skinned copies count at their worst case
+    std::vector<uint32_t> counts(n_static, 0u);
+    if (n_static) HIP_TRY(I, hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
+    I->n_blas_nodes = node_total - static_nodes;
+    for (uint32_t c : counts) I->n_blas_nodes += c;
+    I->node_counts_stale = false;
+    I->d_sah_ws.release(); // ~350 B per triangle of build scratch: not kept between scene changes
+    for (auto& L : I->lanes) { L.ws.release(); L.boxes.release(); }
+    I->tri_end = static_tris;
+    I->node_end = static_nodes;
+    I->hole_tris = 0;
+    I->layout_valid = I->derived.empty(); // the incremental path does not move skinned copies around
+    I->full_builds++;
+    return RFW_HIP_OK;
+}
+
+// Only the meshes that changed (gpu-rt/src/lib.rs:1345-1383 rebuilds / refits `mesh.dirty` ones only): a changed mesh keeps its region of the
+// mega-buffers when it still fits and gets a new one behind the others when it grew; a new mesh is appended; an unloaded mesh leaves a hole.
+// Returns 1 when the layout has to be redone by a full build (too many holes), 0 on success, < 0 on error.
+int build_blas_device_incremental(Instance* I)
+{
+    // what went away
+    for (auto it = I->mesh_index.begin(); it != I->mesh_index.end();) {
+        if (I->meshes.find(it->first) == I->meshes.end()) {
+            I->hole_tris += I->record_tri_cap[it->second];
+            I->mesh_records[it->second].tri_count = 0;
+            it = I->mesh_index.erase(it);
+        } else ++it;
+    }
+    std::vector<uint32_t> todo; // record indices to (re)build
+    uint32_t max_n = 0;
+    for (auto& kv : I->meshes) {
+        MeshHost& m = kv.second;
+        if (!m.dirty) continue;
+        const uint32_t n = (uint32_t)m.tris.size();
+        uint32_t q;
+        const auto it = I->mesh_index.find(kv.first);
+        if (it != I->mesh_index.end() && n <= I->record_tri_cap[it->second]) {
+            q = it->second; // rebuilt in place
+        } else {
+            if (it != I->mesh_index.end()) { // grew: the old region becomes a hole, the record moves behind the others
+                q = it->second;
+                I->hole_tris += I->record_tri_cap[q];
+            } else {
+                q = (uint32_t)I->mesh_records.size();
+                MeshRecord r;
+                std::memset(&r, 0, sizeof(r));
+                I->mesh_records.push_back(r);
+                I->record_tri_cap.push_back(0);
+                I->mesh_index[kv.first] = q;
+            }
+            if ((uint64_t)I->tri_end + n > kLeafFirstMask || (uint64_t)I->node_end + std::max(n, 1u) > 0x7fffffffu) return 1;
+            I->mesh_records[q].tri_base = I->tri_end;
+            I->mesh_records[q].node_base = I->node_end;
+            I->record_tri_cap[q] = n;
+            I->tri_end += n;
+            I->node_end += std::max(n, 1u);
+        }
+        I->mesh_records[q].tri_count = n;
+        I->mesh_records[q].node_count = std::max(I->record_tri_cap[q], 1u);
+        todo.push_back(q);
+        max_n = std::max(max_n, n);
+        m.dirty = false;
+    }
+    if (I->hole_tris > std::max<uint64_t>(I->tri_end / 2, 1u << 16)) return 1; // mostly holes: compact by a full build
+    assign_logical_ids(I);
+    HIP_TRY(I, I->d_triangles.grow_keep(I->tri_end, I->d_triangles.cap, I->stream));
+    HIP_TRY(I, I->d_packets.grow_keep(I->tri_end, I->d_packets.cap, I->stream));
+    HIP_TRY(I, I->d_blas_order.grow_keep(I->tri_end, I->d_blas_order.cap, I->stream));
+    {
+        const size_t nodes_before = I->d_blas_nodes.cap; // (the regions in use end below the old capacity)
+        HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
+        HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, nodes_before, I->stream));
+    }
+    HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
+    HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
+    HIP_TRY(I, I->d_mesh_records.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), 0, I->stream));
+    HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, 1u)));
+    int rc;
+    if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
+    for (auto& ev : I->ev_build)
+        if (!ev) HIP_TRY(I, hipEventCreate(&ev));
+    HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    uint64_t upload_bytes = 0, kernel_bytes = 0;
+    for (const uint32_t q : todo) { // the changed meshes' triangles first (their regions are disjoint) ...
+        const MeshRecord& r = I->mesh_records[q];
+        const MeshHost* mh = nullptr;
+        for (auto& kv : I->mesh_index)
+            if (kv.second == q) mh = &I->meshes[kv.first];
+        if (r.tri_count && mh) {
+            upload_bytes += (uint64_t)r.tri_count * sizeof(rfw_rt_triangle);
+            // through the pinned ring when small (the host copy may be replaced by the next set_3d_mesh before a pageable copy has run)
+            if ((size_t)r.tri_count * sizeof(rfw_rt_triangle) <= (8u << 20))
+                HIP_TRY(I, I->pins.upload(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), I->stream));
+            else {
+                HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), hipMemcpyHostToDevice, I->stream));
+                HIP_TRY(I, hipStreamSynchronize(I->stream));
+            }
+        }
+    }
+    HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
+    for (const uint32_t q : todo) kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count);
+    if ((rc = build_meshes(I, todo, true))) return rc; // ... then their trees
+    HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
+    I->build_events_pending = true;
+    I->blas_upload_bytes = upload_bytes;
+    I->blas_kernel_bytes = kernel_bytes;
+    HIP_TRY(I, hipGetLastError());
+    HIP_TRY(I, I->pins.upload(I->d_mesh_records.ptr, I->mesh_records.data(), I->mesh_records.size() * sizeof(MeshRecord), I->stream));
+    uint64_t live = 0;
+    for (auto& kv : I->mesh_index) live += I->mesh_records[kv.second].tri_count;
+    I->n_tris = live;
+    I->node_counts_stale = true;
+    I->incremental_builds++;
+    return RFW_HIP_OK;
+}
+
+int build_blas_device(Instance* I)
+{
+    bool any_dirty = false, removed = false, all_dirty = !I->meshes.empty();
+    for (auto& kv : I->meshes) { any_dirty = any_dirty || kv.second.dirty; all_dirty = all_dirty && kv.second.dirty; }
+    for (auto& kv : I->mesh_index) removed = removed || I->meshes.find(kv.first) == I->meshes.end();
+    // (every mesh changed: nothing to keep — the full build lays the buffers out afresh and builds all meshes in one pass)
+    if (I->layout_valid && I->derived.empty() && wanted_derived(I).empty() && (any_dirty || removed) && !(all_dirty && I->meshes.size() >= 2)) {
+        const int rc = build_blas_device_incremental(I);
+        // build scratch is not kept between scene changes when it is large (as after a full build: ~350 B per triangle); the scratch of small
+        // edits stays — hipFree waits for the device, and an edit of one 5120-triangle mesh would pay its own build time on the host for it
+        if (I->d_sah_ws.cap > (64u << 20)) I->d_sah_ws.release();
+        for (auto& L : I->lanes)
+            if (L.ws.cap > (64u << 20)) { L.ws.release(); L.boxes.release(); }
+        if (rc < 0) { // an error part-way through: records, capacities and dirty flags may be half-updated — the next synchronize() starts over
+            I->layout_valid = false;
+            for (auto& kv : I->meshes) kv.second.dirty = true;
+            I->meshes_dirty = true;
+        }
+        if (rc <= 0) return rc;
+        for (auto& kv : I->meshes) kv.second.dirty = true; // (only matters for the host builder; the full device build takes every mesh)
+    }
+    return build_blas_device_full(I);
+}
+
+// BLAS on the host cores (binned SAH, multi-threaded), flattened into the mega-buffers (gpu-rt/src/lib.rs:1387-1548)
+int build_blas_host(Instance* I)
+{
+    for (auto& kv : I->meshes)
+        if (kv.second.dirty) build_mesh(I, kv.second);
+    I->mesh_records.clear();
+    I->mesh_index.clear();
+    I->layout_valid = false;
+    std::vector<Node4> nodes;
+    std::vector<TriPacket> packets;
+    std::vector<rfw_rt_triangle> tris;
+    for (auto& kv : I->meshes) {
+        MeshHost& m = kv.second;
+        MeshRecord r;
+        std::memset(&r, 0, sizeof(r));
+        r.node_base = (uint32_t)nodes.size();
+        r.node_count = (uint32_t)m.bvh.nodes.size();
+        r.tri_base = (uint32_t)tris.size();
+        r.tri_count = (uint32_t)m.tris.size();
+        I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
+        I->mesh_records.push_back(r);
+        nodes.insert(nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
+        const size_t p0 = packets.size();
+        packets.insert(packets.end(), m.packets.begin(), m.packets.end());
+        for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
+        tris.insert(tris.end(), m.tris.begin(), m.tris.end());
+    }
+    uint32_t tri_total = (uint32_t)tris.size(), node_total = (uint32_t)nodes.size();
+    int rc;
+    if ((rc = layout_derived(I, tri_total, node_total))) return rc;
+    assign_logical_ids(I);
+    I->n_tris = tri_total;
+    I->n_blas_nodes = node_total;
+    HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, I->d_packets.ensure(tri_total));
+    HIP_TRY(I, I->d_triangles.ensure(tri_total));
+    std::vector<Node4Q> qnodes(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) qnodes[k] = quantize_node(nodes[k]);
+    if ((rc = upload(I, I->d_blas_nodes, qnodes.data(), qnodes.size()))) return rc;
+    launch_expand_nodes(I->stream, I->d_blas_nodes.ptr, copies_of(I->d_blas_wide, I->d_blas_oct), 0u, (uint32_t)qnodes.size());
+    if ((rc = upload(I, I->d_packets, packets.data(), packets.size()))) return rc;
+    if ((rc = upload(I, I->d_triangles, tris.data(), tris.size()))) return rc;
+    if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
+    HIP_TRY(I, hipStreamSynchronize(I->stream)); // the host vectors above go out of scope
+    return RFW_HIP_OK;
+}
+
+// instances + TLAS (gpu-rt/src/lib.rs:1576-1615): global instance id = mesh_base[mesh] + slot
+int build_instances(Instance* I, Instance* T)
+{
+    // I: the scene (instance lists, mesh records, skins); T: whose instance-level device buffers, staging blocks and stream are used —
+    // I itself, or one of its frame slots (each slot keeps its own TLAS so that a scene whose instances move every frame still pipelines)
+    const auto wait0 = std::chrono::steady_clock::now();
+    // sizes first, then ONE pinned staging block: [matrices | mesh_of | valid_gids | mesh_local]
+    size_t n_all = 0;
+    for (auto& kv : I->inst_lists) n_all += kv.second.matrices.size();
+    const size_t n_mesh = I->mesh_records.size();
+    const size_t off_mats = 0, off_meshof = off_mats + n_all * sizeof(rfw_mat4), off_valid = off_meshof + n_all * 4,
+                 off_local = (off_valid + n_all * 4 + 63) / 64 * 64, off_joints = off_local + std::max<size_t>(n_mesh, 1) * sizeof(DevBox);
+    size_t n_joints = 0;
+    std::vector<size_t> joint_off(I->skins.size(), 0);
+    if (!I->derived.empty())
+        for (size_t k = 0; k < I->skins.size(); k++) { joint_off[k] = n_joints; n_joints += I->skins[k].size(); }
+    const size_t total = off_joints + n_joints * sizeof(rfw_mat4);
+    if (T->stage_pending[T->stage_next]) { // the upload that last used this block (two synchronizes ago) must have left it
+        HIP_TRY(I, hipEventSynchronize(T->stage_event[T->stage_next]));
+        T->stage_pending[T->stage_next] = false;
+    }
+    // back-pressure, not work: a host that runs ahead of the GPU waits here for the copy of two synchronizes ago
+    T->ms_stage_wait = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wait0).count();
+    int rc;
+    if ((rc = ensure_stage(T, total))) return rc;
+    char* st = static_cast<char*>(T->stage);
+    rfw_mat4* mats = reinterpret_cast<rfw_mat4*>(st + off_mats);
+    uint32_t* mesh_of = reinterpret_cast<uint32_t*>(st + off_meshof);
+    uint32_t* valid = reinterpret_cast<uint32_t*>(st + off_valid);
+    DevBox* local = reinterpret_cast<DevBox*>(st + off_local);
+    rfw_mat4* joints = reinterpret_cast<rfw_mat4*>(st + off_joints);
+    std::memset(local, 0, std::max<size_t>(n_mesh, 1) * sizeof(DevBox));
+    if (n_joints)
+        for (size_t k = 0; k < I->skins.size(); k++)
+            if (!I->skins[k].empty()) std::memcpy(joints + joint_off[k], I->skins[k].data(), I->skins[k].size() * sizeof(rfw_mat4));
+    uint32_t gid = 0, n_valid = 0;
+    for (auto& kv : I->inst_lists) {
+        const auto mit = I->mesh_index.find(kv.first);
+        const bool mesh_ok = mit != I->mesh_index.end() && I->mesh_records[mit->second].tri_count > 0;
+        if (mesh_ok) {
+            DevBox& lb = local[mit->second];
+            for (int a = 0; a < 3; a++) { lb.lo[a] = kv.second.local_aabb.min[a]; lb.hi[a] = kv.second.local_aabb.max[a]; }
+        }
+        const size_t cnt = kv.second.matrices.size();
+        if (cnt) std::memcpy(mats + gid, kv.second.matrices.data(), cnt * sizeof(rfw_mat4));
+        for (size_t s = 0; s < cnt; s++, gid++) {
+            mesh_of[gid] = mesh_ok ? mit->second : 0xffffffffu;
+            const int32_t sk = s < kv.second.skin_ids.size() ? kv.second.skin_ids[s] : -1;
+            if (mesh_ok && sk >= 0 && !I->derived.empty()) { // skinned slot: its own record (geometry, BVH, bounds)
+                const auto dit = I->derived.find(std::make_pair(kv.first, sk));
+                if (dit != I->derived.end()) mesh_of[gid] = dit->second.record;
+            }
+            if (mesh_ok && !is_zero_matrix(kv.second.matrices[s])) valid[n_valid++] = gid; // zero matrix = removed slot (instances_3d.rs:79-86)
+        }
+    }
+    T->n_instances = n_all;
+    T->n_valid_instances = n_valid;
+    HIP_TRY(I, T->d_matrices.ensure(n_all));
+    HIP_TRY(I, T->d_mesh_of_instance.ensure(n_all));
+    HIP_TRY(I, T->d_valid_gids.ensure(n_all));
+    HIP_TRY(I, T->d_mesh_local.ensure(std::max<size_t>(n_mesh, 1)));
+    HIP_TRY(I, T->d_xforms.ensure(n_all));
+    HIP_TRY(I, T->d_normals.ensure(n_all));
+    HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
+    HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, T->stream));
+    HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
+    HIP_TRY(I, T->d_node_count.ensure(1));
+    hipStream_t s = T->stream;
+    if (n_all) {
+        HIP_TRY(I, hipMemcpyAsync(T->d_matrices.ptr, mats, n_all * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(T->d_mesh_of_instance.ptr, mesh_of, n_all * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(I, hipMemcpyAsync(T->d_valid_gids.ptr, valid, n_all * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(I, hipMemcpyAsync(T->d_mesh_local.ptr, local, std::max<size_t>(n_mesh, 1) * sizeof(DevBox), hipMemcpyHostToDevice, s));
+    if (!I->derived.empty()) {
+        // skinned copies (structs.rs:820-877) and their BLAS, every synchronize, all on-stream: skin -> refit of the tree built over the
+        // first pose (gpu-rt: refit_bvh, lib.rs:1350-1352) -> packets -> bounds; with builder = DEVICE_LBVH: skin -> boxes -> LBVH rebuild
+        HIP_TRY(I, I->d_joints.ensure(n_joints));
+        HIP_TRY(I, hipMemcpyAsync(I->d_joints.ptr, joints, n_joints * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
+        if ((rc = ensure_lbvh_ws(T, std::max<uint32_t>(I->max_derived_tris, n_valid)))) return rc;
+        const bool refit = I->builder != RFW_HIP_BUILDER_DEVICE_LBVH; // DEVICE_LBVH keeps the rebuild-every-frame path
+        if (refit) {
+            const size_t raw_nodes = I->d_blas_raw.cap;
+            HIP_TRY(I, I->d_refit_parent.ensure(raw_nodes));
+            HIP_TRY(I, I->d_refit_nint.ensure(raw_nodes));
+            HIP_TRY(I, I->d_refit_arrive.ensure(raw_nodes));
+        }
+        for (auto& kv : I->derived) {
+            DerivedMesh& d = kv.second;
+            const MeshRecord& r = I->mesh_records[d.record];
+            const MeshRecord& src = I->mesh_records[d.src_record];
+            rfw_rt_triangle* tris = I->d_triangles.ptr + r.tri_base;
+            const size_t raw_off = r.node_base - I->raw_node_origin;
+            Node4* raw = I->d_blas_raw.ptr + raw_off;
+            uint32_t* order = I->d_blas_order.ptr + r.tri_base;
+            launch_skin_triangles(s, I->d_triangles.ptr + src.tri_base, I->d_skin_data.ptr + d.skin_offset, I->d_joints.ptr + joint_off[kv.first.second],
+                                  (uint32_t)I->skins[kv.first.second].size(), r.tri_count, tris);
+            uint32_t quantise_count = r.node_count;
+            if (!refit) {
+                launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
+                HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, raw, order, nullptr));
+            } else if (!d.topology_built) {
+                // first pose of this (mesh, skin) pair: the tree, by binned SAH (blocking, once), and what a refit needs to climb it
+                launch_triangle_boxes(s, tris, r.tri_count, I->d_tri_boxes.ptr);
+                HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
+                HIP_TRY(I, T->d_node_count.ensure(1));
+                const hipError_t se = sah_build(s, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, raw, order, T->d_node_count.ptr, I->sah_max_leaf,
+                                                I->sah_trav_cost);
+                if (se == hipErrorInvalidValue) { // deeper than the SAH builder's level budget: LBVH always terminates (as for static meshes)
+                    HIP_TRY(I, lbvh_build(s, I->d_tri_boxes.ptr, r.tri_count, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, raw, order, T->d_node_count.ptr));
+                } else {
+                    HIP_TRY(I, se);
+                }
+                HIP_TRY(I, hipMemcpyAsync(&d.node_count, T->d_node_count.ptr, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(I, hipStreamSynchronize(s));
+                if (d.node_count == 0 || d.node_count > r.node_count) return fail(I, RFW_HIP_E_STATE, "skinned BLAS: node count out of range");
+                launch_refit_setup(s, raw, d.node_count, I->d_refit_parent.ptr + raw_off, I->d_refit_nint.ptr + raw_off);
+                d.topology_built = true;
+                quantise_count = d.node_count;
+            } else {
+                launch_refit(s, raw, d.node_count, tris, order, I->d_refit_parent.ptr + raw_off, I->d_refit_nint.ptr + raw_off, I->d_refit_arrive.ptr + raw_off);
+                quantise_count = d.node_count;
+            }
+            launch_make_packets(s, tris, order, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+            launch_quantize_nodes(s, raw, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count);
+            launch_mesh_bounds(s, tris, r.tri_count, I->d_bounds_scratch.ptr, T->d_mesh_local.ptr + d.record);
+        }
+        HIP_TRY(I, hipGetLastError());
+        if (!I->tlas_on_device) { // the host TLAS needs the deformed bounds
+            HIP_TRY(I, hipStreamSynchronize(s));
+            for (const auto& kv : I->derived)
+                HIP_TRY(I, hipMemcpy(local + kv.second.record, T->d_mesh_local.ptr + kv.second.record, sizeof(DevBox), hipMemcpyDeviceToHost));
+        }
+    }
+    launch_prepare_instances(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, I->d_mesh_records.ptr, (uint32_t)n_all, T->d_xforms.ptr, T->d_normals.ptr);
+    if (I->tlas_on_device) {
+        HIP_TRY(I, T->d_inst_boxes.ensure(std::max<size_t>(n_valid, 1)));
+        HIP_TRY(I, T->d_tlas_order.ensure(std::max<size_t>(n_valid, 1)));
+        if ((rc = ensure_lbvh_ws(T, n_valid))) return rc;
+        launch_instance_boxes(s, T->d_matrices.ptr, T->d_mesh_of_instance.ptr, T->d_mesh_local.ptr, T->d_valid_gids.ptr, n_valid, T->d_inst_boxes.ptr);
+        HIP_TRY(I, lbvh_build(s, T->d_inst_boxes.ptr, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_tlas_raw.ptr, T->d_tlas_order.ptr,
+                              T->d_node_count.ptr));
+        launch_quantize_nodes(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, std::max<uint32_t>(n_valid, 1u), T->d_node_count.ptr);
+        launch_gather_u32(s, T->d_valid_gids.ptr, T->d_tlas_order.ptr, n_valid, T->d_tlas_prims.ptr);
+        HIP_TRY(I, hipGetLastError());
+        T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
+        HIP_TRY(I, hipEventRecord(T->stage_event[T->stage_next], s));
+        T->stage_pending[T->stage_next] = true;
+        T->stage_next = (T->stage_next + 1) % Instance::kStages;
+    } else {
+        // host TLAS (builder = HOST_SAH): boxes on the host, binned SAH, upload
+        std::vector<PrimBox> boxes(n_valid);
+        for (uint32_t k = 0; k < n_valid; k++) {
+            const rfw_mat4& m = mats[valid[k]];
+            const DevBox& lb = local[mesh_of[valid[k]]];
+            PrimBox b;
+            for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            for (int c = 0; c < 8; c++) {
+                const float x = (c & 1) ? lb.hi[0] : lb.lo[0], y = (c & 2) ? lb.hi[1] : lb.lo[1], z = (c & 4) ? lb.hi[2] : lb.lo[2];
+                const float w[3] = {m.m[0] * x + m.m[4] * y + m.m[8] * z + m.m[12], m.m[1] * x + m.m[5] * y + m.m[9] * z + m.m[13],
+                                    m.m[2] * x + m.m[6] * y + m.m[10] * z + m.m[14]};
+                for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], w[a]); b.hi[a] = std::max(b.hi[a], w[a]); }
+            }
+            for (int a = 0; a < 3; a++) {
+                const float ext = b.hi[a] - b.lo[a];
+                const float e = 2e-4f + 1e-5f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + 1e-5f * ext;
+                b.lo[a] -= e;
+                b.hi[a] += e;
+            }
+            boxes[k] = b;
+        }
+        HostBvh4 tlas;
+        build_bvh4_host(boxes, 1, I->build_threads, tlas);
+        std::vector<uint32_t> prims(tlas.prim_order.size());
+        for (size_t k = 0; k < prims.size(); k++) prims[k] = valid[tlas.prim_order[k]];
+        T->n_tlas_nodes = tlas.nodes.size();
+        std::vector<Node4Q> qn(tlas.nodes.size());
+        for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
+        if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
+        HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, s));
+        launch_expand_nodes(s, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, (uint32_t)qn.size());
+        if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
+        HIP_TRY(I, hipGetLastError());
+        HIP_TRY(I, hipStreamSynchronize(s));
+    }
+    return RFW_HIP_OK;
+}
+
+// one table of the new version: the old version copied on the device, then the changed elements (runs of consecutive indices) from
+// the host copy through the pinned ring; everything from the host when the table was handed over whole or its length changed
+template <typename T> int write_table(Instance* I, DevBuf<T>& dst, size_t& dst_n, const DevBuf<T>& old, size_t old_n, const std::vector<T>& host, const Instance::Dirty& d)
+{
+    const size_t n = host.size();
+    HIP_TRY(I, dst.ensure(std::max<size_t>(n, 1)));
+    dst_n = n;
+    hipStream_t s = I->upload_stream;
+    const bool partial = d.any && !d.all && old.ptr && old_n == n;
+    if ((!d.any || partial) && old.ptr && old_n == n && n) HIP_TRY(I, hipMemcpyAsync(dst.ptr, old.ptr, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (!d.any && old_n == n) return RFW_HIP_OK; // unchanged table: the copy is all
+    if (!partial) {
+        if (n) HIP_TRY(I, I->pins.upload(dst.ptr, host.data(), n * sizeof(T), s));
+        return RFW_HIP_OK;
+    }
+    std::vector<uint32_t> idx = d.idx;
+    std::sort(idx.begin(), idx.end());
+    {   // many scattered elements (every other material of thousands, say): one copy of the whole table beats a pinned block and a copy per run
+        size_t runs = 0;
+        for (size_t a = 0; a < idx.size(); a++) runs += (a == 0 || idx[a] > idx[a - 1] + 1) ? 1 : 0;
+        if (runs > 16 || idx.size() * 4 > n) {
+            HIP_TRY(I, I->pins.upload(dst.ptr, host.data(), n * sizeof(T), s));
+            return RFW_HIP_OK;
+        }
+    }
+    for (size_t a = 0; a < idx.size();) {
+        size_t b = a + 1;
+        while (b < idx.size() && idx[b] <= idx[b - 1] + 1) b++;
+        const size_t lo = idx[a], hi = std::min<size_t>((size_t)idx[b - 1] + 1, n);
+        if (lo < hi) HIP_TRY(I, I->pins.upload(dst.ptr + lo, host.data() + lo, (hi - lo) * sizeof(T), s));
+        a = b;
+    }
+    return RFW_HIP_OK;
+}
+
+int upload_tables(Instance* I)
+{
+    if (!I->upload_stream) HIP_TRY(I, hipStreamCreateWithFlags(&I->upload_stream, hipStreamNonBlocking));
+    if (!I->tables_ready) HIP_TRY(I, hipEventCreateWithFlags(&I->tables_ready, hipEventDisableTiming));
+    const uint64_t nv = I->tables_version + 1;
+    Instance::Tables& dst = I->tables[nv % Instance::kTableVersions];
+    const Instance::Tables& old = I->tables[I->tables_version % Instance::kTableVersions];
+    // the buffer being recycled last held version nv - kTableVersions: a frame still reading it (possible only when more than
+    // kTableVersions - 1 edits were synchronized since that frame was issued) has to finish first — a dependency of the UPLOAD on that
+    // frame, on the device; the host does not wait
+    if (nv >= (uint64_t)Instance::kTableVersions) {
+        const uint64_t stale = nv - Instance::kTableVersions;
+        // frame_done is recorded behind a slot's LATEST frame and a stream runs in order: waiting for it covers every earlier frame of the slot
+        auto order_behind = [&](Instance* c) -> int {
+            if (c->tables_oldest_pending > stale) return RFW_HIP_OK; // no frame of this slot that may still run reads the buffer
+            if (c->frame_done && !I->slots.empty()) HIP_TRY(I, hipStreamWaitEvent(I->upload_stream, c->frame_done, 0));
+            else HIP_TRY(I, hipStreamSynchronize(c->stream)); // no frame_done event without slots
+            c->tables_oldest_pending = ~0ull;
+            return RFW_HIP_OK;
+        };
+        int orc;
+        if ((orc = order_behind(I))) return orc;
+        for (Instance* c : I->slots)
+            if ((orc = order_behind(c))) return orc;
+    }
+    int rc;
+    if ((rc = write_table(I, dst.materials, dst.n_mat, old.materials, old.n_mat, I->materials, I->mat_dirty))) return rc;
+    if ((rc = write_table(I, dst.area, dst.n_area, old.area, old.n_area, I->area_lights, I->area_dirty))) return rc;
+    if ((rc = write_table(I, dst.point, dst.n_point, old.point, old.n_point, I->point_lights, I->point_dirty))) return rc;
+    if ((rc = write_table(I, dst.spot, dst.n_spot, old.spot, old.n_spot, I->spot_lights, I->spot_dirty))) return rc;
+    if ((rc = write_table(I, dst.dir, dst.n_dir, old.dir, old.n_dir, I->directional_lights, I->dir_dirty))) return rc;
+    HIP_TRY(I, hipEventRecord(I->tables_ready, I->upload_stream));
+    I->tables_version = nv;
+    I->mat_dirty.clear(); I->area_dirty.clear(); I->point_dirty.clear(); I->spot_dirty.clear(); I->dir_dirty.clear();
+    return RFW_HIP_OK;
+}
+
+int do_synchronize(Instance* I)
+{
+    HIP_TRY(I, hipSetDevice(I->device));
+    bool any_change = false;
+    int rc;
+    // A new (mesh, skin) pair needs its region of the mega-buffers, i.e. a BLAS rebuild: decided FIRST, so that everything below —
+    // which frames to wait for, whether scene_ready is recorded — sees the final dirty flags
+    if (!I->meshes_dirty && I->instances_dirty) {
+        const auto want = wanted_derived(I);
+        bool same = want.size() == I->derived.size();
+        if (same)
+            for (auto a = want.cbegin(), b = I->derived.cbegin(); a != want.cend(); ++a, ++b)
+                if (a->first != b->first) { same = false; break; }
+        if (!same) I->meshes_dirty = true;
+    }
+    // does this call queue work on the owner's stream that the frame slots have to wait for (anything but a per-slot TLAS update)?
+    // (per_slot_tlas() may flip inside build_blas_* when skinned copies appear or disappear; meshes_dirty covers both directions)
+    // (material and light edits do not count: they go into a new version of their tables, see upload_tables)
+    const bool shared_work = I->meshes_dirty || I->textures_dirty || (I->instances_dirty && !per_slot_tlas(I));
+    if (!I->slots.empty() && shared_work) {
+        // frames still in flight on the slots read the scene that is about to change: the uploads queue behind them
+        for (Instance* c : I->slots)
+            if (c->frame_done) HIP_TRY(I, hipStreamWaitEvent(I->stream, c->frame_done, 0));
+    }
+    if (I->meshes_dirty || I->instances_dirty) clear_overflow(I); // new trees: an earlier stack overflow no longer describes the scene
+    if (I->meshes_dirty) { // BLAS per changed mesh (gpu-rt/src/lib.rs:1345-1383)
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = I->blas_on_device ? build_blas_device(I) : build_blas_host(I))) return rc;
+        I->ms_blas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        I->meshes_dirty = false;
+        I->instances_dirty = true;
+        any_change = true;
+    }
+    if (I->instances_dirty) {
+        const auto t0 = std::chrono::steady_clock::now();
+        I->instances_version++;
+        if (!per_slot_tlas(I)) { // else: every frame slot rebuilds its own TLAS from the new lists when it renders next
+            if ((rc = build_instances(I, I))) return rc;
+            I->tlas_version = I->instances_version;
+        }
+        // host-side work (the device part is asynchronous), without the time spent waiting for the GPU to release a staging block
+        I->ms_tlas_build = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() - I->ms_stage_wait;
+        I->instances_dirty = false;
+        any_change = true;
+    }
+    if (I->materials_dirty || I->lights_dirty) {
+        if ((rc = upload_tables(I))) return rc;
+        I->materials_dirty = false;
+        I->lights_dirty = false;
+        any_change = true;
+    }
+    if (I->textures_dirty && !I->tex_layout_dirty && I->tex_offsets.size() == I->textures.size()) {
+        // only some textures changed and each keeps its place: their texels go over the old ones (the frame slots were drained above)
+        std::sort(I->tex_dirty_idx.begin(), I->tex_dirty_idx.end());
+        I->tex_dirty_idx.erase(std::unique(I->tex_dirty_idx.begin(), I->tex_dirty_idx.end()), I->tex_dirty_idx.end());
+        for (const uint32_t k : I->tex_dirty_idx) {
+            const TexHost& t = I->textures[k];
+            if (!t.texels.empty()) HIP_TRY(I, hipMemcpyAsync(I->d_tex_data.ptr + I->tex_offsets[k], t.texels.data(), t.texels.size() * 4, hipMemcpyHostToDevice, I->stream));
+        }
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->tex_dirty_idx.clear();
+        I->textures_dirty = false;
+        any_change = true;
+    }
+    if (I->textures_dirty) { // texels of every texture, then the skybox, in one array + descriptor table
+        std::vector<uint32_t> data;
+        std::vector<TexDesc> desc(I->textures.size());
+        auto put = [&](const TexHost& t) {
+            TexDesc d;
+            std::memset(&d, 0, sizeof(d));
+            d.offset = (uint32_t)data.size();
+            d.w = t.w; d.h = t.h; d.mips = t.mips; d.format = t.format;
+            data.insert(data.end(), t.texels.begin(), t.texels.end());
+            return d;
+        };
+        I->tex_offsets.resize(I->textures.size());
+        for (size_t k = 0; k < I->textures.size(); k++) { desc[k] = put(I->textures[k]); I->tex_offsets[k] = desc[k].offset; }
+        I->skybox_desc = put(I->skybox);
+        I->tex_layout_dirty = false;
+        I->tex_dirty_idx.clear();
+        I->n_textures = (uint32_t)desc.size();
+        if ((rc = upload(I, I->d_tex_data, data.data(), data.size()))) return rc;
+        if ((rc = upload(I, I->d_tex_desc, desc.data(), desc.size()))) return rc;
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        I->textures_dirty = false;
+        any_change = true;
+    }
+    if (any_change) {
+        I->sample_count = 0; // the accumulated image no longer matches the scene
+        I->scene_version++;
+        // recorded only when something was queued here: the owner's stream also carries slot 0's frames, and an event behind them
+        // would make every slot wait for slot 0
+        if (I->scene_ready && shared_work) HIP_TRY(I, hipEventRecord(I->scene_ready, I->stream));
+    }
+    I->synchronized = true;
+    return RFW_HIP_OK;
+}
+
+// frame slots with their own TLAS: (re)build the TLAS and instance descriptors of slot T from the owner's current instance lists
+int ensure_slot_tlas(Instance* S, Instance* T)
+{
+    if (!per_slot_tlas(S) || !S->synchronized || T->tlas_version == S->instances_version) return RFW_HIP_OK;
+    if (T != S && S->scene_ready) HIP_TRY(S, hipStreamWaitEvent(T->stream, S->scene_ready, 0)); // the mesh records it reads may still be uploading
+    const int rc = build_instances(S, T);
+    if (rc == RFW_HIP_OK) T->tlas_version = S->instances_version;
+    return rc;
+}
+
+} // namespace rfwapi
+
+extern "C" {
+
+int rfw_hip_set_2d_mesh(void* inst, uint32_t, const void*, uint32_t, int32_t) { LOCK(inst); return RFW_HIP_OK; }
+int rfw_hip_set_2d_instances(void* inst, uint32_t, const rfw_mat4*, uint32_t) { LOCK(inst); return RFW_HIP_OK; }
+
+static void copy_triangles(std::vector<rfw_rt_triangle>& dst, const rfw_rt_triangle* src, size_t n, int threads)
+{
+    if (dst.size() != n) { dst.clear(); dst.shrink_to_fit(); dst.resize(n); } // (value-initialised once; a mesh re-sent at the same size is only copied)
+    const size_t bytes = n * sizeof(rfw_rt_triangle);
+    const int nt = (int)std::min<size_t>((size_t)std::max(threads, 1), bytes >> 22); // at least 4 MB per thread
+    if (nt <= 1) { if (n) std::memcpy(dst.data(), src, bytes); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + nt - 1) / nt;
+    for (int k = 0; k < nt; k++) {
+        const size_t a = std::min(n, per * k), b = std::min(n, a + per);
+        if (a < b) pool.emplace_back([&dst, src, a, b] { std::memcpy(dst.data() + a, src + a, (b - a) * sizeof(rfw_rt_triangle)); });
+    }
+    for (auto& t : pool) t.join();
+}
+
+int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
+{
+    LOCK(inst);
+    if (!d || (d->num_triangles && !d->triangles)) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: null data");
+    if (d->num_triangles > kLeafFirstMask) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: more than 2^27 triangles in one mesh");
+    MeshHost& m = I->meshes[id];
+    // copy: the borrow ends with this call.  A large mesh is copied by several threads (one thread moves ~10 GB/s: 185 MB of C4 took 18 of
+    // the 45 ms a re-sent scene cost before anything reached the device)
+    copy_triangles(m.tris, d->triangles, d->num_triangles, I->build_threads);
+    m.skin.clear();
+    if (d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING))
+        m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
+    m.dirty = true;
+    I->meshes_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_unload_3d_meshes(void* inst, const uint32_t* ids, uint32_t n)
+{
+    LOCK(inst);
+    if (n && !ids) return fail(I, RFW_HIP_E_INVALID, "unload_3d_meshes: null ids");
+    for (uint32_t i = 0; i < n; i++) {
+        I->meshes.erase(ids[i]);
+        I->inst_lists.erase(ids[i]);
+    }
+    I->meshes_dirty = true;
+    I->instances_dirty = true;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_3d_instances(void* inst, uint32_t mesh, const rfw_instances_data_3d* d)
+{
+    LOCK(inst);
+    if (!d || (d->num_matrices && !d->matrices)) return fail(I, RFW_HIP_E_INVALID, "set_3d_instances: null data");
+    InstList& l = I->inst_lists[mesh];
+    l.local_aabb = d->local_aabb;
+    l.matrices.assign(d->matrices, d->matrices + d->num_matrices);
+    l.skin_ids.assign(d->num_matrices, -1);
+    if (d->skin_ids)
+        for (uint32_t i = 0; i < d->num_matrices && i < d->num_skin_ids; i++) l.skin_ids[i] = d->skin_ids[i];
+    I->instances_dirty = true;
+    return RFW_HIP_OK;
+}
+
+// The trait's `changed` bit slice (packed u32 words, bit i = element i; NULL = everything) folded into what the next synchronize() uploads
+static void mark_dirty(Instance::Dirty& d, size_t old_n, uint32_t n, const uint32_t* changed)
+{
+    if (!changed || old_n != n) { // handed over whole, or the list changed its length
+        d.any = true; d.all = true; d.idx.clear();
+        return;
+    }
+    const bool was_all = d.any && d.all;
+    bool some = false;
+    for (uint32_t i = 0; i < n; i++)
+        if (changed[i >> 5] & (1u << (i & 31u))) {
+            some = true;
+            if (!was_all) d.idx.push_back(i);
+        }
+    if (some && !was_all) { d.any = true; d.all = false; }
+}
+
+int rfw_hip_set_materials(void* inst, const rfw_device_material* m, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !m) return fail(I, RFW_HIP_E_INVALID, "set_materials: null data");
+    mark_dirty(I->mat_dirty, I->materials.size(), n, changed);
+    I->materials.assign(m, m + n);
+    I->materials_dirty = I->materials_dirty || I->mat_dirty.any;
+    return RFW_HIP_OK;
+}
+
+// gpu-rt keeps every material texture as one layer of a 1024 x 1024 array with 5 mip levels: a texture of another size is resampled to
+// 1024^2 and its mip chain regenerated on the host (backends/gpu-rt/src/lib.rs:1230-1246: `t.resized(1024, 1024)` +
+// `generate_mipmaps(Texture::MIP_LEVELS)`, both from the un-vendored crate l3d 0.3, crates/rfw-scene/Cargo.toml), so shade.comp's LOD
+// arithmetic (MIPLEVELCOUNT 5, shade.comp:39,273-281) always sees that geometry.  Restated here with the one meaning this project pins
+// for l3d's two helpers: point resampling (source texel of the destination texel's centre) and a 2 x 2 box filter per channel, rounded to
+// nearest — the filter rfw-rs_amd/host already uses for the mips it hands over.  Option "texture_array" = 0 samples at native size.
+constexpr uint32_t kTexArraySize = 1024, kTexArrayMips = 5;
+static void normalise_texture(TexHost& t)
+{
+    if (t.w == 0 || t.h == 0 || (t.w == kTexArraySize && t.h == kTexArraySize)) return; // already an array layer: kept as handed over
+    std::vector<uint32_t> out;
+    out.reserve((size_t)kTexArraySize * kTexArraySize * 4 / 3 + 16);
+    out.resize((size_t)kTexArraySize * kTexArraySize);
+    for (uint32_t y = 0; y < kTexArraySize; y++) {
+        const uint32_t sy = (uint32_t)(((uint64_t)(2 * y + 1) * t.h) / (2 * kTexArraySize)); // floor((y + 0.5) * h / 1024)
+        for (uint32_t x = 0; x < kTexArraySize; x++) {
+            const uint32_t sx = (uint32_t)(((uint64_t)(2 * x + 1) * t.w) / (2 * kTexArraySize));
+            out[(size_t)y * kTexArraySize + x] = t.texels[(size_t)sy * t.w + sx];
+        }
+    }
+    size_t src = 0;
+    uint32_t w = kTexArraySize, h = kTexArraySize;
+    for (uint32_t l = 1; l < kTexArrayMips; l++) {
+        const uint32_t nw = w >> 1, nh = h >> 1;
+        const size_t dst = out.size();
+        out.resize(dst + (size_t)nw * nh);
+        for (uint32_t y = 0; y < nh; y++)
+            for (uint32_t x = 0; x < nw; x++) {
+                const uint32_t a = out[src + (size_t)(2 * y) * w + 2 * x], b = out[src + (size_t)(2 * y) * w + 2 * x + 1],
+                               c = out[src + (size_t)(2 * y + 1) * w + 2 * x], d = out[src + (size_t)(2 * y + 1) * w + 2 * x + 1];
+                uint32_t r = 0;
+                for (int ch = 0; ch < 4; ch++) {
+                    const uint32_t sum = ((a >> (8 * ch)) & 255u) + ((b >> (8 * ch)) & 255u) + ((c >> (8 * ch)) & 255u) + ((d >> (8 * ch)) & 255u);
+                    r |= ((sum + 2u) / 4u) << (8 * ch);
+                }
+                out[dst + (size_t)y * nw + x] = r;
+            }
+        src = dst;
+        w = nw; h = nh;
+    }
+    t.texels.swap(out);
+    t.w = kTexArraySize; t.h = kTexArraySize; t.mips = kTexArrayMips;
+}
+
+static bool copy_texture(TexHost& t, const rfw_texture_data* d)
+{
+    t = TexHost();
+    if (!d || !d->bytes || d->width == 0 || d->height == 0) return true; // an empty texture samples as zero
+    if (d->format != RFW_FORMAT_BGRA8 && d->format != RFW_FORMAT_RGBA8) return false;
+    t.w = d->width; t.h = d->height; t.format = d->format;
+    uint32_t w = d->width, h = d->height, levels = 0;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < (d->mip_levels ? d->mip_levels : 1u) && w > 0 && h > 0; l++) { // structs.rs:79-121: level l is (w >> l) x (h >> l)
+        texels += (size_t)w * h;
+        w >>= 1; h >>= 1;
+        levels++;
+    }
+    t.mips = levels;
+    t.texels.resize(texels);
+    std::memcpy(t.texels.data(), d->bytes, texels * 4); // copy: the borrow ends with this call
+    return true;
+}
+
+// `changed` (the trait's BitSlice, bit k = texture k): textures whose bit is clear are not looked at — not copied, not resampled into the
+// 1024 x 1024 x 5 array — and synchronize() uploads only the changed ones in place when the array's layout stays the same (same count,
+// same stored size per texture; with texture_array on, every texture has the same stored size).
+int rfw_hip_set_textures(void* inst, const rfw_texture_data* textures, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !textures) return fail(I, RFW_HIP_E_INVALID, "set_textures: null data");
+    const bool partial = changed && I->textures.size() == n && I->tex_offsets.size() == n; // a laid-out array of the same length exists
+    I->textures.resize(n);
+    for (uint32_t k = 0; k < n; k++) {
+        if (partial && !((changed[k / 32] >> (k % 32)) & 1u)) continue;
+        TexHost t;
+        if (!copy_texture(t, textures + k)) return fail(I, RFW_HIP_E_INVALID, "set_textures: unknown texel format");
+        if (I->texture_array) normalise_texture(t);
+        const TexHost& old = I->textures[k];
+        if (partial && !I->tex_layout_dirty && t.texels.size() == old.texels.size() && t.w == old.w && t.h == old.h && t.mips == old.mips && t.format == old.format)
+            I->tex_dirty_idx.push_back(k);
+        else
+            I->tex_layout_dirty = true;
+        I->textures[k] = std::move(t);
+    }
+    if (!partial) I->tex_layout_dirty = true;
+    I->textures_dirty = true;
+    return RFW_HIP_OK;
+}
+
+
+int rfw_hip_synchronize(void* inst)
+{
+    LOCK(inst);
+    return do_synchronize(I);
+}
+
+
+int rfw_hip_set_blue_noise(void* inst, const uint32_t* table, uint32_t n_words)
+{
+    LOCK(inst);
+    HIP_TRY(I, hipSetDevice(I->device));
+    if (n_words != 0 && (!table || n_words != kBlueNoiseWords))
+        return fail(I, RFW_HIP_E_INVALID, "set_blue_noise: expected the 5 * 65536 words of gpu_rt::blue_noise::create_blue_noise_buffer() (or 0 words to clear)");
+    std::vector<uint8_t> bytes(n_words);
+    for (uint32_t k = 0; k < n_words; k++) {
+        if (table[k] > 255u) return fail(I, RFW_HIP_E_INVALID, "set_blue_noise: table entries are bytes (0..255)");
+        bytes[k] = (uint8_t)table[k];
+    }
+    // frames in flight may still sample the old tables
+    HIP_TRY(I, hipStreamSynchronize(I->stream));
+    for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream));
+    if (n_words) {
+        HIP_TRY(I, I->d_blue_noise.ensure(n_words));
+        HIP_TRY(I, hipMemcpy(I->d_blue_noise.ptr, bytes.data(), n_words, hipMemcpyHostToDevice));
+    }
+    I->has_blue_noise = n_words != 0;
+    I->sample_count = 0; // the image accumulated so far was drawn from other numbers
+    I->restart = true;
+    return RFW_HIP_OK;
+}
+
+
+int rfw_hip_set_point_lights(void* inst, const rfw_point_light* l, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_point_lights: null data");
+    mark_dirty(I->point_dirty, I->point_lights.size(), n, changed);
+    I->point_lights.assign(l, l + n);
+    I->lights_dirty = I->lights_dirty || I->point_dirty.any;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_spot_lights(void* inst, const rfw_spot_light* l, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_spot_lights: null data");
+    mark_dirty(I->spot_dirty, I->spot_lights.size(), n, changed);
+    I->spot_lights.assign(l, l + n);
+    I->lights_dirty = I->lights_dirty || I->spot_dirty.any;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_area_lights(void* inst, const rfw_area_light* l, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_area_lights: null data");
+    mark_dirty(I->area_dirty, I->area_lights.size(), n, changed);
+    I->area_lights.assign(l, l + n);
+    I->lights_dirty = I->lights_dirty || I->area_dirty.any;
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_directional_lights(void* inst, const rfw_directional_light* l, uint32_t n, const uint32_t* changed)
+{
+    LOCK(inst);
+    if (n && !l) return fail(I, RFW_HIP_E_INVALID, "set_directional_lights: null data");
+    mark_dirty(I->dir_dirty, I->directional_lights.size(), n, changed);
+    I->directional_lights.assign(l, l + n);
+    I->lights_dirty = I->lights_dirty || I->dir_dirty.any;
+    return RFW_HIP_OK;
+}
+
+int rfw_hip_set_skybox(void* inst, const rfw_texture_data* skybox)
+{
+    LOCK(inst);
+    if (!copy_texture(I->skybox, skybox)) return fail(I, RFW_HIP_E_INVALID, "set_skybox: unknown texel format");
+    I->textures_dirty = true;
+    I->tex_layout_dirty = true; // the skybox lives behind the textures in the same array
+    return RFW_HIP_OK;
+}
+int rfw_hip_set_skins(void* inst, const rfw_skin_data* skins, uint32_t n, const uint32_t* /*changed*/)
+{
+    LOCK(inst);
+    if (n && !skins) return fail(I, RFW_HIP_E_INVALID, "set_skins: null data");
+    I->skins.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (skins[i].num_joint_matrices && !skins[i].joint_matrices) return fail(I, RFW_HIP_E_INVALID, "set_skins: null joint matrices");
+        I->skins[i].assign(skins[i].joint_matrices, skins[i].joint_matrices + skins[i].num_joint_matrices);
+    }
+    I->instances_dirty = true; // the skinned copies and their BLAS are rebuilt with the instances (gpu-rt/src/lib.rs:1318-1336)
+    return RFW_HIP_OK;
+}
+
+
+int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
+{
+    LOCK(inst);
+    if (!out) return fail(I, RFW_HIP_E_INVALID, "get_scene_stats: null out");
+    if (per_slot_tlas(I) && I->synchronized) {
+        (void)hipSetDevice(I->device);
+        const int trc = ensure_slot_tlas(I, I); // the owner's own TLAS may be stale: its slots rebuild theirs independently
+        if (trc != RFW_HIP_OK) return trc;
+    }
+    if (I->node_counts_stale && I->d_mesh_node_counts.ptr) { // after an incremental build: the builders' node counts, read when somebody asks
+        (void)hipSetDevice(I->device);
+        (void)hipStreamSynchronize(I->stream);
+        std::vector<uint32_t> counts(I->mesh_records.size(), 0u);
+        if (!counts.empty() && hipMemcpy(counts.data(), I->d_mesh_node_counts.ptr, counts.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t n = 0;
+            for (auto& kv : I->mesh_index) n += counts[kv.second];
+            I->n_blas_nodes = n;
+            I->node_counts_stale = false;
+        }
+    }
+    out->triangles = I->n_tris;
+    out->instances = I->n_valid_instances;
+    out->blas_nodes = I->n_blas_nodes;
+    if (I->tlas_on_device && I->d_node_count.ptr && I->synchronized) {
+        uint32_t nc = 0;
+        (void)hipSetDevice(I->device);
+        (void)hipStreamSynchronize(I->stream);
+        if (hipMemcpy(&nc, I->d_node_count.ptr, 4, hipMemcpyDeviceToHost) == hipSuccess) I->n_tlas_nodes = nc;
+    }
+    out->tlas_nodes = I->n_tlas_nodes;
+    out->node_bytes = sizeof(Node4Q);
+    out->tri_bytes = sizeof(TriPacket);
+    out->ms_blas_build = I->ms_blas_build;
+    out->ms_tlas_build = I->ms_tlas_build;
+    if (I->build_events_pending) {
+        (void)hipSetDevice(I->device);
+        if (hipEventSynchronize(I->ev_build[2]) == hipSuccess) {
+            (void)hipEventElapsedTime(&I->ms_blas_upload, I->ev_build[0], I->ev_build[1]);
+            (void)hipEventElapsedTime(&I->ms_blas_kernels, I->ev_build[1], I->ev_build[2]);
+        }
+        I->build_events_pending = false;
+    }
+    out->ms_blas_upload = I->ms_blas_upload;
+    out->ms_blas_kernels = I->ms_blas_kernels;
+    out->blas_upload_bytes = I->blas_upload_bytes;
+    out->blas_kernel_bytes = I->blas_kernel_bytes;
+    return RFW_HIP_OK;
+}
+
+} // extern "C"

@@ -32,6 +32,7 @@
 #ifndef RFW_STATIC_ORDER
 #define RFW_STATIC_ORDER 1
 #endif
+
 #ifndef RFW_RAY_IN_LDS
 #define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
 #endif
