@@ -242,6 +242,15 @@ int main(int argc, char** argv)
                 }
                 (void)anyl;
                 masked.node_steps++;
+                {   // accounting only: the node's LEAF children tested at once, every lane looping over the leaves IT hit (wave cost = the busiest lane)
+                    uint32_t worst = 0;
+                    for (int l = 0; l < 64; l++) {
+                        uint32_t mine = 0;
+                        for (int i = 0; i < 4; i++) if (((m[i] >> l) & 1) && n.child[i] != kInvalidRef && (n.child[i] & kLeafBit)) mine += ((n.child[i] >> 27) & 15u) + 1u;
+                        worst = std::max(worst, mine);
+                    }
+                    masked.handover_sp += worst; // (reported as "handover stack": triangle steps with sibling leaves tested concurrently)
+                }
                 int idx[4], k = 0;
                 for (int i = 0; i < 4; i++) if (m[i]) idx[k++] = i;
                 std::sort(idx, idx + k, [&](int a, int b2) { return key[a] < key[b2] || (key[a] == key[b2] && a < b2); });
@@ -251,6 +260,53 @@ int main(int argc, char** argv)
             for (auto& l : A) { masked.lane_nodes += l.nodes; masked.lane_tris += l.tris; }
         }
     }
+    // ---- masked packets with DEFERRED leaves: a leaf is not tested when it comes off the shared stack; the lanes that hit its box queue it, and
+    // when some lane holds Q leaves every lane tests its own queue (per-lane triangle loop: wave cost = the busiest lane).  t shrinks later.
+    auto deferred = [&](int Q, WaveCost& out) {
+        srand(12345);
+        for (int b = 0; b < nblocks; b++) {
+            const uint32_t bx = (uint32_t)rand() % (W / 8), by = (uint32_t)rand() % (H / 8);
+            std::vector<Lane> A(64);
+            for (int l = 0; l < 64; l++) A[l].r = make_ray(bx * 8 + (l & 7), by * 8 + (l >> 3));
+            std::vector<std::vector<uint32_t>> queue(64);
+            auto flush = [&]() {
+                uint32_t worst = 0; bool any = false;
+                for (int l = 0; l < 64; l++) {
+                    uint32_t mine = 0;
+                    for (uint32_t ref : queue[l]) { uint32_t tests = 0; leaf_test(ref, A[l].r, A[l].t, tests); mine += tests; A[l].tris += tests; any = true; }
+                    queue[l].clear();
+                    worst = std::max(worst, mine);
+                }
+                if (any) { out.leaf_steps++; out.tri_steps += worst; }
+            };
+            struct E { uint32_t ref; uint64_t mask; };
+            std::vector<E> st; E cur{0, ~0ull};
+            for (;;) {
+                if (cur.ref == kInvalidRef) { if (st.empty()) break; cur = st.back(); st.pop_back(); }
+                if (cur.ref & kLeafBit) {
+                    bool full = false;
+                    for (int l = 0; l < 64; l++) if ((cur.mask >> l) & 1) { queue[l].push_back(cur.ref); full |= (int)queue[l].size() >= Q; }
+                    if (full) flush();
+                    cur.ref = kInvalidRef; continue;
+                }
+                const Node4Q& n = g_nodes[cur.ref];
+                uint64_t m[4] = {0, 0, 0, 0}; float key[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+                for (int l = 0; l < 64; l++) if ((cur.mask >> l) & 1) {
+                    const SlabOut s = slab(n, A[l].r, A[l].t);
+                    A[l].nodes++;
+                    for (int i = 0; i < 4; i++) if (s.hit[i]) { m[i] |= 1ull << l; key[i] = std::min(key[i], s.tn[i]); }
+                }
+                out.node_steps++;
+                int idx[4], k = 0;
+                for (int i = 0; i < 4; i++) if (m[i]) idx[k++] = i;
+                std::sort(idx, idx + k, [&](int a, int b2) { return key[a] < key[b2] || (key[a] == key[b2] && a < b2); });
+                if (k == 0) cur.ref = kInvalidRef;
+                else { cur = E{n.child[idx[0]], m[idx[0]]}; for (int j = k - 1; j >= 1; j--) st.push_back(E{n.child[idx[j]], m[idx[j]]}); }
+            }
+            flush();
+            for (auto& l : A) { out.lane_nodes += l.nodes; out.lane_tris += l.tris; }
+        }
+    };
     auto rep = [&](const char* name, const WaveCost& c) {
         printf("%-8s per wave: node steps %.1f (uniform %.1f) + packet steps %.1f, leaf steps %.1f, triangle steps %.1f | per lane: nodes %.1f tris %.2f | handover stack %.1f\n", name,
                c.node_steps / nblocks, c.uniform / nblocks, c.packet_steps / nblocks, c.leaf_steps / nblocks, c.tri_steps / nblocks, c.lane_nodes / nblocks / 64, c.lane_tris / nblocks / 64,
@@ -273,5 +329,6 @@ int main(int argc, char** argv)
     }
     rep("strict", strict);
     rep("masked", masked);
+    for (int Q : {1, 2, 3, 4, 1000}) { WaveCost d; deferred(Q, d); char nm[32]; snprintf(nm, sizeof nm, "defer%d", Q); rep(nm, d); }
     return 0;
 }
