@@ -357,6 +357,45 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
     flush_counters<COUNT>(sc.counters, tc, 0);
 }
 
+// ... and the packet flavour for a batch of frames: a wavefront's 64 paths belong to ONE frame (a frame's range is a multiple of the workgroup
+// size), so they are one 8x8-pixel block of one view as in k_primary_packet
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_primary_batch_packet(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
+{
+    const uint32_t block = xcd_block(blockIdx.x);
+    const uint32_t idx = block * kTraceBlock + threadIdx.x;
+    const uint32_t f = (block * kTraceBlock) / cam.frame_capacity;
+    TravCounters tc{0, 0, 0};
+    uint32_t px = 0, py = 0;
+    const bool valid = f < cam.batch && slab_to_pixel(cam, idx - f * cam.frame_capacity, px, py);
+    f3 O = mk3(0.0f), D = mk3(0.0f);
+    if (valid) {
+        const uint32_t sample = cam.batch_sample[f];
+        if (!(f == 0u && cam.sample_count != 0u)) p.acc[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        CameraParams c = cam;
+        const FrameView& v = views.v[f];
+        for (int k = 0; k < 3; k++) { c.pos[k] = v.pos[k]; c.right[k] = v.right[k]; c.up[k] = v.up[k]; c.p1[k] = v.p1[k]; }
+        c.lens_size = v.lens_size;
+        const uint32_t path_id = px + py * cam.width;
+        uint32_t seed = wang_hash(path_id * 16789u + sample * 1791u + 0u * 720898027u);
+        generate_eye_ray(c, O, D, px, py, seed, sc.blue_noise, sample);
+        p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id | (f << 24)));
+        p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
+    }
+    float t = 1e26f, hu = 0.0f, hv = 0.0f;
+    int32_t hi = -1, ht = -1;
+    bool occluded;
+    const SceneView sv = scene_view(sc);
+    traverse_packet<false, COUNT>(sv, sc.tlas_wide, sc.tlas_wide_stride, sc.blas_wide, sc.blas_wide_stride, valid, O, D, 1e-4f, t, hu, hv, hi, ht, occluded, tc);
+    if (valid) {
+        const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
+        p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
+    } else if (f < cam.batch) {
+        p.hit[0][idx] = make_uint4(kNoPath, 0u, 0u, 0u);
+    }
+    flush_counters<COUNT>(sc.counters, tc, 0);
+}
+
 // ---------------------------------------------------------------- extension rays in spatial order (option "sort_extension_rays")
 // Extension rays leave a surface in BSDF-sampled directions: a wavefront of 64 consecutive queue entries (neighbouring pixels) shares
 // little of its traversal (node-test lane utilisation 0.2).  Key = 9-bit-per-axis Morton code of the ray's origin inside the scene's
@@ -1151,6 +1190,11 @@ void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, 
 void launch_primary_batch(hipStream_t s, const CameraParams& cam, const BatchViews& views, const SceneDev& sc, const PathDev& p, bool count)
 {
     const dim3 grid((ceil_div(p.capacity, kTraceBlock) + 511u) & ~511u), block(kTraceBlock);
+    if ((cam.flags & kFlagPacketPrimary) && sc.tlas_wide && sc.blas_wide) {
+        if (count) hipLaunchKernelGGL(k_primary_batch_packet<true>, grid, block, 0, s, cam, views, sc, p);
+        else hipLaunchKernelGGL(k_primary_batch_packet<false>, grid, block, 0, s, cam, views, sc, p);
+        return;
+    }
     if (count) hipLaunchKernelGGL(k_primary_batch<true>, grid, block, 0, s, cam, views, sc, p);
     else hipLaunchKernelGGL(k_primary_batch<false>, grid, block, 0, s, cam, views, sc, p);
 }

@@ -29,6 +29,9 @@
 // box through are in fixed words (no per-plane selects), and the children are stored front to back along the octant's diagonal, so the hit
 // ones go on the stack in the stored order — no keys, no sorting network (tools/probes/packet_model.cpp: 20.5 instead of 20.4 node visits
 // per camera ray with the static order).  0 = round 3's visit: plain nodes, children ordered by entry distance.
+#ifndef RFW_ANY_LEAF_GATE
+#define RFW_ANY_LEAF_GATE 1 // any hit: a lane that holds a leaf waits for the next even trip of the loop, which batches the triangle tests (round 1; re-measured with the static order: see EXPERIMENTS.md)
+#endif
 #ifndef RFW_STATIC_ORDER
 #define RFW_STATIC_ORDER 1
 #endif
@@ -40,7 +43,10 @@ namespace rfwhip {
 
 constexpr int kTraceBlock = 64;   // threads per workgroup of the trace kernels (one wavefront)
 constexpr int kStackLds = 16;     // stack entries per lane kept in LDS
-constexpr int kStackLdsAny = 12;  // the same for any hit when its ray is parked in LDS too (RFW_ANY_PARK): 18 rows = 4.5 KB per wavefront
+#ifndef RFW_STACK_LDS_ANY
+#define RFW_STACK_LDS_ANY 12
+#endif
+constexpr int kStackLdsAny = RFW_STACK_LDS_ANY;  // the same for any hit when its ray is parked in LDS too (RFW_ANY_PARK): 18 rows = 4.5 KB per wavefront
 constexpr int kStackSpill = 48;   // further entries per lane in HBM (rarely touched)
 
 struct SceneView {
@@ -168,7 +174,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 #define RFW_TRAV_OCCLUDED return true;
 #define RFW_TRAV_AFTER_LEAF
 #define RFW_TRAV_EXHAUSTED break;
-#define RFW_TRAV_LEAF_GATE if (ANY_HIT && (iteration & 1u) != 0u) continue;
+#define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration & 1u) != 0u) continue;
 #define RFW_TRAV_TLAS_GATE
 #include "traverse_body.inc"
 #undef RFW_TRAV_TOP
