@@ -5,7 +5,7 @@ A step = one frame: one 1920x1080 image of the ~1M-triangle synthetic atrium (th
 BASELINE.json north_star; SURVEY.md §8d C4 geometry, primary + shadow rays), every input resident in HBM.
 
 N = 1: `value` is what a client of the reference's plugin trait gets — ONE `Backend::render` call per frame and nothing else
-(rfw_hip_render; 8 frame slots inside the instance keep frames in flight because every frame has its own camera view, a slow dolly,
+(rfw_hip_render; 12 frame slots inside the instance keep frames in flight because every frame has its own camera view, a slow dolly,
 so each call starts a new image).  Two further modes are measured after the timed region and reported beside it (`config.modes`):
 strictly one frame at a time, and frames traced 8 per launch through the rfw_hip_render_batch extension.  The first and the last
 frame of the timed region are read back and compared, bit for bit, with the CPU oracle's frames of the same views at the same
@@ -167,7 +167,8 @@ def main():
         B = 1
     # (C3: a frame's chain is longer — instance upload, TLAS rebuild, then the trace — and 16 slots, the most an instance takes, hide it best:
     # measured 5000 / 4910 / 5080 / 5160 Mrays/s with 4 / 8 / 12 / 16 slots on one box)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 16 if (animated and world == 1) else 8 if world <= 2 else 12)
+    # (static scenes, round 4: 8 / 12 / 16 slots give 7050 / 7096 / 7118 Mrays/s over 400 frames and 6560 / 6680 / 6730 over the driver's 20: 12 it is)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 16 if (animated and world == 1) else 12 if world == 1 else 8 if world <= 2 else 12)
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.

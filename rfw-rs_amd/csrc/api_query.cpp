@@ -37,6 +37,48 @@ int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf,
             }
         }
     }
+    // the eight per-octant copies of every node (device_types.h: make_packet_node for the packet kernels, make_octant_node for the one-ray-per-
+    // lane kernels): the same children in the same permutation in both, every child's box still enclosed — its ENTRY planes at or below
+    // the box on the axes the octant travels upwards, at or above it where it travels downwards, the EXIT planes on the other side — and the
+    // children in front-to-back order along the octant's diagonal, empty slots last
+    for (const Node4& nd : bvh.nodes) {
+        const Node4Q q = quantize_node(nd);
+        const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+        const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+        for (uint32_t oct = 0; oct < 8; oct++) {
+            const PacketNode pn = make_packet_node(q, oct);
+            const Node4Q on = make_octant_node(q, oct);
+            const float* pnear[3] = {pn.nx, pn.ny, pn.nz};
+            const float* pfar[3] = {pn.fx, pn.fy, pn.fz};
+            const float o[3] = {on.ox, on.oy, on.oz}, sc[3] = {on.sx, on.sy, on.sz};
+            bool used[4] = {false, false, false, false};
+            float prev_key = -INFINITY;
+            bool seen_empty = false;
+            for (int k = 0; k < 4; k++) {
+                if (pn.child[k] != on.child[k]) errors++;
+                if (pn.child[k] == kInvalidRef) { seen_empty = true; continue; }
+                if (seen_empty) errors++; // an empty slot in front of a child
+                int src = -1;
+                for (int i = 0; i < 4; i++)
+                    if (!used[i] && nd.child[i] == pn.child[k]) { src = i; break; }
+                if (src < 0) { errors++; continue; }
+                used[src] = true;
+                float key = 0.0f;
+                for (int a = 0; a < 3; a++) {
+                    const bool neg = ((oct >> a) & 1u) != 0u;
+                    const float box_near = neg ? hi[a][src] : lo[a][src], box_far = neg ? lo[a][src] : hi[a][src];
+                    const float qn = o[a] + (float)((on.qlo[a] >> (8 * k)) & 0xffu) * sc[a], qf = o[a] + (float)((on.qhi[a] >> (8 * k)) & 0xffu) * sc[a];
+                    if (neg ? (pnear[a][k] < box_near || pfar[a][k] > box_far || qn < box_near || qf > box_far)
+                            : (pnear[a][k] > box_near || pfar[a][k] < box_far || qn > box_near || qf < box_far)) errors++;
+                    key += neg ? -pnear[a][k] : pnear[a][k];
+                }
+                if (key < prev_key) errors++;
+                prev_key = key;
+            }
+            for (int i = 0; i < 4; i++)
+                if (nd.child[i] != kInvalidRef && !used[i]) errors++; // a child got lost
+        }
+    }
     if (out_nodes) *out_nodes = (uint32_t)bvh.nodes.size();
     return errors;
 }

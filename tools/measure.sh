@@ -6,7 +6,7 @@
 #   <tag>_<cfg>_kernel_stats_one_at_a_time.csv      rocprofv3 --kernel-trace --stats with ONE frame at a time: kernels of different frames do
 #                                                   not overlap, so these average durations are kernel properties and agree with
 #                                                   roofline.contract.per_kernel.*.ms (HIP events) of <tag>_<cfg>_bench_one_at_a_time.json
-#   <tag>_<cfg>_kernel_stats_frames_in_flight.csv   the same trace of the DEFAULT command (8 frame slots): durations include the time a
+#   <tag>_<cfg>_kernel_stats_frames_in_flight.csv   the same trace of the DEFAULT command (12 frame slots; C3: 16): durations include the time a
 #                                                   kernel shares the chip with the other frames' kernels — not kernel properties
 #   <tag>_<cfg>_pmc.json / _pmc_valu.json / _pmc_cache.json   counters per launch (separate --pmc passes), each carrying the hash of the
 #                                                   kernel sources they were measured on: bench.py refuses them when the sources changed
@@ -79,6 +79,11 @@ if [ -z "$QUICK" ]; then
   python3 bench.py --workload atrium262k --no-cpu-baseline > $OUT/bench_c2_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c2_final.json profiles/${TAG}_c2_bench.json
   python3 bench.py --workload spheres10k > $OUT/bench_c3_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c3_final.json profiles/${TAG}_c3_bench.json
   python3 bench.py --max-path-length 3 > $OUT/bench_c4path_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c4path_final.json profiles/${TAG}_c4path_bench.json
+fi
+# the driver's own command (one fill-and-drain of the frame slots) and the builder's timings, for BASELINE.md / DESIGN.md
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_c4_20_steps.json 2> $OUT/bench_c4_20_steps.err && cp $OUT/bench_c4_20_steps.json profiles/${TAG}_c4_bench_20_steps.json
+if [ -z "$QUICK" ]; then
+  python3 tools/probes/build_time.py 0 > $OUT/build_time.json 2> $OUT/build_time.err && cp $OUT/build_time.json profiles/${TAG}_build_time.json
 fi
 # gpurun only brings gpurun_out/ back: the condensed files ride along in it (copy them into profiles/ of the checkout afterwards)
 mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/
