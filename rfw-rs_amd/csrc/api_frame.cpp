@@ -471,6 +471,11 @@ void rfw_hip_destroy(void* inst)
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
         for (auto& ev : I->ev_build)
             if (ev) (void)hipEventDestroy(ev);
+        if (I->ev_heads) (void)hipEventDestroy(I->ev_heads);
+        if (I->ev_records) (void)hipEventDestroy(I->ev_records);
+        if (I->records_stream) (void)hipStreamDestroy(I->records_stream);
+        I->d_heads.release();
+        I->meshes.clear(); // (unregisters the pinned host copies while the runtime is still up)
         for (auto& L : I->lanes) {
             if (L.s) (void)hipStreamDestroy(L.s);
             if (L.done) (void)hipEventDestroy(L.done);

@@ -169,6 +169,23 @@ struct PinnedRing {
 
 struct MeshHost {
     std::vector<rfw_rt_triangle> tris;
+    // The first 48 B of every record (vertex0 u0 | vertex1 u1 | vertex2 u2), copied beside it by set_3d_mesh: all the device builders read
+    // of a triangle.  A full build sends these first (27 % of the bytes) and builds the trees while the records follow on another stream.
+    std::vector<TriHead> heads;
+    // both arrays registered with the HIP runtime (meshes of >= 128 KB, from their first re-send on): copies from them are asynchronous and run at the link's rate.
+    // Nothing reads them behind the host's back once synchronize() has returned (it waits for both uploads).
+    bool pinned = false, pin_failed = false;
+    void unpin()
+    {
+        if (!pinned) return;
+        (void)hipHostUnregister(tris.data());
+        (void)hipHostUnregister(heads.data());
+        pinned = false;
+    }
+    MeshHost() = default;
+    MeshHost(const MeshHost&) = delete;
+    MeshHost& operator=(const MeshHost&) = delete;
+    ~MeshHost() { unpin(); }
     HostBvh4 bvh;
     std::vector<TriPacket> packets; // leaf order
     std::vector<rfw_joint_data> skin; // per vertex (3 per triangle); empty = not skinnable
@@ -338,7 +355,7 @@ struct Instance {
     uint64_t hole_tris = 0;                   // triangles' worth of regions abandoned since the last full build
     bool layout_valid = false;                // a full device build has laid the buffers out; cleared by anything the incremental path does not cover
     bool node_counts_stale = false;           // n_blas_nodes is re-read lazily (get_scene_stats) after an incremental build
-    uint32_t incremental_builds = 0, full_builds = 0;
+    uint32_t incremental_builds = 0, full_builds = 0, heads_first_builds = 0;
     PinnedRing pins;
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
@@ -349,6 +366,12 @@ struct Instance {
     static constexpr int kBuildLanes = 8;
     BuildLane lanes[kBuildLanes];
     hipEvent_t ev_build[3] = {nullptr, nullptr, nullptr};
+    // full device build: the 48-B heads go up on `stream`, the 176-B records behind them on `records_stream` while the trees are built
+    DevBuf<TriHead> d_heads;
+    hipStream_t records_stream = nullptr;
+    hipEvent_t ev_heads = nullptr, ev_records = nullptr;
+    bool build_from_heads = false; // (inside build_blas_device_full only)
+    bool records_timed = false;    // the last build recorded ev_records (scene stats: upload time = until the records have arrived)
     bool build_events_pending = false; // recorded, not read yet (rfw_hip_get_scene_stats reads them: no synchronisation for them in synchronize())
 
     // device path state

@@ -244,6 +244,15 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     if (!what || !dst) return fail(I, RFW_HIP_E_INVALID, "debug_read: null pointer");
     HIP_TRY(I, hipSetDevice(I->device));
     const std::string w(what);
+    if (w == "build_counters") { // host-side: full builds, incremental builds, full builds that sent the 48-B heads first, meshes registered with the runtime
+        uint32_t pinned = 0;
+        for (auto& kv : I->meshes) pinned += kv.second.pinned ? 1u : 0u;
+        const uint32_t v[4] = {I->full_builds, I->incremental_builds, I->heads_first_builds, pinned};
+        const uint64_t n = std::min<uint64_t>(bytes, sizeof(v));
+        std::memcpy(dst, v, n);
+        if (written) *written = n;
+        return RFW_HIP_OK;
+    }
     if (!I->slots.empty() && I->cur_slot != 0 && w != "xforms" && w != "normals" && w != "triangles" && w != "blas_raw" && w != "blas_order") {
         Instance* c = slot_ptr(I, I->cur_slot); // per-frame buffers of the latest frame
         const int rc = rfw_hip_debug_read(c, what, dst, bytes, written);

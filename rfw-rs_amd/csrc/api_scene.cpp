@@ -1,6 +1,9 @@
 // api_scene.cpp — the scene side of the C ABI: set_* calls and synchronize().  Host-side counterpart of backends/gpu-rt/src/lib.rs:1309-1683:
 // BLAS builds per changed mesh (device binned SAH / LBVH, host SAH), skinned copies, the per-frame TLAS, versioned material / light tables, textures.
 #include "api_internal.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 using namespace rfwapi;
 
@@ -174,7 +177,8 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
 {
     const MeshRecord& r = I->mesh_records[q];
     if (r.tri_count == 0) return RFW_HIP_OK;
-    launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+    if (I->build_from_heads) launch_triangle_boxes(I->stream, I->d_heads.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+    else launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
     if (I->blas_sah_on_device) {
         HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
         const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
@@ -189,7 +193,8 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
         HIP_TRY(I, lbvh_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_lbvh_ws.ptr, I->d_lbvh_ws.cap, I->d_blas_raw.ptr + r.node_base,
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
-    launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    // (a full build makes the packets of all meshes at its end: they need the records, which are still on their way while the trees are built)
+    if (!I->build_from_heads) launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
     launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count, I->d_mesh_node_counts.ptr + q);
     return RFW_HIP_OK;
 }
@@ -229,12 +234,13 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                 for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) {
                     const uint32_t q = small[i];
                     const MeshRecord& r = I->mesh_records[q];
-                    launch_triangle_boxes(L.s, I->d_triangles.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
+                    if (I->build_from_heads) launch_triangle_boxes(L.s, I->d_heads.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
+                    else launch_triangle_boxes(L.s, I->d_triangles.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
                     const hipError_t e = sah_build(L.s, L.boxes.ptr, r.tri_count, L.ws.ptr, L.ws.cap, I->d_blas_raw.ptr + r.node_base, I->d_blas_order.ptr + r.tri_base,
                                                    I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
-                    launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+                    if (!I->build_from_heads) launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
                     if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
                 }
                 (void)hipEventRecord(L.done, L.s);
@@ -272,6 +278,11 @@ void assign_logical_ids(Instance* I)
 // BLAS for every mesh on the device: lay the mega-buffers out afresh, upload all triangles, build every mesh
 int build_blas_device_full(Instance* I)
 {
+    static const bool kTrace = getenv("RFW_BUILD_TRACE") != nullptr; // (stderr: where a full build's host time goes)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto trace = [&](const char* what) {
+        if (kTrace) fprintf(stderr, "[build] %-28s %7.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     I->mesh_records.clear();
     I->mesh_index.clear();
     I->record_tri_cap.clear();
@@ -305,14 +316,56 @@ int build_blas_device_full(Instance* I)
     for (auto& ev : I->ev_build)
         if (!ev) HIP_TRY(I, hipEventCreate(&ev));
     HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    // Heads first: the builders read 48 of a record's 176 B, so those go up on the instance's stream and the trees are built while the records
+    // follow on a stream of their own (registered host memory: both copies are asynchronous).  Only the packets and the renderer need the
+    // records; the stream waits for them before the packets are made.  (C4, 185 MB: upload 3.5 ms + kernels 4.5 ms one after the other before.)
     uint32_t max_n = 0;
     size_t k = 0;
-    for (auto& kv : I->meshes) {
-        const MeshRecord& r = I->mesh_records[k++];
-        max_n = std::max(max_n, r.tri_count);
-        if (r.tri_count)
-            HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle),
-                                      hipMemcpyHostToDevice, I->stream));
+    bool any_pinned = false; // (a scene of small meshes only: nothing to overlap; an unregistered mesh is staged by the runtime on either stream)
+    for (auto& kv : I->meshes) any_pinned = any_pinned || kv.second.pinned;
+    I->build_from_heads = any_pinned && static_tris > 0 && !getenv("RFW_NO_HEADS_FIRST");
+    I->records_timed = I->build_from_heads;
+    if (I->build_from_heads) I->heads_first_builds++;
+    if (I->build_from_heads) {
+        HIP_TRY(I, I->d_heads.ensure(static_tris));
+        if (!I->records_stream) HIP_TRY(I, hipStreamCreateWithFlags(&I->records_stream, hipStreamNonBlocking));
+        if (!I->ev_heads) HIP_TRY(I, hipEventCreate(&I->ev_heads));
+        if (!I->ev_records) HIP_TRY(I, hipEventCreate(&I->ev_records));
+        // meshes too small to be registered go through the pinned ring, and FIRST: a staged copy may have to wait for a ring block, i.e. for
+        // an earlier copy on its stream — behind a 127 MB record copy that would hold the host back from queuing the build
+        for (int pass = 0; pass < 2; pass++) {
+            k = 0;
+            for (auto& kv : I->meshes) {
+                const MeshRecord& r = I->mesh_records[k++];
+                max_n = std::max(max_n, r.tri_count);
+                if (!r.tri_count || (int)kv.second.pinned != pass) continue;
+                const size_t bytes = (size_t)r.tri_count * sizeof(TriHead);
+                if (kv.second.pinned) HIP_TRY(I, hipMemcpyAsync(I->d_heads.ptr + r.tri_base, kv.second.heads.data(), bytes, hipMemcpyHostToDevice, I->stream));
+                else HIP_TRY(I, I->pins.upload(I->d_heads.ptr + r.tri_base, kv.second.heads.data(), bytes, I->stream));
+            }
+        }
+        HIP_TRY(I, hipEventRecord(I->ev_heads, I->stream));
+        HIP_TRY(I, hipStreamWaitEvent(I->records_stream, I->ev_heads, 0)); // (behind the heads on the link, and behind everything the instance's stream waited for)
+        for (int pass = 0; pass < 2; pass++) {
+            k = 0;
+            for (auto& kv : I->meshes) {
+                const MeshRecord& r = I->mesh_records[k++];
+                if (!r.tri_count || (int)kv.second.pinned != pass) continue;
+                const size_t bytes = (size_t)r.tri_count * sizeof(rfw_rt_triangle);
+                if (kv.second.pinned) HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), bytes, hipMemcpyHostToDevice, I->records_stream));
+                else HIP_TRY(I, I->pins.upload(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), bytes, I->records_stream));
+            }
+        }
+        HIP_TRY(I, hipEventRecord(I->ev_records, I->records_stream));
+        trace("uploads queued");
+    } else {
+        for (auto& kv : I->meshes) {
+            const MeshRecord& r = I->mesh_records[k++];
+            max_n = std::max(max_n, r.tri_count);
+            if (r.tri_count)
+                HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, kv.second.tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle),
+                                          hipMemcpyHostToDevice, I->stream));
+        }
     }
     HIP_TRY(I, I->d_tri_boxes.ensure(std::max(max_n, I->max_derived_tris)));
     if ((rc = ensure_lbvh_ws(I, max_n))) return rc;
@@ -334,10 +387,12 @@ int build_blas_device_full(Instance* I)
             HIP_TRY(I, I->pins.upload(I->d_forest.ptr, trees.data(), n_static * sizeof(ForestTree), I->stream));
             HIP_TRY(I, I->d_tri_boxes.ensure(std::max(static_tris, I->max_derived_tris)));
             HIP_TRY(I, I->d_sah_ws.ensure(sah_forest_workspace_bytes(static_tris, (uint32_t)n_static)));
-            launch_triangle_boxes(I->stream, I->d_triangles.ptr, static_tris, I->d_tri_boxes.ptr);
+            if (I->build_from_heads) launch_triangle_boxes(I->stream, I->d_heads.ptr, static_tris, I->d_tri_boxes.ptr);
+            else launch_triangle_boxes(I->stream, I->d_triangles.ptr, static_tris, I->d_tri_boxes.ptr);
             const hipError_t fe = sah_build_forest(I->stream, I->d_tri_boxes.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static, max_n, I->d_sah_ws.ptr, I->d_sah_ws.cap,
                                                    I->d_blas_raw.ptr, I->d_blas_order.ptr, I->d_mesh_node_counts.ptr, I->sah_max_leaf, I->sah_trav_cost);
             if (fe == hipSuccess) {
+                if (I->build_from_heads) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
                 launch_make_packets(I->stream, I->d_triangles.ptr, I->d_blas_order.ptr, static_tris, 0u, I->d_packets.ptr); // global positions: one launch
                 launch_forest_relative_order(I->stream, I->d_blas_order.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static);
                 forest_done = true;
@@ -345,7 +400,19 @@ int build_blas_device_full(Instance* I)
                 HIP_TRY(I, fe);
             } // else: some tree is deeper than the builder's level budget: mesh by mesh, where LBVH can take over for that one
         }
-        if (!forest_done && (rc = build_meshes(I, all, false))) return rc;
+        if (!forest_done) {
+            rc = build_meshes(I, all, false);
+            trace("trees queued");
+            if (I->build_from_heads) { // the packets of every mesh, now that the records are (about to be) there
+                I->build_from_heads = false;
+                HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
+                if (rc == RFW_HIP_OK)
+                    for (const MeshRecord& r : I->mesh_records)
+                        if (r.tri_count) launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+            }
+            if (rc) return rc;
+        }
+        I->build_from_heads = false;
     }
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     // all static regions in one launch; the slots behind a tree's last node are skipped (the builders left the node counts on the device)
@@ -354,7 +421,17 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
+    trace("all queued");
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    trace("device done");
+    if (kTrace && I->records_timed) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&c, I->ev_build[0], I->ev_heads);
+        fprintf(stderr, "[build] by events: heads arrived %.3f ms\n", c);
+        (void)hipEventElapsedTime(&a, I->ev_build[0], I->ev_records);
+        (void)hipEventElapsedTime(&b, I->ev_build[0], I->ev_build[2]);
+        fprintf(stderr, "[build] by events: records arrived %.3f ms, build done %.3f ms after the start\n", a, b);
+    }
     I->build_events_pending = true;
     I->blas_upload_bytes = (uint64_t)static_tris * sizeof(rfw_rt_triangle);
     I->blas_kernel_bytes = kernel_bytes;
@@ -364,8 +441,12 @@ int build_blas_device_full(Instance* I)
     I->n_blas_nodes = node_total - static_nodes;
     for (uint32_t c : counts) I->n_blas_nodes += c;
     I->node_counts_stale = false;
-    I->d_sah_ws.release(); // ~350 B per triangle of build scratch: not kept between scene changes
-    for (auto& L : I->lanes) { L.ws.release(); L.boxes.release(); }
+    // ~350 B per triangle of build scratch: kept between scene changes up to 1 GB.  Not for the allocation's own cost: a hipFree / hipMalloc of
+    // 0.4 GB between two builds made the NEXT build's record upload crawl beside its kernels (measured, C4: records arrived after 7.5 ms instead
+    // of 4.4, every warm build 7.9 ms instead of 5.6 — tools/probes/h2d_overlap.cpp shows the copy itself overlaps kernels at full rate)
+    if (I->d_sah_ws.cap > (size_t(1) << 30)) I->d_sah_ws.release();
+    for (auto& L : I->lanes)
+        if (L.ws.cap > (size_t(1) << 30)) { L.ws.release(); L.boxes.release(); }
     I->tri_end = static_tris;
     I->node_end = static_nodes;
     I->hole_tris = 0;
@@ -379,6 +460,8 @@ int build_blas_device_full(Instance* I)
 // Returns 1 when the layout has to be redone by a full build (too many holes), 0 on success, < 0 on error.
 int build_blas_device_incremental(Instance* I)
 {
+    I->build_from_heads = false;
+    I->records_timed = false;
     // what went away
     for (auto it = I->mesh_index.begin(); it != I->mesh_index.end();) {
         if (I->meshes.find(it->first) == I->meshes.end()) {
@@ -923,17 +1006,54 @@ extern "C" {
 int rfw_hip_set_2d_mesh(void* inst, uint32_t, const void*, uint32_t, int32_t) { LOCK(inst); return RFW_HIP_OK; }
 int rfw_hip_set_2d_instances(void* inst, uint32_t, const rfw_mat4*, uint32_t) { LOCK(inst); return RFW_HIP_OK; }
 
-static void copy_triangles(std::vector<rfw_rt_triangle>& dst, const rfw_rt_triangle* src, size_t n, int threads)
+// The host copy of a mesh: the records, and their 48-B heads beside them (MeshHost).  Several threads for a large mesh (one thread moves
+// ~10 GB/s: 185 MB of C4 took 18 of the 45 ms a re-sent scene cost before anything reached the device).  A mesh of >= 128 KB is registered
+// with the runtime the first time it is RE-sent at an unchanged size.
+static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads)
 {
-    if (dst.size() != n) { dst.clear(); dst.shrink_to_fit(); dst.resize(n); } // (value-initialised once; a mesh re-sent at the same size is only copied)
+    if (m.tris.size() != n) {
+        m.unpin();
+        m.tris.clear(); m.tris.shrink_to_fit(); m.tris.resize(n);
+        m.heads.clear(); m.heads.shrink_to_fit(); m.heads.resize(n);
+    } else if (!m.pinned && !m.pin_failed && I->blas_on_device && n * sizeof(rfw_rt_triangle) >= (128u << 10) && !getenv("RFW_NO_PINNED_MESHES") &&
+               hipSetDevice(I->device) == hipSuccess) {
+        // re-sent at the same size: a mesh that changes.  Registering costs ~0.2 ms per MB, once (a scene that is loaded and never re-sent does not pay it)
+        const bool a = hipHostRegister(m.tris.data(), n * sizeof(rfw_rt_triangle), hipHostRegisterDefault) == hipSuccess;
+        const bool b = a && hipHostRegister(m.heads.data(), n * sizeof(TriHead), hipHostRegisterDefault) == hipSuccess;
+        if (a && !b) (void)hipHostUnregister(m.tris.data());
+        m.pinned = a && b;
+        if (!m.pinned) { (void)hipGetLastError(); m.pin_failed = true; } // (the limit on locked memory, say: the uploads are staged by the runtime as before)
+    }
+    // one pass over the source: every record is read once and goes out through non-temporal stores, its head a second time into the heads
+    // array (a memcpy of the records plus a pass for the heads reads 44 % of the source twice; chunked memcpys lose the streaming stores)
+    auto part = [&m, src](size_t a, size_t b) {
+#if defined(__SSE2__)
+        if ((reinterpret_cast<uintptr_t>(m.tris.data()) & 15u) == 0 && (reinterpret_cast<uintptr_t>(m.heads.data()) & 15u) == 0) {
+            constexpr int kWords = (int)(sizeof(rfw_rt_triangle) / 16);
+            for (size_t i = a; i < b; i++) {
+                const __m128i* in = reinterpret_cast<const __m128i*>(src + i);
+                __m128i* out = reinterpret_cast<__m128i*>(m.tris.data() + i);
+                __m128i* head = reinterpret_cast<__m128i*>(m.heads.data() + i);
+                __m128i w[kWords];
+                for (int k = 0; k < kWords; k++) w[k] = _mm_loadu_si128(in + k);
+                for (int k = 0; k < kWords; k++) _mm_stream_si128(out + k, w[k]);
+                for (int k = 0; k < 3; k++) _mm_stream_si128(head + k, w[k]);
+            }
+            _mm_sfence();
+            return;
+        }
+#endif
+        if (a < b) std::memcpy(m.tris.data() + a, src + a, (b - a) * sizeof(rfw_rt_triangle));
+        for (size_t k = a; k < b; k++) std::memcpy(&m.heads[k], src + k, sizeof(TriHead));
+    };
     const size_t bytes = n * sizeof(rfw_rt_triangle);
     const int nt = (int)std::min<size_t>((size_t)std::max(threads, 1), bytes >> 22); // at least 4 MB per thread
-    if (nt <= 1) { if (n) std::memcpy(dst.data(), src, bytes); return; }
+    if (nt <= 1) { part(0, n); return; }
     std::vector<std::thread> pool;
     const size_t per = (n + nt - 1) / nt;
     for (int k = 0; k < nt; k++) {
         const size_t a = std::min(n, per * k), b = std::min(n, a + per);
-        if (a < b) pool.emplace_back([&dst, src, a, b] { std::memcpy(dst.data() + a, src + a, (b - a) * sizeof(rfw_rt_triangle)); });
+        if (a < b) pool.emplace_back(part, a, b);
     }
     for (auto& t : pool) t.join();
 }
@@ -944,9 +1064,9 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
     if (!d || (d->num_triangles && !d->triangles)) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: null data");
     if (d->num_triangles > kLeafFirstMask) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: more than 2^27 triangles in one mesh");
     MeshHost& m = I->meshes[id];
-    // copy: the borrow ends with this call.  A large mesh is copied by several threads (one thread moves ~10 GB/s: 185 MB of C4 took 18 of
-    // the 45 ms a re-sent scene cost before anything reached the device)
-    copy_triangles(m.tris, d->triangles, d->num_triangles, I->build_threads);
+    const auto t_copy = std::chrono::steady_clock::now();
+    copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads); // copy: the borrow ends with this call
+    if (getenv("RFW_BUILD_TRACE")) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
     m.skin.clear();
     if (d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING))
         m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
@@ -1227,7 +1347,9 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
     if (I->build_events_pending) {
         (void)hipSetDevice(I->device);
         if (hipEventSynchronize(I->ev_build[2]) == hipSuccess) {
-            (void)hipEventElapsedTime(&I->ms_blas_upload, I->ev_build[0], I->ev_build[1]);
+            // (a full build overlaps the two: the records are still on the bus while the trees are built, so upload + kernels > the build)
+            if (I->ev_records && I->records_timed) (void)hipEventElapsedTime(&I->ms_blas_upload, I->ev_build[0], I->ev_records);
+            else (void)hipEventElapsedTime(&I->ms_blas_upload, I->ev_build[0], I->ev_build[1]);
             (void)hipEventElapsedTime(&I->ms_blas_kernels, I->ev_build[1], I->ev_build[2]);
         }
         I->build_events_pending = false;

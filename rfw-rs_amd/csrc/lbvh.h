@@ -43,6 +43,11 @@ void launch_instance_boxes(hipStream_t s, const rfw_mat4* matrices, const uint32
 void launch_gather_u32(hipStream_t s, const uint32_t* src, const uint32_t* order, uint32_t n, uint32_t* dst);
 // triangle boxes (padded) from the boundary's RTTriangle array
 void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, DevBox* out);
+// the same from the 48-B heads of the records (vertex0 u0 | vertex1 u1 | vertex2 u2): all a builder needs of a triangle, and what a full
+// build uploads FIRST so that the trees are built while the other 128 B per triangle are still on the bus
+struct TriHead { float v[12]; };
+static_assert(sizeof(TriHead) == 48, "TriHead = the first three float4 of rfw_rt_triangle");
+void launch_triangle_boxes(hipStream_t s, const TriHead* heads, uint32_t n, DevBox* out);
 // leaf-ordered traversal packets: packet k = triangle order[k]; tri_id = order[k] + id_offset
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out);
 

@@ -300,11 +300,12 @@ __global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* _
     if (k < n) dst[k] = src[order[k]];
 }
 
-__global__ void k_triangle_boxes(const rfw_rt_triangle* __restrict__ tris, uint32_t n, DevBox* out)
+// `tris`: records of `stride16` float4s whose first three hold the vertices — the 176-B rfw_rt_triangle (11), or its 48-B head alone (3: TriHead)
+__global__ void k_triangle_boxes(const float4* __restrict__ tris, uint32_t stride16, uint32_t n, DevBox* out)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const float4* tp = reinterpret_cast<const float4*>(tris + i);
+    const float4* tp = tris + (size_t)i * stride16;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     DevBox bx;
     const float va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z}, vc[3] = {c.x, c.y, c.z};
@@ -589,7 +590,11 @@ void launch_gather_u32(hipStream_t s, const uint32_t* src, const uint32_t* order
 }
 void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t n, DevBox* out)
 {
-    if (n) hipLaunchKernelGGL(k_triangle_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, tris, n, out);
+    if (n) hipLaunchKernelGGL(k_triangle_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, reinterpret_cast<const float4*>(tris), (uint32_t)(sizeof(rfw_rt_triangle) / 16), n, out);
+}
+void launch_triangle_boxes(hipStream_t s, const TriHead* heads, uint32_t n, DevBox* out)
+{
+    if (n) hipLaunchKernelGGL(k_triangle_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, reinterpret_cast<const float4*>(heads), (uint32_t)(sizeof(TriHead) / 16), n, out);
 }
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out)
 {
