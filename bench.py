@@ -32,6 +32,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZ
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured for a float4 copy)
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
 L1_PEAK_GBS = 256 * 64 * 2.4  # 64 B per clock and CU out of the vector L1 / TA return path x 256 CUs x 2.4 GHz = 39.3 TB/s
+ISSUE_MEASURED = {}          # filled on rank 0 by rfw_hip_issue_probe after the timed region: G wave64 instructions/s this device sustains in this job
 VALU_PEAK_GIPS = 1228.8      # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 FP32 instruction (= the 157 TFLOP/s vector peak)
 CLOCK_GHZ = 2.4              # peak engine clock (the busy-cycle fractions below are conservative if the chip clocks lower under load)
 N_VIEWS = 16                 # distinct camera views the frames cycle through
@@ -506,6 +507,8 @@ def main():
         try:
             pb = bes[0] if bes else HipBackend.init(64, 64, 1.0, device=dev)
             bw_measured = pb.bandwidth_probe(1 << 30, 20)
+            # ... and its vector-issue ceilings: v_fma_f32 alone, and the instruction mix of the node test (rfw_hip.h: rfw_hip_issue_probe)
+            ISSUE_MEASURED.update({"fma_only": round(pb.issue_probe(0), 1), "node_test_mix": round(pb.issue_probe(1), 1)})
             if not bes:
                 pb.close()
         except Exception:
@@ -719,6 +722,12 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
             a = tot["valu"] / seconds / 1e9
             c["valu_issue"] = {"achieved": round(a, 1), "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s", "frac": round(a / VALU_PEAK_GIPS, 4),
                                "per_launch": int(tot["valu"])}
+            if ISSUE_MEASURED.get("node_test_mix"):
+                # the guide's peak is one v_fma_f32 per 2 cycles per SIMD at 2.4 GHz; conversions, min / max, compares and packed FMAs — what a
+                # node test is made of — issue at half that or less, and the clock sags under load: both rates measured live, 8 waves per SIMD
+                c["valu_issue"]["measured_ceiling"] = dict(ISSUE_MEASURED, unit="G wave64 instructions/s, chip-wide, 8 wavefronts per SIMD",
+                                                           frac_of_node_test_mix=round(a / ISSUE_MEASURED["node_test_mix"], 4),
+                                                           frac_of_fma_only=round(a / ISSUE_MEASURED["fma_only"], 4))
         if have["ta"] and tot["ta_busy"]:
             # the texture-address / vector-L1 path of a CU, the unit every 16-B-per-lane load goes through: busy cycles (mean over the CUs)
             # of the launches over the cycles they took.  Its cost per wave instruction grows with the cache lines the 64 lanes touch

@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes", "rfw_hip_debug_occludes_depth",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_p2p_export", "rfw_hip_p2p_connect", "rfw_hip_p2p_disconnect", "rfw_hip_intersect4", "rfw_hip_occludes4", "rfw_hip_debug_lbvh_stress",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_p2p_export", "rfw_hip_p2p_connect", "rfw_hip_p2p_disconnect", "rfw_hip_intersect4", "rfw_hip_occludes4", "rfw_hip_debug_lbvh_stress", "rfw_hip_issue_probe",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def hip_lib():
         l.rfw_hip_debug_read.argtypes = [vp, cp, vp, u64, C.POINTER(u64)]
         l.rfw_hip_debug_lbvh_stress.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
         l.rfw_hip_bandwidth_probe.argtypes = [vp, u64, C.c_uint32, C.POINTER(C.c_double)]
+        l.rfw_hip_issue_probe.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
         _lib = l
     return _lib
 
@@ -454,6 +455,13 @@ class HipBackend:
         """Measured device copy bandwidth in GB/s (read + written bytes): the job's own HBM roofline."""
         out = C.c_double(0.0)
         self._check(self._l.rfw_hip_bandwidth_probe(self._h, nbytes, iterations, C.byref(out)))
+        return float(out.value)
+
+    def issue_probe(self, mix, trips=4000):
+        """Measured vector-issue rate in G wave64 instructions / s, chip-wide, at 8 wavefronts per SIMD: mix 0 = v_fma_f32 alone, mix 1 = the
+        instruction mix of the 4-wide node test (conversions, packed FMAs, min / max, compares)."""
+        out = C.c_double(0.0)
+        self._check(self._l.rfw_hip_issue_probe(self._h, mix, trips, C.byref(out)))
         return float(out.value)
 
     def lbvh_stress(self, num_boxes, iterations, seed=1):

@@ -344,4 +344,35 @@ int rfw_hip_bandwidth_probe(void* inst, uint64_t bytes, uint32_t iterations, dou
     return RFW_HIP_OK;
 }
 
+int rfw_hip_issue_probe(void* inst, int mix, uint32_t trips, double* g_instructions_per_s)
+{
+    LOCK(inst);
+    if (!g_instructions_per_s || mix < 0 || mix > 1 || trips == 0 || trips > (1u << 20)) return fail(I, RFW_HIP_E_INVALID, "issue_probe: bad arguments");
+    HIP_TRY(I, hipSetDevice(I->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(I, hipGetDeviceProperties(&prop, I->device));
+    const uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
+    float* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&out, (size_t)cus * 8u * 256u * sizeof(float));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        launch_issue_probe(I->stream, mix, cus, trips, out); // warm
+        (void)hipEventRecord(e0, I->stream);
+        launch_issue_probe(I->stream, mix, cus, trips, out);
+        (void)hipEventRecord(e1, I->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("issue_probe: ") + hipGetErrorString(e));
+    const double wave_instructions = (double)cus * 8.0 * 4.0 * (double)trips * 32.0; // blocks x wavefronts per block x trips x instructions per trip
+    *g_instructions_per_s = ms > 0.0f ? wave_instructions / (ms * 1e-3) / 1e9 : 0.0;
+    return RFW_HIP_OK;
+}
+
 } // extern "C"

@@ -1298,6 +1298,48 @@ __global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src4
         }
     }
 }
+// Issue-rate probe (rfw_hip_issue_probe): streams of independent vector instructions, 8 accumulators per lane, 8 wavefronts per SIMD on every
+// CU.  MIX 0 = v_fma_f32 alone (the instruction the guide's FP32 peak is quoted on); MIX 1 = one child of the per-lane node test of
+// traverse_body.inc, instruction for instruction: 6 byte -> float conversions, 3 packed FMAs, max3, min3, min, two compares.  The trace
+// kernels are made of the second kind, and conversions, min / max, compares and packed FMAs issue at half the FMA rate or less
+// (tools/probes/valu_peak.cpp lists them one by one) — this is the ceiling "valu_issue" is held against in bench.py beside the guide's.
+template <int MIX> __global__ __launch_bounds__(256) void k_issue_probe(float* out, const uint32_t trips, const float seed)
+{
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    float v[8];
+    for (int i = 0; i < 8; i++) v[i] = seed + (float)(threadIdx.x + i);
+    const float a = seed * 1.0001f, b = seed * 0.5f;
+    const uint32_t u = fbits(seed) | 0x01020304u;
+    v2 p[3] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}};
+    const v2 pa = {a, a}, pb = {b, b};
+    for (uint32_t it = 0; it < trips; it++) {
+        if (MIX == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(a), "v"(b));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) { // 2 x 16 instructions per trip
+                asm volatile("v_cvt_f32_ubyte0 %0, %6\n\tv_cvt_f32_ubyte1 %1, %6\n\tv_cvt_f32_ubyte2 %2, %6\n\tv_cvt_f32_ubyte3 %3, %6\n\tv_cvt_f32_ubyte0 %4, %6\n\tv_cvt_f32_ubyte1 %5, %6"
+                             : "=v"(p[0].x), "=v"(p[0].y), "=v"(p[1].x), "=v"(p[1].y), "=v"(p[2].x), "=v"(p[2].y) : "v"(u));
+                asm volatile("v_pk_fma_f32 %0, %0, %3, %4\n\tv_pk_fma_f32 %1, %1, %3, %4\n\tv_pk_fma_f32 %2, %2, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(pa), "v"(pb));
+                asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %5, %6, %7" : "=v"(v[6]), "=v"(v[7]) : "v"(p[0].x), "v"(p[1].x), "v"(p[2].x), "v"(p[0].y), "v"(p[1].y), "v"(p[2].y));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[7]) : "v"(a));
+                asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cmp_ge_f32 vcc, %0, %2" : : "v"(v[7]), "v"(v[6]), "v"(b) : "vcc");
+            }
+        }
+    }
+    float r = p[0].x + p[1].y + p[2].x;
+    for (int i = 0; i < 8; i++) r += v[i];
+    out[blockIdx.x * 256u + threadIdx.x] = r;
+}
+// (blocks of 256 threads, 8 per CU: every SIMD holds 8 wavefronts; `out` holds cus * 8 * 256 floats)
+void launch_issue_probe(hipStream_t s, int mix, uint32_t cus, uint32_t trips, float* out)
+{
+    if (mix == 0) hipLaunchKernelGGL(k_issue_probe<0>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
+    else hipLaunchKernelGGL(k_issue_probe<1>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
+}
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {
     if (n) hipLaunchKernelGGL(k_copy_f4, dim3(16384), dim3(256), 0, s, src, dst, n);
