@@ -471,6 +471,7 @@ void rfw_hip_destroy(void* inst)
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
         for (auto& ev : I->ev_build)
             if (ev) (void)hipEventDestroy(ev);
+        if (I->records_stream) (void)hipStreamSynchronize(I->records_stream);
         if (I->ev_heads) (void)hipEventDestroy(I->ev_heads);
         if (I->ev_records) (void)hipEventDestroy(I->ev_records);
         if (I->records_stream) (void)hipStreamDestroy(I->records_stream);

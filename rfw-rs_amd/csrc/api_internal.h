@@ -371,6 +371,7 @@ struct Instance {
     hipStream_t records_stream = nullptr;
     hipEvent_t ev_heads = nullptr, ev_records = nullptr;
     bool build_from_heads = false; // (inside build_blas_device_full only)
+    bool records_pending = false;  // an upload from a registered host copy was queued and nobody has waited for ev_records yet
     bool records_timed = false;    // the last build recorded ev_records (scene stats: upload time = until the records have arrived)
     bool build_events_pending = false; // recorded, not read yet (rfw_hip_get_scene_stats reads them: no synchronisation for them in synchronize())
 

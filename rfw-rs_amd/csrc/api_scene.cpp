@@ -423,6 +423,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     trace("all queued");
     HIP_TRY(I, hipStreamSynchronize(I->stream));
+    I->records_pending = false;
     trace("device done");
     if (kTrace && I->records_timed) {
         float a = 0, b = 0, c = 0;
@@ -525,7 +526,35 @@ int build_blas_device_incremental(Instance* I)
         if (!ev) HIP_TRY(I, hipEventCreate(&ev));
     HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
     uint64_t upload_bytes = 0, kernel_bytes = 0;
+    // ONE large registered mesh changed (a deforming mesh that is re-sent every frame): heads first, as in a full build — the tree is built
+    // from the 48-B heads while the records follow on the second stream, the packets are made when they are there.  Nothing is synchronised
+    // here: the next set_3d_mesh waits for ev_records before it overwrites the host copy the upload reads (records_pending).
+    bool heads_first = false;
+    if (todo.size() == 1 && I->mesh_records[todo[0]].tri_count * sizeof(rfw_rt_triangle) >= (size_t(1) << 20) && !getenv("RFW_NO_HEADS_FIRST")) {
+        const uint32_t q = todo[0];
+        MeshHost* mh = nullptr;
+        for (auto& kv : I->mesh_index)
+            if (kv.second == q) mh = &I->meshes[kv.first];
+        if (mh && mh->pinned) {
+            const MeshRecord& r = I->mesh_records[q];
+            HIP_TRY(I, I->d_heads.ensure(I->tri_end));
+            if (!I->records_stream) HIP_TRY(I, hipStreamCreateWithFlags(&I->records_stream, hipStreamNonBlocking));
+            if (!I->ev_heads) HIP_TRY(I, hipEventCreate(&I->ev_heads));
+            if (!I->ev_records) HIP_TRY(I, hipEventCreate(&I->ev_records));
+            HIP_TRY(I, hipMemcpyAsync(I->d_heads.ptr + r.tri_base, mh->heads.data(), (size_t)r.tri_count * sizeof(TriHead), hipMemcpyHostToDevice, I->stream));
+            HIP_TRY(I, hipEventRecord(I->ev_heads, I->stream));
+            HIP_TRY(I, hipStreamWaitEvent(I->records_stream, I->ev_heads, 0));
+            HIP_TRY(I, hipMemcpyAsync(I->d_triangles.ptr + r.tri_base, mh->tris.data(), (size_t)r.tri_count * sizeof(rfw_rt_triangle), hipMemcpyHostToDevice, I->records_stream));
+            HIP_TRY(I, hipEventRecord(I->ev_records, I->records_stream));
+            I->records_pending = true;
+            I->records_timed = true;
+            I->heads_first_builds++;
+            upload_bytes += (uint64_t)r.tri_count * sizeof(rfw_rt_triangle);
+            heads_first = true;
+        }
+    }
     for (const uint32_t q : todo) { // the changed meshes' triangles first (their regions are disjoint) ...
+        if (heads_first) break;
         const MeshRecord& r = I->mesh_records[q];
         const MeshHost* mh = nullptr;
         for (auto& kv : I->mesh_index)
@@ -543,7 +572,15 @@ int build_blas_device_incremental(Instance* I)
     }
     HIP_TRY(I, hipEventRecord(I->ev_build[1], I->stream));
     for (const uint32_t q : todo) kernel_bytes += build_pass_bytes(I->mesh_records[q].tri_count);
-    if ((rc = build_meshes(I, todo, true))) return rc; // ... then their trees
+    I->build_from_heads = heads_first;
+    rc = build_meshes(I, todo, true); // ... then their trees
+    I->build_from_heads = false;
+    if (rc) return rc;
+    if (heads_first) {
+        const MeshRecord& r = I->mesh_records[todo[0]];
+        HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
+        launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    }
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     I->build_events_pending = true;
     I->blas_upload_bytes = upload_bytes;
@@ -1064,6 +1101,11 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
     if (!d || (d->num_triangles && !d->triangles)) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: null data");
     if (d->num_triangles > kLeafFirstMask) return fail(I, RFW_HIP_E_INVALID, "set_3d_mesh: more than 2^27 triangles in one mesh");
     MeshHost& m = I->meshes[id];
+    if (I->records_pending) { // an incremental build's upload may still be reading a registered host copy
+        HIP_TRY(I, hipSetDevice(I->device));
+        HIP_TRY(I, hipEventSynchronize(I->ev_records));
+        I->records_pending = false;
+    }
     const auto t_copy = std::chrono::steady_clock::now();
     copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads); // copy: the borrow ends with this call
     if (getenv("RFW_BUILD_TRACE")) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
@@ -1079,6 +1121,11 @@ int rfw_hip_unload_3d_meshes(void* inst, const uint32_t* ids, uint32_t n)
 {
     LOCK(inst);
     if (n && !ids) return fail(I, RFW_HIP_E_INVALID, "unload_3d_meshes: null ids");
+    if (I->records_pending) { // (a registered host copy must not go away under an upload)
+        HIP_TRY(I, hipSetDevice(I->device));
+        HIP_TRY(I, hipEventSynchronize(I->ev_records));
+        I->records_pending = false;
+    }
     for (uint32_t i = 0; i < n; i++) {
         I->meshes.erase(ids[i]);
         I->inst_lists.erase(ids[i]);

@@ -623,3 +623,19 @@ def test_resent_meshes_upload_heads_first_and_give_the_same_image():
     assert np.array_equal(frame(be).view(np.uint32), frame(ref).view(np.uint32))
     ref.close()
     be.close()
+    # a scene of ONE large mesh that is re-sent: the incremental path, heads first from the second re-send on
+    scene = Scene().build("atrium", 120000, 0, 0.0, 5)
+    assert scene.counts()["meshes"] == 1                    # (everything changed = one mesh changed: the incremental path)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=2)
+    scene.sync(be)
+    first = frame(be)
+    before = counters(be)
+    for k in range(3):
+        scene.mark_all_changed()
+        scene.sync(be)
+        assert np.array_equal(frame(be).view(np.uint32), first.view(np.uint32)), k
+    after = counters(be)
+    assert after[1] == before[1] + 3 and after[2] >= before[2] + 2, (before, after)   # (the first re-send registers the copy and already goes heads first)
+    be.close()
