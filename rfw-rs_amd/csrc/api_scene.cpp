@@ -380,7 +380,8 @@ int build_blas_device_full(Instance* I)
         // mesh is a root of the same level-by-level pass) — ~45 launches for the scene instead of ~30 per mesh
         bool forest_done = false;
         // (measured: two meshes of 720 k + 330 k triangles 5.4 ms together, 4.4 ms one after the other; 65 meshes 5.5 ms against 10.4 on lanes, 38 one by one)
-        if (I->blas_sah_on_device && n_static >= 4 && static_tris > 0 && !getenv("RFW_NO_FOREST")) {
+        static const size_t forest_min = getenv("RFW_FOREST_MIN") ? (size_t)std::max(atoi(getenv("RFW_FOREST_MIN")), 2) : 4;
+        if (I->blas_sah_on_device && n_static >= forest_min && static_tris > 0 && !getenv("RFW_NO_FOREST")) {
             std::vector<ForestTree> trees(n_static);
             for (size_t q = 0; q < n_static; q++) trees[q] = ForestTree{I->mesh_records[q].tri_base, I->mesh_records[q].tri_count, I->mesh_records[q].node_base, 0u};
             HIP_TRY(I, I->d_forest.ensure(n_static));

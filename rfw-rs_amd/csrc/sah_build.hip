@@ -959,41 +959,76 @@ __global__ void k_forest_init(Counters* ctr, uint32_t n_trees)
 {
     if (threadIdx.x == 0) { ctr->node_count = n_trees; ctr->n_active[0] = 0; ctr->n_active[1] = 0; ctr->n_small = 0; }
 }
-// one workgroup per tree: bounds and centroid bounds of its range, identity order, the root node, and where the root goes next
-__global__ __launch_bounds__(kBlock) void k_forest_roots(const DevBox* __restrict__ boxes, const ForestTree* __restrict__ trees, Counters* ctr, SNode* nodes,
-                                                        uint32_t* order, uint32_t* node_of_pos, uint32_t* active, uint32_t* small, uint32_t* bin_slot, uint8_t* stamp,
-                                                        Bin* bins, uint32_t replicas, uint32_t small_cap)
+// Bounds and centroid bounds of every tree, identity order, tree of every position: ALL positions by a fixed grid of workgroups, each over a
+// contiguous chunk (round 3 gave a tree to ONE workgroup: a 720 k-primitive tree among 64 small ones — or two big meshes — kept a single CU busy
+// for ~0.9 ms while 255 idled; that, not the level kernels, was why two large meshes built faster one after the other).  A thread accumulates
+// for the tree of its current position and flushes (12 atomics on the tree's words) when its next position is another tree's; at the end the
+// lanes of a wavefront that all hold the same tree are reduced in registers first.
+constexpr uint32_t kForestBoundsBlocks = 1024;
+__device__ inline uint32_t tree_of_position(const ForestTree* __restrict__ trees, uint32_t n_trees, uint32_t i)
 {
-    __shared__ uint32_t s_b[12];
-    __shared__ uint32_t s_slot;
-    const uint32_t m = blockIdx.x;
-    const ForestTree t = trees[m];
-    if (threadIdx.x < 12) s_b[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
-    if (threadIdx.x == 0) s_slot = kNone;
-    __syncthreads();
+    uint32_t lo = 0, hi = n_trees; // the last tree whose first position is <= i (trees lie one after the other; empty trees share a first)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (trees[mid].first <= i) lo = mid; else hi = mid;
+    }
+    while (lo > 0 && trees[lo].count == 0) lo--; // (an empty tree at the same offset as its successor owns nothing)
+    return lo;
+}
+__global__ __launch_bounds__(kBlock) void k_forest_bounds(const DevBox* __restrict__ boxes, const ForestTree* __restrict__ trees, uint32_t n_trees, uint32_t n, uint32_t chunk,
+                                                         uint32_t* order, uint32_t* node_of_pos, uint32_t* bounds)
+{
+    const uint32_t begin = blockIdx.x * chunk, end = min(n, begin + chunk);
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = t.first + threadIdx.x; i < t.first + t.count; i += kBlock) {
+    uint32_t m = kNone, m_end = 0;
+    auto flush = [&]() {
+        uint32_t* b = bounds + (size_t)m * 12u;
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&b[a], f_order(lo[a])); atomicMax(&b[3 + a], f_order(hi[a]));
+            atomicMin(&b[6 + a], f_order(clo[a])); atomicMax(&b[9 + a], f_order(chi[a]));
+            lo[a] = INFINITY; hi[a] = -INFINITY; clo[a] = INFINITY; chi[a] = -INFINITY;
+        }
+    };
+    for (uint32_t i = begin + threadIdx.x; i < end; i += kBlock) {
+        if (m == kNone || i >= m_end) {
+            if (m != kNone) flush();
+            m = tree_of_position(trees, n_trees, i);
+            m_end = trees[m].first + trees[m].count;
+        }
         order[i] = i;
         node_of_pos[i] = m;
+        const DevBox bx = boxes[i];
         for (int a = 0; a < 3; a++) {
-            const float l = boxes[i].lo[a], h = boxes[i].hi[a], c = 0.5f * (l + h);
+            const float l = bx.lo[a], h = bx.hi[a], c = 0.5f * (l + h);
             lo[a] = fminf(lo[a], l); hi[a] = fmaxf(hi[a], h);
             clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
         }
     }
-    for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); clo[a] = wave_min(clo[a]); chi[a] = wave_max(chi[a]); }
-    if ((threadIdx.x & 63) == 0)
-        for (int a = 0; a < 3; a++) {
-            atomicMin(&s_b[a], f_order(lo[a])); atomicMax(&s_b[3 + a], f_order(hi[a]));
-            atomicMin(&s_b[6 + a], f_order(clo[a])); atomicMax(&s_b[9 + a], f_order(chi[a]));
-        }
-    __syncthreads();
+    // what is left: one set of atomics per wavefront when its lanes agree on the tree (a large tree: every wavefront of the chunk), else per lane
+    const unsigned long long have = __ballot(m != kNone);
+    if (have == 0ull) return;
+    const uint32_t lead_m = (uint32_t)__builtin_amdgcn_readlane((int)m, __ffsll((long long)have) - 1);
+    if (__ballot(m != kNone && m != lead_m) == 0ull) {
+        for (int a = 0; a < 3; a++) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); clo[a] = wave_min(clo[a]); chi[a] = wave_max(chi[a]); }
+        m = lead_m;
+        if ((threadIdx.x & 63u) == 0u) flush();
+    } else if (m != kNone) flush();
+}
+// one wavefront per tree: the root node from the tree's bounds, where the root goes next, and its bins on level 0
+__global__ __launch_bounds__(64) void k_forest_roots(const ForestTree* __restrict__ trees, const uint32_t* __restrict__ bounds, Counters* ctr, SNode* nodes, uint32_t* active,
+                                                    uint32_t* small, uint32_t* bin_slot, uint8_t* stamp, Bin* bins, uint32_t replicas, uint32_t small_cap)
+{
+    __shared__ uint32_t s_slot;
+    const uint32_t m = blockIdx.x;
+    const ForestTree t = trees[m];
     if (threadIdx.x == 0) {
+        s_slot = kNone;
+        const uint32_t* b = bounds + (size_t)m * 12u;
         SNode r;
         for (int a = 0; a < 3; a++) {
-            r.lo[a] = f_unorder(s_b[a]); r.hi[a] = f_unorder(s_b[3 + a]);
-            r.cb[a] = s_b[6 + a]; r.cb[3 + a] = s_b[9 + a];
+            r.lo[a] = f_unorder(b[a]); r.hi[a] = f_unorder(b[3 + a]);
+            r.cb[a] = b[6 + a]; r.cb[3 + a] = b[9 + a];
         }
         r.first = t.first; r.count = t.count; r.left = kNone; r.parent = kNone;
         nodes[m] = r;
@@ -1009,8 +1044,13 @@ __global__ __launch_bounds__(kBlock) void k_forest_roots(const DevBox* __restric
     if (s_slot != kNone) { // the root's bins on level 0 (every replica)
         Bin e; e.count = 0;
         for (int a = 0; a < 3; a++) { e.lo[a] = 0xffffffffu; e.hi[a] = 0u; }
-        for (uint32_t k = threadIdx.x; k < replicas * 3 * kBins; k += kBlock) bins[(size_t)s_slot * replicas * 3 * kBins + k] = e;
+        for (uint32_t k = threadIdx.x; k < replicas * 3 * kBins; k += 64u) bins[(size_t)s_slot * replicas * 3 * kBins + k] = e;
     }
+}
+__global__ void k_forest_bounds_init(uint32_t* bounds, uint32_t n_words)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_words) bounds[i] = (i % 6u) < 3u ? 0xffffffffu : 0u;
 }
 // even-depth interior nodes become wide nodes; every node learns its tree (= the id of its root)
 __global__ void k_flag_forest(uint32_t n_nodes_cap, const Counters* __restrict__ ctr, const SNode* __restrict__ nodes, uint32_t* flag4, uint32_t* tree_of)
@@ -1315,7 +1355,8 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
 
 size_t sah_forest_workspace_bytes(uint32_t n, uint32_t n_trees)
 {
-    return make_layout(n + n_trees).total + align_up((size_t)(4 * ((size_t)n + n_trees) + 64 + n_trees) * 4, 256) + align_up((size_t)n_trees * 4, 256);
+    return make_layout(n + n_trees).total + align_up((size_t)(4 * ((size_t)n + n_trees) + 64 + n_trees) * 4, 256) + align_up((size_t)n_trees * 4, 256) +
+           align_up((size_t)n_trees * 12 * 4, 256); // (+ tree_of, tree_nodes, and 12 words of bounds per tree)
 }
 
 hipError_t sah_build_forest(hipStream_t s, const DevBox* boxes, uint32_t n, const ForestTree* trees, uint32_t n_trees, uint32_t largest_tree, void* workspace,
@@ -1348,6 +1389,7 @@ hipError_t sah_build_forest(hipStream_t s, const DevBox* boxes, uint32_t n, cons
     uint32_t* idx4 = (uint32_t*)(w + L.idx4);
     uint32_t* tree_of = (uint32_t*)(w + tree_of_off);
     uint32_t* tree_nodes = (uint32_t*)(w + tree_nodes_off);
+    uint32_t* tree_bounds = (uint32_t*)(w + tree_nodes_off + align_up((size_t)n_trees * 4, 256));
     hipError_t e = hipMemsetAsync(nodes, 0xff, (size_t)L.node_cap * sizeof(SNode), s);
     if (e == hipSuccess) e = hipMemsetAsync(stamp, 0xff, (size_t)L.node_cap, s);
     if (e == hipSuccess) e = hipMemsetAsync(tree_nodes, 0, (size_t)n_trees * 4, s);
@@ -1358,7 +1400,12 @@ hipError_t sah_build_forest(hipStream_t s, const DevBox* boxes, uint32_t n, cons
     const uint32_t bin_groups = blocks(n);
     auto level_replicas = [&](int l) { return std::max(1u, std::min(32u, bin_groups / (8u * level_ub(l)))); };
     hipLaunchKernelGGL(k_forest_init, dim3(1), dim3(64), 0, s, ctr, n_trees);
-    hipLaunchKernelGGL(k_forest_roots, dim3(n_trees), dim3(kBlock), 0, s, boxes, trees, ctr, nodes, order[0], nop[0], active[0], small, bin_slot, stamp, bins[0], level_replicas(0), small_cap);
+    hipLaunchKernelGGL(k_forest_bounds_init, dim3(blocks(n_trees * 12u)), dim3(kBlock), 0, s, tree_bounds, n_trees * 12u);
+    {
+        const uint32_t chunk = (uint32_t)align_up(((size_t)n + kForestBoundsBlocks - 1) / kForestBoundsBlocks, kBlock);
+        hipLaunchKernelGGL(k_forest_bounds, dim3(blocks(n, chunk)), dim3(kBlock), 0, s, boxes, trees, n_trees, n, chunk, order[0], nop[0], tree_bounds);
+    }
+    hipLaunchKernelGGL(k_forest_roots, dim3(n_trees), dim3(64), 0, s, trees, tree_bounds, ctr, nodes, active[0], small, bin_slot, stamp, bins[0], level_replicas(0), small_cap);
     int cur = 0, level = 0;
     auto run_level = [&]() {
         const uint32_t par = (uint32_t)(level & 1);
