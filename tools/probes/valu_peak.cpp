@@ -126,12 +126,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_stream(float* out, 
 #define I(k) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(u) : "v"(v[k]));
             BODY32(I)
 #undef I
-        } else if (KIND == 24) { // a mask combined on the scalar unit into vcc, then a VOP2 select on it
-            const uint64_t m1 = 0x5555aaaa5555aaaaull ^ (uint64_t)u, m2 = 0x0f0f0f0ff0f0f0f0ull | (uint64_t)u;
-#define I(k) asm volatile("s_and_b64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(a), "s"(m1), "s"(m2) : "vcc");
-            BODY8(I) BODY8(I)
-#undef I
-        } else if (KIND == 25) { // the same with the mask in another SGPR pair and the VOP3 form
+        } else if (KIND == 25) { // a mask combined on the scalar unit into an SGPR pair, then a VOP3 select on it
             const uint64_t m1 = 0x5555aaaa5555aaaaull ^ (uint64_t)u, m2 = 0x0f0f0f0ff0f0f0f0ull | (uint64_t)u;
             uint64_t m3;
 #define I(k) asm volatile("s_and_b64 %1, %3, %4\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(v[k]), "=&s"(m3) : "v"(a), "s"(m1), "s"(m2) : "scc");
@@ -200,7 +195,6 @@ int main()
     run<13>("v_cndmask_b32_e64 (sgpr mask)", 32, d_out, d_cyc, e0, e1);
     run<15>("v_cndmask_b32 (vcc set, dst!=src)", 32, d_out, d_cyc, e0, e1);
     run<14>("v_cmp + v_cndmask (x16 pairs)", 32, d_out, d_cyc, e0, e1);
-    run<24>("s_and_b64 vcc + v_cndmask vcc (x16)", 32, d_out, d_cyc, e0, e1);
     run<25>("s_and_b64 sN + v_cndmask_e64 sN (x16)", 32, d_out, d_cyc, e0, e1);
     run<26>("v_cmp vcc, add, mul, v_cndmask vcc (x8)", 32, d_out, d_cyc, e0, e1);
     run<16>("v_min_f32", 32, d_out, d_cyc, e0, e1);
