@@ -847,10 +847,15 @@ int build_instances(Instance* I, Instance* T)
         T->n_tlas_nodes = tlas.nodes.size();
         std::vector<Node4Q> qn(tlas.nodes.size());
         for (size_t k = 0; k < qn.size(); k++) qn[k] = quantize_node(tlas.nodes[k]);
-        if ((rc = upload(I, T->d_tlas_nodes, qn.data(), qn.size()))) return rc;
+        // on the stream of the instance whose TLAS this is (a frame slot builds its own): upload() copies on the OWNER's stream, and the expansion
+        // below — on the slot's — read nodes that had not arrived yet (tests/soak_gpu.py, round 4: host builder x frame slots, in a process
+        // whose earlier backends had left other bytes in the recycled allocation)
+        HIP_TRY(I, T->d_tlas_nodes.ensure(qn.size()));
+        if (!qn.empty()) HIP_TRY(I, hipMemcpyAsync(T->d_tlas_nodes.ptr, qn.data(), qn.size() * sizeof(Node4Q), hipMemcpyHostToDevice, s));
         HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, s));
         launch_expand_nodes(s, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, (uint32_t)qn.size());
-        if ((rc = upload(I, T->d_tlas_prims, prims.data(), prims.size()))) return rc;
+        HIP_TRY(I, T->d_tlas_prims.ensure(prims.size()));
+        if (!prims.empty()) HIP_TRY(I, hipMemcpyAsync(T->d_tlas_prims.ptr, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(I, hipGetLastError());
         HIP_TRY(I, hipStreamSynchronize(s));
     }

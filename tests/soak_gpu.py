@@ -2,7 +2,11 @@
 Random soups x instance counts x builders x frame slots x frame batches x odd resolutions: ray queries (closest / any hit, incl. axis-parallel rays) and two
 accumulated frames must be bit-identical; then two large atrium scenes.  Round 1: 300 + 2 configurations, then 200 + 2 and, on the final kernels of the round, 300 + 2 more with frame batches and downloads in the mix: 0 mismatches.
 Round 2 (blue-noise tables, sorted extension rays, single-material edits with `changed` bits and rfw_hip_render_samples in the mix): 250 + 2 configurations, 0 mismatches;
-on the final build of the round 300 + 2 more and 60 random times of an animated, twice-instantiated glTF document: 0 mismatches."""
+on the final build of the round 300 + 2 more and 60 random times of an animated, twice-instantiated glTF document: 0 mismatches.
+Round 4 (packets, per-octant node copies, heads-first uploads): the first 200 configurations found 26 mismatching images, every one of them host
+builder x three frame slots — the per-slot TLAS of the host builder was uploaded on the owner's stream and expanded into its octant copies on the
+slot's, visible only in a process whose earlier backends had dirtied the recycled allocation (now a GPU test:
+test_backends_one_after_the_other_in_one_process).  After the fix 300 + 2 + 60: 0 mismatches.  A failing configuration now names its failed checks."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,13 +36,17 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)] * rng.choice([-1, 1], (50, 1))  # axis-parallel
     g, r = be.intersect(o, d), orc.intersect(o, d)
+    failed = []   # names of the checks that failed
     ok = np.array_equal(g["inst"], r["inst"]) and np.array_equal(g["tri"], r["tri"]) and np.array_equal(g["t"][r["inst"] >= 0].view(np.uint32), r["t"][r["inst"] >= 0].view(np.uint32))
+    if not ok: failed.append("intersect")
     tm = rng.uniform(0.05, 9.0, 20000).astype(np.float32)
-    ok = ok and np.array_equal(be.occludes(o, d, tm), orc.occludes(o, d, tm))
+    c = np.array_equal(be.occludes(o, d, tm), orc.occludes(o, d, tm)); ok = ok and c
+    if not c: failed.append("occludes")
     view = scene.view(w, h)
     for _ in range(2):
         be.render(view); orc.render(view)
-    ok = ok and np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    c = np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)); ok = ok and c
+    if not c: failed.append("two frames")
     if mb:  # a batch of independent views in one launch per stage: every frame == the oracle's render of that view
         views = []
         for k in range(int(rng.integers(2, mb + 1))):
@@ -48,9 +56,11 @@ for it in range(int(os.environ.get("ITERS", "24"))):
         host = be.host_frame()
         for k, v in enumerate(views):
             orc.reset(); orc.render(v)
-            ok = ok and np.array_equal(be.accumulator_at(k).view(np.uint32), orc.accumulator().view(np.uint32))
+            c = np.array_equal(be.accumulator_at(k).view(np.uint32), orc.accumulator().view(np.uint32)); ok = ok and c
+            if not c: failed.append(f"batch frame {k}")
             be.download_frame(host, frame=k); be.wait_downloads(host)
-            ok = ok and np.array_equal(host.view(np.uint32), orc.framebuffer().view(np.uint32))
+            c = np.array_equal(host.view(np.uint32), orc.framebuffer().view(np.uint32)); ok = ok and c
+            if not c: failed.append(f"batch download {k}")
     if mb:  # k samples of one image in one launch per stage: the sum of the per-sample images, i.e. k render() calls up to rounding
         k = int(rng.integers(2, mb + 1))
         be.render_samples(view, k)     # a different call sequence after the batch above: a new image of `view`
@@ -58,9 +68,10 @@ for it in range(int(os.environ.get("ITERS", "24"))):
         for _ in range(k):
             orc.render(view)
         ga, ra = be.accumulator().astype(np.float64), orc.accumulator().astype(np.float64)
-        ok = ok and np.linalg.norm(ga - ra) <= 1e-6 * max(np.linalg.norm(ra), 1e-30)
+        c = np.linalg.norm(ga - ra) <= 1e-6 * max(np.linalg.norm(ra), 1e-30); ok = ok and c
+        if not c: failed.append("samples")
     s, so = be.frame_stats(), orc.stats()
-    print(it, "tris", tris, "batch", mb, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "OK" if ok else "MISMATCH", flush=True)
+    print(it, "tris", tris, "batch", mb, "inst", inst, "builder", builder, "fif", fif, f"{w}x{h}", "bn", bn, "OK" if ok else "MISMATCH " + ", ".join(failed), flush=True)
     bad += 0 if ok else 1
     be.close()
 print("mismatches:", bad, "time", round(time.time() - t0, 1))

@@ -639,3 +639,28 @@ def test_resent_meshes_upload_heads_first_and_give_the_same_image():
     after = counters(be)
     assert after[1] == before[1] + 3 and after[2] >= before[2] + 2, (before, after)   # (the first re-send registers the copy and already goes heads first)
     be.close()
+
+
+def test_backends_one_after_the_other_in_one_process():
+    """Every builder x (no frame slots, three) on small scenes, one backend after the other in ONE process, two frames back to back against the
+    oracle.  A later backend gets device memory an earlier one has used: what a fresh process hands out zeroed is not zero here.  Found by
+    tests/soak_gpu.py in round 4: the host builder's per-slot TLAS was uploaded on the owner's stream and expanded into its octant copies on the
+    slot's — the expansion could read nodes that had not arrived, and only a recycled allocation showed it."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    rng = np.random.default_rng(7)
+    w, h = 96, 70
+    for rep in range(2):
+        for builder in (0, 1, 2, 3):
+            for fif in (3, 0):
+                tris, inst, seed = int(rng.integers(300, 5000)), int(rng.integers(1, 20)), int(rng.integers(1, 1 << 30))
+                scene = Scene().build("soup", tris, inst, 0.0, seed)
+                scene.set_aspect(w / h)
+                be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif)
+                orc = Oracle(w, h, threads=8, max_path_length=3)
+                scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+                view = scene.view(w, h)
+                for _ in range(2):
+                    be.render(view); orc.render(view)
+                assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), (rep, builder, fif, tris, inst)
+                be.close()
