@@ -113,3 +113,55 @@ for it, tris in enumerate((60000, 262267)):
     ok = ok and np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
     print("large", tris, "OK" if ok else "MISMATCH", (g["inst"] >= 0).mean(), flush=True)
     be.close()
+# round 4: re-sent meshes (registered host copies, heads-first uploads on two streams, incremental edits from registered copies) with frames in
+# flight on frame slots — every image against a single-slot backend that is given the same scene state synchronously
+scene = Scene().build("atrium", 700000, 1, 0.0, 21)
+w, h = 160, 90
+scene.set_aspect(w / h)
+views = []
+for i in range(4):
+    scene.set_camera([0.6 * i - 1.0, 1.6, -6.0 + 0.3 * i], [0.05 * i, 0.0, 1.0], fov=55.0, aspect=w / h)
+    views.append(scene.view(w, h))
+be = HipBackend.init(w, h, 1.0, max_path_length=2, frames_in_flight=3)
+ref = HipBackend.init(w, h, 1.0, max_path_length=2)
+scene.sync(be); scene.mark_all_changed(); scene.sync(ref)
+rbad = 0
+def edit(kind):
+    if kind == 0:
+        scene.mark_all_changed()                                   # everything re-sent: the full build, heads first
+    elif kind == 1:
+        scene.replace_mesh_with_sphere(int(rng.integers(1, 65)), int(rng.integers(2, 5)), int(rng.integers(1, 1000)))   # one mesh: incremental
+    elif kind == 2:
+        for _ in range(int(rng.integers(2, 6))):
+            scene.replace_mesh_with_sphere(int(rng.integers(1, 65)), int(rng.integers(2, 5)), int(rng.integers(1, 1000)))
+    else:
+        scene.replace_mesh_with_sphere(int(rng.integers(1, 65)), int(rng.integers(2, 5)), int(rng.integers(1, 1000)))
+        scene.mark_all_changed()
+pending = None   # (iteration, kind, host frames of `be`, reference frames): compared one iteration LATER, after the next synchronize has been issued
+n_resend = int(os.environ.get("RESEND_ITERS", "40"))
+for it in range(n_resend + 1):
+    if it < n_resend:
+        kind = int(rng.integers(0, 4))
+        edit(kind)
+        scene.sync(be)                                             # the previous iteration's frames may still be in flight on the slots
+        frames = [be.host_frame() for _ in views]
+        for v, dst in zip(views, frames):
+            be.render(v); be.download_frame(dst)                   # nothing waits
+    if pending is not None:
+        pit, pkind, pframes, prefs = pending
+        be.wait_downloads()
+        okr = all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(pframes, prefs))
+        for dst in pframes:
+            be.free_host_frame(dst)
+        print("resend", pit, "kind", pkind, "OK" if okr else "MISMATCH", flush=True)
+        rbad += 0 if okr else 1
+        pending = None
+    if it < n_resend:
+        scene.mark_all_changed(); scene.sync(ref)
+        refs = []
+        for v in views:
+            ref.reset_accumulation(); ref.render(v); ref.device_synchronize()
+            refs.append(ref.framebuffer().copy())
+        pending = (it, kind, frames, refs)
+print("re-sent meshes with frames in flight, mismatches:", rbad)
+be.close(); ref.close()
