@@ -42,6 +42,8 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     tm = rng.uniform(0.05, 9.0, 20000).astype(np.float32)
     c = np.array_equal(be.occludes(o, d, tm), orc.occludes(o, d, tm)); ok = ok and c
     if not c: failed.append("occludes")
+    if rng.integers(0, 3) == 0:   # round 4: a thin-lens camera (every camera ray of a packet has its own origin)
+        scene.set_camera([0.3, 0.4, -5.0], [0.05, -0.02, 1.0], fov=50.0, aperture=float(rng.choice([0.03, 0.3])), aspect=w / h)
     view = scene.view(w, h)
     for _ in range(2):
         be.render(view); orc.render(view)

@@ -276,3 +276,27 @@ def test_shadow_order_option_never_changes_the_image(kind, a, b):
         visits.append(s["nodes_visited"][2] if "nodes_visited" in s else None)
     assert visits[0] is None or len(set(visits)) > 1      # the orders are really different traversals
     be.close()
+
+
+@pytest.mark.parametrize("aperture", [0.04, 0.4])
+def test_thin_lens_camera_matches_oracle(aperture):
+    """ray_gen.comp:93-135: a lens of nine blades, the lens point drawn per pixel and sample — with the blue-noise tables for the first 256 samples
+    and xorshift without them.  Every camera ray then has an origin of its own, which the wavefront packets must not care about
+    (option packet_trace 0 / 1 give the same image)."""
+    from rfw_rs_amd import HipBackend
+    w, h = 136, 72
+    scene, be, orc = make("soup", w, h, 2200, 5, seed=41, max_path_length=3, frames_in_flight=2)
+    scene.set_camera([0.3, 0.4, -5.0], [0.05, -0.02, 1.0], fov=50.0, aperture=aperture, aspect=w / h)
+    view = scene.view(w, h)
+    assert view.lens_size > 0.0
+    for tables in (False, True):
+        if tables:
+            t = np.random.default_rng(5).integers(0, 256, 5 * 65536).astype(np.uint32)
+            be.set_blue_noise(t); orc.set_blue_noise(t)
+        for pk in (1, 0):
+            be.set_option("packet_trace", pk)
+            be.reset_accumulation(); orc.reset()
+            for _ in range(3):
+                be.render(view); orc.render(view)
+            assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), (aperture, tables, pk)
+    be.close()

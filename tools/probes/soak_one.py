@@ -26,7 +26,10 @@ print("intersect inst", np.array_equal(g["inst"], r["inst"]), "tri", np.array_eq
       "differing rays", int((g["inst"] != r["inst"]).sum()))
 tm = rng.uniform(0.05, 9.0, 20000).astype(np.float32)
 print("occludes", np.array_equal(be.occludes(o, d, tm), orc.occludes(o, d, tm)))
+if os.environ.get("APERTURE"):
+    scene.set_camera([0.3, 0.4, -5.0], [0.05, -0.02, 1.0], fov=50.0, aperture=float(os.environ["APERTURE"]), aspect=w / h)
 view = scene.view(w, h)
+print("lens_size", view.lens_size)
 if os.environ.get("BACK_TO_BACK"):
     for _ in range(2):
         be.render(view); orc.render(view)
