@@ -66,7 +66,13 @@ RFW_DI uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv
 // ray, so it needs no test of its own.
 // a: nx[4] ny[4] nz[4] fx[4]   b: fy[4] fz[4] child[4] pad[4]  (the 128-B node, in scalar registers)
 // m[i] = lanes whose ray enters child i before t (6 fma + max3 + min3 + min + 2 compares per child)
-RFW_DI void slab4(const su16 a, const su16 b, const SlabRay& r, const float t, const uint64_t packet, uint64_t (&m)[4])
+#ifndef RFW_PACKET_ONE_COMPARE
+#define RFW_PACKET_ONE_COMPARE 1
+#endif
+#ifndef RFW_PACKET_NAN_MASK
+#define RFW_PACKET_NAN_MASK 1 // closest hit: the lanes outside the packet carry a NaN ray (they fail every compare) instead of being masked out of every vote
+#endif
+template <bool MASK> RFW_DI void slab4(const su16 a, const su16 b, const SlabRay& r, const float t, const uint64_t packet, uint64_t (&m)[4])
 {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -75,7 +81,13 @@ RFW_DI void slab4(const su16 a, const su16 b, const SlabRay& r, const float t, c
                                          __builtin_fmaf(bitsf(a[8 + i]), r.inv.z, r.bn.z));
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bitsf(a[12 + i]), r.inv.x, r.bf.x), __builtin_fmaf(bitsf(b[i]), r.inv.y, r.bf.y)),
                                          __builtin_fmaf(bitsf(b[4 + i]), r.inv.z, r.bf.z));
-        m[i] = ballot64(__builtin_fminf(tf, t) >= tn) & ballot64(tf >= 0.0f) & packet;
+#if RFW_PACKET_ONE_COMPARE
+        // min(tf, t) >= max(tn, 0)  <=>  min(tf, t) >= tn  &&  tf >= 0  (t >= 0): one vector max instead of a compare and a scalar AND
+        m[i] = ballot64(__builtin_fminf(tf, t) >= __builtin_fmaxf(tn, 0.0f));
+#else
+        m[i] = ballot64(__builtin_fminf(tf, t) >= tn) & ballot64(tf >= 0.0f);
+#endif
+        if (MASK) m[i] &= packet;
     }
 }
 
@@ -88,7 +100,10 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
 {
     uint32_t stack = 0u; // the shared stack: entry k = lane k of this register
     occluded = false;
-    uint64_t todo = ballot64(active);
+    // a direction of exact zeros or with a NaN makes every plane distance NaN, and NaNs are IGNORED by min / max: with the single compare of
+    // slab4 such a ray would enter every box.  It hits nothing (as in traverse()): it is not part of any packet
+    const bool sane = (D.x == D.x) && (D.y == D.y) && (D.z == D.z) && (D.x != 0.0f || D.y != 0.0f || D.z != 0.0f);
+    uint64_t todo = ballot64(active && sane);
     const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t world_oct = octant_of(slab_inv(D));
     if (COUNT && active) tc.nodes++; // the root
@@ -133,7 +148,10 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                 if (COUNT && in_mask(packet)) { tc.insts++; tc.nodes++; }
                 cur = 0u;
             }
-            const SlabRay r = slab_ray(o, d);
+            SlabRay r = slab_ray(o, d);
+            constexpr bool kNanMask = RFW_PACKET_NAN_MASK && !ANY_HIT; // (any hit: the packet shrinks inside the loop as rays find their occluders)
+            // a lane outside the packet leaves every box at -inf, before it could enter it: min(-inf, t) >= max(tn, 0) is false whatever tn is
+            if (kNanMask && !in_mask(packet)) { r.inv = mk3(1.0f); r.bf = mk3(-INFINITY); }
             const uint32_t lead = first_lane(packet); // (COUNT: the lane that counts the wavefront-level steps)
             bool leave = false, finished = false;
             const uint32_t floor_sp = in_blas ? blas_sp : 0u; // stack height at which this space is exhausted
@@ -141,10 +159,13 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
             // test) comes back as kInvalidRef and is skipped
             auto pop = [&]() {
                 cur = kInvalidRef;
-                while (sp != floor_sp) {
+                if (sp != floor_sp) {
                     sp--;
                     cur = lane_read(stack, sp);
-                    if (cur != kInvalidRef) break;
+                    while (__builtin_expect(cur == kInvalidRef && sp != floor_sp, 0)) { // (never taken since degenerate rays stay out of the packets)
+                        sp--;
+                        cur = lane_read(stack, sp);
+                    }
                 }
             };
             if (cur == kInvalidRef) pop(); // back in world space behind an instance: carry on with what the stack holds
@@ -156,7 +177,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     const scalar_ptr16 np = (scalar_ptr16)(uintptr_t)(nodes + cur);
                     const su16 a = np[0], b = np[1];
                     uint64_t m[4];
-                    slab4(a, b, r, t, packet, m);
+                    slab4<!kNanMask>(a, b, r, t, packet, m);
                     const uint32_t c[4] = {b[8], b[9], b[10], b[11]};
                     if (COUNT) {
                         // per lane: the nodes and triangles a traversal of its own would go on to visit (the children whose boxes IT hits)
@@ -171,14 +192,15 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     // The children are stored front to back for this octant: the hit ones go on the stack in reverse (far first: in forward) order,
                     // without a branch — every child is written to the top slot and the slot only advances past the hit ones — and the
                     // nearest comes straight back off the top.
-                    if (sp + 4u > kPacketStack) *sc.overflow_flag = 1u; // dropped: the host reports RFW_HIP_E_STATE
-                    else {
+                    // (a stack that would not take four more entries: flagged — the host reports RFW_HIP_E_STATE — and the top entries are
+                    // overwritten; the pushes themselves stay unconditional: as the else-branch of this test they made the compiler keep two
+                    // copies of the stack register and move one into the other on every trip)
+                    if (__builtin_expect(sp + 4u > kPacketStack, 0)) { *sc.overflow_flag = 1u; sp = kPacketStack - 4u; }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int i = (ANY_HIT && FAR_FIRST) ? j : 3 - j;
-                            lane_write(stack, c[i], sp);
-                            asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0" : "+s"(sp) : "s"(m[i]) : "scc"); // sp += (m[i] != 0), on the scalar unit (the compiler converts the bool on the vector unit)
-                        }
+                    for (int j = 0; j < 4; j++) {
+                        const int i = (ANY_HIT && FAR_FIRST) ? j : 3 - j;
+                        lane_write(stack, c[i], sp);
+                        asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0" : "+s"(sp) : "s"(m[i]) : "scc"); // sp += (m[i] != 0), on the scalar unit (the compiler converts the bool on the vector unit)
                     }
                     pop();
                 }
