@@ -136,6 +136,54 @@ template <int KIND> __global__ __launch_bounds__(256) void k_stream(float* out, 
 #define I(k) asm volatile("v_cmp_ge_f32 vcc, %0, %2\n\tv_add_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(a), "v"(b) : "vcc");
             BODY8(I)
 #undef I
+        } else if (KIND == 27) { // 64-bit address arithmetic of the per-lane node fetch
+            uint64_t q[4] = {u, u + 1u, u + 2u, u + 3u};
+#define I(k) asm volatile("v_lshl_add_u64 %0, %0, 6, %1" : "+v"(q[k & 3]) : "v"(q[(k + 1) & 3]));
+            BODY32(I)
+#undef I
+            u += (uint32_t)(q[0] + q[1] + q[2] + q[3]);
+        } else if (KIND == 28) {
+            uint64_t q[4] = {u, u + 1u, u + 2u, u + 3u};
+#define I(k) asm volatile("v_lshlrev_b64 %0, 6, %0" : "+v"(q[k & 3]));
+            BODY32(I)
+#undef I
+            u += (uint32_t)(q[0] + q[1] + q[2] + q[3]);
+        } else if (KIND == 29) {
+            uint64_t q[4] = {u, u + 1u, u + 2u, u + 3u};
+#define I(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(q[k & 3]) : "v"(u) : "vcc");
+            BODY32(I)
+#undef I
+            u += (uint32_t)(q[0] + q[1] + q[2] + q[3]);
+        } else if (KIND == 30) {
+            uint32_t w[8]; for (int i = 0; i < 8; i++) w[i] = u + i;
+#define I(k) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(w[k]) : "v"(u) : "vcc");
+            BODY32(I)
+#undef I
+            u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        } else if (KIND == 31) {
+            uint32_t w[8]; for (int i = 0; i < 8; i++) w[i] = u + i;
+#define I(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(w[k]) : "v"(u));
+            BODY32(I)
+#undef I
+            u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        } else if (KIND == 32) {
+            uint32_t w[8]; for (int i = 0; i < 8; i++) w[i] = u + i;
+#define I(k) asm volatile("v_mov_b32 %0, %1" : "=v"(w[k]) : "v"(u));
+            BODY32(I)
+#undef I
+            u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        } else if (KIND == 33) {
+            uint32_t w[8]; for (int i = 0; i < 8; i++) w[i] = u + i;
+#define I(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(w[k]) : "v"(u));
+            BODY32(I)
+#undef I
+            u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        } else if (KIND == 34) {
+            uint32_t w[8]; for (int i = 0; i < 8; i++) w[i] = u + i;
+#define I(k) asm volatile("v_lshl_add_u32 %0, %0, 6, %1" : "+v"(w[k]) : "v"(u));
+            BODY32(I)
+#undef I
+            u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
         } else if (KIND == 12) { // VALU and SALU interleaved 1 : 1 (do they share an issue slot?)
             uint32_t s = u;
 #define I(k) asm volatile("v_fma_f32 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 3" : "+v"(v[k]), "+s"(s) : "v"(a), "v"(b) : "scc");
@@ -205,6 +253,14 @@ int main()
     run<21>("v_cmp_ge_f32_e64 -> sgpr", 32, d_out, d_cyc, e0, e1);
     run<22>("v_mad_u32_u24", 32, d_out, d_cyc, e0, e1);
     run<23>("v_readlane_b32", 32, d_out, d_cyc, e0, e1);
+    run<27>("v_lshl_add_u64", 32, d_out, d_cyc, e0, e1);
+    run<28>("v_lshlrev_b64", 32, d_out, d_cyc, e0, e1);
+    run<29>("v_mad_u64_u32", 32, d_out, d_cyc, e0, e1);
+    run<30>("v_add_co_u32", 32, d_out, d_cyc, e0, e1);
+    run<31>("v_add_u32", 32, d_out, d_cyc, e0, e1);
+    run<32>("v_mov_b32", 32, d_out, d_cyc, e0, e1);
+    run<33>("v_mul_lo_u32", 32, d_out, d_cyc, e0, e1);
+    run<34>("v_lshl_add_u32", 32, d_out, d_cyc, e0, e1);
     run<10>("s_add_u32", 32, d_out, d_cyc, e0, e1);
     run<11>("cvt+fma+max3+cmp (x8)", 32, d_out, d_cyc, e0, e1);
     run<12>("v_fma_f32 + s_add_u32 (x16 pairs)", 32, d_out, d_cyc, e0, e1);
