@@ -66,6 +66,9 @@ RFW_DI uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv
 // ray, so it needs no test of its own.
 // a: nx[4] ny[4] nz[4] fx[4]   b: fy[4] fz[4] child[4] pad[4]  (the 128-B node, in scalar registers)
 // m[i] = lanes whose ray enters child i before t (6 fma + max3 + min3 + min + 2 compares per child)
+#ifndef RFW_PACKET_DIRECT_NEAR
+#define RFW_PACKET_DIRECT_NEAR 1
+#endif
 #ifndef RFW_PACKET_ONE_COMPARE
 #define RFW_PACKET_ONE_COMPARE 1
 #endif
@@ -196,6 +199,18 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     // overwritten; the pushes themselves stay unconditional: as the else-branch of this test they made the compiler keep two
                     // copies of the stack register and move one into the other on every trip)
                     if (__builtin_expect(sp + 4u > kPacketStack, 0)) { *sc.overflow_flag = 1u; sp = kPacketStack - 4u; }
+#if RFW_PACKET_DIRECT_NEAR
+                    // ... except the one that would come straight back: when the first child of the visiting order is hit it IS the next node
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const int i = (ANY_HIT && FAR_FIRST) ? j : 3 - j;
+                        lane_write(stack, c[i], sp);
+                        asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0" : "+s"(sp) : "s"(m[i]) : "scc"); // sp += (m[i] != 0), on the scalar unit (the compiler converts the bool on the vector unit)
+                    }
+                    constexpr int kFirst = (ANY_HIT && FAR_FIRST) ? 3 : 0;
+                    if (m[kFirst] != 0ull) cur = c[kFirst];
+                    else pop();
+#else
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int i = (ANY_HIT && FAR_FIRST) ? j : 3 - j;
@@ -203,6 +218,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                         asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0" : "+s"(sp) : "s"(m[i]) : "scc"); // sp += (m[i] != 0), on the scalar unit (the compiler converts the bool on the vector unit)
                     }
                     pop();
+#endif
                 }
                 if (cur == kInvalidRef) { // the space is exhausted
                     if (in_blas) leave = true;
