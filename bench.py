@@ -768,6 +768,12 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
         if steady:
             sb = max(steady, key=lambda k: steady[k]["frac"])
             r["timed_region"] = {"bound": sb, "frac": steady[sb]["frac"], "ms_per_frame": round(ms_step, 4), "ceilings": steady}
+        if ISSUE_MEASURED.get("fma_only") and bound == "valu_issue":
+            # `peak` above is the guide's figure; what THIS device issued in THIS job (rfw_hip_issue_probe), and the fractions of it
+            r["measured_peak"] = dict(ISSUE_MEASURED, unit=c["unit"])
+            r["frac_of_measured_peak"] = {"kernel_alone": {k: round(c["achieved"] / v, 4) for k, v in ISSUE_MEASURED.items()}}
+            if steady and "valu_issue" in steady:
+                r["frac_of_measured_peak"]["timed_region"] = {k: round(steady["valu_issue"]["achieved"] / v, 4) for k, v in ISSUE_MEASURED.items()}
     else:
         # no committed counters for this configuration: only the contract's rate can be given; `frac` stays null rather than a number above 1
         r.update({"bound": None, "kernel": dom, "achieved": contract["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": None, "traffic": None, "contract": contract})
