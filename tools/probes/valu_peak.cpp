@@ -184,6 +184,39 @@ template <int KIND> __global__ __launch_bounds__(256) void k_stream(float* out, 
             BODY32(I)
 #undef I
             u += w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        } else if (KIND == 35) { // mixed-precision FMA: source 0 an f16 half of a register, converted on the fly
+#define I(k) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v[k]) : "v"(u), "v"(a));
+            BODY32(I)
+#undef I
+        } else if (KIND == 36) { // ... the high half
+#define I(k) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[k]) : "v"(u), "v"(a));
+            BODY32(I)
+#undef I
+        } else if (KIND == 37) {
+#define I(k) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(v[k]) : "v"(u));
+            BODY32(I)
+#undef I
+        } else if (KIND == 38) { // one child of the per-lane node test as it is: 6 cvt, 3 pk_fma, max, min, min3, max3, cmp (14 instructions)
+            typedef float v2 __attribute__((ext_vector_type(2)));
+            v2 p[3]; const v2 pa = {a, a}, pb = {b, b};
+            for (int r = 0; r < 2; r++) {
+                asm volatile("v_cvt_f32_ubyte0 %0, %6\n\tv_cvt_f32_ubyte1 %1, %6\n\tv_cvt_f32_ubyte2 %2, %6\n\tv_cvt_f32_ubyte3 %3, %6\n\tv_cvt_f32_ubyte0 %4, %6\n\tv_cvt_f32_ubyte1 %5, %6"
+                             : "=v"(p[0].x), "=v"(p[0].y), "=v"(p[1].x), "=v"(p[1].y), "=v"(p[2].x), "=v"(p[2].y) : "v"(u));
+                asm volatile("v_pk_fma_f32 %0, %0, %3, %4\n\tv_pk_fma_f32 %1, %1, %3, %4\n\tv_pk_fma_f32 %2, %2, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(pa), "v"(pb));
+                asm volatile("v_max_f32 %0, %2, %4\n\tv_min_f32 %1, %3, %5\n\tv_min3_f32 %1, %1, %7, %8\n\tv_max3_f32 %0, %0, %6, 0\n\tv_cmp_ge_f32 vcc, %1, %0"
+                             : "=&v"(v[6]), "=&v"(v[7]) : "v"(p[0].x), "v"(p[0].y), "v"(p[1].x), "v"(p[1].y), "v"(p[2].x), "v"(p[2].y), "v"(a) : "vcc");
+            }
+            v[0] += p[0].x;
+        } else if (KIND == 39) { // ... with the planes as f16 halves read by v_fma_mix_f32: 6 fma_mix, max, min, min3, max3, cmp (11 instructions)
+            float q[6];
+#define I(k) asm volatile("v_fma_mix_f32 %0, %8, %9, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %8, %9, %10 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                          "v_fma_mix_f32 %2, %11, %9, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %11, %9, %10 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                          "v_fma_mix_f32 %4, %8, %10, %9 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %11, %10, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                          "v_max_f32 %6, %0, %2\n\tv_min_f32 %7, %1, %3\n\tv_min3_f32 %7, %7, %5, %9\n\tv_max3_f32 %6, %6, %4, 0\n\tv_cmp_ge_f32 vcc, %7, %6" \
+                          : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(u), "v"(a), "v"(b), "v"(u ^ 0x3c003c00u) : "vcc");
+            I(0) I(1)
+#undef I
+            v[0] += q[0];
         } else if (KIND == 12) { // VALU and SALU interleaved 1 : 1 (do they share an issue slot?)
             uint32_t s = u;
 #define I(k) asm volatile("v_fma_f32 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 3" : "+v"(v[k]), "+s"(s) : "v"(a), "v"(b) : "scc");
@@ -261,6 +294,11 @@ int main()
     run<32>("v_mov_b32", 32, d_out, d_cyc, e0, e1);
     run<33>("v_mul_lo_u32", 32, d_out, d_cyc, e0, e1);
     run<34>("v_lshl_add_u32", 32, d_out, d_cyc, e0, e1);
+    run<35>("v_fma_mix_f32 (f16 lo source)", 32, d_out, d_cyc, e0, e1);
+    run<36>("v_fma_mix_f32 (f16 hi source)", 32, d_out, d_cyc, e0, e1);
+    run<37>("v_cvt_f32_f16", 32, d_out, d_cyc, e0, e1);
+    run<38>("node test child, bytes (14 instr x2)", 28, d_out, d_cyc, e0, e1);
+    run<39>("node test child, f16 + fma_mix (11 instr x2)", 22, d_out, d_cyc, e0, e1);
     run<10>("s_add_u32", 32, d_out, d_cyc, e0, e1);
     run<11>("cvt+fma+max3+cmp (x8)", 32, d_out, d_cyc, e0, e1);
     run<12>("v_fma_f32 + s_add_u32 (x16 pairs)", 32, d_out, d_cyc, e0, e1);
