@@ -133,6 +133,21 @@ def test_bandwidth_probe_reports_a_plausible_hbm_rate():
     be.close()
 
 
+def test_issue_probe_reports_plausible_vector_issue_rates():
+    """rfw_hip_issue_probe: what bench.py holds the (issue-bound) trace kernels against beside the data-sheet peak.  The node test's instruction
+    mix — conversions, min / max, compares, packed FMAs — issues slower than v_fma_f32 alone, and neither exceeds one wave64 instruction per
+    2 cycles per SIMD at 2.4 GHz."""
+    from rfw_rs_amd import BackendError, HipBackend
+    be = HipBackend.init(64, 64, 1.0)
+    fma, mix = be.issue_probe(0, 2000), be.issue_probe(1, 2000)
+    assert 300.0 < mix < fma < 1300.0, (fma, mix)
+    with pytest.raises(BackendError):
+        be.issue_probe(2)
+    with pytest.raises(BackendError):
+        be.issue_probe(0, 0)
+    be.close()
+
+
 @pytest.mark.parametrize("builder", [2, 3])
 def test_device_built_trees_are_structurally_valid(builder):
     """Reads the device builders' f32 BVH4 back and checks it the way bvh_host.cpp's validate_bvh4 checks the host builder's: every
