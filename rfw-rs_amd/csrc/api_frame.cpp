@@ -115,6 +115,10 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
     c.rank = I->rank * I->substreams + sub; c.world = I->world * I->substreams; c.local_tiles = I->local_tiles_v;
     c.flags = I->flags;
+    {   // (api_internal.h: far outside the caches one ray per lane wins; RFW_PACKET_AUTO_MAX_TRIANGLES moves the limit, for tests)
+        static const uint64_t limit = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES") ? strtoull(getenv("RFW_PACKET_AUTO_MAX_TRIANGLES"), nullptr, 10) : kPacketAutoMaxTriangles;
+        if (S->packet_auto && S->n_tris > limit) c.flags &= ~kFlagPacketPrimary;
+    }
     c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
     c.batch = 1;
@@ -357,6 +361,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
     {
         const char* e = getenv("RFW_PACKET_TRACE"); // A/B runs: the default of option "packet_trace"
         const int pt = e ? atoi(e) : kDefaultPacketTrace;
+        I->packet_auto = e == nullptr;
         if (pt & 1) I->flags |= kFlagPacketPrimary;
         if (pt & 2) I->flags |= kFlagPacketShadow;
     }
@@ -623,6 +628,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     }
     else if (k == "packet_trace") { // which rays walk the tree as wavefront packets (traverse_packet.h): bit 0 camera rays, bit 1 the camera paths' shadow rays
         I->flags &= ~(kFlagPacketPrimary | kFlagPacketShadow);
+        I->packet_auto = false; // an explicit choice holds whatever the scene's size
         if ((int)value & 1) I->flags |= kFlagPacketPrimary;
         if ((int)value & 2) I->flags |= kFlagPacketShadow;
     }

@@ -214,6 +214,12 @@ struct InstList {
 // option "packet_trace" when nobody sets it: camera rays as packets (C4 5920 -> 7040 Mrays/s, C2 6980 -> 7780, C3 5160 -> 5850; the camera paths'
 // shadow rays are not coherent enough for it: k_shadow 0.32 -> 1.09 ms, EXPERIMENTS.md)
 constexpr int kDefaultPacketTrace = 1;
+// ... for scenes the caches still help with.  A packet fetches its next node through the scalar cache, one dependent load per wavefront and
+// step: far outside every cache (33.5 M triangles: 1.1 GB of nodes per octant copy) each of those is a trip to HBM and the one-ray-per-lane
+// kernel, with 64 independent loads in flight per wavefront, wins — `bench.py --workload atrium32m`: 2310 Mrays/s with packets, 3090 without
+// (round 3: 2630); tools/probes/packet_crossover.py puts the crossover between 8 M and 17 M triangles.  While nobody sets the option the
+// camera rays of a scene beyond this many triangles go one per lane.
+constexpr uint64_t kPacketAutoMaxTriangles = 12u << 20;
 enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow
@@ -356,6 +362,7 @@ struct Instance {
     bool layout_valid = false;                // a full device build has laid the buffers out; cleared by anything the incremental path does not cover
     bool node_counts_stale = false;           // n_blas_nodes is re-read lazily (get_scene_stats) after an incremental build
     uint32_t incremental_builds = 0, full_builds = 0, heads_first_builds = 0;
+    bool packet_auto = true; // option "packet_trace" / RFW_PACKET_TRACE not set: packets only below kPacketAutoMaxTriangles
     PinnedRing pins;
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;

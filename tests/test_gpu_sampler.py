@@ -300,3 +300,35 @@ def test_thin_lens_camera_matches_oracle(aperture):
                 be.render(view); orc.render(view)
             assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), (aperture, tables, pk)
     be.close()
+
+
+def test_camera_rays_leave_the_packets_when_the_scene_outgrows_the_caches():
+    """While nobody sets option packet_trace, camera rays walk the tree as packets only up to kPacketAutoMaxTriangles (api_internal.h: far
+    outside every cache a packet's one dependent scalar load per step loses to 64 independent vector loads per wavefront — bench.py
+    --workload atrium32m: 2310 Mrays/s with packets, 3060 without).  The limit is lowered through the environment here (it is read once per
+    process: a child process), and the traversal counters tell which kernel ran."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from rfw_rs_amd import HipBackend, Scene
+w, h = 128, 80
+scene = Scene().build("soup", 2500, 3, 0.0, 17); scene.set_aspect(w / h)
+view = scene.view(w, h)
+be = HipBackend.init(w, h, 1.0, max_path_length=2)
+be.set_option("count_traversal", 1)
+scene.sync(be)
+def run():
+    be.reset_accumulation(); be.render(view)
+    return be.accumulator().copy(), tuple(be.frame_stats()["nodes_visited"])
+img_auto, v_auto = run()
+be.set_option("packet_trace", 0); img0, v0 = run()
+be.set_option("packet_trace", 1); img1, v1 = run()
+assert np.array_equal(img_auto.view(np.uint32), img0.view(np.uint32)) and np.array_equal(img0.view(np.uint32), img1.view(np.uint32))
+print("VISITS", v_auto == v0, v_auto == v1)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for limit, want in (("1000", "VISITS True False"), ("100000000", "VISITS False True")):
+        env = dict(os.environ, RFW_PACKET_AUTO_MAX_TRIANGLES=limit)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert want in out.stdout, (limit, out.stdout, out.stderr[-500:])
