@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 # Every frame slot / renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by
 # default): two streams on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
+QUEUES_SET_BY_CALLER = "GPU_MAX_HW_QUEUES" in os.environ
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 2 else "16")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured for a float4 copy)
@@ -77,9 +78,63 @@ def dolly_views(base, n, step):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` without a launcher around it: start N ranks of this same script as CHILD processes, one per GPU, relay
+    rank 0's JSON line, and fail if any rank fails.  Runs BEFORE anything in this process touches the GPU (no torch.cuda / HIP call has
+    happened, torch is not even imported), and never replaces a process (no os.exec*): the parent only waits.  The children see
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exactly as `python -m torch.distributed.run` would set them."""
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RFW_BENCH_LAUNCHED_BY=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if not QUEUES_SET_BY_CALLER:
+            env.pop("GPU_MAX_HW_QUEUES", None)  # (this process chose it for ONE rank: a child chooses for its own WORLD_SIZE)
+        # rank 0's stdout is the job's stdout (the ONE JSON line); what the other ranks print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else 2))  # (fd 2: this process's stderr, inherited as is)
+    lines = []
+
+    def relay():
+        for raw in procs[0].stdout:
+            line = raw.decode(errors="replace")
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in alive:  # exactly the processes started above, by handle
+                    procs[o].terminate()
+        time.sleep(0.05)
+    t.join(timeout=10)
+    if rc == 0 and not any(l.startswith("{") for l in lines):
+        print("bench.py: every rank exited 0 but rank 0 printed no result line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher self-test (runs without a GPU): the ranks only meet (gloo), rank 0 prints who it saw; no scene, no rendering")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="atrium1m", choices=["atrium1m", "atrium262k", "cornell", "spheres10k", "atrium32m"],
@@ -117,25 +172,58 @@ def main():
     ap.add_argument("--mode-frames", type=int, default=48, help="frames per secondary mode")
     args = ap.parse_args()
 
+    # ---- who runs the ranks.  `--gpus N` is the number of ranks, whoever starts them:
+    #   * under a launcher (python -m torch.distributed.run: WORLD_SIZE = N in the environment) this process IS one of the N ranks;
+    #   * plain `python3 bench.py --gpus N` starts the N ranks itself, as child processes, before it touches the GPU (launch_ranks);
+    #   * `--gpus 1` is ONE rank whatever a stray WORLD_SIZE in the environment says.
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and env_world == 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus > 1 and env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks: refusing to report a number for a job of another size")
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    # RFW_BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets two ranks share one GPU (RCCL refuses duplicate devices) so the
+    # N > 1 code path can be exercised on a 1-GPU box; slabs are then staged through host memory.  Default: nccl (= RCCL).
+    dist_backend = os.environ.get("RFW_BENCH_DIST_BACKEND", "nccl")
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rendezvous_only:
+        # the launcher's self-test: the ranks meet over gloo and say who they are; nothing else of the bench runs (no GPU needed)
+        seen = [None]
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = [None] * dist.get_world_size()
+            dist.all_gather_object(seen, {"rank": dist.get_rank(), "pid": os.getpid(), "launched_by": os.environ.get("RFW_BENCH_LAUNCHED_BY")})
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = [{"rank": 0, "pid": os.getpid(), "launched_by": os.environ.get("RFW_BENCH_LAUNCHED_BY")}]
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": len(seen), "ranks_seen": len(seen), "ranks": seen}), flush=True)
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    # RFW_BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets two ranks share one GPU (RCCL refuses duplicate devices) so the
-    # N > 1 code path can be exercised on a 1-GPU box; slabs are then staged through host memory.  Default: nccl (= RCCL).
-    dist_backend = os.environ.get("RFW_BENCH_DIST_BACKEND", "nccl")
-    dev = (local_rank % torch.cuda.device_count()) if world > 1 else 0
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and dist_backend == "nccl":
+        raise SystemExit(f"bench.py: --gpus {world} but this node shows {n_dev} device(s) (RCCL takes one rank per device; RFW_BENCH_DIST_BACKEND=gloo is the "
+                         "test hook that lets ranks share a device)")
+    dev = (local_rank % n_dev) if world > 1 else 0
     torch.cuda.set_device(dev)
     if world > 1:
         if dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(dist_backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {world}")
 
     from rfw_rs_amd import HipBackend, Scene
 
@@ -286,6 +374,25 @@ def main():
 
     def view_rays(i):
         return rays_of_view_total[i % len(rays_of_view_total)]
+
+    # ---- who rendered: one record per rank — the device it ran on and the rays of ITS shard of view 0 — gathered over the process group.
+    # `n_gpus` in the result line is what this list shows, not what the command line asked for: a launcher detail that left N - 1 ranks
+    # out would otherwise print a single-GPU number under `n_gpus: N`.
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": dev, "device_name": props.name,
+          "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "rays_of_view_0": int(rays_of_view[0]), "tiles": be.shard_info()["tiles_local"]}
+    ranks_report = [me]
+    if world > 1:
+        ranks_report = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_report, me)
+    ranks_seen = len(ranks_report)
+    ranks_rendered = sum(1 for r_ in ranks_report if r_ and r_["rays_of_view_0"] > 0)
+    distinct_devices = len({(r_["device_uuid"] or r_["pci_bus_id"] or r_["device"]) for r_ in ranks_report})
+    if ranks_seen != world or ranks_rendered != world:
+        raise SystemExit(f"bench.py: --gpus {world}, but {ranks_seen} rank(s) met and {ranks_rendered} rendered a shard: refusing to print a line under n_gpus = {world}")
+    if world > 1 and dist_backend == "nccl" and distinct_devices != world:
+        raise SystemExit(f"bench.py: {world} ranks on {distinct_devices} distinct device(s): not a {world}-GPU job")
 
     # ---- one frame / one batch of frames
     host_ring = {id(b_): [[b_.host_frame(presented=args.readback == "presented") for _ in range(2 * max(F if use_slots else 1, B))], 0] for b_ in bes} if args.readback else {}
@@ -561,7 +668,7 @@ def main():
                                                "wave_uniform_node_tests": round(mean("uniform_node_test_executions", k) / max(mean("node_test_executions", k), 1), 3)}
                                         for k, name in ((0, "primary"), (1, "extension"), (2, "shadow")) if mean("node_test_executions", k)}
         out = {
-            "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+            "metric": "Mrays/s (primary+shadow, 1spp)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": ranks_rendered,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic atrium ({'glTF scene' if not args.procedural else 'procedural'}), {sstats['triangles']} triangles in {sstats['instances']} instance(s), {w}x{h}, 1 spp, "
@@ -574,6 +681,10 @@ def main():
                        "frames_in_flight_held_by": "frame slots of one instance (one scene copy)" if use_slots else (f"{F} renderer instances" if F > 1 else "-"),
                        "modes": modes,
                        "readback_every_frame": args.readback or False, "sharded_frame_equals_single_gpu_frame": shard_check,
+                       "ranks_seen": ranks_seen, "ranks_rendered": ranks_rendered, "distinct_devices": distinct_devices, "ranks": ranks_report,
+                       "launched_by": ("bench.py itself (--gpus N without a launcher: N child processes)" if os.environ.get("RFW_BENCH_LAUNCHED_BY") else
+                                       ("an external launcher (WORLD_SIZE in the environment)" if world > 1 else "-")),
+                       "dist_backend": (("nccl (RCCL)" if dist_backend == "nccl" else dist_backend + " (TEST HOOK: ranks may share a device)") if world > 1 else None),
                        "tile_shard": "64x64 round-robin" if world > 1 else "none", "collective": (args.collective if world > 1 else None),
                        "gather_format": (args.gather_format if (world > 1 or args.emulate_shard) else None), "present_rank": (args.present_rank if world > 1 else None),
                        "gather_bytes_per_frame": ({"f32": 12, "f16": 6, "bgra8": 4}[args.gather_format] * w * h if world > 1 else None),

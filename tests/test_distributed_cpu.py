@@ -74,3 +74,49 @@ def test_shard_geometry_covers_image():
         assert counts.sum() == w * h
         if g["tiles_total"] >= 4 * world:
             assert counts.max() / max(counts.min(), 1) < 1.6   # round-robin dealing balances pixels
+
+
+def _bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_plain_bench_command_launches_n_ranks():
+    """`python3 bench.py --gpus N` with no launcher: bench.py starts N child ranks itself (before any GPU call; here without a GPU at all:
+    --rendezvous-only lets the ranks meet over gloo and report).  One JSON line, from rank 0; every rank a process of its own."""
+    import json
+    for n in (2, 3):
+        r = _bench(["--gpus", str(n), "--rendezvous-only"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["ranks_seen"] == n
+        assert sorted(x["rank"] for x in out["ranks"]) == list(range(n)) and len({x["pid"] for x in out["ranks"]}) == n
+        assert len({x["launched_by"] for x in out["ranks"]}) == 1 and out["ranks"][0]["launched_by"] is not None
+
+
+def test_bench_rank_count_follows_gpus_flag_not_stray_environment():
+    import json
+    # --gpus 1 under a stray WORLD_SIZE: one rank
+    r = _bench(["--gpus", "1", "--rendezvous-only"], {"WORLD_SIZE": "8", "RANK": "5", "LOCAL_RANK": "5"}, drop=())
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["ranks"][0]["rank"] == 0
+    # a launcher that started another number of ranks than --gpus says: refused, not reported under the wrong N
+    r = _bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port())}, drop=())
+    assert r.returncode != 0 and "refusing" in r.stderr
+    # under the driver's launcher (python -m torch.distributed.run) the script is one of the launcher's ranks: no second generation of children
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and all(x["launched_by"] is None for x in out["ranks"])
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies takes the job down with a non-zero exit code (and no result line): here every rank dies at once, for want of a device."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cornell"], {"HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

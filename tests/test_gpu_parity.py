@@ -292,6 +292,38 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook(gather_format):
     assert "distinct" in out["config"]["views"] or "cycled" in out["config"]["views"]
 
 
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher around it and no WORLD_SIZE in the environment must run two ranks (the
+    driver's scaling command may be exactly that): bench.py starts them as child processes before it touches the GPU, and the line says who
+    rendered.  Two ranks share this box's one device through the gloo hook."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RFW_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cornell", "--width", "320", "--height", "200",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line: rank 0's
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["ranks_rendered"] == 2 and c["sharded_frame_equals_single_gpu_frame"] is True
+    assert sorted(x["rank"] for x in c["ranks"]) == [0, 1] and len({x["pid"] for x in c["ranks"]}) == 2
+    assert all(x["rays_of_view_0"] > 0 and x["tiles"] > 0 for x in c["ranks"])
+    assert "bench.py itself" in c["launched_by"] and c["collective"] == "torch" and "gloo" in c["dist_backend"]
+    # ... and one rank stays one rank whatever a stray WORLD_SIZE says
+    env1 = dict(env, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "cornell", "--width", "320",
+                        "--height", "200", "--no-cpu-baseline", "--no-modes"], env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1 and out["config"]["ranks"][0]["rank"] == 0
+
+
 @pytest.mark.parametrize("present_rank", [0, -1])
 def test_bench_two_ranks_on_one_gpu_p2p(present_rank):
     """bench.py --collective p2p with one process per rank (both on this GPU): the handles travel through torch.distributed once, the

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The 1 / 2 / 4 / 8 GPU table of SURVEY §8(e), ready to run on an 8 x MI355X node:
 #     bash tools/scale.sh [tag] [steps]          (one node, from the repository root; needs the built libraries: python3 -c 'import __graft_entry__ as g; g.build()')
-# Runs bench.py exactly as the driver does (python -m torch.distributed.run, one rank per GPU) for every N in $GPUS and, at N > 1, for every
+# Runs the plain command `python3 bench.py --gpus N` (bench.py starts its N ranks itself, one per GPU, when no launcher has: launch_ranks;
+# under `python -m torch.distributed.run` the same script is one of the launcher's ranks) for every N in $GPUS and, at N > 1, for every
 # (collective, gather format) pair in $VARIANTS; prints one row per run with the whole-job rate, the speed-up over N = 1, and whether the
 # sharded frame equalled the single-GPU frame (config.sharded_frame_equals_single_gpu_frame: rank 0 re-renders the last timed frames on one
 # GPU and compares in the format that travelled).  Raw lines: gpurun_out/<tag>/scale_*.json; table: gpurun_out/<tag>/scale.md.
@@ -21,10 +22,10 @@ if [ "$1" = "--dry" ]; then
     case "$v" in *finegrained-flags) extra="RFW_P2P_FLAGS_FINEGRAINED=1";; *cached-data) extra="RFW_P2P_DATA_CACHED=1";; esac
     barg=""; case "$v" in *latency) barg="--batch 1";; esac
     PORT=$((PORT + 1)); f=$OUT/dry_${v//:/_}.json
-    env $extra timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus 2 \
+    env $extra timeout 600 python3 bench.py --gpus 2 \
       --steps 12 --warmup 4 --workload cornell --width 320 --height 200 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $barg > "$f" 2> "${f%.json}.err"
     rc=$?
-    ok=$(python3 -c "import json,sys; l=[x for x in open('$f') if x.startswith('{')]; d=json.loads(l[-1]) if l else {}; print(int(d.get('config',{}).get('sharded_frame_equals_single_gpu_frame') is True and d.get('n_gpus')==2))" 2>/dev/null)
+    ok=$(python3 -c "import json,sys; l=[x for x in open('$f') if x.startswith('{')]; d=json.loads(l[-1]) if l else {}; print(int(d.get('config',{}).get('sharded_frame_equals_single_gpu_frame') is True and d.get('n_gpus')==2 and d.get('config',{}).get('ranks_seen')==2))" 2>/dev/null)
     if [ "$rc" -ne 0 ] || [ "$ok" != "1" ]; then FAILED="$FAILED $v(rc=$rc)"; echo "FAIL $v"; tail -5 "${f%.json}.err"; else echo "ok   $v"; fi
   done
   if [ -n "$FAILED" ]; then echo "scale.sh --dry: FAILED:$FAILED"; exit 1; fi
@@ -52,8 +53,7 @@ run() { # n collective format [latency]
   if [ "$n" -eq 1 ]; then
     python3 bench.py --gpus 1 --steps "$STEPS" --warmup 24 --no-cpu-baseline --no-modes > "$f" 2> "${f%.json}.err"
   else
-    PORT=$((PORT + 1))
-    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$n" \
+    python3 bench.py --gpus "$n" \
       --steps "$STEPS" --warmup 24 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $extra > "$f" 2> "${f%.json}.err"
   fi
   echo "$n $coll ${fmt}${lat:+(one-frame-per-exchange)} $f" >> "$ROWS"
