@@ -357,8 +357,10 @@ RFW_HIP_API int rfw_hip_bandwidth_probe(void* instance, uint64_t bytes, uint32_t
 /* Measured vector-issue ceiling of this device in this job, for the roofline of the (issue-bound) trace kernels: 8 wavefronts per SIMD on
  * every CU run `trips` x 32 independent instructions each, timed with HIP events; *g_instructions_per_s = wave64 instructions retired per
  * second, chip-wide, in units of 1e9.  mix 0: v_fma_f32 alone (what the FP32 peak of the data sheet is quoted on).  mix 1: the
- * instruction mix of one child of the 4-wide node test (6 byte->float conversions, 3 packed FMAs, max3, min3, min, 2 compares), most of
- * which issue at half the FMA rate or less on gfx950.  Nothing of the scene is touched. */
+ * instruction mix of one child of the PER-LANE 4-wide node test (6 byte->float conversions, 3 packed FMAs, max3, min3, min, 2 compares), most of
+ * which issue at half the FMA rate or less on gfx950.  mix 2: one node step of the PACKET kernel the camera rays run (per child 6 v_fma_f32
+ * with a scalar operand, max3, min3, min, max, one compare into a scalar register pair) with the step's 27 scalar instructions issued beside
+ * the 44 vector ones; the VECTOR instructions per second are returned.  Nothing of the scene is touched. */
 RFW_HIP_API int rfw_hip_issue_probe(void* instance, int mix, uint32_t trips, double* g_instructions_per_s);
 
 #ifdef __cplusplus

@@ -347,7 +347,7 @@ int rfw_hip_bandwidth_probe(void* inst, uint64_t bytes, uint32_t iterations, dou
 int rfw_hip_issue_probe(void* inst, int mix, uint32_t trips, double* g_instructions_per_s)
 {
     LOCK(inst);
-    if (!g_instructions_per_s || mix < 0 || mix > 1 || trips == 0 || trips > (1u << 20)) return fail(I, RFW_HIP_E_INVALID, "issue_probe: bad arguments");
+    if (!g_instructions_per_s || mix < 0 || mix > 2 || trips == 0 || trips > (1u << 20)) return fail(I, RFW_HIP_E_INVALID, "issue_probe: bad arguments");
     HIP_TRY(I, hipSetDevice(I->device));
     hipDeviceProp_t prop;
     HIP_TRY(I, hipGetDeviceProperties(&prop, I->device));
@@ -370,7 +370,7 @@ int rfw_hip_issue_probe(void* inst, int mix, uint32_t trips, double* g_instructi
     if (e1) (void)hipEventDestroy(e1);
     if (out) (void)hipFree(out);
     if (e != hipSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("issue_probe: ") + hipGetErrorString(e));
-    const double wave_instructions = (double)cus * 8.0 * 4.0 * (double)trips * 32.0; // blocks x wavefronts per block x trips x instructions per trip
+    const double wave_instructions = (double)cus * 8.0 * 4.0 * (double)trips * (double)issue_probe_vector_per_trip(mix); // blocks x wavefronts per block x trips x vector instructions per trip
     *g_instructions_per_s = ms > 0.0f ? wave_instructions / (ms * 1e-3) / 1e9 : 0.0;
     return RFW_HIP_OK;
 }

@@ -67,7 +67,8 @@ void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, 
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce);
 void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count);
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n); // bandwidth probe
-void launch_issue_probe(hipStream_t s, int mix, uint32_t cus, uint32_t trips, float* out); // issue-rate probe: 32 instructions per trip and wavefront
+void launch_issue_probe(hipStream_t s, int mix, uint32_t cus, uint32_t trips, float* out); // issue-rate probe (mix 0, 1, 2: kernels.hip)
+uint32_t issue_probe_vector_per_trip(int mix);                                                // vector instructions per trip and wavefront of that mix
 // The eight per-octant copies of a node array (PacketNode for the packet kernels, Node4Q for the one-ray-per-lane kernels): copy `oct` of
 // node i at [oct * stride + i] of both
 struct OctantCopies {

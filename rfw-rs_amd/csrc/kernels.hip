@@ -275,7 +275,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
         const SceneView sv = scene_view(sc);
         p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id)); // before the trace: the ray need not stay live across it
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
-        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, block * kTraceBlock, tc);
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     } else if (idx < p.capacity) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
         const SceneView sv = scene_view(sc);
         p.ray_o[0][idx] = make_float4(O.x, O.y, O.z, bitsf(path_id | (f << 24)));
         p.ray_d[0][idx] = make_float4(D.x, D.y, D.z, 0.0f);
-        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, block * kTraceBlock, tc);
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[0][idx] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     } else if (f < cam.batch) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const C
         float t = 1e26f, hu = 0.0f, hv = 0.0f;
         int32_t hi = -1, ht = -1;
         const SceneView sv = scene_view(sc);
-        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, idx, tc);
+        traverse<false, COUNT>(sv, O, D, 1e-4f, t, hu, hv, hi, ht, s_stack, threadIdx.x, block * kTraceBlock, tc);
         const uint32_t bary = f2u(65535.0f * hu) + (f2u(65535.0f * hv) << 16);
         p.hit[half][j] = make_uint4((uint32_t)hi, (uint32_t)ht, fbits(t), bary);
     }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES) void k_extend_stream
     TravCounters tc{0, 0, 0};
     ExtendStream st{p, order, bounce & 1u, block * run, min(count, (block + 1u) * run), 0u};
     const SceneView sv = scene_view(sc);
-    traverse_stream<false, COUNT, false>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, blockIdx.x * kTraceBlock + threadIdx.x, tc);
+    traverse_stream<false, COUNT, false>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, blockIdx.x * kTraceBlock, tc);
     flush_counters<COUNT>(sc.counters, tc, 1);
 }
 
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
     // the queue is bucketed by light (shade pushes directional lights into the last region, positional lights into region light % 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
     uint32_t block = xcd_block(blockIdx.x);
-    const uint32_t spill_slot = block * kTraceBlock + threadIdx.x;
+    const uint32_t spill_base = block * kTraceBlock; // (of the launch index's block: unique per wavefront, whatever bucket it lands in)
     uint32_t bucket = 0, count = 0;
     {
         bool found = false;
@@ -555,10 +555,14 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         // light's rays under the last bucket, so the bucket tells the kind of light.
         const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional)
                                                                                                  : (cam.flags & kFlagFarFirstPositional) != 0u); // option "shadow_order" overrides the default per light kind
-        const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc)
-                                        : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_slot, tc);
+        const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_base, tc)
+                                        : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_base, tc);
         if (!occluded) {
-            const float4 e = p.sh_e[idx];
+            // (the entry's index is formed again from the wave-uniform part and the lane: kept across the traversal it is a 64-bit register
+            // pair that went to scratch memory at 8 waves per SIMD)
+            uint32_t lane = threadIdx.x;
+            asm volatile("" : "+v"(lane));
+            const float4 e = p.sh_e[bucket * p.capacity + block * kTraceBlock + lane];
             const uint32_t slot = fbits(e.w); // the path's accumulator slot rides in the queue entry (k_shade knows it without arithmetic)
             // single writer per pixel per pass (one shadow ray per path per bounce), as ray_shadow.comp:268
             float4 a = p.acc[slot];
@@ -678,13 +682,14 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_st
     TravCounters tc{0, 0, 0};
     ShadowStream st{p, bucket * p.capacity, block * run, min(count, (block + 1u) * run), 0u};
     const SceneView sv = scene_view(sc);
-    const uint32_t spill_slot = blockIdx.x * kTraceBlock + threadIdx.x;
-    traverse_stream<true, COUNT, FAR>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, spill_slot, tc);
+    traverse_stream<true, COUNT, FAR>(sv, st, cam.stream_refill & 0xffu, cam.stream_refill >> 8, s_stack, threadIdx.x, blockIdx.x * kTraceBlock, tc);
     flush_counters<COUNT>(sc.counters, tc, 2);
 }
 
 // ---------------------------------------------------------------- shade.comp:70-266
 constexpr int kShadeBlock = 512; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
+// the octant-major filing of the extension rays below lets the SECOND wavefront prefix-sum the 8 x (kShadeBlock / 64) counts, one per lane
+static_assert(kShadeBlock >= 128 && 8 * (kShadeBlock / 64) <= 64, "k_shade: the extension-ray filing needs a second wavefront and at most 64 (octant, wavefront) counts");
 template <bool BATCH>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
@@ -938,13 +943,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         s_base[threadIdx.x] = base;
     }
     uint32_t ext_before = 0;
-    if (any_ext && threadIdx.x >= 64u && threadIdx.x < 128u) { // the second wavefront: (octant, wavefront) t's offset = everything filed before it, octant-major
+    constexpr uint32_t kExtCounts = 8u * (kShadeBlock / 64);
+    if (any_ext && threadIdx.x >= 64u && threadIdx.x < 64u + kExtCounts) { // the second wavefront: (octant, wavefront) t's offset = everything filed before it, octant-major
         const uint32_t t8 = threadIdx.x - 64u;
         const uint32_t* flat = &s_ext[0][0];
         for (uint32_t k = 0; k < t8; k++) ext_before += flat[k];
     }
     __syncthreads();
-    if (any_ext && threadIdx.x >= 64u && threadIdx.x < 128u) (&s_ext[0][0])[threadIdx.x - 64u] = ext_before;
+    if (any_ext && threadIdx.x >= 64u && threadIdx.x < 64u + kExtCounts) (&s_ext[0][0])[threadIdx.x - 64u] = ext_before;
     __syncthreads();
     if (push_shadow) {
         uint32_t off = s_base[light_bucket];
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
     int32_t hi = -1, ht = -1;
     TravCounters tc{0, 0, 0};
     const SceneView sv = scene_view(sc);
-    traverse<false, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    traverse<false, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)((idx - threadIdx.x) % sc.spill_stride), tc);
     if (hi < 0) t = t_max;
     rfw_hip_hit h;
     if (hi >= 0) { // storage order -> the boundary's triangle numbering (identical after a full build)
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
     int32_t hi = -1, ht = -1;
     TravCounters tc{0, 0, 0};
     const SceneView sv = scene_view(sc);
-    const bool occ = traverse<true, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)(idx % sc.spill_stride), tc);
+    const bool occ = traverse<true, DEPTH>(sv, O, D, t_min, t, hu, hv, hi, ht, s_stack, threadIdx.x, (uint32_t)((idx - threadIdx.x) % sc.spill_stride), tc);
     occluded[idx] = occ ? 1 : 0;
     if (DEPTH) depth[idx] = tc.nodes; // 4-wide nodes visited until the first occluder / the end of the traversal
 }
@@ -1298,11 +1304,15 @@ __global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src4
         }
     }
 }
-// Issue-rate probe (rfw_hip_issue_probe): streams of independent vector instructions, 8 accumulators per lane, 8 wavefronts per SIMD on every
-// CU.  MIX 0 = v_fma_f32 alone (the instruction the guide's FP32 peak is quoted on); MIX 1 = one child of the per-lane node test of
-// traverse_body.inc, instruction for instruction: 6 byte -> float conversions, 3 packed FMAs, max3, min3, min, two compares.  The trace
-// kernels are made of the second kind, and conversions, min / max, compares and packed FMAs issue at half the FMA rate or less
-// (tools/probes/valu_peak.cpp lists them one by one) — this is the ceiling "valu_issue" is held against in bench.py beside the guide's.
+// Issue-rate probe (rfw_hip_issue_probe): streams of vector instructions, 8 wavefronts per SIMD on every CU.
+//   MIX 0 = v_fma_f32 alone (the instruction the guide's FP32 peak is quoted on): 32 per trip;
+//   MIX 1 = one child of the PER-LANE node test of traverse_body.inc, instruction for instruction, twice per trip: 6 byte -> float
+//           conversions, 3 packed FMAs, max3, min3, min, two compares = 14, i.e. 28 per trip (round 4 counted 32: ADVICE r04);
+//   MIX 2 = one node step of the PACKET kernel (traverse_packet.h, slab4 + pushes): per child 6 v_fma_f32 with the plane as a scalar
+//           operand, v_max3, v_min3, v_min, v_max and ONE v_cmp into a scalar register pair = 11, four children = 44 vector instructions per
+//           trip, with the step's 27 scalar instructions issued beside them (they take issue slots too; only the vector ones are counted).
+// Conversions, min / max, compares and packed FMAs issue at half the FMA rate or less (tools/probes/valu_peak.cpp lists them one by one).
+// kIssueProbeVectorPerTrip is what the host multiplies by; tests/test_isa_budget.py counts the v_* instructions of each loop body in the ISA.
 template <int MIX> __global__ __launch_bounds__(256) void k_issue_probe(float* out, const uint32_t trips, const float seed)
 {
     typedef float v2 __attribute__((ext_vector_type(2)));
@@ -1312,15 +1322,16 @@ template <int MIX> __global__ __launch_bounds__(256) void k_issue_probe(float* o
     const uint32_t u = fbits(seed) | 0x01020304u;
     v2 p[3] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}};
     const v2 pa = {a, a}, pb = {b, b};
+    uint32_t sc0 = trips, sc1 = trips + 1u, sc2 = trips + 2u; // (MIX 2) scalar registers the scalar companions count in
     for (uint32_t it = 0; it < trips; it++) {
         if (MIX == 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(a), "v"(b));
-        } else {
+        } else if (MIX == 1) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) { // 2 x 16 instructions per trip
+            for (int r = 0; r < 2; r++) { // 2 x 14 instructions per trip
                 asm volatile("v_cvt_f32_ubyte0 %0, %6\n\tv_cvt_f32_ubyte1 %1, %6\n\tv_cvt_f32_ubyte2 %2, %6\n\tv_cvt_f32_ubyte3 %3, %6\n\tv_cvt_f32_ubyte0 %4, %6\n\tv_cvt_f32_ubyte1 %5, %6"
                              : "=v"(p[0].x), "=v"(p[0].y), "=v"(p[1].x), "=v"(p[1].y), "=v"(p[2].x), "=v"(p[2].y) : "v"(u));
                 asm volatile("v_pk_fma_f32 %0, %0, %3, %4\n\tv_pk_fma_f32 %1, %1, %3, %4\n\tv_pk_fma_f32 %2, %2, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(pa), "v"(pb));
@@ -1328,17 +1339,36 @@ template <int MIX> __global__ __launch_bounds__(256) void k_issue_probe(float* o
                 asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[7]) : "v"(a));
                 asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cmp_ge_f32 vcc, %0, %2" : : "v"(v[7]), "v"(v[6]), "v"(b) : "vcc");
             }
+        } else {
+            // inv / b of the lane's ray in v[0..5] and a, b; the planes of the node in scalar registers (here: one, the probe measures issue, not values)
+            const float plane = __builtin_amdgcn_readfirstlane(seed);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { // 4 children x 11 vector instructions
+                uint64_t m;
+                asm volatile("v_fma_f32 %0, %6, %7, %8\n\tv_fma_f32 %1, %6, %8, %7\n\tv_fma_f32 %2, %6, %7, %7\n\tv_fma_f32 %3, %6, %8, %8\n\tv_fma_f32 %4, %6, %7, %8\n\tv_fma_f32 %5, %6, %8, %7"
+                             : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]) : "s"(plane), "v"(a), "v"(b));
+                asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %5, %6, %7" : "=v"(v[6]), "=v"(v[7]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]));
+                asm volatile("v_min_f32 %0, %0, %2\n\tv_max_f32 %1, %1, 0" : "+v"(v[7]), "+v"(v[6]) : "v"(a));
+                asm volatile("v_cmp_ge_f32 %0, %1, %2" : "=s"(m) : "v"(v[7]), "v"(v[6]));
+                // the scalar companions of a child: stack push (compare + add with carry), mask bookkeeping: 6 per child, 3 more per step below = 27
+                asm volatile("s_cmp_lg_u64 %3, 0\n\ts_addc_u32 %0, %0, 0\n\ts_add_u32 %1, %1, 1\n\ts_and_b32 %2, %2, %1\n\ts_add_u32 %2, %2, %0\n\ts_lshl_b32 %1, %1, 1"
+                             : "+s"(sc0), "+s"(sc1), "+s"(sc2) : "s"(m) : "scc");
+            }
+            asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %2\n\ts_add_u32 %2, %2, 1" : "+s"(sc0), "+s"(sc1), "+s"(sc2) : : "scc");
         }
     }
-    float r = p[0].x + p[1].y + p[2].x;
+    float r = p[0].x + p[1].y + p[2].x + (float)(sc0 ^ sc1 ^ sc2);
     for (int i = 0; i < 8; i++) r += v[i];
     out[blockIdx.x * 256u + threadIdx.x] = r;
 }
+// vector instructions per trip of the loop above (what rfw_hip_issue_probe multiplies by)
+uint32_t issue_probe_vector_per_trip(int mix) { return mix == 0 ? 32u : (mix == 1 ? 28u : 44u); }
 // (blocks of 256 threads, 8 per CU: every SIMD holds 8 wavefronts; `out` holds cus * 8 * 256 floats)
 void launch_issue_probe(hipStream_t s, int mix, uint32_t cus, uint32_t trips, float* out)
 {
     if (mix == 0) hipLaunchKernelGGL(k_issue_probe<0>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
-    else hipLaunchKernelGGL(k_issue_probe<1>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
+    else if (mix == 1) hipLaunchKernelGGL(k_issue_probe<1>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
+    else hipLaunchKernelGGL(k_issue_probe<2>, dim3(cus * 8u), dim3(256), 0, s, out, trips, 1.5f);
 }
 void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 {

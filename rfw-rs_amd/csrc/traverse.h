@@ -105,7 +105,7 @@ struct TravCounters {
 // occluder starts at the far end of the ray.  The triangle tests, and therefore the answer, are the same in either order.
 template <bool ANY_HIT, bool COUNT, bool FAR_FIRST = false>
 RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_min, float& t, float& hu, float& hv, int32_t& hit_inst,
-                     int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot, TravCounters& tc)
+                     int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_base, TravCounters& tc)
 {
     constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds; // LDS stack rows of this kernel flavour
     constexpr bool kPark = RFW_RAY_IN_LDS && (!ANY_HIT || RFW_ANY_PARK);
@@ -149,9 +149,17 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     // compiler builds, because every other formulation of their pop tried (ds_read, top of stack in a register) changed their loop nest
     // for the worse (k_primary 0.335 -> 0.39 ms)
     constexpr bool kDsPop = ((RFW_POP_DS_READ >> (ANY_HIT ? 0 : 1)) & 1) != 0;
+    // A lane's column of the HBM spill rows = spill_base (wave-uniform: lane 0's column) + its lane.  Formed where it is used, behind a
+    // barrier the optimiser cannot look through: hoisted out of the loop the 64-bit address of the column is a register pair that lives
+    // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
+    auto spill_slot = [&]() -> uint32_t {
+        uint32_t l = lane_slot;
+        asm volatile("" : "+v"(l));
+        return spill_base + l;
+    };
     auto push = [&](uint32_t v) {
         if (sp < kStack) lds_stack[sp * kTraceBlock + lane_slot] = v;
-        else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
+        else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()] = v;
         else {
             // overflow (a tree deeper than LDS + spill rows): the entry is dropped and sp does NOT advance, so pop() never indexes
             // past the spill rows — the ray finishes deterministically on what it has (possibly missing a hit), and the host reports
@@ -169,13 +177,13 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
             // vector-memory instruction through the texture-address unit, for every pop, although the entry is in LDS
             uint32_t v = lds_stack[(sp < kStack ? sp : kStack - 1) * kTraceBlock + lane_slot];
             if (__builtin_expect(sp >= kStack, 0)) {
-                v = sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
+                v = sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
                 asm volatile("" : "+v"(v)); // the merged value is not a load: keeps the compiler from folding both loads into one flat load again
             }
             return v;
         }
         if (sp < kStack) return lds_stack[sp * kTraceBlock + lane_slot];
-        return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
+        return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
     };
 
 #define RFW_TRAV_TOP
@@ -205,7 +213,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 //   st.fetch(idle, O, D, t)   the calling lanes (all idle) take the next entries; false for a lane that gets none (Stream::kTMin: the queue's t_min)
 //   st.commit(occluded, t, hu, hv, hit_inst, hit_tri)   the calling lane's finished ray
 template <bool ANY_HIT, bool COUNT, bool FAR_FIRST, class Stream>
-RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refill, const uint32_t leaf_gate, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_slot,
+RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refill, const uint32_t leaf_gate, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_base,
                             TravCounters& tc)
 {
     constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds;
@@ -232,9 +240,17 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
     uint32_t cur = 0;
     const Node4Q* nodes = sc.tlas_nodes; // (set with every ray a lane takes)
     constexpr bool kDsPop = ((RFW_POP_DS_READ >> (ANY_HIT ? 0 : 1)) & 1) != 0;
+    // A lane's column of the HBM spill rows = spill_base (wave-uniform: lane 0's column) + its lane.  Formed where it is used, behind a
+    // barrier the optimiser cannot look through: hoisted out of the loop the 64-bit address of the column is a register pair that lives
+    // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
+    auto spill_slot = [&]() -> uint32_t {
+        uint32_t l = lane_slot;
+        asm volatile("" : "+v"(l));
+        return spill_base + l;
+    };
     auto push = [&](uint32_t v) {
         if (sp < kStack) lds_stack[sp * kTraceBlock + lane_slot] = v;
-        else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot] = v;
+        else if (sp < kStack + (int)sc.spill_rows) sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()] = v;
         else {
             *sc.overflow_flag = 1u;
             return;
@@ -246,13 +262,13 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
         if (kDsPop) {
             uint32_t v = lds_stack[(sp < kStack ? sp : kStack - 1) * kTraceBlock + lane_slot];
             if (__builtin_expect(sp >= kStack, 0)) {
-                v = sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
+                v = sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
                 asm volatile("" : "+v"(v));
             }
             return v;
         }
         if (sp < kStack) return lds_stack[sp * kTraceBlock + lane_slot];
-        return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot];
+        return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
     };
     bool have = false, pending = false, occluded = false;
     const uint64_t everyone = __ballot(1);
@@ -273,18 +289,20 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
                 if (!have) {                                                                                                          \
                     if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);                                                   \
                     pending = false;                                                                                                  \
-                    have = st.fetch(idle, O, D, t);                                                                            \
+                    have = st.fetch(idle, o, d, t);                                                                            \
                     if (have) {                                                                                                       \
-                        o = O; d = D; inv = slab_inv(d);                                                                              \
+                        /* the fetched ray lands in the traversal's own registers and is parked at once: a second copy of it (O, D) waiting */ \
+                        /* for the park went to scratch memory at 8 waves per SIMD */                                                  \
+                        if (kPark) {                                                                                                  \
+                            uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;                                            \
+                            park[0] = fbits(o.x); park[kTraceBlock] = fbits(o.y); park[2 * kTraceBlock] = fbits(o.z);                 \
+                            park[3 * kTraceBlock] = fbits(d.x); park[4 * kTraceBlock] = fbits(d.y); park[5 * kTraceBlock] = fbits(d.z); \
+                        } else { O = o; D = d; }                                                                                      \
+                        inv = slab_inv(d);                                                                                            \
                         sp = 0; blas_sp = -1; cur_inst = -1; tri_base = 0; cur = 0; nodes = space_nodes(sc, false, 0u, inv);          \
                         hu = 0.0f; hv = 0.0f; hit_inst = -1; hit_tri = -1; occluded = false;                                          \
                         /* a degenerate direction hits nothing (see traverse()): finished before it starts */                          \
-                        if (RFW_SLAB_ONE_COMPARE && !((D.x == D.x) && (D.y == D.y) && (D.z == D.z) && (D.x != 0.0f || D.y != 0.0f || D.z != 0.0f))) { have = false; pending = true; } \
-                        if (kPark) {                                                                                                  \
-                            uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;                                            \
-                            park[0] = fbits(O.x); park[kTraceBlock] = fbits(O.y); park[2 * kTraceBlock] = fbits(O.z);                 \
-                            park[3 * kTraceBlock] = fbits(D.x); park[4 * kTraceBlock] = fbits(D.y); park[5 * kTraceBlock] = fbits(D.z); \
-                        }                                                                                                             \
+                        if (RFW_SLAB_ONE_COMPARE && !((d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f))) { have = false; pending = true; } \
                     }                                                                                                                 \
                 }                                                                                                                     \
                 st.advance(idle);                                                                                                     \

@@ -32,10 +32,13 @@ typedef const uint32_t __attribute__((address_space(4))) * scalar_ptr1;
 
 constexpr uint32_t kPacketStack = 64; // one entry per lane of the stack register
 
-// lane `lane` of `reg` = value (both wave-uniform); v_writelane_b32 may read ONE scalar register besides M0 on gfx9, hence the move
+// lane `lane` of `reg` = value (both wave-uniform).  v_writelane_b32 may read ONE scalar register besides M0 on gfx9, so the lane index has
+// to travel through M0 — and the COMPILER puts it there: this is the LLVM intrinsic itself (this clang has no __builtin_amdgcn_writelane;
+// the declaration binds the intrinsic by name, as the HIP headers do for theirs).  Round 4's inline asm wrote M0 behind the compiler's back.
+extern "C" __device__ int rfw_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 RFW_DI void lane_write(uint32_t& reg, const uint32_t value, const uint32_t lane)
 {
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane) : "m0");
+    reg = (uint32_t)rfw_llvm_writelane((int)value, (int)lane, (int)reg);
 }
 RFW_DI uint32_t lane_read(const uint32_t reg, const uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)lane); }
 RFW_DI uint64_t ballot64(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -153,8 +156,15 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
             }
             SlabRay r = slab_ray(o, d);
             constexpr bool kNanMask = RFW_PACKET_NAN_MASK && !ANY_HIT; // (any hit: the packet shrinks inside the loop as rays find their occluders)
-            // a lane outside the packet leaves every box at -inf, before it could enter it: min(-inf, t) >= max(tn, 0) is false whatever tn is
-            if (kNanMask && !in_mask(packet)) { r.inv = mk3(1.0f); r.bf = mk3(-INFINITY); }
+            // a lane outside the packet leaves every box at -inf, before it could enter it: min(-inf, t) >= max(tn, 0) is false whatever tn is.
+            // Its reciprocal direction is +-1 with the OCTANT's signs, so that the far plane of an EMPTY slot — -inf on an axis the octant
+            // travels up, +inf on one it travels down — times it is -inf as well: with +1 throughout, (+inf) * 1 + (-inf) was a NaN, min / max
+            // ignore NaNs, and such lanes voted for the empty slots of the octants with a negative axis (harmless — the pop skips
+            // kInvalidRef — but every such vote was a wasted push on the shared stack)
+            if (kNanMask && !in_mask(packet)) {
+                r.inv = mk3((sgn & 1u) ? -1.0f : 1.0f, (sgn & 2u) ? -1.0f : 1.0f, (sgn & 4u) ? -1.0f : 1.0f);
+                r.bf = mk3(-INFINITY);
+            }
             const uint32_t lead = first_lane(packet); // (COUNT: the lane that counts the wavefront-level steps)
             bool leave = false, finished = false;
             const uint32_t floor_sp = in_blas ? blas_sp : 0u; // stack height at which this space is exhausted
@@ -165,7 +175,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                 if (sp != floor_sp) {
                     sp--;
                     cur = lane_read(stack, sp);
-                    while (__builtin_expect(cur == kInvalidRef && sp != floor_sp, 0)) { // (never taken since degenerate rays stay out of the packets)
+                    while (__builtin_expect(cur == kInvalidRef && sp != floor_sp, 0)) { // (an empty slot somebody voted for: a NaN corner of the slab test; lanes outside the packet no longer produce one)
                         sp--;
                         cur = lane_read(stack, sp);
                     }
