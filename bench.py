@@ -615,7 +615,8 @@ def main():
             pb = bes[0] if bes else HipBackend.init(64, 64, 1.0, device=dev)
             bw_measured = pb.bandwidth_probe(1 << 30, 20)
             # ... and its vector-issue ceilings: v_fma_f32 alone, and the instruction mix of the node test (rfw_hip.h: rfw_hip_issue_probe)
-            ISSUE_MEASURED.update({"fma_only": round(pb.issue_probe(0), 1), "node_test_mix": round(pb.issue_probe(1), 1)})
+            ISSUE_MEASURED.update({"fma_only": round(pb.issue_probe(0), 1), "per_lane_node_test_mix": round(pb.issue_probe(1), 1),
+                                   "packet_node_step_mix": round(pb.issue_probe(2), 1)})
             if not bes:
                 pb.close()
         except Exception:
@@ -833,12 +834,17 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
             a = tot["valu"] / seconds / 1e9
             c["valu_issue"] = {"achieved": round(a, 1), "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instructions/s", "frac": round(a / VALU_PEAK_GIPS, 4),
                                "per_launch": int(tot["valu"])}
-            if ISSUE_MEASURED.get("node_test_mix"):
-                # the guide's peak is one v_fma_f32 per 2 cycles per SIMD at 2.4 GHz; conversions, min / max, compares and packed FMAs — what a
-                # node test is made of — issue at half that or less, and the clock sags under load: both rates measured live, 8 waves per SIMD
-                c["valu_issue"]["measured_ceiling"] = dict(ISSUE_MEASURED, unit="G wave64 instructions/s, chip-wide, 8 wavefronts per SIMD",
-                                                           frac_of_node_test_mix=round(a / ISSUE_MEASURED["node_test_mix"], 4),
-                                                           frac_of_fma_only=round(a / ISSUE_MEASURED["fma_only"], 4))
+            if ISSUE_MEASURED.get("fma_only"):
+                # the guide's peak is one v_fma_f32 per 2 cycles per SIMD at 2.4 GHz.  Three rates measured live in this job (rfw_hip_issue_probe,
+                # 8 wavefronts per SIMD, chip-wide): v_fma_f32 alone; the instruction mix of ONE CHILD OF THE PER-LANE NODE TEST (k_shadow,
+                # k_extend, k_primary without packets: byte conversions, packed FMAs, min / max, compares); the mix of ONE NODE STEP OF THE
+                # PACKET KERNEL (k_primary_packet: FMAs with a scalar operand, min / max, one compare per child, its scalar instructions beside
+                # them).  The kernels are made of MORE than their node test (triangle tests, shading: mostly full-rate multiplies and adds), so
+                # a kernel's own rate can lie above the rate of its node test's mix: the ratios below compare, they are not fractions of a ceiling.
+                c["valu_issue"]["measured_rates"] = dict(ISSUE_MEASURED, unit="G wave64 VECTOR instructions/s, chip-wide, 8 wavefronts per SIMD",
+                                                         ratio_to_per_lane_node_test_mix=round(a / ISSUE_MEASURED["per_lane_node_test_mix"], 4),
+                                                         ratio_to_packet_node_step_mix=round(a / ISSUE_MEASURED["packet_node_step_mix"], 4),
+                                                         frac_of_fma_only=round(a / ISSUE_MEASURED["fma_only"], 4))
         if have["ta"] and tot["ta_busy"]:
             # the texture-address / vector-L1 path of a CU, the unit every 16-B-per-lane load goes through: busy cycles (mean over the CUs)
             # of the launches over the cycles they took.  Its cost per wave instruction grows with the cache lines the 64 lanes touch
@@ -880,11 +886,11 @@ def build_roofline(alg, kms, ms_step, alg_frame, bw_measured, args, single, laun
             sb = max(steady, key=lambda k: steady[k]["frac"])
             r["timed_region"] = {"bound": sb, "frac": steady[sb]["frac"], "ms_per_frame": round(ms_step, 4), "ceilings": steady}
         if ISSUE_MEASURED.get("fma_only") and bound == "valu_issue":
-            # `peak` above is the guide's figure; what THIS device issued in THIS job (rfw_hip_issue_probe), and the fractions of it
-            r["measured_peak"] = dict(ISSUE_MEASURED, unit=c["unit"])
-            r["frac_of_measured_peak"] = {"kernel_alone": {k: round(c["achieved"] / v, 4) for k, v in ISSUE_MEASURED.items()}}
+            # `peak` above is the guide's figure; what THIS device issued in THIS job: the one rate that IS a ceiling for any mix is v_fma_f32 alone
+            r["measured_peak"] = {"fma_only": ISSUE_MEASURED["fma_only"], "unit": c["unit"]}
+            r["frac_of_measured_peak"] = {"kernel_alone": round(c["achieved"] / ISSUE_MEASURED["fma_only"], 4)}
             if steady and "valu_issue" in steady:
-                r["frac_of_measured_peak"]["timed_region"] = {k: round(steady["valu_issue"]["achieved"] / v, 4) for k, v in ISSUE_MEASURED.items()}
+                r["frac_of_measured_peak"]["timed_region"] = round(steady["valu_issue"]["achieved"] / ISSUE_MEASURED["fma_only"], 4)
     else:
         # no committed counters for this configuration: only the contract's rate can be given; `frac` stays null rather than a number above 1
         r.update({"bound": None, "kernel": dom, "achieved": contract["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": None, "traffic": None, "contract": contract})

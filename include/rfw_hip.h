@@ -124,6 +124,9 @@ typedef struct {
     float ms_blas_kernels;
     uint64_t blas_upload_bytes;   /* triangles x 176 B */
     uint64_t blas_kernel_bytes;   /* ALGORITHMIC bytes of those kernels (what each pass reads and writes per primitive) */
+    /* spatial splits (option "spatial_splits"): references the trees hold beyond one per triangle — duplicates of the few triangles whose
+     * boxes waste the most (a wall of two triangles across the scene); `triangles` above counts the caller's triangles only */
+    uint64_t split_references;
 } rfw_hip_scene_stats;
 
 /* Hit record of the ray-query extension: what ray_gen/ray_extend store per path
@@ -143,6 +146,11 @@ RFW_HIP_API const char* rfw_hip_last_error(void* instance);
 RFW_HIP_API uint32_t rfw_hip_abi_version(void);
 /* Host-only self test of the CPU-side builder + node quantiser (no GPU needed): boxes6 = n x (lo.xyz, hi.xyz); returns the
  * number of structural violations (0 = pass). */
+/* Host-only self test of the spatial splits set_3d_mesh computes (no GPU needed): returns the number of references (n + duplicates), -1 on
+ * bad arguments.  pieces7 = n_pieces x (mesh-local index, lo.xyz, hi.xyz): the box of every reference of a split triangle (index < n: the
+ * triangle's own entry; >= n: a duplicate); duplicate_of[j] = the triangle duplicate n + j stands for.  split_tau as option "spatial_splits". */
+RFW_HIP_API int64_t rfw_hip_selftest_splits(const rfw_rt_triangle* tris, uint32_t n, float split_tau, uint32_t threads, float* pieces7, uint32_t pieces_cap,
+                                            uint32_t* duplicate_of, uint32_t duplicates_cap, uint32_t* n_pieces);
 RFW_HIP_API int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf, uint32_t threads, uint32_t* out_nodes);
 
 /* ---- Backend trait, in declaration order (crates/rfw-backend/src/lib.rs:36-81) ---- */

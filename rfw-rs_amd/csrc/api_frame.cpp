@@ -359,6 +359,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
     }
     {
+        if (const char* st = getenv("RFW_SPATIAL_SPLITS")) I->split_tau = (float)std::max(0.0, atof(st)); // A/B runs: the default of option "spatial_splits"
         const char* e = getenv("RFW_PACKET_TRACE"); // A/B runs: the default of option "packet_trace"
         const int pt = e ? atoi(e) : kDefaultPacketTrace;
         I->packet_auto = e == nullptr;
@@ -654,6 +655,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
     else if (k == "sky_b") I->sky[2] = (float)value;
     else if (k == "sah_max_leaf") I->sah_max_leaf = std::max(1, std::min((int)value, kMaxLeafTris));
     else if (k == "sah_trav_cost") I->sah_trav_cost = (float)value;
+    else if (k == "spatial_splits") I->split_tau = (float)std::max(0.0, value); // meshes handed over from now on: a part of a triangle is cut while its box wastes more than this x the mesh box's area; 0 = off
     else if (k == "stream_run") {
         const uint32_t r = (uint32_t)value;
         if (r != 0 && (r > 64 || (r & (r - 1)) != 0)) return fail(I, RFW_HIP_E_INVALID, "set_option: stream_run must be 0 or a power of two up to 64");

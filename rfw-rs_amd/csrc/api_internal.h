@@ -167,7 +167,22 @@ struct PinnedRing {
     }
 };
 
+// Spatial splits (round 5): a triangle whose box is much larger than the triangle needs — a wall of two triangles across the whole scene —
+// is referenced SEVERAL times, every reference with the tight box of one part of the triangle (the triangle clipped at the middle of the
+// longest axis of the part's box, recursively).  The tree is built over the references.  Reference 0 of a split triangle is the triangle's
+// own entry with another box; the further ones are DUPLICATE records appended behind the caller's triangles (records [n_orig, n_refs)),
+// whose packets carry the original's id — hits, ties (lowest id) and shading never see a duplicate.  set_3d_mesh computes them on the host.
+struct SplitPiece {
+    uint32_t index;     // mesh-local primitive: the triangle itself (< n_orig) or one of its duplicates (>= n_orig)
+    float lo[3], hi[3]; // unpadded box of the part (padded on the device like every primitive box)
+    uint32_t pad;
+};
+static_assert(sizeof(SplitPiece) == 32, "SplitPiece");
 struct MeshHost {
+    // the caller's n_orig records, then (n_refs - n_orig) duplicates of split triangles; the arrays are allocated with room for the
+    // duplicates (slack) so that a registered array never moves.  Everything that STORES the mesh counts n_refs, everything the caller sees n_orig.
+    size_t n_orig = 0, n_refs = 0;
+    std::vector<SplitPiece> pieces;   // box overrides of every reference of a split triangle (sorted by index)
     std::vector<rfw_rt_triangle> tris;
     // The first 48 B of every record (vertex0 u0 | vertex1 u1 | vertex2 u2), copied beside it by set_3d_mesh: all the device builders read
     // of a triangle.  A full build sends these first (27 % of the bytes) and builds the trees while the records follow on another stream.
@@ -357,6 +372,11 @@ struct Instance {
     // incremental synchronize (device builders, no skinned copies): a changed mesh is rebuilt in its own region of the mega-buffers (or
     // appended behind the others when it grew), the other meshes are not touched (gpu-rt/src/lib.rs:1345-1383 refits only changed meshes)
     std::vector<uint32_t> record_tri_cap;     // triangles the region of record k can hold (its node region holds max(cap, 1) nodes)
+    std::vector<uint32_t> record_tri_orig;    // the caller's triangles of record k (tri_count counts the references: + duplicates of split triangles)
+    DevBuf<SplitPiece> d_split_pieces;        // box overrides of the meshes being built (build-time only)
+    std::vector<uint32_t> record_piece_off, record_piece_n; // where record k's overrides lie in d_split_pieces during the current build
+    float split_tau = 2e-4f;                  // option "spatial_splits": a part is cut while its box wastes more than this x the mesh box's area (0 = off)
+    uint64_t n_split_refs = 0;                // duplicates in the scene (scene_stats)
     uint32_t tri_end = 0, node_end = 0;       // first free triangle / node slot behind the regions in use
     uint64_t hole_tris = 0;                   // triangles' worth of regions abandoned since the last full build
     bool layout_valid = false;                // a full device build has laid the buffers out; cleared by anything the incremental path does not cover
@@ -364,7 +384,8 @@ struct Instance {
     uint32_t incremental_builds = 0, full_builds = 0, heads_first_builds = 0;
     bool packet_auto = true; // option "packet_trace" / RFW_PACKET_TRACE not set: packets only below kPacketAutoMaxTriangles
     PinnedRing pins;
-    uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0;
+    uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0; // (n_tris: stored primitives, duplicates included)
+    uint64_t n_tris_logical = 0; // the caller's triangles
     float ms_blas_build = 0, ms_tlas_build = 0, ms_stage_wait = 0;
     float ms_blas_upload = 0, ms_blas_kernels = 0; // the last full device build, by events
     uint64_t blas_upload_bytes = 0, blas_kernel_bytes = 0;

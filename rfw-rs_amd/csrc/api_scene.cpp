@@ -49,7 +49,7 @@ inline void pad_box(PrimBox& b)
 
 void build_mesh(Instance* I, MeshHost& m)
 {
-    const size_t n = m.tris.size();
+    const size_t n = m.n_refs; // the caller's triangles + the duplicates of split triangles
     std::vector<PrimBox> boxes(n);
     for (size_t i = 0; i < n; i++) {
         const rfw_rt_triangle& t = m.tris[i];
@@ -60,6 +60,10 @@ void build_mesh(Instance* I, MeshHost& m)
         }
         pad_box(boxes[i]);
     }
+    for (const SplitPiece& sp : m.pieces) { // spatial splits: every reference of a split triangle has the box of its part
+        for (int a = 0; a < 3; a++) { boxes[sp.index].lo[a] = sp.lo[a]; boxes[sp.index].hi[a] = sp.hi[a]; }
+        pad_box(boxes[sp.index]);
+    }
     build_bvh4_host(boxes, I->sah_max_leaf, I->build_threads, m.bvh, I->sah_trav_cost);
     m.packets.resize(n);
     for (size_t k = 0; k < n; k++) {
@@ -68,6 +72,7 @@ void build_mesh(Instance* I, MeshHost& m)
         TriPacket p;
         p.v0x = t.vertex0.x; p.v0y = t.vertex0.y; p.v0z = t.vertex0.z;
         p.tri_id = id; // mesh-local; the global offset is added when the mega-buffer is assembled
+        if (id >= m.n_orig) std::memcpy(&p.tri_id, reinterpret_cast<const float*>(&t) + 15, 4); // a duplicate reports the triangle it duplicates
         // edge1 = v1 - v0, edge2 = v2 - v0 (intersection.glsl:7-8), single IEEE subtractions
         p.e1x = t.vertex1.x - t.vertex0.x; p.e1y = t.vertex1.y - t.vertex0.y; p.e1z = t.vertex1.z - t.vertex0.z;
         p.e2x = t.vertex2.x - t.vertex0.x; p.e2y = t.vertex2.y - t.vertex0.y; p.e2z = t.vertex2.z - t.vertex0.z;
@@ -140,13 +145,15 @@ int layout_derived(Instance* I, uint32_t& tri_total, uint32_t& node_total)
         MeshRecord r;
         std::memset(&r, 0, sizeof(r));
         r.tri_base = tri_total;
-        r.tri_count = (uint32_t)src.tris.size();
+        r.tri_count = (uint32_t)src.n_orig; // (a skinnable mesh is never split: n_refs == n_orig)
         r.node_base = node_total;
         r.node_count = std::max<uint32_t>(r.tri_count, 1u);
         tri_total += r.tri_count;
         node_total += r.node_count;
         d.record = (uint32_t)I->mesh_records.size();
         I->mesh_records.push_back(r);
+        I->record_tri_orig.resize(I->mesh_records.size(), 0u);
+        I->record_tri_orig.back() = r.tri_count;
         I->max_derived_tris = std::max(I->max_derived_tris, r.tri_count);
     }
     if (I->derived.empty()) return RFW_HIP_OK;
@@ -170,6 +177,52 @@ uint64_t build_pass_bytes(uint64_t n)
     return n * (208u + 116u * levels + 40u + 228u) + (n / 4u) * 320u;
 }
 
+// Spatial splits at build time.  upload_split_pieces: the box overrides of the records about to be built go up as one table (used only while
+// those records are built); patch_boxes: behind k_triangle_boxes, the references of split triangles get the boxes of their parts (`boxes` =
+// the record's first box); resolve_duplicates: behind k_make_packets, the packets of duplicate records take their original's id.
+int upload_split_pieces(Instance* I, const std::vector<uint32_t>& qs)
+{
+    I->record_piece_off.assign(I->mesh_records.size(), 0u);
+    I->record_piece_n.assign(I->mesh_records.size(), 0u);
+    std::vector<SplitPiece> all;
+    for (const auto& kv : I->mesh_index) {
+        if (std::find(qs.begin(), qs.end(), kv.second) == qs.end()) continue;
+        const auto mit = I->meshes.find(kv.first);
+        if (mit == I->meshes.end() || mit->second.pieces.empty()) continue;
+        I->record_piece_off[kv.second] = (uint32_t)all.size();
+        I->record_piece_n[kv.second] = (uint32_t)mit->second.pieces.size();
+        all.insert(all.end(), mit->second.pieces.begin(), mit->second.pieces.end());
+    }
+    if (all.empty()) return RFW_HIP_OK;
+    HIP_TRY(I, I->d_split_pieces.ensure(all.size()));
+    HIP_TRY(I, I->pins.upload(I->d_split_pieces.ptr, all.data(), all.size() * sizeof(SplitPiece), I->stream));
+    return RFW_HIP_OK;
+}
+inline void patch_boxes(Instance* I, hipStream_t s, uint32_t q, DevBox* boxes)
+{
+    if (q < I->record_piece_n.size() && I->record_piece_n[q]) launch_patch_boxes(s, I->d_split_pieces.ptr + I->record_piece_off[q], I->record_piece_n[q], boxes);
+}
+inline void resolve_duplicates(Instance* I, hipStream_t s, uint32_t q)
+{
+    const MeshRecord& r = I->mesh_records[q];
+    if (q < I->record_tri_orig.size() && I->record_tri_orig[q] < r.tri_count)
+        launch_resolve_duplicates(s, I->d_packets.ptr + r.tri_base, r.tri_count, r.tri_base, I->record_tri_orig[q], I->d_triangles.ptr + r.tri_base);
+}
+// boxes of a record's primitives (from the heads while a build runs ahead of the records), references of split triangles patched
+inline void record_boxes(Instance* I, hipStream_t s, uint32_t q, DevBox* out)
+{
+    const MeshRecord& r = I->mesh_records[q];
+    if (I->build_from_heads) launch_triangle_boxes(s, I->d_heads.ptr + r.tri_base, r.tri_count, out);
+    else launch_triangle_boxes(s, I->d_triangles.ptr + r.tri_base, r.tri_count, out);
+    patch_boxes(I, s, q, out);
+}
+inline void record_packets(Instance* I, hipStream_t s, uint32_t q)
+{
+    const MeshRecord& r = I->mesh_records[q];
+    launch_make_packets(s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    resolve_duplicates(I, s, q);
+}
+
 // One static mesh on the device, into the region its record names: boxes -> BVH (binned SAH, or LBVH) -> leaf-ordered packets ->
 // quantised nodes.  The triangles are already in d_triangles.  `quantise_count` nodes of the region are quantised (the region is sized for
 // the worst case, one node per primitive; nodes behind the tree's own are never referenced).
@@ -177,8 +230,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
 {
     const MeshRecord& r = I->mesh_records[q];
     if (r.tri_count == 0) return RFW_HIP_OK;
-    if (I->build_from_heads) launch_triangle_boxes(I->stream, I->d_heads.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
-    else launch_triangle_boxes(I->stream, I->d_triangles.ptr + r.tri_base, r.tri_count, I->d_tri_boxes.ptr);
+    record_boxes(I, I->stream, q, I->d_tri_boxes.ptr);
     if (I->blas_sah_on_device) {
         HIP_TRY(I, I->d_sah_ws.ensure(sah_workspace_bytes(r.tri_count)));
         const hipError_t se = sah_build(I->stream, I->d_tri_boxes.ptr, r.tri_count, I->d_sah_ws.ptr, I->d_sah_ws.cap, I->d_blas_raw.ptr + r.node_base,
@@ -194,7 +246,7 @@ int build_mesh_device(Instance* I, uint32_t q, uint32_t quantise_count)
                               I->d_blas_order.ptr + r.tri_base, I->d_mesh_node_counts.ptr + q));
     }
     // (a full build makes the packets of all meshes at its end: they need the records, which are still on their way while the trees are built)
-    if (!I->build_from_heads) launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+    if (!I->build_from_heads) record_packets(I, I->stream, q);
     launch_quantize_nodes(I->stream, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, quantise_count, I->d_mesh_node_counts.ptr + q);
     return RFW_HIP_OK;
 }
@@ -234,13 +286,12 @@ int build_meshes(Instance* I, const std::vector<uint32_t>& qs, bool incremental)
                 for (size_t i = next.fetch_add(1); i < small.size(); i = next.fetch_add(1)) {
                     const uint32_t q = small[i];
                     const MeshRecord& r = I->mesh_records[q];
-                    if (I->build_from_heads) launch_triangle_boxes(L.s, I->d_heads.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
-                    else launch_triangle_boxes(L.s, I->d_triangles.ptr + r.tri_base, r.tri_count, L.boxes.ptr);
+                    record_boxes(I, L.s, q, L.boxes.ptr);
                     const hipError_t e = sah_build(L.s, L.boxes.ptr, r.tri_count, L.ws.ptr, L.ws.cap, I->d_blas_raw.ptr + r.node_base, I->d_blas_order.ptr + r.tri_base,
                                                    I->d_mesh_node_counts.ptr + q, I->sah_max_leaf, I->sah_trav_cost);
                     if (e == hipErrorInvalidValue) { redo[q] = 1; continue; } // deeper than the builder's level budget: LBVH, below
                     if (e != hipSuccess) { lane_err[k] = e; return; }
-                    if (!I->build_from_heads) launch_make_packets(L.s, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+                    if (!I->build_from_heads) record_packets(I, L.s, q);
                     if (incremental) launch_quantize_nodes(L.s, I->d_blas_raw.ptr + r.node_base, I->d_blas_nodes.ptr + r.node_base, copies_of(I->d_blas_wide, I->d_blas_oct), r.node_base, std::max(r.tri_count, 1u), I->d_mesh_node_counts.ptr + q);
                 }
                 (void)hipEventRecord(L.done, L.s);
@@ -267,12 +318,13 @@ void assign_logical_ids(Instance* I)
         const auto it = I->mesh_index.find(kv.first);
         if (it == I->mesh_index.end()) continue;
         I->mesh_records[it->second].tri_logical = logical;
-        logical += I->mesh_records[it->second].tri_count;
+        logical += I->record_tri_orig[it->second]; // the caller's triangles: duplicates of split triangles have no id of their own
     }
     for (auto& kv : I->derived) {
         I->mesh_records[kv.second.record].tri_logical = logical;
         logical += I->mesh_records[kv.second.record].tri_count;
     }
+    I->n_tris_logical = logical;
 }
 
 // BLAS for every mesh on the device: lay the mega-buffers out afresh, upload all triangles, build every mesh
@@ -286,12 +338,14 @@ int build_blas_device_full(Instance* I)
     I->mesh_records.clear();
     I->mesh_index.clear();
     I->record_tri_cap.clear();
+    I->record_tri_orig.clear();
     uint32_t tri_total = 0, node_total = 0;
     for (auto& kv : I->meshes) {
         MeshRecord r;
         std::memset(&r, 0, sizeof(r));
         r.tri_base = tri_total;
-        r.tri_count = (uint32_t)kv.second.tris.size();
+        r.tri_count = (uint32_t)kv.second.n_refs; // stored primitives: the caller's triangles + the duplicates of split ones
+        I->record_tri_orig.push_back((uint32_t)kv.second.n_orig);
         r.node_base = node_total;
         r.node_count = std::max<uint32_t>(r.tri_count, 1u); // worst case (one primitive per leaf => at most n - 1 wide nodes)
         tri_total += r.tri_count;
@@ -316,6 +370,11 @@ int build_blas_device_full(Instance* I)
     for (auto& ev : I->ev_build)
         if (!ev) HIP_TRY(I, hipEventCreate(&ev));
     HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    {
+        std::vector<uint32_t> all_static(n_static);
+        for (size_t q = 0; q < n_static; q++) all_static[q] = (uint32_t)q;
+        if ((rc = upload_split_pieces(I, all_static))) return rc;
+    }
     // Heads first: the builders read 48 of a record's 176 B, so those go up on the instance's stream and the trees are built while the records
     // follow on a stream of their own (registered host memory: both copies are asynchronous).  Only the packets and the renderer need the
     // records; the stream waits for them before the packets are made.  (C4, 185 MB: upload 3.5 ms + kernels 4.5 ms one after the other before.)
@@ -390,11 +449,13 @@ int build_blas_device_full(Instance* I)
             HIP_TRY(I, I->d_sah_ws.ensure(sah_forest_workspace_bytes(static_tris, (uint32_t)n_static)));
             if (I->build_from_heads) launch_triangle_boxes(I->stream, I->d_heads.ptr, static_tris, I->d_tri_boxes.ptr);
             else launch_triangle_boxes(I->stream, I->d_triangles.ptr, static_tris, I->d_tri_boxes.ptr);
+            for (size_t q = 0; q < n_static; q++) patch_boxes(I, I->stream, (uint32_t)q, I->d_tri_boxes.ptr + I->mesh_records[q].tri_base);
             const hipError_t fe = sah_build_forest(I->stream, I->d_tri_boxes.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static, max_n, I->d_sah_ws.ptr, I->d_sah_ws.cap,
                                                    I->d_blas_raw.ptr, I->d_blas_order.ptr, I->d_mesh_node_counts.ptr, I->sah_max_leaf, I->sah_trav_cost);
             if (fe == hipSuccess) {
                 if (I->build_from_heads) HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
                 launch_make_packets(I->stream, I->d_triangles.ptr, I->d_blas_order.ptr, static_tris, 0u, I->d_packets.ptr); // global positions: one launch
+                for (size_t q = 0; q < n_static; q++) resolve_duplicates(I, I->stream, (uint32_t)q);
                 launch_forest_relative_order(I->stream, I->d_blas_order.ptr, static_tris, I->d_forest.ptr, (uint32_t)n_static);
                 forest_done = true;
             } else if (fe != hipErrorInvalidValue) {
@@ -408,8 +469,8 @@ int build_blas_device_full(Instance* I)
                 I->build_from_heads = false;
                 HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
                 if (rc == RFW_HIP_OK)
-                    for (const MeshRecord& r : I->mesh_records)
-                        if (r.tri_count) launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+                    for (size_t q = 0; q < n_static; q++)
+                        if (I->mesh_records[q].tri_count) record_packets(I, I->stream, (uint32_t)q);
             }
             if (rc) return rc;
         }
@@ -421,6 +482,8 @@ int build_blas_device_full(Instance* I)
                             I->d_mesh_node_counts.ptr, (uint32_t)n_static);
     HIP_TRY(I, hipGetLastError());
     I->n_tris = tri_total;
+    I->n_split_refs = 0;
+    for (size_t q = 0; q < n_static; q++) I->n_split_refs += I->mesh_records[q].tri_count - I->record_tri_orig[q];
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     trace("all queued");
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -477,7 +540,7 @@ int build_blas_device_incremental(Instance* I)
     for (auto& kv : I->meshes) {
         MeshHost& m = kv.second;
         if (!m.dirty) continue;
-        const uint32_t n = (uint32_t)m.tris.size();
+        const uint32_t n = (uint32_t)m.n_refs;
         uint32_t q;
         const auto it = I->mesh_index.find(kv.first);
         if (it != I->mesh_index.end() && n <= I->record_tri_cap[it->second]) {
@@ -492,6 +555,7 @@ int build_blas_device_incremental(Instance* I)
                 std::memset(&r, 0, sizeof(r));
                 I->mesh_records.push_back(r);
                 I->record_tri_cap.push_back(0);
+                I->record_tri_orig.push_back(0);
                 I->mesh_index[kv.first] = q;
             }
             if ((uint64_t)I->tri_end + n > kLeafFirstMask || (uint64_t)I->node_end + std::max(n, 1u) > 0x7fffffffu) return 1;
@@ -502,6 +566,7 @@ int build_blas_device_incremental(Instance* I)
             I->node_end += std::max(n, 1u);
         }
         I->mesh_records[q].tri_count = n;
+        I->record_tri_orig[q] = (uint32_t)m.n_orig;
         I->mesh_records[q].node_count = std::max(I->record_tri_cap[q], 1u);
         todo.push_back(q);
         max_n = std::max(max_n, n);
@@ -526,6 +591,7 @@ int build_blas_device_incremental(Instance* I)
     for (auto& ev : I->ev_build)
         if (!ev) HIP_TRY(I, hipEventCreate(&ev));
     HIP_TRY(I, hipEventRecord(I->ev_build[0], I->stream));
+    if ((rc = upload_split_pieces(I, todo))) return rc;
     uint64_t upload_bytes = 0, kernel_bytes = 0;
     // ONE large registered mesh changed (a deforming mesh that is re-sent every frame): heads first, as in a full build — the tree is built
     // from the 48-B heads while the records follow on the second stream, the packets are made when they are there.  Nothing is synchronised
@@ -580,7 +646,8 @@ int build_blas_device_incremental(Instance* I)
     if (heads_first) {
         const MeshRecord& r = I->mesh_records[todo[0]];
         HIP_TRY(I, hipStreamWaitEvent(I->stream, I->ev_records, 0));
-        launch_make_packets(I->stream, I->d_triangles.ptr + r.tri_base, I->d_blas_order.ptr + r.tri_base, r.tri_count, r.tri_base, I->d_packets.ptr + r.tri_base);
+        (void)r;
+        record_packets(I, I->stream, todo[0]);
     }
     HIP_TRY(I, hipEventRecord(I->ev_build[2], I->stream));
     I->build_events_pending = true;
@@ -591,6 +658,8 @@ int build_blas_device_incremental(Instance* I)
     uint64_t live = 0;
     for (auto& kv : I->mesh_index) live += I->mesh_records[kv.second].tri_count;
     I->n_tris = live;
+    I->n_split_refs = 0;
+    for (auto& kv : I->mesh_index) I->n_split_refs += I->mesh_records[kv.second].tri_count - I->record_tri_orig[kv.second];
     I->node_counts_stale = true;
     I->incremental_builds++;
     return RFW_HIP_OK;
@@ -627,6 +696,8 @@ int build_blas_host(Instance* I)
         if (kv.second.dirty) build_mesh(I, kv.second);
     I->mesh_records.clear();
     I->mesh_index.clear();
+    I->record_tri_orig.clear();
+    I->n_split_refs = 0;
     I->layout_valid = false;
     std::vector<Node4> nodes;
     std::vector<TriPacket> packets;
@@ -638,14 +709,16 @@ int build_blas_host(Instance* I)
         r.node_base = (uint32_t)nodes.size();
         r.node_count = (uint32_t)m.bvh.nodes.size();
         r.tri_base = (uint32_t)tris.size();
-        r.tri_count = (uint32_t)m.tris.size();
+        r.tri_count = (uint32_t)m.n_refs;
         I->mesh_index[kv.first] = (uint32_t)I->mesh_records.size();
         I->mesh_records.push_back(r);
+        I->record_tri_orig.push_back((uint32_t)m.n_orig);
+        I->n_split_refs += m.n_refs - m.n_orig;
         nodes.insert(nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
         const size_t p0 = packets.size();
         packets.insert(packets.end(), m.packets.begin(), m.packets.end());
         for (size_t k = p0; k < packets.size(); k++) packets[k].tri_id += r.tri_base; // global triangle id
-        tris.insert(tris.end(), m.tris.begin(), m.tris.end());
+        tris.insert(tris.end(), m.tris.begin(), m.tris.begin() + (ptrdiff_t)m.n_refs);
     }
     uint32_t tri_total = (uint32_t)tris.size(), node_total = (uint32_t)nodes.size();
     int rc;
@@ -1052,24 +1125,260 @@ int rfw_hip_set_2d_instances(void* inst, uint32_t, const rfw_mat4*, uint32_t) { 
 // The host copy of a mesh: the records, and their 48-B heads beside them (MeshHost).  Several threads for a large mesh (one thread moves
 // ~10 GB/s: 185 MB of C4 took 18 of the 45 ms a re-sent scene cost before anything reached the device).  A mesh of >= 128 KB is registered
 // with the runtime the first time it is RE-sent at an unchanged size.
-static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads)
+// ---- spatial splits (MeshHost, api_internal.h).  Everything here is host arithmetic on the caller's vertices: deterministic, the same on every rank.
+namespace {
+struct SplitPoly { int n; float p[10][3]; }; // a triangle clipped by axis planes: at most 3 + 6 vertices ... and one spare
+inline void clip_poly(const SplitPoly& in, int axis, float pos, bool keep_below, SplitPoly& out)
 {
-    if (m.tris.size() != n) {
+    out.n = 0;
+    for (int i = 0; i < in.n && out.n < 9; i++) {
+        const float* a = in.p[i];
+        const float* b = in.p[(i + 1) % in.n];
+        const bool ia = keep_below ? a[axis] <= pos : a[axis] >= pos, ib = keep_below ? b[axis] <= pos : b[axis] >= pos;
+        if (ia) std::memcpy(out.p[out.n++], a, 12);
+        if (ia != ib && out.n < 10) {
+            // the same expression in both halves (same endpoints, same order): the two parts share their cut points exactly
+            const float t = (pos - a[axis]) / (b[axis] - a[axis]);
+            float* q = out.p[out.n++];
+            for (int k = 0; k < 3; k++) q[k] = a[k] + t * (b[k] - a[k]);
+            q[axis] = pos;
+        }
+    }
+}
+inline void poly_box(const SplitPoly& p, float lo[3], float hi[3])
+{
+    for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int i = 0; i < p.n; i++)
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p.p[i][a]); hi[a] = std::max(hi[a], p.p[i][a]); }
+}
+inline double box_area6(const float lo[3], const float hi[3])
+{
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+inline double poly_area(const SplitPoly& q)
+{
+    double ax = 0, ay = 0, az = 0;
+    for (int k = 1; k + 1 < q.n; k++) {
+        double u[3], w[3];
+        for (int a = 0; a < 3; a++) { u[a] = (double)q.p[k][a] - q.p[0][a]; w[a] = (double)q.p[k + 1][a] - q.p[0][a]; }
+        ax += u[1] * w[2] - u[2] * w[1]; ay += u[2] * w[0] - u[0] * w[2]; az += u[0] * w[1] - u[1] * w[0];
+    }
+    return 0.5 * std::sqrt(ax * ax + ay * ay + az * az);
+}
+// what the box of a triangle wastes: its area minus the area the flattest box of a triangle of this orientation and size must have
+// (|n_x| + |n_y| + |n_z| of the edge cross product: Karras & Aila 2013, "Fast parallel construction of high-quality bounding volume hierarchies", §4.2)
+inline float triangle_waste(const float* v0, const float* v1, const float* v2, float* ideal_out = nullptr)
+{
+    float lo[3], hi[3], e1[3], e2[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = std::min(v0[a], std::min(v1[a], v2[a])); hi[a] = std::max(v0[a], std::max(v1[a], v2[a]));
+        e1[a] = v1[a] - v0[a]; e2[a] = v2[a] - v0[a];
+    }
+    const float ideal = std::fabs(e1[1] * e2[2] - e1[2] * e2[1]) + std::fabs(e1[2] * e2[0] - e1[0] * e2[2]) + std::fabs(e1[0] * e2[1] - e1[1] * e2[0]);
+    if (ideal_out) *ideal_out = ideal;
+    return (float)box_area6(lo, hi) - ideal;
+}
+struct SplitScan {          // what one copy thread learns about its share of the triangles
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<std::pair<float, uint32_t>> top; // min-heap of the kKeep most wasteful (waste, index)
+    bool overflowed = false; // more than kKeep candidates passed through: the smallest kept one bounds what was dropped
+    float dropped_max = 0.0f;
+    // A triangle is a candidate when its box wastes more than tau_rel x the area of the MESH's box, which the thread does not know yet — but
+    // the box of what it has seen so far is inside it, and a triangle's waste is at most its box's area: a triangle whose box area is below
+    // tau_rel x (area of the bounds so far) cannot be one.  `floor_area` is that bound, refreshed every 256 triangles.
+    float tau_rel = 0.0f, floor_area = 0.0f;
+    uint32_t since_refresh = 0;
+};
+constexpr size_t kSplitKeep = 2048;
+inline void scan_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i)
+{
+    float area2 = 0.0f;
+    {
+        float ext[3];
+        for (int a = 0; a < 3; a++) {
+            const float l = std::min(v0[a], std::min(v1[a], v2[a])), h = std::max(v0[a], std::max(v1[a], v2[a]));
+            sc.lo[a] = std::min(sc.lo[a], l); sc.hi[a] = std::max(sc.hi[a], h);
+            ext[a] = h - l;
+        }
+        area2 = 2.0f * (ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]);
+    }
+    if (++sc.since_refresh >= 256u) {
+        sc.since_refresh = 0;
+        const double a = box_area6(sc.lo, sc.hi);
+        sc.floor_area = a < 1e30 ? (float)((double)sc.tau_rel * a) : 0.0f;
+    }
+    if (!(area2 > sc.floor_area)) return; // (the common small triangle leaves here)
+    // (waste <= box area: the common small triangle leaves after this compare)
+    if (!(area2 > (sc.top.size() < kSplitKeep ? 0.0f : sc.top.front().first))) return;
+    const float w = triangle_waste(v0, v1, v2);
+    if (!(w > 0.0f) || !(w < INFINITY)) return;
+    const auto greater = [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); };
+    if (sc.top.size() < kSplitKeep) {
+        sc.top.emplace_back(w, i);
+        std::push_heap(sc.top.begin(), sc.top.end(), greater);
+    } else if (w > sc.top.front().first) {
+        sc.overflowed = true;
+        sc.dropped_max = std::max(sc.dropped_max, sc.top.front().first);
+        std::pop_heap(sc.top.begin(), sc.top.end(), greater);
+        sc.top.back() = std::make_pair(w, i);
+        std::push_heap(sc.top.begin(), sc.top.end(), greater);
+    } else {
+        sc.overflowed = true;
+        sc.dropped_max = std::max(sc.dropped_max, w);
+    }
+}
+} // namespace
+
+// References of the mesh's most wasteful triangles (MeshHost): the part with the largest waste is cut first (at the middle of the longest axis
+// of its box) until no part wastes more than tau = split_tau x the area of the mesh's box, or the budget of duplicates is spent.
+static void split_references(const float split_tau, MeshHost& m, const std::vector<SplitScan>& scans, size_t budget)
+{
+    m.pieces.clear();
+    m.n_refs = m.n_orig;
+    if (!(split_tau > 0.0f) || budget == 0 || m.n_orig < 64) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const SplitScan& sc : scans)
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], sc.lo[a]); hi[a] = std::max(hi[a], sc.hi[a]); }
+    const double root_area = box_area6(lo, hi);
+    if (!(root_area > 0.0) || !(root_area < 1e30)) return;
+    const float tau = (float)((double)split_tau * root_area);
+    // the candidates: every triangle that wastes more than tau.  The threads kept their kSplitKeep most wasteful ones; if one of them dropped
+    // a triangle above tau the heads are scanned again (a mesh of more than kSplitKeep huge triangles per thread: rare, and correct either way)
+    std::vector<std::pair<float, uint32_t>> cand;
+    bool rescan = false;
+    for (const SplitScan& sc : scans) {
+        rescan = rescan || (sc.overflowed && sc.dropped_max > tau);
+        for (const auto& c : sc.top)
+            if (c.first > tau) cand.push_back(c);
+    }
+    if (rescan) {
+        cand.clear();
+        for (size_t i = 0; i < m.n_orig; i++) {
+            const float* h = m.heads[i].v;
+            const float w = triangle_waste(h, h + 4, h + 8);
+            if (w > tau && w < INFINITY) cand.emplace_back(w, (uint32_t)i);
+        }
+    }
+    if (cand.empty()) return;
+    struct Part { float waste; uint32_t tri; uint32_t serial; SplitPoly poly; float lo[3], hi[3]; };
+    // max-heap on (waste, then the earlier part): a total order, the same whatever the thread count was
+    const auto less = [](const Part& a, const Part& b) { return a.waste < b.waste || (a.waste == b.waste && a.serial > b.serial); };
+    std::sort(cand.begin(), cand.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
+    std::vector<Part> heap;
+    std::vector<float> ideal(cand.size()), tri_area(cand.size());
+    std::vector<uint32_t> parts_of(cand.size(), 1u);
+    uint32_t serial = 0;
+    for (size_t c = 0; c < cand.size(); c++) {
+        const float* h = m.heads[cand[c].second].v;
+        Part p;
+        p.tri = (uint32_t)c; p.serial = serial++;
+        p.poly.n = 3;
+        for (int k = 0; k < 3; k++) std::memcpy(p.poly.p[k], h + 4 * k, 12);
+        poly_box(p.poly, p.lo, p.hi);
+        p.waste = triangle_waste(h, h + 4, h + 8, &ideal[c]);
+        tri_area[c] = (float)poly_area(p.poly);
+        heap.push_back(p);
+    }
+    std::make_heap(heap.begin(), heap.end(), less);
+    std::vector<Part> done;
+    size_t extra = 0;
+    constexpr uint32_t kMaxPartsPerTriangle = 64;
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), less);
+        Part p = heap.back();
+        heap.pop_back();
+        int axis = 0;
+        for (int a = 1; a < 3; a++)
+            if (p.hi[a] - p.lo[a] > p.hi[axis] - p.lo[axis]) axis = a;
+        const float pos = 0.5f * (p.lo[axis] + p.hi[axis]);
+        bool cut = p.waste > tau && extra < budget && parts_of[p.tri] < kMaxPartsPerTriangle && pos > p.lo[axis] && pos < p.hi[axis];
+        Part a = p, b = p;
+        if (cut) {
+            clip_poly(p.poly, axis, pos, true, a.poly);
+            clip_poly(p.poly, axis, pos, false, b.poly);
+            cut = a.poly.n >= 3 && b.poly.n >= 3;
+        }
+        if (!cut) { done.push_back(p); continue; }
+        for (Part* q : {&a, &b}) {
+            poly_box(q->poly, q->lo, q->hi);
+            const double share = tri_area[p.tri] > 0.0f ? poly_area(q->poly) / (double)tri_area[p.tri] : 1.0;
+            q->waste = (float)(box_area6(q->lo, q->hi) - share * (double)ideal[p.tri]);
+            q->serial = serial++;
+            heap.push_back(*q);
+            std::push_heap(heap.begin(), heap.end(), less);
+        }
+        parts_of[p.tri]++;
+        extra++;
+    }
+    // parts -> references: per split triangle (in index order) its parts in creation order; the first keeps the triangle's own entry
+    std::sort(done.begin(), done.end(), [](const Part& a, const Part& b) { return a.tri < b.tri || (a.tri == b.tri && a.serial < b.serial); });
+    size_t next_dup = m.n_orig;
+    for (size_t k = 0; k < done.size();) {
+        size_t e = k;
+        while (e < done.size() && done[e].tri == done[k].tri) e++;
+        if (e - k >= 2) {
+            const uint32_t orig = cand[done[k].tri].second;
+            for (size_t j = k; j < e; j++) {
+                SplitPiece sp;
+                sp.index = j == k ? orig : (uint32_t)next_dup;
+                for (int a = 0; a < 3; a++) { sp.lo[a] = done[j].lo[a]; sp.hi[a] = done[j].hi[a]; }
+                sp.pad = 0u;
+                m.pieces.push_back(sp);
+                if (j != k) {
+                    // the duplicate: the original's record (the packet kernel needs its vertices and normal) with the original's index where
+                    // k_resolve_duplicates looks for it (the v0 texture coordinate; a duplicate is never shaded)
+                    m.tris[next_dup] = m.tris[orig];
+                    const uint32_t o = orig;
+                    std::memcpy(reinterpret_cast<float*>(&m.tris[next_dup]) + 15, &o, 4);
+                    m.heads[next_dup] = m.heads[orig];
+                    next_dup++;
+                }
+            }
+        }
+        k = e;
+    }
+    m.n_refs = next_dup;
+    std::sort(m.pieces.begin(), m.pieces.end(), [](const SplitPiece& a, const SplitPiece& b) { return a.index < b.index; });
+}
+
+// room for the duplicates of split triangles behind the caller's n triangles (allocated with the arrays: a registered array never moves)
+static size_t split_slack(const float split_tau, size_t n, bool skinned)
+{
+    if (!(split_tau > 0.0f) || skinned || n < 64) return 0;
+    return std::min<size_t>(n / 32 + 64, size_t(1) << 20);
+}
+
+static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack);
+static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, bool skinned)
+{
+    const size_t slack = split_slack(I->split_tau, n, skinned), alloc = n + slack;
+    if (m.tris.size() != alloc) {
         m.unpin();
-        m.tris.clear(); m.tris.shrink_to_fit(); m.tris.resize(n);
-        m.heads.clear(); m.heads.shrink_to_fit(); m.heads.resize(n);
+        m.tris.clear(); m.tris.shrink_to_fit(); m.tris.resize(alloc);
+        m.heads.clear(); m.heads.shrink_to_fit(); m.heads.resize(alloc);
     } else if (!m.pinned && !m.pin_failed && I->blas_on_device && n * sizeof(rfw_rt_triangle) >= (128u << 10) && !getenv("RFW_NO_PINNED_MESHES") &&
                hipSetDevice(I->device) == hipSuccess) {
         // re-sent at the same size: a mesh that changes.  Registering costs ~0.2 ms per MB, once (a scene that is loaded and never re-sent does not pay it)
-        const bool a = hipHostRegister(m.tris.data(), n * sizeof(rfw_rt_triangle), hipHostRegisterDefault) == hipSuccess;
-        const bool b = a && hipHostRegister(m.heads.data(), n * sizeof(TriHead), hipHostRegisterDefault) == hipSuccess;
+        const bool a = hipHostRegister(m.tris.data(), alloc * sizeof(rfw_rt_triangle), hipHostRegisterDefault) == hipSuccess;
+        const bool b = a && hipHostRegister(m.heads.data(), alloc * sizeof(TriHead), hipHostRegisterDefault) == hipSuccess;
         if (a && !b) (void)hipHostUnregister(m.tris.data());
         m.pinned = a && b;
         if (!m.pinned) { (void)hipGetLastError(); m.pin_failed = true; } // (the limit on locked memory, say: the uploads are staged by the runtime as before)
     }
+    copy_and_split(m, src, n, threads, I->split_tau, slack);
+}
+// (host arithmetic only: also what rfw_hip_selftest_splits runs, without a device)
+static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack)
+{
+    m.n_orig = n;
+    m.n_refs = n;
+    m.pieces.clear();
+    const bool scan = slack != 0;
     // one pass over the source: every record is read once and goes out through non-temporal stores, its head a second time into the heads
-    // array (a memcpy of the records plus a pass for the heads reads 44 % of the source twice; chunked memcpys lose the streaming stores)
-    auto part = [&m, src](size_t a, size_t b) {
+    // array (a memcpy of the records plus a pass for the heads reads 44 % of the source twice; chunked memcpys lose the streaming stores).
+    // The same pass looks for the triangles worth splitting (bounds of the share, its most wasteful triangles: SplitScan)
+    auto part = [&m, src, scan](size_t a, size_t b, SplitScan* sc) {
 #if defined(__SSE2__)
         if ((reinterpret_cast<uintptr_t>(m.tris.data()) & 15u) == 0 && (reinterpret_cast<uintptr_t>(m.heads.data()) & 15u) == 0) {
             constexpr int kWords = (int)(sizeof(rfw_rt_triangle) / 16);
@@ -1081,24 +1390,57 @@ static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src,
                 for (int k = 0; k < kWords; k++) w[k] = _mm_loadu_si128(in + k);
                 for (int k = 0; k < kWords; k++) _mm_stream_si128(out + k, w[k]);
                 for (int k = 0; k < 3; k++) _mm_stream_si128(head + k, w[k]);
+                if (scan) {
+                    alignas(16) float v[12];
+                    for (int k = 0; k < 3; k++) _mm_store_si128(reinterpret_cast<__m128i*>(v) + k, w[k]);
+                    scan_triangle(*sc, v, v + 4, v + 8, (uint32_t)i);
+                }
             }
             _mm_sfence();
             return;
         }
 #endif
         if (a < b) std::memcpy(m.tris.data() + a, src + a, (b - a) * sizeof(rfw_rt_triangle));
-        for (size_t k = a; k < b; k++) std::memcpy(&m.heads[k], src + k, sizeof(TriHead));
+        for (size_t k = a; k < b; k++) {
+            std::memcpy(&m.heads[k], src + k, sizeof(TriHead));
+            if (scan) scan_triangle(*sc, m.heads[k].v, m.heads[k].v + 4, m.heads[k].v + 8, (uint32_t)k);
+        }
     };
     const size_t bytes = n * sizeof(rfw_rt_triangle);
-    const int nt = (int)std::min<size_t>((size_t)std::max(threads, 1), bytes >> 22); // at least 4 MB per thread
-    if (nt <= 1) { part(0, n); return; }
-    std::vector<std::thread> pool;
-    const size_t per = (n + nt - 1) / nt;
-    for (int k = 0; k < nt; k++) {
-        const size_t a = std::min(n, per * k), b = std::min(n, a + per);
-        if (a < b) pool.emplace_back(part, a, b);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), bytes >> 22)); // at least 4 MB per thread
+    std::vector<SplitScan> scans((size_t)nt);
+    for (SplitScan& sc : scans) sc.tau_rel = split_tau;
+    if (nt <= 1) part(0, n, &scans[0]);
+    else {
+        std::vector<std::thread> pool;
+        const size_t per = (n + nt - 1) / nt;
+        for (int k = 0; k < nt; k++) {
+            const size_t a = std::min(n, per * k), b = std::min(n, a + per);
+            if (a < b) pool.emplace_back(part, a, b, &scans[(size_t)k]);
+        }
+        for (auto& t : pool) t.join();
     }
-    for (auto& t : pool) t.join();
+    if (scan) split_references(split_tau, m, scans, slack);
+}
+
+// Host-only self test of the spatial splits (no GPU needed): runs what set_3d_mesh runs on `tris` and hands back the references.
+int64_t rfw_hip_selftest_splits(const rfw_rt_triangle* tris, uint32_t n, float split_tau, uint32_t threads, float* pieces7, uint32_t pieces_cap, uint32_t* duplicate_of,
+                                uint32_t duplicates_cap, uint32_t* n_pieces)
+{
+    if (!tris || !n_pieces) return -1;
+    MeshHost m;
+    const size_t slack = split_slack(split_tau, n, false);
+    m.tris.resize(n + slack);
+    m.heads.resize(n + slack);
+    copy_and_split(m, tris, n, (int)std::max(threads, 1u), split_tau, slack);
+    *n_pieces = (uint32_t)m.pieces.size();
+    for (size_t k = 0; k < m.pieces.size() && k < pieces_cap && pieces7; k++) {
+        pieces7[7 * k] = (float)m.pieces[k].index;
+        for (int a = 0; a < 3; a++) { pieces7[7 * k + 1 + a] = m.pieces[k].lo[a]; pieces7[7 * k + 4 + a] = m.pieces[k].hi[a]; }
+    }
+    for (size_t j = m.n_orig; j < m.n_refs && j - m.n_orig < duplicates_cap && duplicate_of; j++)
+        std::memcpy(&duplicate_of[j - m.n_orig], reinterpret_cast<const float*>(&m.tris[j]) + 15, 4);
+    return (int64_t)m.n_refs;
 }
 
 int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
@@ -1113,11 +1455,11 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
         I->records_pending = false;
     }
     const auto t_copy = std::chrono::steady_clock::now();
-    copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads); // copy: the borrow ends with this call
+    const bool skinned = d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING);
+    copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads, skinned); // copy: the borrow ends with this call (a skinned mesh is refitted, not split)
     if (getenv("RFW_BUILD_TRACE")) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
     m.skin.clear();
-    if (d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING))
-        m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
+    if (skinned) m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
     m.dirty = true;
     I->meshes_dirty = true;
     return RFW_HIP_OK;
@@ -1383,7 +1725,8 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
             I->node_counts_stale = false;
         }
     }
-    out->triangles = I->n_tris;
+    out->triangles = I->n_tris_logical; // the caller's triangles (I->n_tris also counts the duplicates of split triangles)
+    out->split_references = I->n_split_refs;
     out->instances = I->n_valid_instances;
     out->blas_nodes = I->n_blas_nodes;
     if (I->tlas_on_device && I->d_node_count.ptr && I->synchronized) {

@@ -48,6 +48,11 @@ void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t 
 struct TriHead { float v[12]; };
 static_assert(sizeof(TriHead) == 48, "TriHead = the first three float4 of rfw_rt_triangle");
 void launch_triangle_boxes(hipStream_t s, const TriHead* heads, uint32_t n, DevBox* out);
+// Spatial splits: boxes[piece.index] = the piece's box, padded like k_triangle_boxes pads (`pieces` = n x {index, lo[3], hi[3], pad}, 32 B each)
+void launch_patch_boxes(hipStream_t s, const void* pieces, uint32_t n, DevBox* boxes);
+// ... and the packets of duplicate records take the id of the triangle they duplicate: a packet whose mesh-local id is >= n_orig reads the
+// original's mesh-local index from the bits of its own record's 16th float (the v0 texture coordinate: set_3d_mesh put it there)
+void launch_resolve_duplicates(hipStream_t s, TriPacket* packets, uint32_t n, uint32_t id_offset, uint32_t n_orig, const rfw_rt_triangle* tris);
 // leaf-ordered traversal packets: packet k = triangle order[k]; tri_id = order[k] + id_offset
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out);
 

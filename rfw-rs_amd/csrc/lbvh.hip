@@ -319,6 +319,31 @@ __global__ void k_triangle_boxes(const float4* __restrict__ tris, uint32_t strid
     out[i] = bx;
 }
 
+struct SplitPieceDev { uint32_t index; float lo[3], hi[3]; uint32_t pad; };
+__global__ void k_patch_boxes(const SplitPieceDev* __restrict__ pieces, uint32_t n, DevBox* boxes)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const SplitPieceDev p = pieces[i];
+    DevBox bx;
+    for (int k = 0; k < 3; k++) {
+        const float e = 1e-4f + 4e-6f * fmaxf(fabsf(p.lo[k]), fabsf(p.hi[k]));
+        bx.lo[k] = p.lo[k] - e;
+        bx.hi[k] = p.hi[k] + e;
+    }
+    bx.lo[3] = 0.0f; bx.hi[3] = 0.0f;
+    boxes[p.index] = bx;
+}
+__global__ void k_resolve_duplicates(TriPacket* packets, uint32_t n, uint32_t id_offset, uint32_t n_orig, const rfw_rt_triangle* __restrict__ tris)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t local = packets[k].tri_id - id_offset;
+    if (local < n_orig) return;
+    const uint32_t orig = __float_as_uint(reinterpret_cast<const float*>(tris + local)[15]);
+    packets[k].tri_id = id_offset + orig;
+}
+
 __global__ void k_make_packets(const rfw_rt_triangle* __restrict__ tris, const uint32_t* __restrict__ order, uint32_t n, uint32_t id_offset,
                                TriPacket* __restrict__ out)
 {
@@ -595,6 +620,14 @@ void launch_triangle_boxes(hipStream_t s, const rfw_rt_triangle* tris, uint32_t 
 void launch_triangle_boxes(hipStream_t s, const TriHead* heads, uint32_t n, DevBox* out)
 {
     if (n) hipLaunchKernelGGL(k_triangle_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, reinterpret_cast<const float4*>(heads), (uint32_t)(sizeof(TriHead) / 16), n, out);
+}
+void launch_patch_boxes(hipStream_t s, const void* pieces, uint32_t n, DevBox* boxes)
+{
+    if (n) hipLaunchKernelGGL(k_patch_boxes, dim3(blocks(n)), dim3(kBlock), 0, s, static_cast<const SplitPieceDev*>(pieces), n, boxes);
+}
+void launch_resolve_duplicates(hipStream_t s, TriPacket* packets, uint32_t n, uint32_t id_offset, uint32_t n_orig, const rfw_rt_triangle* tris)
+{
+    if (n && n_orig < n) hipLaunchKernelGGL(k_resolve_duplicates, dim3(blocks(n)), dim3(kBlock), 0, s, packets, n, id_offset, n_orig, tris);
 }
 void launch_make_packets(hipStream_t s, const rfw_rt_triangle* tris, const uint32_t* order, uint32_t n, uint32_t id_offset, TriPacket* out)
 {

@@ -127,7 +127,7 @@ class SceneStats(C.Structure):
     _fields_ = [
         ("triangles", u64), ("instances", u64), ("blas_nodes", u64), ("tlas_nodes", u64), ("node_bytes", u32), ("tri_bytes", u32),
         ("ms_blas_build", f32), ("ms_tlas_build", f32), ("ms_blas_upload", f32), ("ms_blas_kernels", f32),
-        ("blas_upload_bytes", u64), ("blas_kernel_bytes", u64),
+        ("blas_upload_bytes", u64), ("blas_kernel_bytes", u64), ("split_references", u64),
     ]
 
 

@@ -139,10 +139,13 @@ def test_issue_probe_reports_plausible_vector_issue_rates():
     2 cycles per SIMD at 2.4 GHz."""
     from rfw_rs_amd import BackendError, HipBackend
     be = HipBackend.init(64, 64, 1.0)
-    fma, mix = be.issue_probe(0, 2000), be.issue_probe(1, 2000)
+    fma, mix, packet = be.issue_probe(0, 2000), be.issue_probe(1, 2000), be.issue_probe(2, 2000)
     assert 300.0 < mix < fma < 1300.0, (fma, mix)
+    # the packet kernel's node step: plain FMAs with a scalar operand plus min / max / compare, and 27 scalar instructions per 44 vector ones
+    # taking issue slots beside them — its VECTOR rate lies below the FMA-only rate
+    assert 200.0 < packet < fma, (fma, packet)
     with pytest.raises(BackendError):
-        be.issue_probe(2)
+        be.issue_probe(3)
     with pytest.raises(BackendError):
         be.issue_probe(0, 0)
     be.close()

@@ -434,6 +434,46 @@ def test_builders_give_identical_answers(builder):
     assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
 
 
+@pytest.mark.parametrize("builder", [1, 2, 3])
+@pytest.mark.parametrize("tau", [0.0, 2e-4, 1e-7])
+def test_spatial_splits_never_change_the_image(builder, tau):
+    """Round 5: the few triangles whose boxes waste the most (walls of two triangles across the atrium) are referenced several times, each
+    reference with the tight box of a part of the triangle; duplicates report the id of the triangle they stand for, so hits, ties and images
+    are those of the unsplit scene — whatever the threshold (off; the default; one that spends the whole budget of duplicates), for every
+    builder, after a full build, after an edit of one mesh (the incremental path) and with the 65 meshes of C4 built as one forest."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 160, 104
+    for sphere_meshes in (0, 1):
+        scene = Scene().build("atrium", 40000, sphere_meshes, 0.0, 0xC0FFEE)
+        scene.set_aspect(w / h)
+        view = scene.view(w, h)
+        be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder)
+        be.set_option("spatial_splits", tau)
+        scene.sync(be)
+        orc = Oracle(w, h, threads=8, max_path_length=3)
+        scene.mark_all_changed(); scene.sync(orc)
+        st = be.scene_stats()
+        assert st["triangles"] == orc.stats()["n_tris"]           # the caller's triangles: duplicates are not counted
+        assert (st["split_references"] > 0) == (tau > 0.0), st
+        if tau == 1e-7:
+            assert st["split_references"] >= st["triangles"] // 64  # (most of the budget of every large mesh)
+        o, d = random_rays(20000, 5, extent=12.0)
+        assert_hits_equal(be.intersect(o, d), orc.intersect(o, d))
+        tmax = np.random.default_rng(7).uniform(0.05, 30.0, size=len(o)).astype(np.float32)
+        assert np.array_equal(be.occludes(o, d, tmax), orc.occludes(o, d, tmax))
+        for _ in range(2):
+            be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+        # everything re-sent (registered host arrays, heads first), then rendered again
+        scene.mark_all_changed(); scene.sync(be)
+        be.reset_accumulation(); orc.reset()
+        be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+        assert be.scene_stats()["split_references"] == st["split_references"]
+        be.close()
+
+
 @pytest.mark.parametrize("forest", [True, False])
 def test_many_meshes_are_built_in_one_pass(forest, monkeypatch):
     """A scene of many meshes of very different sizes (2-triangle walls, boxes, an icosphere mesh with 30 instances, a 30 000-triangle soup,
