@@ -375,7 +375,7 @@ struct Instance {
     std::vector<uint32_t> record_tri_orig;    // the caller's triangles of record k (tri_count counts the references: + duplicates of split triangles)
     DevBuf<SplitPiece> d_split_pieces;        // box overrides of the meshes being built (build-time only)
     std::vector<uint32_t> record_piece_off, record_piece_n; // where record k's overrides lie in d_split_pieces during the current build
-    float split_tau = 2e-4f;                  // option "spatial_splits": a part is cut while its box wastes more than this x the mesh box's area (0 = off)
+    float split_tau = 8e-5f;                  // option "spatial_splits": a part is cut while its box wastes more than this x the mesh box's area (0 = off)
     uint64_t n_split_refs = 0;                // duplicates in the scene (scene_stats)
     uint32_t tri_end = 0, node_end = 0;       // first free triangle / node slot behind the regions in use
     uint64_t hole_tris = 0;                   // triangles' worth of regions abandoned since the last full build

@@ -1191,6 +1191,8 @@ struct SplitScan {          // what one copy thread learns about its share of th
     uint32_t since_refresh = 0;
 };
 constexpr size_t kSplitKeep = 2048;
+// a triangle that passed the floor: into the thread's heap of the most wasteful ones
+inline void consider_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i);
 inline void scan_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i)
 {
     float area2 = 0.0f;
@@ -1209,8 +1211,10 @@ inline void scan_triangle(SplitScan& sc, const float* v0, const float* v1, const
         sc.floor_area = a < 1e30 ? (float)((double)sc.tau_rel * a) : 0.0f;
     }
     if (!(area2 > sc.floor_area)) return; // (the common small triangle leaves here)
-    // (waste <= box area: the common small triangle leaves after this compare)
-    if (!(area2 > (sc.top.size() < kSplitKeep ? 0.0f : sc.top.front().first))) return;
+    consider_triangle(sc, v0, v1, v2, i);
+}
+inline void consider_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i)
+{
     const float w = triangle_waste(v0, v1, v2);
     if (!(w > 0.0f) || !(w < INFINITY)) return;
     const auto greater = [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); };
@@ -1262,10 +1266,16 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
     }
     if (cand.empty()) return;
     struct Part { float waste; uint32_t tri; uint32_t serial; SplitPoly poly; float lo[3], hi[3]; };
-    // max-heap on (waste, then the earlier part): a total order, the same whatever the thread count was
-    const auto less = [](const Part& a, const Part& b) { return a.waste < b.waste || (a.waste == b.waste && a.serial > b.serial); };
     std::sort(cand.begin(), cand.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
-    std::vector<Part> heap;
+    // the parts live in `pool`; the heap orders their indices: max-heap on (waste, then the earlier part) — a total order, the same whatever
+    // the thread count was
+    std::vector<Part> pool;
+    pool.reserve(cand.size() + 2 * budget + 2);
+    const auto less = [&pool](uint32_t x, uint32_t y) {
+        const Part &a = pool[x], &b = pool[y];
+        return a.waste < b.waste || (a.waste == b.waste && a.serial > b.serial);
+    };
+    std::vector<uint32_t> heap;
     std::vector<float> ideal(cand.size()), tri_area(cand.size());
     std::vector<uint32_t> parts_of(cand.size(), 1u);
     uint32_t serial = 0;
@@ -1278,39 +1288,51 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
         poly_box(p.poly, p.lo, p.hi);
         p.waste = triangle_waste(h, h + 4, h + 8, &ideal[c]);
         tri_area[c] = (float)poly_area(p.poly);
-        heap.push_back(p);
+        heap.push_back((uint32_t)pool.size());
+        pool.push_back(p);
     }
     std::make_heap(heap.begin(), heap.end(), less);
-    std::vector<Part> done;
+    std::vector<uint32_t> done_idx;
     size_t extra = 0;
     constexpr uint32_t kMaxPartsPerTriangle = 64;
     while (!heap.empty()) {
         std::pop_heap(heap.begin(), heap.end(), less);
-        Part p = heap.back();
+        const uint32_t pi = heap.back();
         heap.pop_back();
+        if (!(pool[pi].waste > tau) || extra >= budget) { // nothing left above the threshold, or the budget is spent: the rest stays whole
+            done_idx.push_back(pi);
+            done_idx.insert(done_idx.end(), heap.begin(), heap.end());
+            break;
+        }
+        const Part p = pool[pi];
         int axis = 0;
         for (int a = 1; a < 3; a++)
             if (p.hi[a] - p.lo[a] > p.hi[axis] - p.lo[axis]) axis = a;
         const float pos = 0.5f * (p.lo[axis] + p.hi[axis]);
-        bool cut = p.waste > tau && extra < budget && parts_of[p.tri] < kMaxPartsPerTriangle && pos > p.lo[axis] && pos < p.hi[axis];
+        bool cut = parts_of[p.tri] < kMaxPartsPerTriangle && pos > p.lo[axis] && pos < p.hi[axis];
         Part a = p, b = p;
         if (cut) {
             clip_poly(p.poly, axis, pos, true, a.poly);
             clip_poly(p.poly, axis, pos, false, b.poly);
             cut = a.poly.n >= 3 && b.poly.n >= 3;
         }
-        if (!cut) { done.push_back(p); continue; }
+        if (!cut) { done_idx.push_back(pi); continue; }
         for (Part* q : {&a, &b}) {
             poly_box(q->poly, q->lo, q->hi);
             const double share = tri_area[p.tri] > 0.0f ? poly_area(q->poly) / (double)tri_area[p.tri] : 1.0;
             q->waste = (float)(box_area6(q->lo, q->hi) - share * (double)ideal[p.tri]);
             q->serial = serial++;
-            heap.push_back(*q);
+            heap.push_back((uint32_t)pool.size());
+            pool.push_back(*q);
             std::push_heap(heap.begin(), heap.end(), less);
         }
         parts_of[p.tri]++;
         extra++;
     }
+    std::vector<Part> done;
+    done.reserve(done_idx.size());
+    for (const uint32_t k : done_idx)
+        if (parts_of[pool[k].tri] >= 2) done.push_back(pool[k]); // (a candidate that was never cut keeps its own box: no reference to write)
     // parts -> references: per split triangle (in index order) its parts in creation order; the first keeps the triangle's own entry
     std::sort(done.begin(), done.end(), [](const Part& a, const Part& b) { return a.tri < b.tri || (a.tri == b.tri && a.serial < b.serial); });
     size_t next_dup = m.n_orig;
@@ -1346,7 +1368,7 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
 static size_t split_slack(const float split_tau, size_t n, bool skinned)
 {
     if (!(split_tau > 0.0f) || skinned || n < 64) return 0;
-    return std::min<size_t>(n / 32 + 64, size_t(1) << 20);
+    return std::min<size_t>(n / 128 + 64, size_t(1) << 18);
 }
 
 static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack);
@@ -1378,10 +1400,16 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
     // one pass over the source: every record is read once and goes out through non-temporal stores, its head a second time into the heads
     // array (a memcpy of the records plus a pass for the heads reads 44 % of the source twice; chunked memcpys lose the streaming stores).
     // The same pass looks for the triangles worth splitting (bounds of the share, its most wasteful triangles: SplitScan)
-    auto part = [&m, src, scan](size_t a, size_t b, SplitScan* sc) {
+    auto part = [&m, src, scan](size_t a, size_t b, SplitScan* sc_out) {
+        // (the thread's own copy: neighbouring elements of the vector share cache lines, and every triangle updates the bounds)
+        SplitScan local = *sc_out;
+        SplitScan* sc = &local;
+        struct Publish { SplitScan* to; SplitScan* from; ~Publish() { *to = std::move(*from); } } publish{sc_out, sc};
 #if defined(__SSE2__)
         if ((reinterpret_cast<uintptr_t>(m.tris.data()) & 15u) == 0 && (reinterpret_cast<uintptr_t>(m.heads.data()) & 15u) == 0) {
             constexpr int kWords = (int)(sizeof(rfw_rt_triangle) / 16);
+            __m128 blo = _mm_set1_ps(INFINITY), bhi = _mm_set1_ps(-INFINITY);
+            uint32_t since = 0;
             for (size_t i = a; i < b; i++) {
                 const __m128i* in = reinterpret_cast<const __m128i*>(src + i);
                 __m128i* out = reinterpret_cast<__m128i*>(m.tris.data() + i);
@@ -1391,12 +1419,35 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
                 for (int k = 0; k < kWords; k++) _mm_stream_si128(out + k, w[k]);
                 for (int k = 0; k < 3; k++) _mm_stream_si128(head + k, w[k]);
                 if (scan) {
-                    alignas(16) float v[12];
-                    for (int k = 0; k < 3; k++) _mm_store_si128(reinterpret_cast<__m128i*>(v) + k, w[k]);
-                    scan_triangle(*sc, v, v + 4, v + 8, (uint32_t)i);
+                    // bounds and box area in vector registers (lane 3 carries texture coordinates: ignored); only a triangle whose box is
+                    // large enough to matter takes the scalar path
+                    const __m128 v0 = _mm_castsi128_ps(w[0]), v1 = _mm_castsi128_ps(w[1]), v2 = _mm_castsi128_ps(w[2]);
+                    const __m128 mn = _mm_min_ps(v0, _mm_min_ps(v1, v2)), mx = _mm_max_ps(v0, _mm_max_ps(v1, v2));
+                    blo = _mm_min_ps(blo, mn);
+                    bhi = _mm_max_ps(bhi, mx);
+                    const __m128 e = _mm_sub_ps(mx, mn);
+                    const __m128 pr = _mm_mul_ps(e, _mm_shuffle_ps(e, e, _MM_SHUFFLE(3, 0, 2, 1))); // (ex ey, ey ez, ez ex, -)
+                    const float area2 = 2.0f * (_mm_cvtss_f32(pr) + _mm_cvtss_f32(_mm_shuffle_ps(pr, pr, 1)) + _mm_cvtss_f32(_mm_shuffle_ps(pr, pr, 2)));
+                    if (++since >= 256u) { // the floor follows the bounds seen so far (SplitScan::floor_area)
+                        since = 0;
+                        alignas(16) float l4[4], h4[4];
+                        _mm_store_ps(l4, blo); _mm_store_ps(h4, bhi);
+                        const double a = box_area6(l4, h4);
+                        sc->floor_area = a < 1e30 ? (float)((double)sc->tau_rel * a) : 0.0f;
+                    }
+                    if (area2 > sc->floor_area) {
+                        alignas(16) float v[12];
+                        for (int k = 0; k < 3; k++) _mm_store_si128(reinterpret_cast<__m128i*>(v) + k, w[k]);
+                        consider_triangle(*sc, v, v + 4, v + 8, (uint32_t)i);
+                    }
                 }
             }
             _mm_sfence();
+            if (scan) {
+                alignas(16) float l4[4], h4[4];
+                _mm_store_ps(l4, blo); _mm_store_ps(h4, bhi);
+                for (int a = 0; a < 3; a++) { sc->lo[a] = std::min(sc->lo[a], l4[a]); sc->hi[a] = std::max(sc->hi[a], h4[a]); }
+            }
             return;
         }
 #endif
