@@ -1182,15 +1182,16 @@ inline float triangle_waste(const float* v0, const float* v1, const float* v2, f
 struct SplitScan {          // what one copy thread learns about its share of the triangles
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     std::vector<std::pair<float, uint32_t>> top; // min-heap of the kKeep most wasteful (waste, index)
-    bool overflowed = false; // more than kKeep candidates passed through: the smallest kept one bounds what was dropped
-    float dropped_max = 0.0f;
     // A triangle is a candidate when its box wastes more than tau_rel x the area of the MESH's box, which the thread does not know yet — but
     // the box of what it has seen so far is inside it, and a triangle's waste is at most its box's area: a triangle whose box area is below
     // tau_rel x (area of the bounds so far) cannot be one.  `floor_area` is that bound, refreshed every 256 triangles.
     float tau_rel = 0.0f, floor_area = 0.0f;
     uint32_t since_refresh = 0;
 };
-constexpr size_t kSplitKeep = 2048;
+// Triangles of a mesh that may be split: its kSplitCandidates most wasteful ones (what the splits buy comes from a few hundred).  Every copy
+// thread keeps that many of ITS share, so the mesh's most wasteful ones are among the kept ones whatever the number of threads.
+constexpr size_t kSplitCandidates = 1024;
+constexpr size_t kSplitKeep = kSplitCandidates;
 // a triangle that passed the floor: into the thread's heap of the most wasteful ones
 inline void consider_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i);
 inline void scan_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i)
@@ -1221,15 +1222,10 @@ inline void consider_triangle(SplitScan& sc, const float* v0, const float* v1, c
     if (sc.top.size() < kSplitKeep) {
         sc.top.emplace_back(w, i);
         std::push_heap(sc.top.begin(), sc.top.end(), greater);
-    } else if (w > sc.top.front().first) {
-        sc.overflowed = true;
-        sc.dropped_max = std::max(sc.dropped_max, sc.top.front().first);
+    } else if (greater(std::make_pair(w, i), sc.top.front())) { // (ties on the waste: the lower index stays, as in the final selection)
         std::pop_heap(sc.top.begin(), sc.top.end(), greater);
         sc.top.back() = std::make_pair(w, i);
         std::push_heap(sc.top.begin(), sc.top.end(), greater);
-    } else {
-        sc.overflowed = true;
-        sc.dropped_max = std::max(sc.dropped_max, w);
     }
 }
 } // namespace
@@ -1246,25 +1242,19 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
         for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], sc.lo[a]); hi[a] = std::max(hi[a], sc.hi[a]); }
     const double root_area = box_area6(lo, hi);
     if (!(root_area > 0.0) || !(root_area < 1e30)) return;
-    const float tau = (float)((double)split_tau * root_area);
-    // the candidates: every triangle that wastes more than tau.  The threads kept their kSplitKeep most wasteful ones; if one of them dropped
-    // a triangle above tau the heads are scanned again (a mesh of more than kSplitKeep huge triangles per thread: rare, and correct either way)
+    // ... and more than 64 times an even share of the mesh's box area: in a small mesh (an icosphere of 5120 triangles) EVERY triangle wastes
+    // 1e-4 of the box — splitting is for the outliers of a mesh, not for its typical triangle
+    const float tau = (float)(std::max((double)split_tau, 64.0 / (double)m.n_orig) * root_area);
+    // the candidates: the triangles that waste more than tau, at most the kSplitCandidates most wasteful ones (every thread kept that many of its share)
     std::vector<std::pair<float, uint32_t>> cand;
-    bool rescan = false;
-    for (const SplitScan& sc : scans) {
-        rescan = rescan || (sc.overflowed && sc.dropped_max > tau);
+    for (const SplitScan& sc : scans)
         for (const auto& c : sc.top)
             if (c.first > tau) cand.push_back(c);
-    }
-    if (rescan) {
-        cand.clear();
-        for (size_t i = 0; i < m.n_orig; i++) {
-            const float* h = m.heads[i].v;
-            const float w = triangle_waste(h, h + 4, h + 8);
-            if (w > tau && w < INFINITY) cand.emplace_back(w, (uint32_t)i);
-        }
-    }
     if (cand.empty()) return;
+    if (cand.size() > kSplitCandidates) { // the most wasteful ones (ties: the lower index), whatever order the threads delivered them in
+        std::sort(cand.begin(), cand.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+        cand.resize(kSplitCandidates);
+    }
     struct Part { float waste; uint32_t tri; uint32_t serial; SplitPoly poly; float lo[3], hi[3]; };
     std::sort(cand.begin(), cand.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
     // the parts live in `pool`; the heap orders their indices: max-heap on (waste, then the earlier part) — a total order, the same whatever
@@ -1368,7 +1358,7 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
 static size_t split_slack(const float split_tau, size_t n, bool skinned)
 {
     if (!(split_tau > 0.0f) || skinned || n < 64) return 0;
-    return std::min<size_t>(n / 128 + 64, size_t(1) << 18);
+    return std::min<size_t>(n / 128 + 64, 1024); // (measured on the bench scenes: 400 ... 2000 duplicates do what 30 000 do, and the host pays per part)
 }
 
 static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack);
@@ -1460,7 +1450,7 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
     const size_t bytes = n * sizeof(rfw_rt_triangle);
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), bytes >> 22)); // at least 4 MB per thread
     std::vector<SplitScan> scans((size_t)nt);
-    for (SplitScan& sc : scans) sc.tau_rel = split_tau;
+    for (SplitScan& sc : scans) sc.tau_rel = std::max(split_tau, 64.0f / (float)std::max<size_t>(n, 1)); // (as split_references)
     if (nt <= 1) part(0, n, &scans[0]);
     else {
         std::vector<std::thread> pool;
@@ -1471,7 +1461,15 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
         }
         for (auto& t : pool) t.join();
     }
+    static const bool kTrace = getenv("RFW_BUILD_TRACE") != nullptr;
+    const auto t_split = std::chrono::steady_clock::now();
     if (scan) split_references(split_tau, m, scans, slack);
+    if (kTrace && scan) {
+        size_t kept = 0;
+        for (const SplitScan& sc : scans) kept += sc.top.size();
+        fprintf(stderr, "[build] spatial splits: %zu candidates kept by %d thread(s), %zu duplicates of %zu triangles, %.3f ms after the copy\n", kept, nt, m.n_refs - m.n_orig, n,
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_split).count());
+    }
 }
 
 // Host-only self test of the spatial splits (no GPU needed): runs what set_3d_mesh runs on `tris` and hands back the references.

@@ -152,14 +152,21 @@ def test_issue_probe_reports_plausible_vector_issue_rates():
 
 
 @pytest.mark.parametrize("builder", [2, 3])
-def test_device_built_trees_are_structurally_valid(builder):
+@pytest.mark.parametrize("splits", [False, True])
+def test_device_built_trees_are_structurally_valid(builder, splits):
     """Reads the device builders' f32 BVH4 back and checks it the way bvh_host.cpp's validate_bvh4 checks the host builder's: every
-    triangle in exactly one leaf, every child box inside its parent's and around its triangles' padded boxes."""
+    primitive in exactly one leaf, every child box inside its parent's and around its triangles' padded boxes.  With spatial splits the
+    primitives are REFERENCES — the caller's triangles, then the duplicates of split ones — and a reference of a split triangle sits in a
+    leaf box that holds its PART of the triangle: inside the triangle's box, not around it."""
     from rfw_rs_amd import HipBackend, Scene
-    scene = Scene().build("soup", 6000, 1, 0.0, 5)
+    scene = Scene().build("atrium", 40000, 0, 0.0, 0xC0FFEE) if splits else Scene().build("soup", 6000, 1, 0.0, 5)
     be = HipBackend.init(32, 32, 1.0, builder=builder)
+    be.set_option("spatial_splits", 8e-5 if splits else 0.0)
     scene.sync(be)
-    n = be.scene_stats()["triangles"]
+    st = be.scene_stats()
+    n_tri = st["triangles"]
+    assert (st["split_references"] > 0) == splits
+    n = n_tri + st["split_references"]
     tris = be.debug_read("triangles", n * 176).view(np.float32).reshape(n, 44)
     v = tris[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(n, 3, 3)
     lo, hi = v.min(axis=1), v.max(axis=1)
@@ -171,6 +178,7 @@ def test_device_built_trees_are_structurally_valid(builder):
     seen = np.zeros(n, np.int32)
     stack = [(0, np.full(3, -np.inf, np.float32), np.full(3, np.inf, np.float32))]
     visited = 0
+    n_parts = 0
     while stack:
         i, plo, phi = stack.pop()
         visited += 1
@@ -185,13 +193,22 @@ def test_device_built_trees_are_structurally_valid(builder):
                 first, count = c & 0x07FFFFFF, ((c >> 27) & 15) + 1
                 ids = order[first:first + count]
                 seen[ids] += 1
-                assert np.all(lo[ids] >= clo) and np.all(hi[ids] <= chi), (i, k)
+                inside = np.all(lo[ids] >= clo, axis=1) & np.all(hi[ids] <= chi, axis=1)
+                if not splits:
+                    assert inside.all(), (i, k)
+                else:  # a part of a split triangle: the leaf box lies inside the triangle's box (and is not empty)
+                    part = ~inside
+                    n_parts += int(part.sum())
+                    assert np.all((clo >= lo[ids[part]] - 1e-3) & (chi <= hi[ids[part]] + 1e-3) & (chi >= clo)), (i, k)
             else:
                 if builder == 3:
                     assert c > i                                   # the SAH builder numbers children after their parents
                 stack.append((c, clo, chi))
     assert np.all(seen == 1)
     assert visited <= be.scene_stats()["blas_nodes"]
+    if splits:
+        # the duplicates are copies of their originals (same vertices), and only references of split triangles sit in part boxes
+        assert 1 <= n_parts <= 2 * st["split_references"] + 64
     be.close()
 
 
