@@ -435,17 +435,18 @@ def test_builders_give_identical_answers(builder):
 
 
 @pytest.mark.parametrize("builder", [1, 2, 3])
-@pytest.mark.parametrize("tau", [0.0, 2e-4, 1e-7])
+@pytest.mark.parametrize("tau", [0.0, 8e-5, 1e-7])
 def test_spatial_splits_never_change_the_image(builder, tau):
     """Round 5: the few triangles whose boxes waste the most (walls of two triangles across the atrium) are referenced several times, each
     reference with the tight box of a part of the triangle; duplicates report the id of the triangle they stand for, so hits, ties and images
-    are those of the unsplit scene — whatever the threshold (off; the default; one that spends the whole budget of duplicates), for every
+    are those of the unsplit scene — whatever the threshold (off; the default; one far below it: the outlier rule decides), for every
     builder, after a full build, after an edit of one mesh (the incremental path) and with the 65 meshes of C4 built as one forest."""
     from oracle.bindings import Oracle
     from rfw_rs_amd import HipBackend, Scene
     w, h = 160, 104
-    for sphere_meshes in (0, 1):
-        scene = Scene().build("atrium", 40000, sphere_meshes, 0.0, 0xC0FFEE)
+    cases = [(40000, 0), (40000, 1)] + ([(262267, 0)] if (builder == 3 and tau == 8e-5) else [])  # (the C2 scene: hundreds of duplicates)
+    for n_target, sphere_meshes in cases:
+        scene = Scene().build("atrium", n_target, sphere_meshes, 0.0, 0xC0FFEE)
         scene.set_aspect(w / h)
         view = scene.view(w, h)
         be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder)
@@ -456,8 +457,8 @@ def test_spatial_splits_never_change_the_image(builder, tau):
         st = be.scene_stats()
         assert st["triangles"] == orc.stats()["n_tris"]           # the caller's triangles: duplicates are not counted
         assert (st["split_references"] > 0) == (tau > 0.0), st
-        if tau == 1e-7:
-            assert st["split_references"] >= st["triangles"] // 256  # (most of the budget of every large mesh)
+        if n_target > 100000:
+            assert 300 <= st["split_references"] <= 1024, st
         o, d = random_rays(20000, 5, extent=12.0)
         assert_hits_equal(be.intersect(o, d), orc.intersect(o, d))
         tmax = np.random.default_rng(7).uniform(0.05, 30.0, size=len(o)).astype(np.float32)
