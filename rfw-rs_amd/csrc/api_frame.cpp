@@ -365,6 +365,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         I->packet_auto = e == nullptr;
         if (pt & 1) I->flags |= kFlagPacketPrimary;
         if (pt & 2) I->flags |= kFlagPacketShadow;
+        if (pt & 4) I->flags |= kFlagPacketShadowFar;
     }
     if (I->max_batch > 1 && I->substreams > 1) {
         g_create_error = "max_batch > 1 needs streams <= 1 (a batch already fills the device with one launch per stage)";
@@ -628,10 +629,11 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         else if ((int)value == 2) I->flags |= kFlagFarFirstPositional;
     }
     else if (k == "packet_trace") { // which rays walk the tree as wavefront packets (traverse_packet.h): bit 0 camera rays, bit 1 the camera paths' shadow rays
-        I->flags &= ~(kFlagPacketPrimary | kFlagPacketShadow);
+        I->flags &= ~(kFlagPacketPrimary | kFlagPacketShadow | kFlagPacketShadowFar);
         I->packet_auto = false; // an explicit choice holds whatever the scene's size
         if ((int)value & 1) I->flags |= kFlagPacketPrimary;
         if ((int)value & 2) I->flags |= kFlagPacketShadow;
+        if ((int)value & 4) I->flags |= kFlagPacketShadowFar; // bit 2: packets only for the buckets traced far to near (the directional lights)
     }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)

@@ -514,6 +514,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES) void k_extend_stream
 #ifndef RFW_SHADOW_ORDER_REV
 #define RFW_SHADOW_ORDER_REV 1
 #endif
+RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket);
 template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         bool found = false;
         for (int kk = 0; kk < kShadowBuckets; kk++) {
             const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            if ((cam.flags & kFlagPacketShadowFar) && bucket_far_first(cam, (uint32_t)k)) continue; // (those went as packets: launch_shadow)
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
             if (!found) {
@@ -1244,8 +1246,11 @@ void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, co
     if (cam.batch > 1) hipLaunchKernelGGL(k_shade<true>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
     else hipLaunchKernelGGL(k_shade<false>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
 }
-void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
+void launch_shadow(hipStream_t s, const CameraParams& cam_in, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {
+    CameraParams cam = cam_in;
+    // (k_shadow leaves the far-to-near buckets to the packet launch below only when that launch happens)
+    if (!(bounce == 0 && sc.tlas_wide && sc.blas_wide && cam.batch <= 1) || (cam.flags & kFlagPacketShadow)) cam.flags &= ~kFlagPacketShadowFar;
     if (bounce == 0 && (cam.flags & kFlagPacketShadow) && sc.tlas_wide && sc.blas_wide && cam.batch <= 1) {
         // worst case: every path pushed a shadow ray, every bucket padded to whole wavefronts; one launch per visiting order
         const uint32_t blocks_ = (p.capacity + kTraceBlock - 1) / kTraceBlock + kShadowBuckets;
@@ -1259,10 +1264,18 @@ void launch_shadow(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
         }
         return;
     }
+    if (cam.flags & kFlagPacketShadowFar) {
+        // packets for the buckets traced far to near only (the directional lights: parallel rays from neighbouring pixels); k_shadow below skips them
+        const uint32_t blocks_ = (p.capacity + kTraceBlock - 1) / kTraceBlock + kShadowBuckets;
+        const dim3 grid_(((blocks_ + 511u) / 512u) * 512u), block_(kTraceBlock);
+        if (count) hipLaunchKernelGGL((k_shadow_packet<true, true>), grid_, block_, 0, s, cam, sc, p, bounce);
+        else hipLaunchKernelGGL((k_shadow_packet<false, true>), grid_, block_, 0, s, cam, sc, p, bounce);
+    }
     const dim3 block(kTraceBlock);
     // streaming pays where a wavefront's rays differ in length and direction: the shadow rays of the bounces.  The camera paths' own shadow rays
     // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too)
-    if (cam.stream_run && bounce >= 1u) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
+    static const bool kStreamShadow0 = getenv("RFW_STREAM_SHADOW0") != nullptr; // (experiment switch: the camera paths' shadow rays stream too)
+    if (cam.stream_run && (bounce >= 1u || kStreamShadow0)) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
         const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + kShadowBuckets + 511u) & ~511u);
         // the two orders' launches follow each other on the stream (no rays of the other kind: the blocks return at once)
         if (count) {

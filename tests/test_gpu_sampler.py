@@ -240,7 +240,7 @@ def test_packet_trace_option_never_changes_the_image(kind, a, b):
     visits = {}
     for count in (0, 1):
         be.set_option("count_traversal", count)
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 5):   # (bit 2: packets only for the shadow buckets traced far to near — the directional lights' parallel rays)
             be.set_option("packet_trace", mode)
             for k, v in enumerate(views):   # a new view each: the two frame slots alternate
                 be.reset_accumulation()
