@@ -127,6 +127,12 @@ typedef struct {
     /* spatial splits (option "spatial_splits"): references the trees hold beyond one per triangle — duplicates of the few triangles whose
      * boxes waste the most (a wall of two triangles across the scene); `triangles` above counts the caller's triangles only */
     uint64_t split_references;
+    /* device memory of the acceleration structures as allocated (capacities): quantised nodes, their eight per-octant copies, the packet form
+     * of those copies (present only where a packet kernel can run: packet_copies = 1), 48-B triangle packets, TLAS included; the 176-B
+     * records the boundary hands over are not counted */
+    uint64_t accel_bytes;
+    uint32_t packet_copies;
+    uint32_t pad;
 } rfw_hip_scene_stats;
 
 /* Hit record of the ray-query extension: what ray_gen/ray_extend store per path

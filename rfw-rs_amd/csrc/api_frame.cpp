@@ -69,8 +69,8 @@ SceneDev scene_dev(Instance* I)
     s.blas_nodes = S->d_blas_nodes.ptr;
     s.tlas_wide = TL->d_tlas_wide.ptr;
     s.blas_wide = S->d_blas_wide.ptr;
-    s.tlas_wide_stride = (uint32_t)(TL->d_tlas_wide.cap / kPacketNodeCopies);
-    s.blas_wide_stride = (uint32_t)(S->d_blas_wide.cap / kPacketNodeCopies);
+    s.tlas_wide_stride = (uint32_t)(TL->d_tlas_oct.cap / kPacketNodeCopies); // (both forms of the copies share the stride; the packet form may be absent)
+    s.blas_wide_stride = (uint32_t)(S->d_blas_oct.cap / kPacketNodeCopies);
     s.tlas_oct = TL->d_tlas_oct.ptr;
     s.blas_oct = S->d_blas_oct.ptr;
     s.tri_packets = S->d_packets.ptr;
@@ -634,6 +634,13 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         if ((int)value & 1) I->flags |= kFlagPacketPrimary;
         if ((int)value & 2) I->flags |= kFlagPacketShadow;
         if ((int)value & 4) I->flags |= kFlagPacketShadowFar; // bit 2: packets only for the buckets traced far to near (the directional lights)
+        if (blas_wide_wanted(I, I->n_tris) && !I->d_blas_wide.ptr && I->n_tris) {
+            // packets asked for on a scene that was built without their copies of the nodes: the next synchronize() rebuilds (until then the
+            // camera rays keep going one per lane)
+            for (auto& kv : I->meshes) kv.second.dirty = true;
+            I->meshes_dirty = true;
+            I->layout_valid = false;
+        }
     }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)

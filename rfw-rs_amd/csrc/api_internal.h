@@ -548,6 +548,7 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
 PathDev path_dev(Instance* I, uint32_t sub = 0);
 int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool samples = false);
 uint32_t spill_stride(const Instance* I);
+bool blas_wide_wanted(const Instance* I, uint64_t n_prims); // api_scene.cpp: does a packet kernel run on a scene of this size under the current options?
 // api_scene.cpp
 int do_synchronize(Instance* I);
 int ensure_slot_tlas(Instance* S, Instance* T);

@@ -8,22 +8,30 @@
 using namespace rfwapi;
 
 namespace rfwapi {
-// The per-octant node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity, in both forms (PacketNode
-// for the packet kernels, Node4Q for the one-ray-per-lane kernels).  (Re)allocates when that capacity changed — the stride with it, so every
-// node in use (`keep` of them) is expanded again.
-hipError_t follow_copies(DevBuf<PacketNode>& wide, DevBuf<Node4Q>& oct, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s)
+// The per-octant node copies follow the quantised arrays: eight copies, stride = the quantised array's capacity, in two forms — Node4Q for
+// the one-ray-per-lane kernels (always) and PacketNode for the packet kernels (`want_wide`: 1 KB per node slot, so only where a packet kernel
+// can run: ADVICE r04).  (Re)allocates when that capacity changed — the stride with it, so every node in use (`keep` of them) is expanded
+// again — or when the packet form is wanted and missing.
+hipError_t follow_copies(DevBuf<PacketNode>& wide, DevBuf<Node4Q>& oct, const DevBuf<Node4Q>& nodes, size_t keep, hipStream_t s, bool want_wide)
 {
     const size_t want = nodes.cap * kPacketNodeCopies;
-    if (wide.cap == want && oct.cap == want) return hipSuccess;
+    if (!want_wide && wide.ptr) wide.release();
+    if (oct.cap == want && (wide.cap == want || !want_wide)) return hipSuccess;
+    const bool oct_kept = oct.cap == want; // (only the packet form is missing: the quantised copies stay where they are)
     wide.release();
-    oct.release();
+    if (!oct_kept) oct.release();
     if (want == 0) return hipSuccess;
-    hipError_t e = hipMalloc((void**)&wide.ptr, want * sizeof(PacketNode));
-    if (e != hipSuccess) { wide.ptr = nullptr; return e; }
-    wide.cap = want;
-    e = hipMalloc((void**)&oct.ptr, want * sizeof(Node4Q));
-    if (e != hipSuccess) { oct.ptr = nullptr; return e; }
-    oct.cap = want;
+    hipError_t e = hipSuccess;
+    if (want_wide) {
+        e = hipMalloc((void**)&wide.ptr, want * sizeof(PacketNode));
+        if (e != hipSuccess) { wide.ptr = nullptr; return e; }
+        wide.cap = want;
+    }
+    if (!oct_kept) {
+        e = hipMalloc((void**)&oct.ptr, want * sizeof(Node4Q));
+        if (e != hipSuccess) { oct.ptr = nullptr; return e; }
+        oct.cap = want;
+    }
     OctantCopies oc;
     oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)nodes.cap;
     launch_expand_nodes(s, nodes.ptr, oc, 0u, (uint32_t)std::min(keep, nodes.cap));
@@ -32,8 +40,17 @@ hipError_t follow_copies(DevBuf<PacketNode>& wide, DevBuf<Node4Q>& oct, const De
 inline OctantCopies copies_of(const DevBuf<PacketNode>& wide, const DevBuf<Node4Q>& oct)
 {
     OctantCopies oc;
-    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)(wide.cap / kPacketNodeCopies);
+    oc.wide = wide.ptr; oc.quant = oct.ptr; oc.stride = (uint32_t)(oct.cap / kPacketNodeCopies);
     return oc;
+}
+// does this scene need the packet form of its BLAS copies?  Only when some option lets a packet kernel run on it: none does when the options
+// say so, or while nobody has chosen (packet_auto) and the scene is beyond the size up to which packets pay (kPacketAutoMaxTriangles).
+// set_option("packet_trace") marks the meshes for a rebuild when it asks for packets on a scene built without them.
+bool blas_wide_wanted(const Instance* I, uint64_t n_prims)
+{
+    static const uint64_t limit = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES") ? strtoull(getenv("RFW_PACKET_AUTO_MAX_TRIANGLES"), nullptr, 10) : kPacketAutoMaxTriangles;
+    if (!(I->flags & (kFlagPacketPrimary | kFlagPacketShadow | kFlagPacketShadowFar))) return false;
+    return !(I->packet_auto && n_prims > limit);
 }
 
 // pad so that the slab test is conservative w.r.t. the rounding of the Moeller-Trumbore arithmetic
@@ -364,7 +381,7 @@ int build_blas_device_full(Instance* I)
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total));
-    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream, blas_wide_wanted(I, tri_total)));
     HIP_TRY(I, I->d_blas_raw.ensure(node_total));
     HIP_TRY(I, I->d_blas_order.ensure(tri_total));
     for (auto& ev : I->ev_build)
@@ -416,6 +433,9 @@ int build_blas_device_full(Instance* I)
             }
         }
         HIP_TRY(I, hipEventRecord(I->ev_records, I->records_stream));
+        // from here on a copy may be reading the registered host arrays: should anything below fail, the next set_3d_mesh / unload waits for
+        // ev_records before it touches them (cleared behind the final synchronisation of a build that went through)
+        I->records_pending = true;
         trace("uploads queued");
     } else {
         for (auto& kv : I->meshes) {
@@ -580,7 +600,7 @@ int build_blas_device_incremental(Instance* I)
     {
         const size_t nodes_before = I->d_blas_nodes.cap; // (the regions in use end below the old capacity)
         HIP_TRY(I, I->d_blas_nodes.grow_keep(I->node_end, I->d_blas_nodes.cap, I->stream));
-        HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, nodes_before, I->stream));
+        HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, nodes_before, I->stream, blas_wide_wanted(I, I->tri_end)));
     }
     HIP_TRY(I, I->d_blas_raw.grow_keep(I->node_end, 0, I->stream)); // build output only: nothing to keep
     HIP_TRY(I, I->d_mesh_node_counts.grow_keep(std::max<size_t>(I->mesh_records.size(), 1), I->d_mesh_node_counts.cap, I->stream));
@@ -727,7 +747,7 @@ int build_blas_host(Instance* I)
     I->n_tris = tri_total;
     I->n_blas_nodes = node_total;
     HIP_TRY(I, I->d_blas_nodes.ensure(node_total)); // room for the skinned copies behind the static meshes
-    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream));
+    HIP_TRY(I, follow_copies(I->d_blas_wide, I->d_blas_oct, I->d_blas_nodes, 0, I->stream, blas_wide_wanted(I, tri_total)));
     HIP_TRY(I, I->d_packets.ensure(tri_total));
     HIP_TRY(I, I->d_triangles.ensure(tri_total));
     std::vector<Node4Q> qnodes(nodes.size());
@@ -806,7 +826,7 @@ int build_instances(Instance* I, Instance* T)
     HIP_TRY(I, T->d_normals.ensure(n_all));
     HIP_TRY(I, T->d_tlas_prims.ensure(n_all));
     HIP_TRY(I, T->d_tlas_nodes.ensure(std::max<size_t>(n_valid, 1)));
-    HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, T->stream));
+    HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, T->stream, true));
     HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_node_count.ensure(1));
     hipStream_t s = T->stream;
@@ -925,7 +945,7 @@ int build_instances(Instance* I, Instance* T)
         // whose earlier backends had left other bytes in the recycled allocation)
         HIP_TRY(I, T->d_tlas_nodes.ensure(qn.size()));
         if (!qn.empty()) HIP_TRY(I, hipMemcpyAsync(T->d_tlas_nodes.ptr, qn.data(), qn.size() * sizeof(Node4Q), hipMemcpyHostToDevice, s));
-        HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, s));
+        HIP_TRY(I, follow_copies(T->d_tlas_wide, T->d_tlas_oct, T->d_tlas_nodes, 0, s, true));
         launch_expand_nodes(s, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), 0u, (uint32_t)qn.size());
         HIP_TRY(I, T->d_tlas_prims.ensure(prims.size()));
         if (!prims.empty()) HIP_TRY(I, hipMemcpyAsync(T->d_tlas_prims.ptr, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, s));
@@ -1776,6 +1796,10 @@ int rfw_hip_get_scene_stats(void* inst, rfw_hip_scene_stats* out)
     }
     out->triangles = I->n_tris_logical; // the caller's triangles (I->n_tris also counts the duplicates of split triangles)
     out->split_references = I->n_split_refs;
+    out->accel_bytes = I->d_blas_nodes.cap * sizeof(Node4Q) + I->d_blas_oct.cap * sizeof(Node4Q) + I->d_blas_wide.cap * sizeof(PacketNode) + I->d_packets.cap * sizeof(TriPacket) +
+                       I->d_tlas_nodes.cap * sizeof(Node4Q) + I->d_tlas_oct.cap * sizeof(Node4Q) + I->d_tlas_wide.cap * sizeof(PacketNode);
+    out->packet_copies = I->d_blas_wide.ptr ? 1u : 0u;
+    out->pad = 0u;
     out->instances = I->n_valid_instances;
     out->blas_nodes = I->n_blas_nodes;
     if (I->tlas_on_device && I->d_node_count.ptr && I->synchronized) {

@@ -1159,7 +1159,7 @@ __global__ void k_expand_nodes(const Node4Q* __restrict__ in, PacketNode* __rest
     const uint32_t i = g >> 3, oct = g & 7u;
     if (i < n && (!live || i < *live)) {
         const Node4Q q = in[i];
-        wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct);
+        if (wide) wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct); // (absent where no packet kernel can run: follow_copies)
         octq[(size_t)oct * wide_stride + i] = make_octant_node(q, oct);
     }
 }
@@ -1185,7 +1185,7 @@ __global__ void k_expand_regions(const Node4Q* __restrict__ in, PacketNode* __re
     const uint32_t i = g >> 3, oct = g & 7u;
     if (i < n && slot_is_live(recs, counts, n_recs, i)) {
         const Node4Q q = in[i];
-        wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct);
+        if (wide) wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct); // (absent where no packet kernel can run: follow_copies)
         octq[(size_t)oct * wide_stride + i] = make_octant_node(q, oct);
     }
 }
@@ -1389,7 +1389,7 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 }
 void launch_expand_nodes(hipStream_t s, const Node4Q* in, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {
-    if (n && oc.wide) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, oc.wide + first, oc.quant + first, oc.stride, n, live);
+    if (n && oc.quant) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, oc.wide + first, oc.quant + first, oc.stride, n, live);
 }
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {
@@ -1400,7 +1400,7 @@ void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, const 
 {
     if (!n || !n_recs) return;
     hipLaunchKernelGGL(k_quantize_regions, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, recs, counts, n_recs);
-    if (oc.wide) hipLaunchKernelGGL(k_expand_regions, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, out, oc.wide, oc.quant, oc.stride, n, recs, counts, n_recs);
+    if (oc.quant) hipLaunchKernelGGL(k_expand_regions, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, out, oc.wide, oc.quant, oc.stride, n, recs, counts, n_recs);
 }
 void launch_assemble(hipStream_t s, const CameraParams& cam, const void* gathered, bool rgb, bool accumulator, uint64_t slab_elems, float4* frame,
                      uint32_t samples)

@@ -128,6 +128,7 @@ class SceneStats(C.Structure):
         ("triangles", u64), ("instances", u64), ("blas_nodes", u64), ("tlas_nodes", u64), ("node_bytes", u32), ("tri_bytes", u32),
         ("ms_blas_build", f32), ("ms_tlas_build", f32), ("ms_blas_upload", f32), ("ms_blas_kernels", f32),
         ("blas_upload_bytes", u64), ("blas_kernel_bytes", u64), ("split_references", u64),
+        ("accel_bytes", u64), ("packet_copies", u32), ("pad", u32),
     ]
 
 

@@ -322,12 +322,16 @@ def run():
     be.reset_accumulation(); be.render(view)
     return be.accumulator().copy(), tuple(be.frame_stats()["nodes_visited"])
 img_auto, v_auto = run()
+copies_auto = be.scene_stats()["packet_copies"]
 be.set_option("packet_trace", 0); img0, v0 = run()
-be.set_option("packet_trace", 1); img1, v1 = run()
+# (a scene built beyond the limit carries no packet form of its node copies — 1 KB per node slot: asking for packets afterwards takes
+# effect with the next synchronize(), which rebuilds with them)
+be.set_option("packet_trace", 1); scene.sync(be); img1, v1 = run()
+assert be.scene_stats()["packet_copies"] == 1
 assert np.array_equal(img_auto.view(np.uint32), img0.view(np.uint32)) and np.array_equal(img0.view(np.uint32), img1.view(np.uint32))
-print("VISITS", v_auto == v0, v_auto == v1)
+print("VISITS", v_auto == v0, v_auto == v1, "COPIES", copies_auto)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for limit, want in (("1000", "VISITS True False"), ("100000000", "VISITS False True")):
+    for limit, want in (("1000", "VISITS True False COPIES 0"), ("100000000", "VISITS False True COPIES 1")):
         env = dict(os.environ, RFW_PACKET_AUTO_MAX_TRIANGLES=limit)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
