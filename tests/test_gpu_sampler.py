@@ -326,7 +326,7 @@ copies_auto = be.scene_stats()["packet_copies"]
 be.set_option("packet_trace", 0); img0, v0 = run()
 # (a scene built beyond the limit carries no packet form of its node copies — 1 KB per node slot: asking for packets afterwards takes
 # effect with the next synchronize(), which rebuilds with them)
-be.set_option("packet_trace", 1); scene.sync(be); img1, v1 = run()
+be.set_option("packet_trace", 1); be.synchronize(); img1, v1 = run()
 assert be.scene_stats()["packet_copies"] == 1
 assert np.array_equal(img_auto.view(np.uint32), img0.view(np.uint32)) and np.array_equal(img0.view(np.uint32), img1.view(np.uint32))
 print("VISITS", v_auto == v0, v_auto == v1, "COPIES", copies_auto)

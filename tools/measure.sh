@@ -10,7 +10,7 @@
 #                                                   kernel shares the chip with the other frames' kernels — not kernel properties
 #   <tag>_<cfg>_pmc.json / _pmc_valu.json / _pmc_cache.json   counters per launch (separate --pmc passes), each carrying the hash of the
 #                                                   kernel sources they were measured on: bench.py refuses them when the sources changed
-# Raw output: gpurun_out/<tag>/ .  `quick` = headline configuration only.
+# Raw output: gpurun_out/<tag>/ .  `quick` = headline configuration only.  WITH_32M=1 adds c32m (atrium32m, procedural: ~10 more minutes).
 TAG=${1:-rXX}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -67,6 +67,8 @@ if [ -z "$QUICK" ]; then
   # with frames in flight the bounces run the streaming kernels (one frame at a time — which is how counters are taken — they do not): the
   # same passes with streaming forced, for the timed region's ceilings
   RFW_STREAM_RUN=8 profile_config c4pathS --max-path-length 3
+  # far outside every cache: the same atrium at 33.5 M triangles (the one configuration where the "% of HBM roofline" clause has a meaning)
+  if [ -n "$WITH_32M" ]; then profile_config c32m --workload atrium32m --procedural --no-cpu-baseline; fi
   cd $R
   python3 bench.py --identical-frames --no-cpu-baseline > $OUT/bench_atrium1m_identical_frames.json 2> $OUT/bench_identical.err
   [ -s $OUT/bench_atrium1m_identical_frames.json ] && cp $OUT/bench_atrium1m_identical_frames.json profiles/${TAG}_c4_bench_identical_frames.json
@@ -76,9 +78,10 @@ rocprofv3 -L > $OUT/counters_available.txt 2>&1
 # the counters are in: the bench lines of the round, now WITH the ceilings of their configuration (bench.py reads profiles/<tag>_<cfg>_pmc*.json)
 python3 bench.py > $OUT/bench_c4_final.json 2> $OUT/bench_c4_final.err && cp $OUT/bench_c4_final.json profiles/${TAG}_c4_bench.json
 if [ -z "$QUICK" ]; then
-  python3 bench.py --workload atrium262k --no-cpu-baseline > $OUT/bench_c2_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c2_final.json profiles/${TAG}_c2_bench.json
+  python3 bench.py --workload atrium262k > $OUT/bench_c2_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c2_final.json profiles/${TAG}_c2_bench.json
   python3 bench.py --workload spheres10k > $OUT/bench_c3_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c3_final.json profiles/${TAG}_c3_bench.json
   python3 bench.py --max-path-length 3 > $OUT/bench_c4path_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c4path_final.json profiles/${TAG}_c4path_bench.json
+  if [ -n "$WITH_32M" ]; then python3 bench.py --workload atrium32m --procedural --no-cpu-baseline > $OUT/bench_c32m_final.json 2>> $OUT/bench_c4_final.err && cp $OUT/bench_c32m_final.json profiles/${TAG}_c32m_bench.json; fi
 fi
 # the driver's own command (one fill-and-drain of the frame slots) and the builder's timings, for BASELINE.md / DESIGN.md
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_c4_20_steps.json 2> $OUT/bench_c4_20_steps.err && cp $OUT/bench_c4_20_steps.json profiles/${TAG}_c4_bench_20_steps.json
