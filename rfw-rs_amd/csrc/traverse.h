@@ -32,6 +32,9 @@
 #ifndef RFW_ANY_LEAF_GATE
 #define RFW_ANY_LEAF_GATE 1 // any hit: a lane that holds a leaf waits for the next even trip of the loop, which batches the triangle tests (round 1; re-measured with the static order: see EXPERIMENTS.md)
 #endif
+#ifndef RFW_ANY_LEAF_PERIOD
+#define RFW_ANY_LEAF_PERIOD 2 // ... every how many trips the waiting leaves are tested (round 5: 3 -> k_shadow 0.278 -> 0.285 ms, 4 -> 0.295)
+#endif
 #ifndef RFW_STATIC_ORDER
 #define RFW_STATIC_ORDER 1
 #endif
@@ -39,6 +42,9 @@
 #define RFW_SLAB_ONE_COMPARE 1 // min(tf, t) >= max(tn, 0) instead of two compares and a scalar AND per child (degenerate directions are turned away at the entry)
 #endif
 
+#ifndef RFW_SPILL_COLUMN_LAZY
+#define RFW_SPILL_COLUMN_LAZY 1 // any hit (64 registers at 8 waves per SIMD): the HBM spill column's address is formed where it is used (0: hoisted out of the loop — a register pair that went to scratch)
+#endif
 #ifndef RFW_RAY_IN_LDS
 #define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
 #endif
@@ -154,7 +160,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
     auto spill_slot = [&]() -> uint32_t {
         uint32_t l = lane_slot;
-        asm volatile("" : "+v"(l));
+        if (RFW_SPILL_COLUMN_LAZY && ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
         return spill_base + l;
     };
     auto push = [&](uint32_t v) {
@@ -190,7 +196,7 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 #define RFW_TRAV_OCCLUDED return true;
 #define RFW_TRAV_AFTER_LEAF
 #define RFW_TRAV_EXHAUSTED break;
-#define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration & 1u) != 0u) continue;
+#define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) != 0u) continue;
 #define RFW_TRAV_TLAS_GATE
 #include "traverse_body.inc"
 #undef RFW_TRAV_TOP
@@ -245,7 +251,7 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
     // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
     auto spill_slot = [&]() -> uint32_t {
         uint32_t l = lane_slot;
-        asm volatile("" : "+v"(l));
+        if (RFW_SPILL_COLUMN_LAZY && ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
         return spill_base + l;
     };
     auto push = [&](uint32_t v) {
