@@ -42,6 +42,9 @@
 #define RFW_SLAB_ONE_COMPARE 1 // min(tf, t) >= max(tn, 0) instead of two compares and a scalar AND per child (degenerate directions are turned away at the entry)
 #endif
 
+#ifndef RFW_TRI_BRANCHFREE
+#define RFW_TRI_BRANCHFREE 1
+#endif
 #ifndef RFW_SPILL_COLUMN_LAZY
 #define RFW_SPILL_COLUMN_LAZY 1 // any hit (64 registers at 8 waves per SIMD): the HBM spill column's address is formed where it is used (0: hoisted out of the loop — a register pair that went to scratch)
 #endif

@@ -244,6 +244,30 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     for (uint32_t k = 0; k < count; k++) {
                         const su4 q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
                         const f3 v0 = mk3(bitsf(q0.x), bitsf(q0.y), bitsf(q0.z)), edge1 = mk3(bitsf(q1.x), bitsf(q1.y), bitsf(q1.z)), edge2 = mk3(bitsf(q2.x), bitsf(q2.y), bitsf(q2.z));
+#if RFW_TRI_BRANCHFREE
+                        // (without the early outs: traverse_body.inc)
+                        const f3 h = cross(d, edge2);
+                        const float a = dot(edge1, h);
+                        const float f = 1.0f / a;
+                        const f3 s = o - v0;
+                        const float u = f * dot(s, h);
+                        const f3 q = cross(s, edge1);
+                        const float v = f * dot(d, q);
+                        const float tt = f * dot(edge2, q);
+                        const bool ok = !((a > -0.0001f) & (a < 0.0001f)) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | ((u + v) > 1.0f));
+                        if (ANY_HIT) {
+                            occluded = occluded | (ok & (tt > t_min) & (tt < t));
+                        } else {
+                            const int32_t prim = (int32_t)q0.w;
+                            const bool lower = (cur_inst < hit_inst) | ((cur_inst == hit_inst) & (prim < hit_tri));
+                            const bool take = ok & (tt > t_min) & ((tt < t) | ((tt == t) & (hit_inst >= 0) & lower));
+                            t = take ? tt : t;
+                            hu = take ? u * bitsf(q1.w) : hu;
+                            hv = take ? v * bitsf(q1.w) : hv;
+                            hit_inst = take ? cur_inst : hit_inst;
+                            hit_tri = take ? prim : hit_tri;
+                        }
+#else
                         const f3 h = cross(d, edge2);
                         const float a = dot(edge1, h);
                         if (a > -0.0001f && a < 0.0001f) continue;
@@ -268,6 +292,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                                 hit_tri = prim;
                             }
                         }
+#endif
                     }
                 }
                 if (ANY_HIT) {

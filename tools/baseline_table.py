@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""Prints the result rows of BASELINE.md §4 from the committed bench lines of a round:  python3 tools/baseline_table.py r04k"""
+"""Prints the result rows of BASELINE.md §4 from the committed bench lines of a round:  python3 tools/baseline_table.py r05k"""
 import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04k"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05k"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 names = {"c2": "C2 262 k tris, primary+shadow, static", "c3": "C3 C2 + 10 k animated instances (TLAS rebuilt on device every frame)",
-         "c4": "C4 geometry (1.05 M tris), primary+shadow = the headline metric", "c4path": "C4 path tracer, max path length 3, NEE"}
+         "c4": "C4 geometry (1.05 M tris), primary+shadow = the headline metric", "c4path": "C4 path tracer, max path length 3, NEE",
+         "c32m": "control: the same atrium at 33.6 M triangles (far outside every cache), primary+shadow"}
 print("| Config | Mrays/s (`value`) | ms/frame | rays/frame | other modes (Mrays/s) | dominant kernel alone: issue / TA / L2 / HBM | timed region: issue / TA / L2 / HBM | CPU restatement Mrays/s (threads) | timed frames vs oracle |")
 print("|---|---|---|---|---|---|---|---|---|")
-for cfg in ("c2", "c3", "c4", "c4path"):
+for cfg in ("c2", "c3", "c4", "c4path", "c32m"):
+    if not os.path.exists(os.path.join(root, f"{tag}_{cfg}_bench.json")):
+        continue
     d = json.load(open(os.path.join(root, f"{tag}_{cfg}_bench.json")))
     r = d["roofline"]
     modes = "; ".join(f"{k}: {v['Mrays_per_s']:.0f}" for k, v in d["config"].get("modes", {}).items() if not v.get("is_value"))
