@@ -43,7 +43,7 @@
 #endif
 
 #ifndef RFW_TRI_BRANCHFREE
-#define RFW_TRI_BRANCHFREE 1
+#define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
 #endif
 #ifndef RFW_SPILL_COLUMN_LAZY
 #define RFW_SPILL_COLUMN_LAZY 1 // any hit (64 registers at 8 waves per SIMD): the HBM spill column's address is formed where it is used (0: hoisted out of the loop — a register pair that went to scratch)
