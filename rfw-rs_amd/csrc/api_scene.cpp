@@ -1211,6 +1211,9 @@ struct SplitScan {          // what one copy thread learns about its share of th
 // Triangles of a mesh that may be split: its kSplitCandidates most wasteful ones (what the splits buy comes from a few hundred).  Every copy
 // thread keeps that many of ITS share, so the mesh's most wasteful ones are among the kept ones whatever the number of threads.
 constexpr size_t kSplitCandidates = 1024;
+// Meshes below kSplitMinTriangles are neither scanned nor split: their copy runs on one thread, where the scan is not hidden behind the
+// memory traffic — 64 icospheres of 5120 triangles cost synchronize() 1.6 ms — and their boxes are small things in the TLAS anyway.
+constexpr size_t kSplitMinTriangles = 8192;
 constexpr size_t kSplitKeep = kSplitCandidates;
 // a triangle that passed the floor: into the thread's heap of the most wasteful ones
 inline void consider_triangle(SplitScan& sc, const float* v0, const float* v1, const float* v2, uint32_t i);
@@ -1256,7 +1259,7 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
 {
     m.pieces.clear();
     m.n_refs = m.n_orig;
-    if (!(split_tau > 0.0f) || budget == 0 || m.n_orig < 64) return;
+    if (!(split_tau > 0.0f) || budget == 0 || m.n_orig < kSplitMinTriangles) return;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (const SplitScan& sc : scans)
         for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], sc.lo[a]); hi[a] = std::max(hi[a], sc.hi[a]); }
@@ -1377,7 +1380,7 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
 // room for the duplicates of split triangles behind the caller's n triangles (allocated with the arrays: a registered array never moves)
 static size_t split_slack(const float split_tau, size_t n, bool skinned)
 {
-    if (!(split_tau > 0.0f) || skinned || n < 64) return 0;
+    if (!(split_tau > 0.0f) || skinned || n < kSplitMinTriangles) return 0;
     return std::min<size_t>(n / 128 + 64, 1024); // (measured on the bench scenes: 400 ... 2000 duplicates do what 30 000 do, and the host pays per part)
 }
 
@@ -1410,16 +1413,15 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
     // one pass over the source: every record is read once and goes out through non-temporal stores, its head a second time into the heads
     // array (a memcpy of the records plus a pass for the heads reads 44 % of the source twice; chunked memcpys lose the streaming stores).
     // The same pass looks for the triangles worth splitting (bounds of the share, its most wasteful triangles: SplitScan)
-    // (a small mesh — one thread's worth — is copied with ordinary stores: streaming stores of one core run at ~3 GB/s, a cached copy of
-    // under 4 MB at several times that, and the upload that follows reads the lines from the cache: 0.33 -> 0.1 ms for a 5120-triangle mesh)
-    const bool streaming = n * sizeof(rfw_rt_triangle) >= (size_t(4) << 20);
-    auto part = [&m, src, scan, streaming](size_t a, size_t b, SplitScan* sc_out) {
+    // (tried in round 5: ordinary stores for meshes of one thread's worth — slower, 0.37 against 0.33 ms for 5120 triangles; the copy of a
+    // small mesh is bound by reading the caller's cold memory, not by the streaming stores)
+    auto part = [&m, src, scan](size_t a, size_t b, SplitScan* sc_out) {
         // (the thread's own copy: neighbouring elements of the vector share cache lines, and every triangle updates the bounds)
         SplitScan local = *sc_out;
         SplitScan* sc = &local;
         struct Publish { SplitScan* to; SplitScan* from; ~Publish() { *to = std::move(*from); } } publish{sc_out, sc};
 #if defined(__SSE2__)
-        if (streaming && (reinterpret_cast<uintptr_t>(m.tris.data()) & 15u) == 0 && (reinterpret_cast<uintptr_t>(m.heads.data()) & 15u) == 0) {
+        if ((reinterpret_cast<uintptr_t>(m.tris.data()) & 15u) == 0 && (reinterpret_cast<uintptr_t>(m.heads.data()) & 15u) == 0) {
             constexpr int kWords = (int)(sizeof(rfw_rt_triangle) / 16);
             __m128 blo = _mm_set1_ps(INFINITY), bhi = _mm_set1_ps(-INFINITY);
             uint32_t since = 0;

@@ -12,7 +12,7 @@ import pytest
 from rfw_rs_amd import backend, pod
 
 
-def mesh(n_small=4000, seed=3, big=True):
+def mesh(n_small=12000, seed=3, big=True):
     """A 20 x 10 x 20 room filled with small triangles, two wall triangles across it and a long diagonal sliver."""
     rng = np.random.default_rng(seed)
     c = rng.uniform([0, 0, 0], [20, 10, 20], (n_small, 1, 3))
@@ -82,7 +82,10 @@ def test_result_does_not_depend_on_the_thread_count_and_zero_switches_it_off():
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     refs, pieces, dup = run(tris, 0.0, 4)
     assert refs == len(tris) and len(pieces) == 0 and len(dup) == 0
-    _, small = mesh(n_small=4000, big=False)                 # nothing wasteful: nothing split
+    _, tiny = mesh(n_small=3000)                              # below 8192 triangles a mesh is neither scanned nor split, whatever it holds
+    refs, pieces, dup = run(tiny, 2e-4, 4)
+    assert refs == len(tiny) and len(pieces) == 0
+    _, small = mesh(n_small=12000, big=False)                # nothing wasteful: nothing split
     refs, pieces, dup = run(small, 2e-4, 4)
     assert refs == len(small) and len(pieces) == 0
 
@@ -90,7 +93,7 @@ def test_result_does_not_depend_on_the_thread_count_and_zero_switches_it_off():
 def test_budget_holds_when_every_triangle_is_wasteful():
     """Long diagonal slivers only: the most wasteful parts are cut first until the budget of duplicates (n / 128 + 64) is spent."""
     rng = np.random.default_rng(5)
-    n = 2000
+    n = 10000
     a = rng.uniform(0, 10, (n, 1, 3))
     v = np.concatenate([a, a + rng.uniform(5, 10, (n, 1, 3)), a + rng.uniform(5, 10, (n, 1, 3)) * [[1, 0.01, 1]]], axis=1).astype(np.float32)
     tris = (pod.RTTriangle * n)()
