@@ -689,7 +689,12 @@ def main():
                        "tile_shard": "64x64 round-robin" if world > 1 else "none", "collective": (args.collective if world > 1 else None),
                        "gather_format": (args.gather_format if (world > 1 or args.emulate_shard) else None), "present_rank": (args.present_rank if world > 1 else None),
                        "gather_bytes_per_frame": ({"f32": 12, "f16": 6, "bgra8": 4}[args.gather_format] * w * h if world > 1 else None),
-                       "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1), "build": build_report},
+                       "bvh": {"blas_nodes": sstats["blas_nodes"], "node_bytes": node_b, "tri_bytes": tri_b, "build_ms": round(sstats["ms_blas_build"], 1), "build": build_report,
+                               # spatial splits (duplicates of the few triangles whose boxes waste the most) and what the acceleration structures take
+                               # in device memory as allocated (nodes, their per-octant copies, the packet form of those where a packet kernel can run, 48-B packets)
+                               "split_references": sstats.get("split_references"), "accel_bytes": sstats.get("accel_bytes"),
+                               "accel_GB_per_million_triangles": round(sstats.get("accel_bytes", 0) / 1e9 / max(sstats["triangles"] / 1e6, 1e-9), 3),
+                               "packet_copies": bool(sstats.get("packet_copies"))},
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
                        "per_frame_synchronize_ms": round(host_sync_ms, 3) if animated else None,
