@@ -6,7 +6,8 @@ on the final build of the round 300 + 2 more and 60 random times of an animated,
 Round 4 (packets, per-octant node copies, heads-first uploads): the first 200 configurations found 26 mismatching images, every one of them host
 builder x three frame slots — the per-slot TLAS of the host builder was uploaded on the owner's stream and expanded into its octant copies on the
 slot's, visible only in a process whose earlier backends had dirtied the recycled allocation (now a GPU test:
-test_backends_one_after_the_other_in_one_process).  After the fix 300 + 2 + 60: 0 mismatches.  A failing configuration now names its failed checks."""
+test_backends_one_after_the_other_in_one_process).  After the fix 300 + 2 + 60: 0 mismatches.  A failing configuration now names its failed checks.
+Round 5 (spatial splits, the triangle test without early outs): every fourth configuration an atrium with split walls under a random threshold."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,9 +19,18 @@ t0 = time.time()
 for it in range(int(os.environ.get("ITERS", "24"))):
     tris = int(rng.integers(200, 6000)); inst = int(rng.integers(1, 24)); seed = int(rng.integers(1, 1 << 30))
     builder = int(rng.integers(0, 4)); fif = int(rng.choice([0, 3])); w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 70]))
-    scene = Scene().build("soup", tris, inst, 0.0, seed); scene.set_aspect(w / h)
+    # round 5: every fourth configuration is an atrium of 9 000 ... 50 000 triangles (walls and floors of two triangles: spatial splits, with
+    # duplicates whose packets must report their originals), under a random split threshold
+    big = int(rng.integers(0, 4)) == 0
+    if big:
+        tris = int(rng.integers(9000, 50000))
+        scene = Scene().build("atrium", tris, int(rng.integers(0, 2)), 0.0, seed)
+    else:
+        scene = Scene().build("soup", tris, inst, 0.0, seed)
+    scene.set_aspect(w / h)
     mb = int(rng.choice([0, 5]))
     be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif, max_batch=mb)
+    be.set_option("spatial_splits", float(rng.choice([0.0, 8e-5, 1e-6])))
     orc = Oracle(w, h, threads=8, max_path_length=3)
     # round 2: the blue-noise sampler with seeded tables, extension rays in sorted order, a material edit with a `changed` bit
     bn = int(rng.integers(0, 3))
@@ -32,7 +42,7 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     if rng.integers(0, 2):
         scene.recolour_material(int(rng.integers(0, 6)), [int(x) for x in rng.integers(20, 250, 3)], int(rng.integers(10, 250)))
         scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
-    o = rng.uniform(-5, 5, (20000, 3)).astype(np.float32); d = rng.normal(size=(20000, 3)).astype(np.float32)
+    o = rng.uniform(-5, 5, (20000, 3)).astype(np.float32) * (2.5 if big else 1.0); d = rng.normal(size=(20000, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)] * rng.choice([-1, 1], (50, 1))  # axis-parallel
     g, r = be.intersect(o, d), orc.intersect(o, d)
