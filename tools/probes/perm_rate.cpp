@@ -28,7 +28,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k(float* out, float s
             B32(I)
 #undef I
         } else if (KIND == 3) {
-#define I(k) asm volatile("v_and_or_b32 %0, %1, 0xff, %2" : "=v"(v[k]) : "v"(u), "v"(magic));
+#define I(k) asm volatile("v_and_or_b32 %0, %1, %3, %2" : "=v"(v[k]) : "v"(u), "v"(magic), "v"(sel));
             B32(I)
 #undef I
         } else if (KIND == 4) {
