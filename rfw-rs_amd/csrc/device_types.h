@@ -190,10 +190,11 @@ struct InstanceXform {
     float inv_r0[4], inv_r1[4], inv_r2[4]; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major inverse
     uint32_t node_base;                    // first node of the mesh's BLAS in blas_nodes
     uint32_t tri_base;                     // first packet of the mesh in tri_packets
-    uint32_t flags;                        // bit0: valid
+    uint32_t flags;                        // bit0: valid; bit 1 (kInstanceIdentity): the inverse is exactly the identity
     uint32_t mesh;
 };
 static_assert(sizeof(InstanceXform) == 64, "InstanceXform");
+constexpr uint32_t kInstanceIdentity = 2u;
 
 // Per-instance record used by shade (48 B): rows of the normal matrix transpose(inverse(M)).
 struct InstanceNormal {

@@ -172,7 +172,12 @@ __global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const
     }
     x.node_base = valid ? meshes[mesh].node_base : 0u;
     x.tri_base = valid ? meshes[mesh].tri_base : 0u;
-    x.flags = valid ? 1u : 0u;
+    // bit 1: the rows of the inverse are EXACTLY (1 0 0 0) (0 1 0 0) (0 0 1 0), bit for bit (+0, not -0): the transform of a ray into this
+    // instance's space is then v * 1 + (+0) + (+0) + (+0) per component, i.e. v + 0.0f — the traversal adds the zero and skips the matrix
+    bool ident = valid;
+    for (int c = 0; c < 4; c++)
+        ident = ident && fbits(x.inv_r0[c]) == (c == 0 ? 0x3f800000u : 0u) && fbits(x.inv_r1[c]) == (c == 1 ? 0x3f800000u : 0u) && fbits(x.inv_r2[c]) == (c == 2 ? 0x3f800000u : 0u);
+    x.flags = (valid ? 1u : 0u) | (ident ? kInstanceIdentity : 0u);
     x.mesh = mesh;
     xf[i] = x;
     nm[i] = nn;

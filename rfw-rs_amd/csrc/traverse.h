@@ -42,6 +42,9 @@
 #define RFW_SLAB_ONE_COMPARE 1 // min(tf, t) >= max(tn, 0) instead of two compares and a scalar AND per child (degenerate directions are turned away at the entry)
 #endif
 
+#ifndef RFW_IDENTITY_FAST
+#define RFW_IDENTITY_FAST 1 // an instance whose inverse matrix is exactly the identity is entered without the matrix product (traverse_body.inc)
+#endif
 #ifndef RFW_TRI_BRANCHFREE
 #define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
 #endif

@@ -141,8 +141,13 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                 const float4 r1 = make_float4(bitsf(xf[4]), bitsf(xf[5]), bitsf(xf[6]), bitsf(xf[7]));
                 const float4 r2 = make_float4(bitsf(xf[8]), bitsf(xf[9]), bitsf(xf[10]), bitsf(xf[11]));
                 // ray into object space with the inverse instance matrix; direction NOT renormalised (ray_gen.comp:340-341)
-                o = xform_rows(r0, r1, r2, O, 1.0f);
-                d = xform_rows(r0, r1, r2, D, 0.0f);
+                if (RFW_IDENTITY_FAST && (xf[14] & kInstanceIdentity)) { // (wave-uniform: traverse_body.inc)
+                    o = mk3(O.x + 0.0f, O.y + 0.0f, O.z + 0.0f);
+                    d = mk3(D.x + 0.0f, D.y + 0.0f, D.z + 0.0f);
+                } else {
+                    o = xform_rows(r0, r1, r2, O, 1.0f);
+                    d = xform_rows(r0, r1, r2, D, 0.0f);
+                }
                 const uint32_t obj_oct = octant_of(slab_inv(d));
                 const uint64_t want = later != 0ull ? later : live;
                 sgn = lane_read(obj_oct, first_lane(want));
