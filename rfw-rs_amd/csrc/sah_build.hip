@@ -623,6 +623,9 @@ __global__ __launch_bounds__(kBlock) void k_partition_chunk(const DevBox* __rest
 //      its own bins, the larger child on a small stack.
 // (Round 2 finished ranges of 256 with one lane per axis sweeping the bins and one split at a time: 12.5 of the builder's 26 ms; the first
 // version of this round handed over at 64 primitives and paid for five more LEVELS of phase 1, ~0.5 ms each at 720 k primitives.)
+#ifndef RFW_SMALL_PAIR_CLOSED_FORM
+#define RFW_SMALL_PAIR_CLOSED_FORM 1
+#endif
 constexpr uint32_t kWaveRange = 64;
 constexpr int kListCap = 96;
 
@@ -657,6 +660,50 @@ template <uint32_t CAP> __device__ inline void finish_range_wave(SmallShared<CAP
 {
     int sp = 0;
     for (;;) {
+#if RFW_SMALL_PAIR_CLOSED_FORM
+        if (count == 2u) {
+            // Two primitives: the only possible split is one from the other (along the first axis on which their centroids differ, the
+            // lower one left), its cost is the two boxes' half areas — no bins, no sweep, and both children are leaves as they stand.  Half
+            // of the ranges a binary tree over 64 primitives evaluates have two primitives, and this chain of dependent evaluations is what
+            // k_small's time consists of (the kernel is bound by the latency of one workgroup).  Every lane computes the same.
+            const uint32_t q0 = S.perm[0][first], q1 = S.perm[0][first + 1u];
+            float l0[3], h0[3], l1[3], h1[3];
+            bool sep = false, swap = false;
+            for (int a = 0; a < 3; a++) {
+                l0[a] = S.lo[a][q0]; h0[a] = S.hi[a][q0]; l1[a] = S.lo[a][q1]; h1[a] = S.hi[a][q1];
+                const float c0 = 0.5f * (l0[a] + h0[a]), c1 = 0.5f * (l1[a] + h1[a]);
+                if (!sep && c0 != c1) { sep = true; swap = c1 < c0; }
+            }
+            const float area = half_area(nlo, nhi);
+            const bool split2 = (sep && half_area(l0, h0) + half_area(l1, h1) + trav_cost * area < 2.0f * area) || 2 > max_leaf;
+            if (split2) {
+                uint32_t li = 0;
+                if (lane == 0) li = atomicAdd(&S.next_id, 2u);
+                li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
+                if (lane == 0) {
+                    SNode l, r;
+                    init_child(l, gfirst + first, 1u, swap ? l1 : l0, swap ? h1 : h0, nid);
+                    init_child(r, gfirst + first + 1u, 1u, swap ? l0 : l1, swap ? h0 : h1, nid);
+                    nodes[li] = l;
+                    nodes[li + 1] = r;
+                    nodes[nid].left = li;
+                    if (swap) { S.perm[0][first] = (uint16_t)q1; S.perm[0][first + 1u] = (uint16_t)q0; }
+                }
+                wave_sync();
+            }
+            // (a leaf, or two leaves: the next range)
+            if (sp == 0) break;
+            sp--;
+            first = S.wstack[wave][3 * sp + 0];
+            count = S.wstack[wave][3 * sp + 1];
+            nid = S.wstack[wave][3 * sp + 2];
+            for (int a = 0; a < 3; a++) { nlo[a] = S.wstack_box[wave][6 * sp + a]; nhi[a] = S.wstack_box[wave][6 * sp + 3 + a]; }
+            wave_sync();
+            continue;
+        }
+#endif
+        // (tried: ranges of 3 and 4 primitives by an exact search over all their bipartitions, every lane alike from the boxes in LDS — the
+        // same trees, and no faster than the bins: 4.13 against 4.10 ms per build)
         const bool mine = lane < count;
         const uint32_t q = mine ? S.perm[0][first + lane] : 0u;
         float cen[3] = {0.0f, 0.0f, 0.0f};
