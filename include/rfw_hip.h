@@ -157,6 +157,9 @@ RFW_HIP_API uint32_t rfw_hip_abi_version(void);
  * triangle's own entry; >= n: a duplicate); duplicate_of[j] = the triangle duplicate n + j stands for.  split_tau as option "spatial_splits". */
 RFW_HIP_API int64_t rfw_hip_selftest_splits(const rfw_rt_triangle* tris, uint32_t n, float split_tau, uint32_t threads, float* pieces7, uint32_t pieces_cap,
                                             uint32_t* duplicate_of, uint32_t duplicates_cap, uint32_t* n_pieces);
+/* Host-only: the reciprocal the kernels use for `n / d` in their index arithmetic (pixel index / frame width, tile / tiles per row):
+ * m with n / d == (n * m) >> 32 for EVERY n <= n_max, or 0 when no such 32-bit constant is exact that far (the kernels then divide). */
+RFW_HIP_API uint32_t rfw_hip_selftest_index_magic(uint32_t d, uint64_t n_max);
 RFW_HIP_API int64_t rfw_hip_selftest_bvh(const float* boxes6, uint32_t n, uint32_t max_leaf, uint32_t threads, uint32_t* out_nodes);
 
 /* ---- Backend trait, in declaration order (crates/rfw-backend/src/lib.rs:36-81) ---- */

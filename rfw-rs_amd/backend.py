@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.environ.get("RFW_HIP_LIB") or os.path.join(_HERE, "csrc", "librfw_hip.so")  # RFW_HIP_LIB: experiment builds (make -C rfw-rs_amd/csrc variant VARIANT=x VFLAGS=-D...)
 
 EXPORTS = [
-    "rfw_hip_create", "rfw_hip_destroy", "rfw_hip_last_error", "rfw_hip_abi_version", "rfw_hip_selftest_bvh", "rfw_hip_selftest_splits",
+    "rfw_hip_create", "rfw_hip_destroy", "rfw_hip_last_error", "rfw_hip_abi_version", "rfw_hip_selftest_bvh", "rfw_hip_selftest_splits", "rfw_hip_selftest_index_magic",
     "rfw_hip_set_2d_mesh", "rfw_hip_set_2d_instances", "rfw_hip_set_3d_mesh", "rfw_hip_unload_3d_meshes",
     "rfw_hip_set_3d_instances", "rfw_hip_set_materials", "rfw_hip_set_textures", "rfw_hip_synchronize",
     "rfw_hip_render", "rfw_hip_resize", "rfw_hip_set_point_lights", "rfw_hip_set_spot_lights",
@@ -57,6 +57,8 @@ def hip_lib():
         l.rfw_hip_selftest_bvh.restype = C.c_int64
         l.rfw_hip_selftest_splits.argtypes = [vp, u32, C.c_float, u32, vp, u32, vp, u32, C.POINTER(u32)]
         l.rfw_hip_selftest_splits.restype = C.c_int64
+        l.rfw_hip_selftest_index_magic.argtypes = [u32, C.c_uint64]
+        l.rfw_hip_selftest_index_magic.restype = u32
         l.rfw_hip_set_2d_mesh.argtypes = [vp, u32, vp, u32, C.c_int32]
         l.rfw_hip_set_2d_instances.argtypes = [vp, u32, vp, u32]
         l.rfw_hip_set_3d_mesh.argtypes = [vp, u32, C.POINTER(pod.MeshData3D)]

@@ -6,6 +6,16 @@ using namespace rfwapi;
 
 namespace rfwapi {
 thread_local std::string g_create_error;
+// m with n / d == (n * m) >> 32 for every n <= n_max, or 0 when the round-up reciprocal m = ceil(2^32 / d) is not exact that far
+// (n * m = n * 2^32 / d + n * e / d with e = m * d - 2^32 < d: exact while n_max * e < 2^32).  The kernels divide when they get 0.
+uint32_t index_magic(const uint32_t d, const uint64_t n_max)
+{
+    if (d < 2u) return 0u;
+    const uint64_t m = ((1ull << 32) + d - 1u) / d, e = m * d - (1ull << 32);
+    if (m > 0xffffffffull || n_max >= (1ull << 32)) return 0u;
+    return (e == 0 || n_max < (1ull << 32) / e) ? (uint32_t)m : 0u;
+}
+
 void compute_shard(Instance* I)
 {
     // virtual sharding: world x substreams virtual ranks; virtual rank rank*S + s belongs to this instance's sub-shard s
@@ -115,6 +125,10 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.tile_size = I->tile_size; c.tiles_x = I->tiles_x; c.tiles_y = I->tiles_y;
     c.rank = I->rank * I->substreams + sub; c.world = I->world * I->substreams; c.local_tiles = I->local_tiles_v;
     c.flags = I->flags;
+    c.tile_shift = (I->tile_size & (I->tile_size - 1u)) == 0u ? (uint32_t)__builtin_ctz(I->tile_size) : 0xffffffffu;
+    c.width_magic = index_magic(I->width, (uint64_t)I->width * I->height);
+    // (slab indices run a little past the last tile: idx < capacity of the rank's slab, tile = lt * world + rank)
+    c.tiles_x_magic = index_magic(I->tiles_x, (uint64_t)I->tiles_x * I->tiles_y + 4096ull * std::max<uint64_t>((uint64_t)I->world * I->substreams, 1ull));
     {   // (api_internal.h: far outside the caches one ray per lane wins; RFW_PACKET_AUTO_MAX_TRIANGLES moves the limit, for tests)
         static const uint64_t limit = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES") ? strtoull(getenv("RFW_PACKET_AUTO_MAX_TRIANGLES"), nullptr, 10) : kPacketAutoMaxTriangles;
         if (S->packet_auto && S->n_tris > limit) c.flags &= ~kFlagPacketPrimary;
@@ -234,7 +248,6 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
     for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back; stage by stage across the sub-shards
         for (uint32_t s = 0; s < S; s++) {
             hipEvent_t* ev = ring_events(I, slot, s);
-            cam[s].path_length = b;
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
             if (b == 0 && k > 1) launch_primary_batch(st[s], cam[s], bv, sc[s], p[s], count);
             else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
@@ -325,6 +338,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
 extern "C" {
 
 uint32_t rfw_hip_abi_version(void) { return RFW_HIP_ABI_VERSION; }
+uint32_t rfw_hip_selftest_index_magic(uint32_t d, uint64_t n_max) { return index_magic(d, n_max); }
 
 
 void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rfw_hip_options* o)

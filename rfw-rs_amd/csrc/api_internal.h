@@ -549,6 +549,7 @@ PathDev path_dev(Instance* I, uint32_t sub = 0);
 int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k = 1, bool samples = false);
 uint32_t spill_stride(const Instance* I);
 bool blas_wide_wanted(const Instance* I, uint64_t n_prims); // api_scene.cpp: does a packet kernel run on a scene of this size under the current options?
+uint32_t index_magic(uint32_t d, uint64_t n_max); // api_frame.cpp: reciprocal for the kernels' index divisions (0: none exact far enough)
 // api_scene.cpp
 int do_synchronize(Instance* I);
 int ensure_slot_tlas(Instance* S, Instance* T);

@@ -227,13 +227,13 @@ struct CameraParams {
     float pos[3]; float lens_size;
     float right[3]; float spread_angle;
     float up[3]; float clamp_value;
-    float p1[3]; float pad0;
-    uint32_t width, height, sample_count, path_length;
+    float p1[3]; uint32_t tile_shift;   // log2(tile_size), or 0xffffffff when the tile size is not a power of two
+    uint32_t width, height, sample_count, width_magic; // (x / width == __umulhi(x, width_magic) for every pixel index; 0: divide.  api_frame.cpp index_magic)
     uint32_t point_light_count, area_light_count, spot_light_count, directional_light_count;
     // shard description: tiles of tile_size^2 pixels dealt round-robin to `world` ranks
     uint32_t tile_size, tiles_x, tiles_y, rank;
     uint32_t world, local_tiles, flags, max_path_length;
-    float sky[3]; float pad2;
+    float sky[3]; uint32_t tiles_x_magic; // tile / tiles_x, as width_magic
     // a batch of independent frames traced as ONE tall virtual frame (rfw_hip_render_batch): frame f owns paths
     // [f * frame_capacity, (f + 1) * frame_capacity); a path carries f in the top byte of its path-id word
     // streaming trace kernels (traverse.h, traverse_stream): a wavefront owns stream_run x 64 consecutive queue entries and hands a new ray to its idle

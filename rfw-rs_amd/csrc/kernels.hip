@@ -39,13 +39,17 @@ namespace rfwhip {
 RFW_DI bool morton_tile(uint32_t ts) { const uint32_t bpr = ts >> 3; return bpr <= 16u && (bpr & (bpr - 1u)) == 0u; }
 RFW_DI uint32_t morton_even_bits(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u) | ((v >> 3) & 8u); }       // bits 0,2,4,6 -> 0..3
 RFW_DI uint32_t morton_spread_bits(uint32_t v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3); }    // bits 0..3 -> 0,2,4,6
+// The index arithmetic below runs once per path and kernel; a 32-bit division is ~25 instructions on this device.  Tile sizes are powers of two
+// in practice (shifts: CameraParams::tile_shift), and the divisions by the frame's width / tiles per row are multiplications by a reciprocal the
+// host has proved exact for every index that can occur (index_magic in api_frame.cpp; 0 = no such constant: divide)
+RFW_DI uint32_t div_magic(const uint32_t n, const uint32_t d, const uint32_t magic) { return magic ? __umulhi(n, magic) : n / d; }
 RFW_DI bool slab_to_pixel(const CameraParams& c, uint32_t idx, uint32_t& px, uint32_t& py)
 {
     const uint32_t ts = c.tile_size, per_tile = ts * ts;
-    const uint32_t lt = idx / per_tile, within = idx - lt * per_tile;
+    const uint32_t lt = c.tile_shift != 0xffffffffu ? idx >> (2u * c.tile_shift) : idx / per_tile, within = idx - lt * per_tile;
     const uint32_t tile = lt * c.world + c.rank;
     if (tile >= c.tiles_x * c.tiles_y) return false;
-    const uint32_t ty = tile / c.tiles_x, tx = tile - ty * c.tiles_x;
+    const uint32_t ty = div_magic(tile, c.tiles_x, c.tiles_x_magic), tx = tile - ty * c.tiles_x;
     const uint32_t block = within >> 6, lane = within & 63u, bpr = ts >> 3;
     uint32_t by, bx;
     if (morton_tile(ts)) {
@@ -62,10 +66,15 @@ RFW_DI bool slab_to_pixel(const CameraParams& c, uint32_t idx, uint32_t& px, uin
 RFW_DI uint32_t pixel_to_slab(const CameraParams& c, uint32_t px, uint32_t py, uint32_t& owner)
 {
     const uint32_t ts = c.tile_size;
-    const uint32_t tx = px / ts, ty = py / ts;
+    const bool pow2 = c.tile_shift != 0xffffffffu;
+    const uint32_t tx = pow2 ? px >> c.tile_shift : px / ts, ty = pow2 ? py >> c.tile_shift : py / ts;
     const uint32_t tile = ty * c.tiles_x + tx;
-    owner = tile % c.world;
-    const uint32_t lt = tile / c.world;
+    uint32_t lt = tile;
+    owner = 0;
+    if (c.world != 1u) { // (uniform)
+        lt = tile / c.world;
+        owner = tile - lt * c.world;
+    }
     const uint32_t ix = px - tx * ts, iy = py - ty * ts;
     const uint32_t block = morton_tile(ts) ? (morton_spread_bits(ix >> 3) | (morton_spread_bits(iy >> 3) << 1)) : (iy >> 3) * (ts >> 3) + (ix >> 3);
     return lt * ts * ts + block * 64u + ((iy & 7u) << 3) + (ix & 7u);
@@ -694,7 +703,10 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_st
 }
 
 // ---------------------------------------------------------------- shade.comp:70-266
-constexpr int kShadeBlock = 512; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
+#ifndef RFW_SHADE_BLOCK
+#define RFW_SHADE_BLOCK 256
+#endif
+constexpr int kShadeBlock = RFW_SHADE_BLOCK; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
 // the octant-major filing of the extension rays below lets the SECOND wavefront prefix-sum the 8 x (kShadeBlock / 64) counts, one per lane
 static_assert(kShadeBlock >= 128 && 8 * (kShadeBlock / 64) <= 64, "k_shade: the extension-ray filing needs a second wavefront and at most 64 (octant, wavefront) counts");
 template <bool BATCH>
@@ -740,7 +752,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
         PATH_WORD = path_word;
         // bounce 0: path idx of the (tall) virtual frame IS its accumulator slot; later bounces recompute it from the pixel
         uint32_t owner, slot = idx;
-        if (bounce != 0) slot = pixel_to_slab(cam, PATH_ID % cam.width, PATH_ID / cam.width, owner) + (BATCH ? (path_word >> 24) * cam.frame_capacity : 0u);
+        if (bounce != 0) {
+            const uint32_t py_ = div_magic(PATH_ID, cam.width, cam.width_magic);
+            slot = pixel_to_slab(cam, PATH_ID - py_ * cam.width, py_, owner) + (BATCH ? (path_word >> 24) * cam.frame_capacity : 0u);
+        }
         const int32_t INST_ID = (int32_t)S.x;
         const uint32_t TRI_ID = S.y;
         const float T_VAL = bitsf(S.z);
@@ -837,7 +852,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                 f3 R = mk3(0.0f);
                 float r1, r2;
                 const bool blue = sc.blue_noise != nullptr && sampleId < 256u; // shade.comp:189-195; the xorshift seed is not advanced on this branch
-                const int bx = (int)(PATH_ID % cam.width), by = (int)(PATH_ID / cam.width);
+                const int by = (int)div_magic(PATH_ID, cam.width, cam.width_magic), bx = (int)(PATH_ID - (uint32_t)by * cam.width);
                 if (blue) {
                     r1 = blueNoiseSampler(sc.blue_noise, sampleId, bx, by, (int)(4u + 4u * path_length));
                     r2 = blueNoiseSampler(sc.blue_noise, sampleId, bx, by, (int)(5u + 4u * path_length));

@@ -46,6 +46,12 @@
 #define RFW_IDENTITY_FAST 1 // an instance whose inverse matrix is exactly the identity is entered without the matrix product (traverse_body.inc)
 #endif
 #ifndef RFW_TRI_BRANCHFREE
+#ifndef RFW_SINGLE_EXIT
+#define RFW_SINGLE_EXIT 1
+#endif
+#ifndef RFW_SINGLE_SWITCH
+#define RFW_SINGLE_SWITCH 1
+#endif
 #define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
 #endif
 #ifndef RFW_SPILL_COLUMN_LAZY
@@ -200,8 +206,14 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 
 #define RFW_TRAV_TOP
 #define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) != 0u) continue;
+#if RFW_SINGLE_EXIT
+    bool occluded = false;
+#define RFW_TRAV_OCCLUDED occluded = true; break;
+#define RFW_TRAV_AFTER_LEAF if (ANY_HIT && occluded) break;
+#else
 #define RFW_TRAV_OCCLUDED return true;
 #define RFW_TRAV_AFTER_LEAF
+#endif
 #define RFW_TRAV_EXHAUSTED break;
 #define RFW_TRAV_TLAS_GATE
 #include "traverse_body.inc"
@@ -211,7 +223,11 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 #undef RFW_TRAV_EXHAUSTED
 #undef RFW_TRAV_LEAF_GATE
 #undef RFW_TRAV_TLAS_GATE
+#if RFW_SINGLE_EXIT
+    return occluded;
+#else
     return false;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ for rep in $(seq 1 ${REPS:-1}); do for cfg in $CONFIGS; do
   (
     export RFW_HIP_LIB=$PWD/rfw-rs_amd/csrc/$lib
     for kv in ${envs//,/ }; do export "$kv"; done
-    timeout 400 python3 bench.py --steps ${STEPS:-300} --warmup 30 --no-cpu-baseline --procedural $BENCH_ARGS 2>/dev/null | tail -1 > gpurun_out/$TAG/${name}_$rep.json
+    timeout 400 python3 bench.py --steps ${STEPS:-300} --warmup ${WARMUP:-30} --no-cpu-baseline --procedural $BENCH_ARGS 2>/dev/null | tail -1 > gpurun_out/$TAG/${name}_$rep.json
     python3 - gpurun_out/$TAG/${name}_$rep.json "$name" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read()); r = d["roofline"]; c = r.get("contract", {}).get("per_kernel", {})
