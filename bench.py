@@ -740,7 +740,8 @@ def profile_kernel(kernels, name):
       k_primary        the packet flavour when that is what ran (option packet_trace), else the one-ray-per-lane kernel
       k_shadow         bounce 0: the packet flavour = one launch per visiting order (<false, true> + <false, false>), else k_shadow<false, false>
       k_shadow_stream  the bounces' streaming launches: one per visiting order as well (both are counted)
-      k_extend         the streaming flavour when that is what ran"""
+      k_extend         the streaming flavour when that is what ran
+      k_shade          either workgroup size (launch_shade picks by what shares the chip)"""
     def pick(*names):
         found = [kernels[n] for n in names if n in kernels]
         return found
@@ -749,6 +750,8 @@ def profile_kernel(kernels, name):
         "k_shadow": [("k_shadow_packet<false, true>", "k_shadow_packet<false, false>"), ("k_shadow<false, false>",), ("k_shadow<false,false>",)],
         "k_shadow_stream": [("k_shadow_stream<false, true>", "k_shadow_stream<false, false>")],
         "k_extend": [("k_extend_stream<false>",), ("k_extend<false>",)],
+        # (workgroups of 512 threads one frame at a time — what the counter passes run — and of 256 with frames in flight: the same instructions)
+        "k_shade": [("k_shade<false, 512>",), ("k_shade<false, 256>",), ("k_shade<false>",)],
     }.get(name, [(name + "<false, false>",), (name + "<false,false>",), (name + "<false>",), (name,)])
     for group in cands:
         found = pick(*group)

@@ -229,6 +229,11 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
         sc[s].spill = I->d_spill.ptr + (size_t)s * (I->cap_v + kSpillMargin);
         p[s] = path_dev(I, s);
         cam[s] = camera_params(I, view, s);
+        {   // k_shade's workgroup size (kernels.hip, k_shade): small where other frames' kernels share the chip with this call
+            const Instance* O = scene_of(I);
+            const int g = O->shade_group;
+            if (g == 256 || (g == 0 && k == 1 && !O->slots.empty())) cam[s].flags |= kFlagShadeSmallGroups;
+        }
     }
     BatchViews bv;
     if (k > 1) {
@@ -655,6 +660,10 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
             I->meshes_dirty = true;
             I->layout_valid = false;
         }
+    }
+    else if (k == "shade_group") { // threads per k_shade workgroup: 0 = automatic (do_render), 256, 512
+        if ((int)value != 0 && (int)value != 256 && (int)value != 512) return fail(I, RFW_HIP_E_INVALID, "set_option: shade_group is 0, 256 or 512");
+        I->shade_group = (int)value;
     }
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)

@@ -410,6 +410,7 @@ struct Instance {
     // extension rays traced in spatial order (option "sort_extension_rays"): (key, queue index) pairs, sorted with hipCUB on the frame's stream
     DevBuf<uint32_t> d_sort_keys[2], d_sort_vals[2];
     DevBuf<char> d_sort_ws;
+    int shade_group = 0; // option "shade_group": threads per k_shade workgroup — 0 = 256 where frames overlap (several frame slots, one frame per call), 512 otherwise; or 256 / 512
     int sort_extension_rays = 2; // 0 never, 1 always, 2 only where it pays: batches of frames / samples (see do_render)
     void* external_slab = nullptr;
     // multi-GPU inside the library (rfw_hip_comm_init): this rank's RGB slab(s) -> ncclAllGather on the instance's stream -> assemble

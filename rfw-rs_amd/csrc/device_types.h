@@ -280,7 +280,7 @@ struct QueueCounters {
 
 enum : uint32_t { kFlagNoNee = 1u, kFlagCount = 2u, kFlagNearFirstDirectional = 4u, kFlagFarFirstPositional = 8u,
                   kFlagPacketPrimary = 16u, kFlagPacketShadow = 32u, // option "packet_trace": which rays walk the tree as wavefront packets (traverse_packet.h)
-                  kFlagPacketShadowFar = 64u }; // ... bit 2: only the camera paths' shadow rays of the buckets traced far to near (the directional lights' bucket: parallel rays)
+                  kFlagPacketShadowFar = 64u, kFlagShadeSmallGroups = 128u }; // (kFlagShadeSmallGroups: k_shade in workgroups of 256 instead of 512, option "shade_group") // ... bit 2: only the camera paths' shadow rays of the buckets traced far to near (the directional lights' bucket: parallel rays)
 // (kFlagNearFirstDirectional, kFlagFarFirstPositional: option "shadow_order")
 
 

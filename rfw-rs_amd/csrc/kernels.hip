@@ -703,15 +703,16 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_st
 }
 
 // ---------------------------------------------------------------- shade.comp:70-266
-#ifndef RFW_SHADE_BLOCK
-#define RFW_SHADE_BLOCK 256
-#endif
-constexpr int kShadeBlock = RFW_SHADE_BLOCK; // 8 wavefronts share ONE atomic per queue (a returning atomic on one address retires at ~88 per us chip-wide)
+// Workgroup size of k_shade: the wavefronts of a workgroup share ONE atomic per queue (a returning atomic on one address retires at ~88 per us
+// chip-wide), so larger is cheaper — but with several frames in flight a workgroup of 8 wavefronts waits for 8 free wavefront slots and
+// its LDS on one CU while the trace kernels' single-wavefront workgroups take every slot the moment it frees (round 5: a launch that takes
+// 0.11 ms alone was resident for 1-2.7 ms).  256 where frames overlap (+1.5 % headline, +4 % path traced), 512 where one call fills the chip
+// by itself (a batch, samples per call, one frame at a time: there 256 only doubles the atomics — path traced batches -9 %): launch_shade
 // the octant-major filing of the extension rays below lets the SECOND wavefront prefix-sum the 8 x (kShadeBlock / 64) counts, one per lane
-static_assert(kShadeBlock >= 128 && 8 * (kShadeBlock / 64) <= 64, "k_shade: the extension-ray filing needs a second wavefront and at most 64 (octant, wavefront) counts");
-template <bool BATCH>
+template <bool BATCH, int kShadeBlock>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
+    static_assert(kShadeBlock >= 128 && 8 * (kShadeBlock / 64) <= 64, "k_shade: the extension-ray filing needs a second wavefront and at most 64 (octant, wavefront) counts");
 #if RFW_STAGE_PRIO
     __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO);
 #endif
@@ -1263,8 +1264,14 @@ void launch_extend(hipStream_t s, const CameraParams& cam, const SceneDev& sc, c
 }
 void launch_shade(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, uint32_t bounce)
 {
-    if (cam.batch > 1) hipLaunchKernelGGL(k_shade<true>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(ceil_div(p.capacity, kShadeBlock)), dim3(kShadeBlock), 0, s, cam, sc, p, bounce);
+    const bool small = (cam.flags & kFlagShadeSmallGroups) != 0u; // (do_render: several frame slots and one frame per call, or option "shade_group")
+    if (cam.batch > 1) {
+        if (small) hipLaunchKernelGGL((k_shade<true, 256>), dim3(ceil_div(p.capacity, 256)), dim3(256), 0, s, cam, sc, p, bounce);
+        else hipLaunchKernelGGL((k_shade<true, 512>), dim3(ceil_div(p.capacity, 512)), dim3(512), 0, s, cam, sc, p, bounce);
+    } else {
+        if (small) hipLaunchKernelGGL((k_shade<false, 256>), dim3(ceil_div(p.capacity, 256)), dim3(256), 0, s, cam, sc, p, bounce);
+        else hipLaunchKernelGGL((k_shade<false, 512>), dim3(ceil_div(p.capacity, 512)), dim3(512), 0, s, cam, sc, p, bounce);
+    }
 }
 void launch_shadow(hipStream_t s, const CameraParams& cam_in, const SceneDev& sc, const PathDev& p, uint32_t bounce, bool count)
 {

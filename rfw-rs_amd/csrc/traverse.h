@@ -45,13 +45,25 @@
 #ifndef RFW_IDENTITY_FAST
 #define RFW_IDENTITY_FAST 1 // an instance whose inverse matrix is exactly the identity is entered without the matrix product (traverse_body.inc)
 #endif
+// Shape of the traversal loop (traverse_body.inc), per flavour: 0 = the nested form of rounds 1-4 (if / else-if / else with `continue`, an instance
+// entered in the TLAS-leaf branch and left in front of the pop, an occluded ray returns from inside the packet loop); 1 = ONE block where the
+// ray changes space and one way out of the loop; 2 = flat (plain flavours only): no else-branches, no continue, no divergent exit, all state in `cur`
+#ifndef RFW_MODE_ANY
+#define RFW_MODE_ANY 2
+#endif
+#ifndef RFW_MODE_CLOSEST
+#define RFW_MODE_CLOSEST 0
+#endif
+#ifndef RFW_MODE_STREAM_ANY
+#define RFW_MODE_STREAM_ANY 1
+#endif
+#ifndef RFW_MODE_STREAM_CLOSEST
+#define RFW_MODE_STREAM_CLOSEST 1
+#endif
+#if RFW_MODE_STREAM_ANY == 2 || RFW_MODE_STREAM_CLOSEST == 2
+#error the streaming flavours refill lanes at the top of a trip: no flat form
+#endif
 #ifndef RFW_TRI_BRANCHFREE
-#ifndef RFW_SINGLE_EXIT
-#define RFW_SINGLE_EXIT 1
-#endif
-#ifndef RFW_SINGLE_SWITCH
-#define RFW_SINGLE_SWITCH 1
-#endif
 #define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
 #endif
 #ifndef RFW_SPILL_COLUMN_LAZY
@@ -206,28 +218,45 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 
 #define RFW_TRAV_TOP
 #define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) != 0u) continue;
-#if RFW_SINGLE_EXIT
-    bool occluded = false;
+#define RFW_TRAV_EXHAUSTED break;
+#define RFW_TRAV_TLAS_GATE
+    // (the body is included once per kind of ray so that each can have the loop shape that measured best for it: RFW_MODE_*)
+    if constexpr (ANY_HIT) {
+#define RFW_TRAV_MODE RFW_MODE_ANY
+#if RFW_TRAV_MODE == 2
+#define RFW_TRAV_OCCLUDED occ_ = 1u; next_ = kDoneRef; break;
+#define RFW_TRAV_AFTER_LEAF
+#include "traverse_body.inc"
+        return occ_ != 0u;
+#elif RFW_TRAV_MODE == 1
+        bool occluded = false;
 #define RFW_TRAV_OCCLUDED occluded = true; break;
-#define RFW_TRAV_AFTER_LEAF if (ANY_HIT && occluded) break;
+#define RFW_TRAV_AFTER_LEAF if (occluded) break;
+#include "traverse_body.inc"
+        return occluded;
 #else
 #define RFW_TRAV_OCCLUDED return true;
 #define RFW_TRAV_AFTER_LEAF
-#endif
-#define RFW_TRAV_EXHAUSTED break;
-#define RFW_TRAV_TLAS_GATE
 #include "traverse_body.inc"
-#undef RFW_TRAV_TOP
+        return false;
+#endif
 #undef RFW_TRAV_OCCLUDED
 #undef RFW_TRAV_AFTER_LEAF
+#undef RFW_TRAV_MODE
+    } else {
+#define RFW_TRAV_MODE RFW_MODE_CLOSEST
+#define RFW_TRAV_OCCLUDED
+#define RFW_TRAV_AFTER_LEAF
+#include "traverse_body.inc"
+#undef RFW_TRAV_OCCLUDED
+#undef RFW_TRAV_AFTER_LEAF
+#undef RFW_TRAV_MODE
+        return false;
+    }
+#undef RFW_TRAV_TOP
 #undef RFW_TRAV_EXHAUSTED
 #undef RFW_TRAV_LEAF_GATE
 #undef RFW_TRAV_TLAS_GATE
-#if RFW_SINGLE_EXIT
-    return occluded;
-#else
-    return false;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -351,7 +380,15 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
         continue;                                                                                                                     \
     }
 #define RFW_TRAV_EXHAUSTED have = false; pending = true; continue;
+    if constexpr (ANY_HIT) {
+#define RFW_TRAV_MODE RFW_MODE_STREAM_ANY
 #include "traverse_body.inc"
+#undef RFW_TRAV_MODE
+    } else {
+#define RFW_TRAV_MODE RFW_MODE_STREAM_CLOSEST
+#include "traverse_body.inc"
+#undef RFW_TRAV_MODE
+    }
 #undef RFW_TRAV_TOP
 #undef RFW_TRAV_OCCLUDED
 #undef RFW_TRAV_AFTER_LEAF

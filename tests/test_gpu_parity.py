@@ -475,6 +475,41 @@ def test_spatial_splits_never_change_the_image(builder, tau):
         be.close()
 
 
+@pytest.mark.parametrize("group", [0, 256, 512])
+@pytest.mark.parametrize("slots", [1, 3])
+def test_shade_workgroup_size_never_changes_the_image(group, slots):
+    """Round 5: k_shade runs in workgroups of 256 threads where frames overlap (several frame slots, one frame per call) and of 512 otherwise
+    (option "shade_group": 0 = that rule).  The queues a workgroup files its rays into are compacted per workgroup, so the ORDER of the shadow
+    and extension queues depends on the size — the image must not: path traced frames, single and as a batch, against the oracle."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 200, 136  # (ragged against the 256 / 512-path groups and the 128-pixel tiles)
+    scene = Scene().build("atrium", 30000, 1, 0.0, 0xBEEF)
+    scene.set_aspect(w / h)
+    views = []
+    for origin in ([0.5, 2.0, 9.0], [-3.0, 1.5, 6.0], [4.0, 3.0, 7.0]):
+        scene.look_at(origin, [0.0, 1.0, 0.0])
+        views.append(scene.view(w, h))
+    be = HipBackend.init(w, h, 1.0, max_path_length=3, frames_in_flight=slots, max_batch=3)
+    be.set_option("shade_group", group)
+    scene.sync(be)
+    orc = Oracle(w, h, threads=8, max_path_length=3)
+    scene.mark_all_changed(); scene.sync(orc)
+    for v in views[:2]:
+        be.reset_accumulation(); orc.reset()
+        for _ in range(2):
+            be.render(v); orc.render(v)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    if slots == 1:
+        be.render_batch(views)
+        for f, v in enumerate(views):
+            orc.reset(); orc.render(v)
+            assert np.array_equal(be.accumulator_at(f).view(np.uint32), orc.accumulator().view(np.uint32)), f
+    with pytest.raises(Exception):
+        be.set_option("shade_group", 128)
+    be.close()
+
+
 @pytest.mark.parametrize("forest", [True, False])
 def test_many_meshes_are_built_in_one_pass(forest, monkeypatch):
     """A scene of many meshes of very different sizes (2-triangle walls, boxes, an icosphere mesh with 30 instances, a 30 000-triangle soup,
