@@ -104,6 +104,23 @@ template <int KIND> __global__ __launch_bounds__(256) void k_stream(float* out, 
 #define I(k) asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(v[k]) : "v"(u));
             BODY32(I)
 #undef I
+        } else if (KIND == 40) { // byte -> float WITHOUT a conversion: 0x4B000000 | byte = 2^23 + byte, as a VOP2 or with an SDWA byte select (full rate?)
+            const uint32_t magic = 0x4B000000u;
+#define I(k) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(v[k]) : "v"(magic), "v"(u));
+            BODY32(I)
+#undef I
+        } else if (KIND == 41) { // the same as one child's planes: 6 or_sdwa + 6 plain FMAs + max3/min3 ... (14 instructions like KIND 38, conversions exchanged)
+            const uint32_t magic = 0x4B000000u;
+            float q[6];
+#define I(k) asm volatile("v_or_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\tv_or_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+                          "v_or_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\tv_or_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+                          "v_or_b32_sdwa %4, %8, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\tv_or_b32_sdwa %5, %8, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+                          "v_fma_f32 %0, %0, %10, %11\n\tv_fma_f32 %1, %1, %10, %11\n\tv_fma_f32 %2, %2, %10, %11\n\tv_fma_f32 %3, %3, %10, %11\n\tv_fma_f32 %4, %4, %10, %11\n\tv_fma_f32 %5, %5, %10, %11\n\t" \
+                          "v_max_f32 %6, %0, %2\n\tv_min_f32 %7, %1, %3\n\tv_min3_f32 %7, %7, %5, %11\n\tv_max3_f32 %6, %6, %4, 0\n\tv_cmp_ge_f32 vcc, %7, %6" \
+                          : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(magic), "v"(u), "v"(a), "v"(b), "v"(u ^ 0x3c003c00u) : "vcc");
+            I(0) I(1)
+#undef I
+            v[0] += q[0];
         } else if (KIND == 19) {
 #define I(k) asm volatile("v_lshrrev_b32 %0, 8, %1" : "=v"(v[k]) : "v"(u));
             BODY32(I)
@@ -299,6 +316,8 @@ int main()
     run<37>("v_cvt_f32_f16", 32, d_out, d_cyc, e0, e1);
     run<38>("node test child, bytes (14 instr x2)", 28, d_out, d_cyc, e0, e1);
     run<39>("node test child, f16 + fma_mix (11 instr x2)", 22, d_out, d_cyc, e0, e1);
+    run<40>("v_or_b32_sdwa BYTE_1 (0x4B000000 | byte)", 32, d_out, d_cyc, e0, e1);
+    run<41>("node test child, or_sdwa + 6 plain fma (17 instr x2)", 34, d_out, d_cyc, e0, e1);
     run<10>("s_add_u32", 32, d_out, d_cyc, e0, e1);
     run<11>("cvt+fma+max3+cmp (x8)", 32, d_out, d_cyc, e0, e1);
     run<12>("v_fma_f32 + s_add_u32 (x16 pairs)", 32, d_out, d_cyc, e0, e1);
