@@ -47,7 +47,9 @@
 #endif
 // Shape of the traversal loop (traverse_body.inc), per flavour: 0 = the nested form of rounds 1-4 (if / else-if / else with `continue`, an instance
 // entered in the TLAS-leaf branch and left in front of the pop, an occluded ray returns from inside the packet loop); 1 = ONE block where the
-// ray changes space and one way out of the loop; 2 = flat (plain flavours only): no else-branches, no continue, no divergent exit, all state in `cur`
+// ray changes space and one way out of the loop; 2 = flat: no else-branches, no continue, no divergent exit, all state in `cur`.  Measured per kind
+// (EXPERIMENTS.md, round 5): any hit and both streaming kinds flat; the plain closest-hit loop (camera rays one per lane: scenes beyond the packets'
+// range, latency-bound in HBM; extension rays when nothing streams) as in round 4 — both other shapes cost it 15-20 % there
 #ifndef RFW_MODE_ANY
 #define RFW_MODE_ANY 2
 #endif
@@ -55,13 +57,10 @@
 #define RFW_MODE_CLOSEST 0
 #endif
 #ifndef RFW_MODE_STREAM_ANY
-#define RFW_MODE_STREAM_ANY 1
+#define RFW_MODE_STREAM_ANY 2
 #endif
 #ifndef RFW_MODE_STREAM_CLOSEST
-#define RFW_MODE_STREAM_CLOSEST 1
-#endif
-#if RFW_MODE_STREAM_ANY == 2 || RFW_MODE_STREAM_CLOSEST == 2
-#error the streaming flavours refill lanes at the top of a trip: no flat form
+#define RFW_MODE_STREAM_CLOSEST 2
 #endif
 #ifndef RFW_TRI_BRANCHFREE
 #define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
@@ -226,7 +225,13 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 #if RFW_TRAV_MODE == 2
 #define RFW_TRAV_OCCLUDED occ_ = 1u; next_ = kDoneRef; break;
 #define RFW_TRAV_AFTER_LEAF
+#define RFW_TRAV_FLAT_WHILE __ballot(cur != kDoneRef) != 0ull
+#define RFW_TRAV_LEAF_TRIP (!RFW_ANY_LEAF_GATE || (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) == 0u)
+#define RFW_TRAV_TLAS_TRIP true
 #include "traverse_body.inc"
+#undef RFW_TRAV_FLAT_WHILE
+#undef RFW_TRAV_LEAF_TRIP
+#undef RFW_TRAV_TLAS_TRIP
         return occ_ != 0u;
 #elif RFW_TRAV_MODE == 1
         bool occluded = false;
@@ -247,7 +252,13 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
 #define RFW_TRAV_MODE RFW_MODE_CLOSEST
 #define RFW_TRAV_OCCLUDED
 #define RFW_TRAV_AFTER_LEAF
+#define RFW_TRAV_FLAT_WHILE __ballot(cur != kDoneRef) != 0ull
+#define RFW_TRAV_LEAF_TRIP true
+#define RFW_TRAV_TLAS_TRIP true
 #include "traverse_body.inc"
+#undef RFW_TRAV_FLAT_WHILE
+#undef RFW_TRAV_LEAF_TRIP
+#undef RFW_TRAV_TLAS_TRIP
 #undef RFW_TRAV_OCCLUDED
 #undef RFW_TRAV_AFTER_LEAF
 #undef RFW_TRAV_MODE
@@ -333,7 +344,7 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
     // with refilled lanes at every depth some lane holds a leaf in almost every trip.  A lane at a leaf sits out until `leaf_gate` lanes
     // are, or until no lane has a node to test.
     bool do_leaves = true;
-#define RFW_TRAV_TOP                                                                                                                  \
+#define RFW_STREAM_TOP_NESTED                                                                                                         \
     {                                                                                                                                 \
         /* `iteration` counts every trip of the WAVEFRONT here (idle lanes included): the loop provably ends, which also keeps the */ \
         /* compiler from reasoning about a lane that spins without side effects; a run that does not end raises the overflow flag */  \
@@ -371,31 +382,108 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
         }                                                                                                                             \
         if (!have) continue;                                                                                                          \
     }
-#define RFW_TRAV_LEAF_GATE if (!do_leaves) continue;
-#define RFW_TRAV_TLAS_GATE if (!do_leaves) continue;
-#define RFW_TRAV_OCCLUDED occluded = true; break;
-#define RFW_TRAV_AFTER_LEAF                                                                                                           \
-    if (ANY_HIT && occluded) {                                                                                                        \
-        have = false; pending = true;                                                                                                 \
-        continue;                                                                                                                     \
+// The same supply of rays for the FLAT loop (RFW_MODE_STREAM_* = 2, traverse_body.inc): a lane's state is `cur` alone — kIdleRef: no ray,
+// kDoneRef: a finished ray waiting to be committed, anything else: at work — so `have`, `pending` and `occluded` are no flags that live
+// across the loop's branches (each an SGPR pair merged with three scalar instructions at every join)
+#define RFW_STREAM_TOP_FLAT                                                                                                           \
+    if (iteration > (1u << 20)) { *sc.overflow_flag = 1u; break; }                                                                    \
+    {                                                                                                                                 \
+        const bool have_ = (cur + 3u) > 1u; /* neither kIdleRef nor kDoneRef */                                                       \
+        const uint64_t idle = __ballot(!have_);                                                                                       \
+        if (idle != 0ull) {                                                                                                           \
+            const bool more = st.more();                                                                                              \
+            if (!more && idle == everyone) break;                                                                                     \
+            if (more && (uint32_t)__popcll(idle) >= refill) {                                                                         \
+                if (!have_) {                                                                                                         \
+                    if (cur == kDoneRef) st.commit(occ_ != 0u, t, hu, hv, hit_inst, hit_tri);                                         \
+                    const bool got_ = st.fetch(idle, o, d, t);                                                                        \
+                    cur = kIdleRef;                                                                                                   \
+                    if (got_) {                                                                                                       \
+                        if (kPark) {                                                                                                  \
+                            uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;                                            \
+                            park[0] = fbits(o.x); park[kTraceBlock] = fbits(o.y); park[2 * kTraceBlock] = fbits(o.z);                 \
+                            park[3 * kTraceBlock] = fbits(d.x); park[4 * kTraceBlock] = fbits(d.y); park[5 * kTraceBlock] = fbits(d.z); \
+                        } else { O = o; D = d; }                                                                                      \
+                        inv = slab_inv(d);                                                                                            \
+                        sp = 0; blas_sp = -1; cur_inst = -1; tri_base = 0; nodes = space_nodes(sc, false, 0u, inv);                   \
+                        hu = 0.0f; hv = 0.0f; hit_inst = -1; hit_tri = -1; occ_ = 0u;                                                 \
+                        /* a degenerate direction hits nothing (see traverse()): finished before it starts */                          \
+                        const bool fine_ = !RFW_SLAB_ONE_COMPARE || ((d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f)); \
+                        cur = fine_ ? 0u : kDoneRef;                                                                                  \
+                    }                                                                                                                 \
+                }                                                                                                                     \
+                st.advance(idle);                                                                                                     \
+            }                                                                                                                         \
+        }                                                                                                                             \
+    }                                                                                                                                 \
+    {                                                                                                                                 \
+        const bool have_ = (cur + 3u) > 1u;                                                                                           \
+        const uint64_t busy = __ballot(have_), at_leaf = __ballot(have_ & ((int32_t)cur < -3));                                       \
+        do_leaves = at_leaf == busy || (uint32_t)__popcll(at_leaf) >= leaf_gate;                                                      \
     }
 #define RFW_TRAV_EXHAUSTED have = false; pending = true; continue;
     if constexpr (ANY_HIT) {
 #define RFW_TRAV_MODE RFW_MODE_STREAM_ANY
+#if RFW_TRAV_MODE == 2
+        cur = 0xfffffffdu; // kIdleRef
+#define RFW_TRAV_TOP RFW_STREAM_TOP_FLAT
+#define RFW_TRAV_OCCLUDED occ_ = 1u; next_ = kDoneRef; break;
+#define RFW_TRAV_AFTER_LEAF
+#define RFW_TRAV_FLAT_WHILE true
+#define RFW_TRAV_LEAF_TRIP do_leaves
+#define RFW_TRAV_TLAS_TRIP do_leaves
 #include "traverse_body.inc"
-#undef RFW_TRAV_MODE
-    } else {
-#define RFW_TRAV_MODE RFW_MODE_STREAM_CLOSEST
+        if (cur == kDoneRef) st.commit(occ_ != 0u, t, hu, hv, hit_inst, hit_tri);
+#undef RFW_TRAV_FLAT_WHILE
+#undef RFW_TRAV_LEAF_TRIP
+#undef RFW_TRAV_TLAS_TRIP
+#else
+#define RFW_TRAV_TOP RFW_STREAM_TOP_NESTED
+#define RFW_TRAV_LEAF_GATE if (!do_leaves) continue;
+#define RFW_TRAV_TLAS_GATE if (!do_leaves) continue;
+#define RFW_TRAV_OCCLUDED occluded = true; break;
+#define RFW_TRAV_AFTER_LEAF if (occluded) { have = false; pending = true; continue; }
 #include "traverse_body.inc"
-#undef RFW_TRAV_MODE
-    }
+        if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);
+#undef RFW_TRAV_LEAF_GATE
+#undef RFW_TRAV_TLAS_GATE
+#endif
 #undef RFW_TRAV_TOP
 #undef RFW_TRAV_OCCLUDED
 #undef RFW_TRAV_AFTER_LEAF
-#undef RFW_TRAV_EXHAUSTED
+#undef RFW_TRAV_MODE
+    } else {
+#define RFW_TRAV_MODE RFW_MODE_STREAM_CLOSEST
+#if RFW_TRAV_MODE == 2
+        cur = 0xfffffffdu; // kIdleRef
+#define RFW_TRAV_TOP RFW_STREAM_TOP_FLAT
+#define RFW_TRAV_OCCLUDED
+#define RFW_TRAV_AFTER_LEAF
+#define RFW_TRAV_FLAT_WHILE true
+#define RFW_TRAV_LEAF_TRIP do_leaves
+#define RFW_TRAV_TLAS_TRIP do_leaves
+#include "traverse_body.inc"
+        if (cur == kDoneRef) st.commit(false, t, hu, hv, hit_inst, hit_tri);
+#undef RFW_TRAV_FLAT_WHILE
+#undef RFW_TRAV_LEAF_TRIP
+#undef RFW_TRAV_TLAS_TRIP
+#else
+#define RFW_TRAV_TOP RFW_STREAM_TOP_NESTED
+#define RFW_TRAV_LEAF_GATE if (!do_leaves) continue;
+#define RFW_TRAV_TLAS_GATE if (!do_leaves) continue;
+#define RFW_TRAV_OCCLUDED
+#define RFW_TRAV_AFTER_LEAF
+#include "traverse_body.inc"
+        if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);
 #undef RFW_TRAV_LEAF_GATE
 #undef RFW_TRAV_TLAS_GATE
-    if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);
+#endif
+#undef RFW_TRAV_TOP
+#undef RFW_TRAV_OCCLUDED
+#undef RFW_TRAV_AFTER_LEAF
+#undef RFW_TRAV_MODE
+    }
+#undef RFW_TRAV_EXHAUSTED
 }
 
 } // namespace rfwhip

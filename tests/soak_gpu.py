@@ -7,7 +7,9 @@ Round 4 (packets, per-octant node copies, heads-first uploads): the first 200 co
 builder x three frame slots — the per-slot TLAS of the host builder was uploaded on the owner's stream and expanded into its octant copies on the
 slot's, visible only in a process whose earlier backends had dirtied the recycled allocation (now a GPU test:
 test_backends_one_after_the_other_in_one_process).  After the fix 300 + 2 + 60: 0 mismatches.  A failing configuration now names its failed checks.
-Round 5 (spatial splits, the triangle test without early outs): every fourth configuration an atrium with split walls under a random threshold."""
+Round 5 (spatial splits, the triangle test without early outs): every fourth configuration an atrium with split walls under a random threshold;
+at the end of the round (flat traversal loops, streaming ones too; k_shade in workgroups of 256 or 512) streaming runs / refills and the shade
+group are random too."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -38,6 +40,13 @@ for it in range(int(os.environ.get("ITERS", "24"))):
         t = np.random.default_rng(seed).integers(0, 256, 5 * 65536).astype(np.uint32)
         be.set_blue_noise(t); orc.set_blue_noise(t)
     be.set_option("sort_extension_rays", int(rng.integers(0, 3)))
+    # round 5 (flat loops, k_shade's workgroup size by situation): the streaming kernels forced on or off for any number of frame slots, with
+    # short runs and early refills in the mix; the shading kernel's workgroup size left to the rule or forced
+    sr = int(rng.choice([-1, 0, 1, 2, 8]))
+    if sr >= 0:
+        be.set_option("stream_run", sr)
+        be.set_option("stream_refill", int(rng.choice([4, 12, 40])))
+    be.set_option("shade_group", int(rng.choice([0, 256, 512])))
     scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
     if rng.integers(0, 2):
         scene.recolour_material(int(rng.integers(0, 6)), [int(x) for x in rng.integers(20, 250, 3)], int(rng.integers(10, 250)))
