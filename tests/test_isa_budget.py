@@ -4,6 +4,9 @@
   register pairs inside its traversal loop at the 64-VGPR / 8-wave cap.
 * Every trace kernel stays inside the register budget of the occupancy it is compiled for.
 * The issue-rate probe's loops hold exactly the vector instructions per trip the host multiplies by (28 were counted as 32).
+* The flat traversal loops (round 5) keep their share of scalar instructions: the nested loops they replaced spent 40-53 % of their
+  instructions on exec-mask arithmetic, which takes the same issue slots as vector work; a change that brings a flag back across the loop's
+  joins shows up here before it shows up in a frame rate.
 * The build is free of the "inline asm clobber list contains reserved registers" warning (round 4's v_writelane asm wrote M0)."""
 import os
 import re
@@ -52,6 +55,26 @@ def test_trace_kernels_fit_their_occupancy(listing):
         for prefix, w in want.items():
             if name.startswith(prefix):
                 assert k["vgpr"] <= budget[w], (name, k["vgpr"], w)
+
+
+def test_flat_loops_keep_their_scalar_share(listing):
+    """Static scalar instruction counts of the kernels whose loops are flat (RFW_MODE_* = 2, traverse_body.inc), against bounds half way
+    between what the flat and the nested forms compile to (round 5, ROCm 7.2: k_shadow 803 / 923, k_shadow_stream 646 / 876,
+    k_extend_stream 423 / 549).  A tripwire for the source and for the compiler, not a performance claim."""
+    _, _, ks = listing
+    src = open(os.path.join(ROOT, "rfw-rs_amd", "csrc", "traverse.h")).read()
+    mode = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (RFW_MODE_\w+) (\d)", src)}
+    want = {}
+    if mode["RFW_MODE_ANY"] == 2:
+        want["k_shadow<false, false>"] = 865
+    if mode["RFW_MODE_STREAM_ANY"] == 2:
+        want["k_shadow_stream<false, false>"] = 760
+    if mode["RFW_MODE_STREAM_CLOSEST"] == 2:
+        want["k_extend_stream<false>"] = 485
+    assert want, mode
+    for name, bound in want.items():
+        assert name in ks, (name, sorted(ks)[:8])
+        assert ks[name]["salu"] <= bound, (name, ks[name]["salu"], bound)
 
 
 def test_issue_probe_loops_hold_the_counted_instructions(listing):
