@@ -1300,7 +1300,8 @@ void launch_shadow(hipStream_t s, const CameraParams& cam_in, const SceneDev& sc
     }
     const dim3 block(kTraceBlock);
     // streaming pays where a wavefront's rays differ in length and direction: the shadow rays of the bounces.  The camera paths' own shadow rays
-    // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too)
+    // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too with the nested
+    // loops of rounds 3-4; break-even, 8012-8080 against 8059-8115 Mrays/s, with the flat ones of round 5)
     static const bool kStreamShadow0 = getenv("RFW_STREAM_SHADOW0") != nullptr; // (experiment switch: the camera paths' shadow rays stream too)
     if (cam.stream_run && (bounce >= 1u || kStreamShadow0)) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
         const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + kShadowBuckets + 511u) & ~511u);

@@ -33,7 +33,7 @@
 #define RFW_ANY_LEAF_GATE 1 // any hit: a lane that holds a leaf waits for the next even trip of the loop, which batches the triangle tests (round 1; re-measured with the static order: see EXPERIMENTS.md)
 #endif
 #ifndef RFW_ANY_LEAF_PERIOD
-#define RFW_ANY_LEAF_PERIOD 2 // ... every how many trips the waiting leaves are tested (round 5: 3 -> k_shadow 0.278 -> 0.285 ms, 4 -> 0.295; waiting for 8 / 16 / 24 lanes at leaves instead, as the streaming kernels do: 0.329 / 0.367 / 0.408)
+#define RFW_ANY_LEAF_PERIOD 2 // ... every how many trips the waiting leaves are tested (round 5, nested loop: 3 -> k_shadow 0.278 -> 0.285 ms, 4 -> 0.295; flat loop: 1 -> frame -2 %, 3 -> +0.4 % = noise; waiting for 8 / 16 / 24 lanes at leaves instead, as the streaming kernels do: 0.329 / 0.367 / 0.408)
 #endif
 #ifndef RFW_STATIC_ORDER
 #define RFW_STATIC_ORDER 1
