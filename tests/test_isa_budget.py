@@ -77,6 +77,24 @@ def test_flat_loops_keep_their_scalar_share(listing):
         assert ks[name]["salu"] <= bound, (name, ks[name]["salu"], bound)
 
 
+def test_block_table_of_a_kernel(listing):
+    """tools/isa_blocks.py (how round 5 read the hot trip of a loop) still parses the listing: the flat any-hit kernel has a loop whose blocks
+    hold a four-child node test (24 byte conversions) and no more than a handful of register copies."""
+    import isa_blocks
+    path, _, _ = listing
+    lines = open(path).read().splitlines()
+    hit = [i for i, _, d in isa_blocks.kernels_of(lines) if "k_shadow<false, false>" in d]
+    assert len(hit) == 1
+    blocks = isa_blocks.blocks_of(isa_blocks.body_of(lines, hit[0]))
+    in_loop = [b for b in blocks if b[2]]
+    assert len(in_loop) > 20
+    node_tests = [b for b in in_loop if sum(1 for x in b[1] if x.startswith("v_cvt_f32_ubyte")) == 24]
+    assert len(node_tests) == 2, len(node_tests)  # (one per visiting order)
+    for b in node_tests:
+        v, mv, s, mem = isa_blocks.count(b[1])
+        assert 70 <= v <= 85 and mv <= 2 and mem == 4, (b[0], v, mv, s, mem)
+
+
 def test_issue_probe_loops_hold_the_counted_instructions(listing):
     path, _, _ = listing
     src = open(os.path.join(ROOT, "rfw-rs_amd", "csrc", "kernels.hip")).read()
