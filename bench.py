@@ -277,7 +277,7 @@ def main():
             # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created), so RCCL's
             # all-gather is ordered against the kernels
             st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
-            for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays", "stream_run", "stream_refill", "stream_leaf_gate"):  # builder / queue-order experiments
+            for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays", "stream_run", "stream_refill", "stream_leaf_gate", "shade_group"):  # A/B experiments: RFW_<OPTION>=value
                 if os.environ.get("RFW_" + key.upper()):
                     be.set_option(key, float(os.environ["RFW_" + key.upper()]))
             if world > 1 or args.emulate_shard:
