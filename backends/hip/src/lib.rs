@@ -28,6 +28,7 @@ struct TextureDataC { width: u32, height: u32, mip_levels: u32, bytes: *const u8
 struct SkinDataC { inverse_bind_matrices: *const Mat4, num_inverse_bind_matrices: u32, joint_matrices: *const Mat4, num_joint_matrices: u32 }
 
 extern "C" {
+    fn rfw_hip_abi_version() -> u32;
     fn rfw_hip_create(width: u32, height: u32, scale: c_double, options: *const Options) -> *mut c_void;
     fn rfw_hip_destroy(instance: *mut c_void);
     fn rfw_hip_last_error(instance: *mut c_void) -> *const c_char;
@@ -90,6 +91,9 @@ impl HipBackend {
 
 impl FromWindowHandle for HipBackend {
     fn init<W: HasRawWindowHandle>(_window: &W, width: u32, height: u32, scale: f64) -> Result<Box<Self>, Box<dyn std::error::Error>> {
+        // the structs above mirror include/rfw_hip.h at RFW_HIP_ABI_VERSION 2: a library of another version is refused, not mis-read
+        let abi = unsafe { rfw_hip_abi_version() };
+        if abi != 2 { return Err(format!("librfw_hip.so speaks ABI version {}, this crate version 2", abi).into()); }
         let opts = Options { struct_size: std::mem::size_of::<Options>() as u32, device: -1, ..Default::default() };
         let instance = unsafe { rfw_hip_create(width, height, scale, &opts) };
         if instance.is_null() {

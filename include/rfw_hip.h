@@ -31,7 +31,9 @@ extern "C" {
 #endif
 
 #define RFW_HIP_API __attribute__((visibility("default")))
-#define RFW_HIP_ABI_VERSION 1
+/* 2 (round 5/6): rfw_hip_scene_stats grew by 24 bytes (split_references, accel_bytes, packet_copies) and its `triangles` became the CALLER'S
+ * triangle count; a binding compiled against version 1 must not call rfw_hip_get_scene_stats.  Bindings check rfw_hip_abi_version() at load. */
+#define RFW_HIP_ABI_VERSION 2
 
 enum {
     RFW_HIP_OK = 0,

@@ -31,6 +31,9 @@ EXPORTS = [
 _lib = None
 
 
+ABI_VERSION = 2  # RFW_HIP_ABI_VERSION of include/rfw_hip.h this file's structs (pod.py) were written against
+
+
 def hip_lib():
     """Load librfw_hip.so (loudly: no fallback)."""
     global _lib
@@ -53,6 +56,8 @@ def hip_lib():
         l.rfw_hip_last_error.argtypes = [vp]
         l.rfw_hip_last_error.restype = cp
         l.rfw_hip_abi_version.restype = u32
+        if l.rfw_hip_abi_version() != ABI_VERSION:  # (pod.py mirrors the structs of ONE version of include/rfw_hip.h)
+            raise RuntimeError(f"{HIP_LIB} speaks ABI version {l.rfw_hip_abi_version()}, this binding version {ABI_VERSION}: rebuild the library")
         l.rfw_hip_selftest_bvh.argtypes = [vp, u32, u32, u32, C.POINTER(u32)]
         l.rfw_hip_selftest_bvh.restype = C.c_int64
         l.rfw_hip_selftest_splits.argtypes = [vp, u32, C.c_float, u32, vp, u32, vp, u32, C.POINTER(u32)]

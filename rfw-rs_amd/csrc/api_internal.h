@@ -182,6 +182,7 @@ struct MeshHost {
     // the caller's n_orig records, then (n_refs - n_orig) duplicates of split triangles; the arrays are allocated with room for the
     // duplicates (slack) so that a registered array never moves.  Everything that STORES the mesh counts n_refs, everything the caller sees n_orig.
     size_t n_orig = 0, n_refs = 0;
+    float split_tau_used = -1.0f;     // option spatial_splits at the last copy (a re-send under the same setting keeps to its region's room)
     std::vector<SplitPiece> pieces;   // box overrides of every reference of a split triangle (sorted by index)
     std::vector<rfw_rt_triangle> tris;
     // The first 48 B of every record (vertex0 u0 | vertex1 u1 | vertex2 u2), copied beside it by set_3d_mesh: all the device builders read

@@ -1148,15 +1148,21 @@ int rfw_hip_set_2d_instances(void* inst, uint32_t, const rfw_mat4*, uint32_t) { 
 // ---- spatial splits (MeshHost, api_internal.h).  Everything here is host arithmetic on the caller's vertices: deterministic, the same on every rank.
 namespace {
 struct SplitPoly { int n; float p[10][3]; }; // a triangle clipped by axis planes: at most 3 + 6 vertices ... and one spare
-inline void clip_poly(const SplitPoly& in, int axis, float pos, bool keep_below, SplitPoly& out)
+// false: the clipped polygon does not fit the 10 entries (vertices ON the plane are kept by both halves, so repeated cuts can grow a part
+// past 3 + 6); the caller then leaves the part uncut — a part with dropped vertices would get a box that does not cover it
+inline bool clip_poly(const SplitPoly& in, int axis, float pos, bool keep_below, SplitPoly& out)
 {
     out.n = 0;
-    for (int i = 0; i < in.n && out.n < 9; i++) {
+    for (int i = 0; i < in.n; i++) {
         const float* a = in.p[i];
         const float* b = in.p[(i + 1) % in.n];
         const bool ia = keep_below ? a[axis] <= pos : a[axis] >= pos, ib = keep_below ? b[axis] <= pos : b[axis] >= pos;
-        if (ia) std::memcpy(out.p[out.n++], a, 12);
-        if (ia != ib && out.n < 10) {
+        if (ia) {
+            if (out.n >= 10) return false;
+            std::memcpy(out.p[out.n++], a, 12);
+        }
+        if (ia != ib) {
+            if (out.n >= 10) return false;
             // the same expression in both halves (same endpoints, same order): the two parts share their cut points exactly
             const float t = (pos - a[axis]) / (b[axis] - a[axis]);
             float* q = out.p[out.n++];
@@ -1164,6 +1170,7 @@ inline void clip_poly(const SplitPoly& in, int axis, float pos, bool keep_below,
             q[axis] = pos;
         }
     }
+    return true;
 }
 inline void poly_box(const SplitPoly& p, float lo[3], float hi[3])
 {
@@ -1325,9 +1332,8 @@ static void split_references(const float split_tau, MeshHost& m, const std::vect
         bool cut = parts_of[p.tri] < kMaxPartsPerTriangle && pos > p.lo[axis] && pos < p.hi[axis];
         Part a = p, b = p;
         if (cut) {
-            clip_poly(p.poly, axis, pos, true, a.poly);
-            clip_poly(p.poly, axis, pos, false, b.poly);
-            cut = a.poly.n >= 3 && b.poly.n >= 3;
+            const bool fits_a = clip_poly(p.poly, axis, pos, true, a.poly), fits_b = clip_poly(p.poly, axis, pos, false, b.poly);
+            cut = fits_a && fits_b && a.poly.n >= 3 && b.poly.n >= 3;
         }
         if (!cut) { done_idx.push_back(pi); continue; }
         for (Part* q : {&a, &b}) {
@@ -1385,7 +1391,7 @@ static size_t split_slack(const float split_tau, size_t n, bool skinned)
 }
 
 static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack);
-static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, bool skinned)
+static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, bool skinned, size_t region_cap)
 {
     const size_t slack = split_slack(I->split_tau, n, skinned), alloc = n + slack;
     if (m.tris.size() != alloc) {
@@ -1401,7 +1407,10 @@ static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src,
         m.pinned = a && b;
         if (!m.pinned) { (void)hipGetLastError(); m.pin_failed = true; } // (the limit on locked memory, say: the uploads are staged by the runtime as before)
     }
-    copy_and_split(m, src, n, threads, I->split_tau, slack);
+    // a re-sent mesh that still fits its region of the device buffers stays there: its duplicates are limited to the room the region has
+    // (one reference more than the region holds would abandon it — a hole, the mesh appended — and duplicates are image-neutral: ADVICE r05)
+    copy_and_split(m, src, n, threads, I->split_tau, (region_cap >= n && m.split_tau_used == I->split_tau) ? std::min(slack, region_cap - n) : slack);
+    m.split_tau_used = I->split_tau;
 }
 // (host arithmetic only: also what rfw_hip_selftest_splits runs, without a device)
 static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, int threads, float split_tau, size_t slack)
@@ -1530,7 +1539,9 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
     }
     const auto t_copy = std::chrono::steady_clock::now();
     const bool skinned = d->skin_data && d->num_skin_data == 3u * d->num_triangles && (d->flags & RFW_MESH_ALLOW_SKINNING);
-    copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads, skinned); // copy: the borrow ends with this call (a skinned mesh is refitted, not split)
+    size_t region_cap = 0; // the triangles this mesh's region on the device holds, when it has one
+    if (const auto it = I->mesh_index.find(id); it != I->mesh_index.end() && I->layout_valid && it->second < I->record_tri_cap.size()) region_cap = I->record_tri_cap[it->second];
+    copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads, skinned, region_cap); // copy: the borrow ends with this call (a skinned mesh is refitted, not split)
     if (getenv("RFW_BUILD_TRACE")) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
     m.skin.clear();
     if (skinned) m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);

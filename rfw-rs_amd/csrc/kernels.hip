@@ -1417,7 +1417,9 @@ void launch_copy_f4(hipStream_t s, const float4* src, float4* dst, uint64_t n)
 }
 void launch_expand_nodes(hipStream_t s, const Node4Q* in, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {
-    if (n && oc.quant) hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, oc.wide + first, oc.quant + first, oc.stride, n, live);
+    if (!n || !oc.quant) return;
+    PacketNode* const wide = oc.wide ? oc.wide + first : nullptr; // (the packet form of the copies may be absent: offset only what exists — ADVICE r05)
+    hipLaunchKernelGGL(k_expand_nodes, dim3(ceil_div((uint64_t)n * 8u, 256)), dim3(256), 0, s, in, wide, oc.quant + first, oc.stride, n, live);
 }
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live)
 {

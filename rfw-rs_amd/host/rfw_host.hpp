@@ -54,6 +54,7 @@ public:
     // FromWindowHandle::init(window, width, height, scale) — headless: the window handle is ignored.
     static HipBackend* init(uint32_t width, uint32_t height, double scale, const rfw_hip_options* options = nullptr)
     {
+        if (rfw_hip_abi_version() != RFW_HIP_ABI_VERSION) throw std::runtime_error("librfw_hip.so was built from another version of include/rfw_hip.h");
         void* inst = rfw_hip_create(width, height, scale, options);
         if (!inst) throw std::runtime_error(std::string("rfw_hip_create: ") + rfw_hip_last_error(nullptr));
         return new HipBackend(inst);

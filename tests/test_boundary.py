@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.rfw_hip_abi_version.restype = C.c_uint32
-    assert lib.rfw_hip_abi_version() == 1
+    assert lib.rfw_hip_abi_version() == 2
 
 
 def test_create_fails_loudly_without_gpu():

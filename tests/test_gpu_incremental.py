@@ -212,3 +212,47 @@ def test_texture_edits_honour_changed_bits():
     if n_tex >= 4:
         assert t_part < t_full, (t_part, t_full)                          # two of n textures resampled and uploaded, not all
     be.close()
+
+
+def test_edits_and_skinned_refits_without_the_packet_form_of_the_node_copies():
+    """with option packet_trace = 0 chosen before the build the packet form of the per-octant node copies is never
+    allocated; an incremental edit of a mesh whose nodes do not start at 0, and the per-frame refit of a skinned copy (which lies behind the
+    static meshes), must then leave that absent buffer alone — both used to hand the expand kernel `nullptr + node_base`."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 160, 96
+    scene = Scene().build("atrium", 620000, 1, 0.0, 0xBEEF)     # (spheres exist above 600 000 triangles) the spheres as meshes of their own: every mesh but the first has node_base > 0
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    assert scene.counts()["meshes"] > 8
+    be = HipBackend.init(w, h, 1.0, max_path_length=2)
+    be.set_option("packet_trace", 0)                            # before the first synchronize: no packet copies
+    orc = Oracle(w, h, threads=THREADS, max_path_length=2)
+    scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+    assert be.scene_stats()["packet_copies"] == 0
+    o, d = rays(20000, 3)
+    assert_same(be, orc, o, d, view, "full build without packet copies")
+    for k, (mesh, seed) in enumerate(((7, 11), (3, 12), (7, 13))):
+        scene.replace_mesh_with_sphere(mesh, mesh - 1, seed)    # incremental: rebuilt in its own region (node_base > 0)
+        scene.sync(be)
+        scene.mark_all_changed(); scene.sync(orc)
+        assert be.scene_stats()["packet_copies"] == 0
+        assert_same(be, orc, o, d, view, f"edit {k} without packet copies")
+    be.close()
+
+    # a skinned copy is refitted every synchronize, behind the static meshes
+    scene = Scene().build("cornell")
+    scene.build("skinned", 0, 0, 0.0, 3)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=2)
+    be.set_option("packet_trace", 0)
+    orc = Oracle(w, h, threads=THREADS, max_path_length=2)
+    for t in (0.3, 1.1, 0.0, 1.7):
+        scene.pose(t)
+        scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+        assert be.scene_stats()["packet_copies"] == 0
+        orc.reset()
+        be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), t
+    be.close()

@@ -104,3 +104,37 @@ def test_budget_holds_when_every_triangle_is_wasteful():
     refs, pieces, dup = run(tris, 1e-6, 4)
     assert refs - n == min(n // 128 + 64, 1024)
     assert len(pieces) >= refs - n
+
+
+def test_vertices_on_successive_mid_planes_never_leave_a_part_uncovered():
+    """a vertex that lies exactly ON a cutting plane is kept by both halves, so a part can collect more vertices than a clipped
+    triangle normally has; a part whose polygon would not fit is left uncut instead of losing vertices (a box that does not cover its part
+    of the triangle means missed hits).  Triangles with vertices on the dyadic mid-planes of their own boxes: the union of the parts' boxes
+    covers every point of the triangle."""
+    rng = np.random.default_rng(11)
+    n_small = 9000
+    c = rng.uniform([0, 0, 0], [16, 16, 16], (n_small, 1, 3))
+    v = (c + rng.uniform(-0.02, 0.02, (n_small, 3, 3))).astype(np.float32)
+    big = np.array([[[0, 0, 0], [16, 8, 4], [8, 16, 12]],      # every coordinate a multiple of the successive mid-planes of its box
+                    [[0, 8, 16], [16, 8, 0], [8, 0, 8]],
+                    [[4, 4, 4], [12, 12, 4], [8, 8, 16]],
+                    [[0, 0, 8], [16, 16, 8], [16, 0, 8.0001]]], dtype=np.float32)
+    v = np.concatenate([v, big])
+    tris = (pod.RTTriangle * len(v))()
+    for i, t in enumerate(v):
+        for k, name in enumerate(("vertex0", "vertex1", "vertex2")):
+            f = getattr(tris[i], name)
+            f.x, f.y, f.z = map(float, t[k])
+    n = len(v)
+    refs, pieces, dup = run(tris, 1e-5, 4)
+    idx = pieces[:, 0].astype(np.int64)
+    owners = np.where(idx < n, idx, dup[np.clip(idx - n, 0, max(len(dup) - 1, 0))])
+    split = set(owners.tolist())
+    assert split & set(range(n_small, n))                      # the big ones are cut
+    for t in sorted(split):
+        mine = pieces[owners == t]
+        b = rng.dirichlet((1, 1, 1), 6000).astype(np.float64)
+        b = np.concatenate([b, np.eye(3), [[0.5, 0.5, 0], [0, 0.5, 0.5], [0.5, 0, 0.5]]])   # corners and edge mid-points too
+        p = b @ v[t].astype(np.float64)
+        inside = ((p[:, None, :] >= mine[None, :, 1:4] - 1e-4) & (p[:, None, :] <= mine[None, :, 4:7] + 1e-4)).all(-1).any(-1)
+        assert inside.all(), (t, p[~inside][:3])
