@@ -232,14 +232,14 @@ int rfw_hip_p2p_export(void* inst, void* handle_out)
     // cached in this device's L2, which a remote store does not invalidate: fine-grained (system-scope coherent) memory instead, so that a
     // frame never de-tiles a stale line whatever the kernel-boundary cache policy is.  RFW_P2P_DATA_CACHED=1 keeps round 3's
     // plain allocation (A/B on a multi-GPU node); a device without fine-grained memory falls back to it as well.
-    if (getenv("RFW_P2P_DATA_CACHED") || hipExtMallocWithFlags((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
+    if (env_switches().p2p_data_cached || hipExtMallocWithFlags((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         P.data = nullptr;
         HIP_TRY(I, hipMalloc((void**)&P.data, P.n_slots * P.slot_words * sizeof(uint32_t)));
     }
     // flag words are polled while peers write them: uncached, so that a poll never reads a stale line of this device's L2
     // (RFW_P2P_FLAGS_FINEGRAINED=1 forces the fall-back kind of memory, so that tests can take that path)
-    if (getenv("RFW_P2P_FLAGS_FINEGRAINED") || hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    if (env_switches().p2p_flags_finegrained || hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         P.flags = nullptr;
         if (hipExtMallocWithFlags((void**)&P.flags, flag_bytes, hipDeviceMallocFinegrained) != hipSuccess) {

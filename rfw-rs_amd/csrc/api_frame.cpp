@@ -6,6 +6,26 @@ using namespace rfwapi;
 
 namespace rfwapi {
 thread_local std::string g_create_error;
+} // namespace rfwapi
+namespace rfwhip {
+static EnvSwitches g_env;
+const EnvSwitches& env_switches() { return g_env; }
+void read_env_switches()
+{
+    EnvSwitches e;
+    auto set = [](const char* name) { const char* v = getenv(name); return v != nullptr && std::strcmp(v, "0") != 0; };
+    e.build_trace = set("RFW_BUILD_TRACE");
+    e.no_forest = set("RFW_NO_FOREST");
+    e.lbvh_fenced = set("RFW_LBVH_FENCED");
+    e.p2p_data_cached = set("RFW_P2P_DATA_CACHED");
+    e.p2p_flags_finegrained = set("RFW_P2P_FLAGS_FINEGRAINED");
+    if (const char* v = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES")) e.packet_auto_max_triangles = strtoull(v, nullptr, 10);
+    if (const char* v = getenv("RFW_SPATIAL_SPLITS")) { e.has_spatial_splits = true; e.spatial_splits = (float)std::max(0.0, atof(v)); }
+    if (const char* v = getenv("RFW_PACKET_TRACE")) e.packet_trace = std::max(0, atoi(v));
+    g_env = e;
+}
+} // namespace rfwhip
+namespace rfwapi {
 // m with n / d == (n * m) >> 32 for every n <= n_max, or 0 when the round-up reciprocal m = ceil(2^32 / d) is not exact that far
 // (n * m = n * 2^32 / d + n * e / d with e = m * d - 2^32 < d: exact while n_max * e < 2^32).  The kernels divide when they get 0.
 uint32_t index_magic(const uint32_t d, const uint64_t n_max)
@@ -129,10 +149,8 @@ CameraParams camera_params(const Instance* I, const rfw_camera_view_3d& v, uint3
     c.width_magic = index_magic(I->width, (uint64_t)I->width * I->height);
     // (slab indices run a little past the last tile: idx < capacity of the rank's slab, tile = lt * world + rank)
     c.tiles_x_magic = index_magic(I->tiles_x, (uint64_t)I->tiles_x * I->tiles_y + 4096ull * std::max<uint64_t>((uint64_t)I->world * I->substreams, 1ull));
-    {   // (api_internal.h: far outside the caches one ray per lane wins; RFW_PACKET_AUTO_MAX_TRIANGLES moves the limit, for tests)
-        static const uint64_t limit = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES") ? strtoull(getenv("RFW_PACKET_AUTO_MAX_TRIANGLES"), nullptr, 10) : kPacketAutoMaxTriangles;
-        if (S->packet_auto && S->n_tris > limit) c.flags &= ~kFlagPacketPrimary;
-    }
+    // (api_internal.h: far outside the caches one ray per lane wins)
+    if (S->packet_auto && S->n_tris > packet_auto_limit()) c.flags &= ~kFlagPacketPrimary;
     c.max_path_length = I->max_path_length;
     c.sky[0] = I->sky[0]; c.sky[1] = I->sky[1]; c.sky[2] = I->sky[2];
     c.batch = 1;
@@ -348,6 +366,7 @@ uint32_t rfw_hip_selftest_index_magic(uint32_t d, uint64_t n_max) { return index
 
 void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rfw_hip_options* o)
 {
+    read_env_switches(); // (the one place the library asks the environment: env_switches.h)
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) {
@@ -378,10 +397,10 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
     }
     {
-        if (const char* st = getenv("RFW_SPATIAL_SPLITS")) I->split_tau = (float)std::max(0.0, atof(st)); // A/B runs: the default of option "spatial_splits"
-        const char* e = getenv("RFW_PACKET_TRACE"); // A/B runs: the default of option "packet_trace"
-        const int pt = e ? atoi(e) : kDefaultPacketTrace;
-        I->packet_auto = e == nullptr;
+        const EnvSwitches& env = env_switches();
+        if (env.has_spatial_splits) I->split_tau = env.spatial_splits; // A/B runs: the default of option "spatial_splits"
+        const int pt = env.packet_trace >= 0 ? env.packet_trace : kDefaultPacketTrace; // A/B runs: the default of option "packet_trace"
+        I->packet_auto = env.packet_trace < 0;
         if (pt & 1) I->flags |= kFlagPacketPrimary;
         if (pt & 2) I->flags |= kFlagPacketShadow;
         if (pt & 4) I->flags |= kFlagPacketShadowFar;

@@ -42,6 +42,7 @@ const char* ncclGetErrorString(ncclResult_t r);
 
 #include "../../include/rfw_hip.h"
 #include "bvh_host.h"
+#include "env_switches.h"
 #include "kernels.h"
 #include "lbvh.h"
 #include "sah_build.h"
@@ -236,6 +237,7 @@ constexpr int kDefaultPacketTrace = 1;
 // (round 3: 2630); tools/probes/packet_crossover.py puts the crossover between 8 M and 17 M triangles.  While nobody sets the option the
 // camera rays of a scene beyond this many triangles go one per lane.
 constexpr uint64_t kPacketAutoMaxTriangles = 12u << 20;
+inline uint64_t packet_auto_limit() { const uint64_t e = env_switches().packet_auto_max_triangles; return e ? e : kPacketAutoMaxTriangles; } // (RFW_PACKET_AUTO_MAX_TRIANGLES moves the limit, for tests)
 enum EvId { EV_FRAME0 = 0, EV_FRAME1, EV_KERNEL_BASE }; // per kernel: start, stop
 constexpr int kMaxBounces = 8;
 constexpr int kKernelsPerBounce = 3; // trace, shade, shadow

@@ -48,9 +48,8 @@ inline OctantCopies copies_of(const DevBuf<PacketNode>& wide, const DevBuf<Node4
 // set_option("packet_trace") marks the meshes for a rebuild when it asks for packets on a scene built without them.
 bool blas_wide_wanted(const Instance* I, uint64_t n_prims)
 {
-    static const uint64_t limit = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES") ? strtoull(getenv("RFW_PACKET_AUTO_MAX_TRIANGLES"), nullptr, 10) : kPacketAutoMaxTriangles;
     if (!(I->flags & (kFlagPacketPrimary | kFlagPacketShadow | kFlagPacketShadowFar))) return false;
-    return !(I->packet_auto && n_prims > limit);
+    return !(I->packet_auto && n_prims > packet_auto_limit());
 }
 
 // pad so that the slab test is conservative w.r.t. the rounding of the Moeller-Trumbore arithmetic
@@ -347,7 +346,7 @@ void assign_logical_ids(Instance* I)
 // BLAS for every mesh on the device: lay the mega-buffers out afresh, upload all triangles, build every mesh
 int build_blas_device_full(Instance* I)
 {
-    static const bool kTrace = getenv("RFW_BUILD_TRACE") != nullptr; // (stderr: where a full build's host time goes)
+    const bool kTrace = env_switches().build_trace; // (stderr: where a full build's host time goes)
     const auto t_start = std::chrono::steady_clock::now();
     auto trace = [&](const char* what) {
         if (kTrace) fprintf(stderr, "[build] %-28s %7.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count());
@@ -399,7 +398,7 @@ int build_blas_device_full(Instance* I)
     size_t k = 0;
     bool any_pinned = false; // (a scene of small meshes only: nothing to overlap; an unregistered mesh is staged by the runtime on either stream)
     for (auto& kv : I->meshes) any_pinned = any_pinned || kv.second.pinned;
-    I->build_from_heads = any_pinned && static_tris > 0 && !getenv("RFW_NO_HEADS_FIRST");
+    I->build_from_heads = any_pinned && static_tris > 0;
     I->records_timed = I->build_from_heads;
     if (I->build_from_heads) I->heads_first_builds++;
     if (I->build_from_heads) {
@@ -459,8 +458,8 @@ int build_blas_device_full(Instance* I)
         // mesh is a root of the same level-by-level pass) — ~45 launches for the scene instead of ~30 per mesh
         bool forest_done = false;
         // (measured: two meshes of 720 k + 330 k triangles 5.4 ms together, 4.4 ms one after the other; 65 meshes 5.5 ms against 10.4 on lanes, 38 one by one)
-        static const size_t forest_min = getenv("RFW_FOREST_MIN") ? (size_t)std::max(atoi(getenv("RFW_FOREST_MIN")), 2) : 4;
-        if (I->blas_sah_on_device && n_static >= forest_min && static_tris > 0 && !getenv("RFW_NO_FOREST")) {
+        constexpr size_t forest_min = 4;
+        if (I->blas_sah_on_device && n_static >= forest_min && static_tris > 0 && !env_switches().no_forest) {
             std::vector<ForestTree> trees(n_static);
             for (size_t q = 0; q < n_static; q++) trees[q] = ForestTree{I->mesh_records[q].tri_base, I->mesh_records[q].tri_count, I->mesh_records[q].node_base, 0u};
             HIP_TRY(I, I->d_forest.ensure(n_static));
@@ -617,7 +616,7 @@ int build_blas_device_incremental(Instance* I)
     // from the 48-B heads while the records follow on the second stream, the packets are made when they are there.  Nothing is synchronised
     // here: the next set_3d_mesh waits for ev_records before it overwrites the host copy the upload reads (records_pending).
     bool heads_first = false;
-    if (todo.size() == 1 && I->mesh_records[todo[0]].tri_count * sizeof(rfw_rt_triangle) >= (size_t(1) << 20) && !getenv("RFW_NO_HEADS_FIRST")) {
+    if (todo.size() == 1 && I->mesh_records[todo[0]].tri_count * sizeof(rfw_rt_triangle) >= (size_t(1) << 20)) {
         const uint32_t q = todo[0];
         MeshHost* mh = nullptr;
         for (auto& kv : I->mesh_index)
@@ -1398,7 +1397,7 @@ static void copy_triangles(Instance* I, MeshHost& m, const rfw_rt_triangle* src,
         m.unpin();
         m.tris.clear(); m.tris.shrink_to_fit(); m.tris.resize(alloc);
         m.heads.clear(); m.heads.shrink_to_fit(); m.heads.resize(alloc);
-    } else if (!m.pinned && !m.pin_failed && I->blas_on_device && n * sizeof(rfw_rt_triangle) >= (128u << 10) && !getenv("RFW_NO_PINNED_MESHES") &&
+    } else if (!m.pinned && !m.pin_failed && I->blas_on_device && n * sizeof(rfw_rt_triangle) >= (128u << 10) &&
                hipSetDevice(I->device) == hipSuccess) {
         // re-sent at the same size: a mesh that changes.  Registering costs ~0.2 ms per MB, once (a scene that is loaded and never re-sent does not pay it)
         const bool a = hipHostRegister(m.tris.data(), alloc * sizeof(rfw_rt_triangle), hipHostRegisterDefault) == hipSuccess;
@@ -1495,7 +1494,7 @@ static void copy_and_split(MeshHost& m, const rfw_rt_triangle* src, size_t n, in
         }
         for (auto& t : pool) t.join();
     }
-    static const bool kTrace = getenv("RFW_BUILD_TRACE") != nullptr;
+    const bool kTrace = env_switches().build_trace;
     const auto t_split = std::chrono::steady_clock::now();
     if (scan) split_references(split_tau, m, scans, slack);
     if (kTrace && scan) {
@@ -1542,7 +1541,7 @@ int rfw_hip_set_3d_mesh(void* inst, uint32_t id, const rfw_mesh_data_3d* d)
     size_t region_cap = 0; // the triangles this mesh's region on the device holds, when it has one
     if (const auto it = I->mesh_index.find(id); it != I->mesh_index.end() && I->layout_valid && it->second < I->record_tri_cap.size()) region_cap = I->record_tri_cap[it->second];
     copy_triangles(I, m, d->triangles, d->num_triangles, I->build_threads, skinned, region_cap); // copy: the borrow ends with this call (a skinned mesh is refitted, not split)
-    if (getenv("RFW_BUILD_TRACE")) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
+    if (env_switches().build_trace) fprintf(stderr, "[build] set_3d_mesh %u: host copy of %u triangles %.3f ms (%s)\n", id, d->num_triangles, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_copy).count(), m.pinned ? "registered" : "pageable");
     m.skin.clear();
     if (skinned) m.skin.assign(d->skin_data, d->skin_data + d->num_skin_data);
     m.dirty = true;

@@ -258,13 +258,10 @@ struct BatchViews {
 
 // Device-side queue counters; one slot per bounce so nothing has to be reset or read back between bounces
 // (the reference reads extensionId/shadowId back to the host every bounce: gpu-rt/src/lib.rs:2052-2069).
-#ifndef RFW_SHADOW_BUCKETS
-#define RFW_SHADOW_BUCKETS 8
-#endif
 // shadow rays are queued per bucket: every directional light's rays in the LAST bucket (they are traced far to near), the positional lights
-// dealt over the other seven (picked light % 7) — a wavefront's rays aim at one light (or one kind of light).  Experiment RFW_SHADOW_BUCKETS = 16: (light & 3)
-// x 4 classes of the surface orientation (dominant axis of the geometric normal), so that a wavefront's rays also leave similar surfaces
-constexpr int kShadowBuckets = RFW_SHADOW_BUCKETS;
+// dealt over the other seven (picked light % 7) — a wavefront's rays aim at one light (or one kind of light).  (16 buckets — light x 4 classes
+// of the surface orientation — were measured in round 3: EXPERIMENTS.md)
+constexpr int kShadowBuckets = 8;
 struct QueueCounters {
     uint32_t ext[8];
     uint32_t shadow[8][kShadowBuckets]; // [bounce][bucket]

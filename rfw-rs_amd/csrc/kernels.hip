@@ -15,18 +15,8 @@
 
 // waves per SIMD the trace kernels are compiled for (register budget 512 / waves), chosen by measurement with frames in flight:
 // closest hit (k_primary, k_extend) 6 (5: -6 %, 7: -2 %, 8: -11 %); any hit (k_shadow: fewer live values) 8 (7: -1.4 %, 6: -2.8 %)
-#ifndef RFW_TRACE_WAVES
-#define RFW_TRACE_WAVES 6
-#endif
-#ifndef RFW_STREAM_WAVES
-#define RFW_STREAM_WAVES 6      // waves per SIMD the streaming closest-hit kernel is compiled for
-#endif
-#ifndef RFW_STREAM_WAVES_ANY
-#define RFW_STREAM_WAVES_ANY 8  // the same for the streaming any-hit kernel
-#endif
-#ifndef RFW_TRACE_WAVES_ANY
-#define RFW_TRACE_WAVES_ANY 8
-#endif
+// the streaming flavours alike; the packet kernels 8 (6 -> 6755, 7 -> 6785, 8 -> 6855 Mrays/s: 16 spilled registers at 8 cost less than the two extra waves hide)
+constexpr int kTraceWaves = 6, kTraceWavesAny = 8, kStreamWaves = 6, kStreamWavesAny = 8, kPacketWaves = 8;
 
 namespace rfwhip {
 
@@ -270,9 +260,9 @@ RFW_DI uint32_t xcd_run(const uint32_t b, const uint32_t per_tile)
 }
 
 // ---------------------------------------------------------------- ray_gen.comp:39-70
-template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
+template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
-    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     TravCounters tc{0, 0, 0};
@@ -300,10 +290,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES)
 
 // The packet flavour (traverse_packet.h): the 64 camera rays of an 8x8-pixel block walk the tree together on one shared stack.  Same rays,
 // same triangle tests, same image; no LDS.
-#ifndef RFW_PACKET_WAVES
-#define RFW_PACKET_WAVES 8 // measured: 6 -> 6755, 7 -> 6785, 8 -> 6855 Mrays/s (16 spilled registers at 8 cost less than the two extra waves hide)
-#endif
-template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_primary_packet(const CameraParams cam, const SceneDev sc, const PathDev p)
+template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kPacketWaves) void k_primary_packet(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
@@ -335,9 +322,9 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES
 
 // the same for a batch of independent frames (rfw_hip_render_batch): one launch covers the tiles of every frame of the batch
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
+__global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_primary_batch(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
 {
-    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t f = (block * kTraceBlock) / cam.frame_capacity; // uniform: a frame's range is a multiple of the workgroup size
@@ -374,7 +361,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_primary_batch(
 // ... and the packet flavour for a batch of frames: a wavefront's 64 paths belong to ONE frame (a frame's range is a multiple of the workgroup
 // size), so they are one 8x8-pixel block of one view as in k_primary_packet
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_primary_batch_packet(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
+__global__ __launch_bounds__(kTraceBlock, kPacketWaves) void k_primary_batch_packet(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
 {
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
@@ -448,10 +435,10 @@ void launch_extension_keys(hipStream_t s, const SceneDev& sc, const PathDev& p, 
 
 // ---------------------------------------------------------------- ray_extend.comp:245-268
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce,
+__global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_extend(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce,
                                                                          const uint32_t* __restrict__ order)
 {
-    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t count = sc.counters->ext[bounce - 1];
@@ -500,10 +487,10 @@ struct ExtendStream {
     }
 };
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES) void k_extend_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce,
+__global__ __launch_bounds__(kTraceBlock, kStreamWaves) void k_extend_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce,
                                                                                 const uint32_t* __restrict__ order)
 {
-    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t run = cam.stream_run * kTraceBlock;
     const uint32_t block = xcd_run(blockIdx.x, 64u / cam.stream_run);
     const uint32_t count = sc.counters->ext[bounce - 1];
@@ -519,23 +506,11 @@ __global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES) void k_extend_stream
 // Buckets are walked from the LAST light index down (directional lights come last in the reference's light order, shade.comp:471-527): a
 // measured choice — k_shadow alone 0.364 -> 0.336 ms when it was made, 0.382 -> 0.329 ms with the far-to-near order of the directional
 // light's rays below; with frames in flight the order of the buckets does not matter.
-#ifndef RFW_SHADOW_FAR_FIRST
-#define RFW_SHADOW_FAR_FIRST 1
-#endif
-#ifndef RFW_STAGE_PRIO
-#define RFW_STAGE_PRIO 0
-#endif
-#ifndef RFW_SHADOW_ORDER_REV
-#define RFW_SHADOW_ORDER_REV 1
-#endif
 RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket);
 template <bool COUNT, bool BATCH = false>
-__global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, kTraceWavesAny) void k_shadow(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
-    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
-#if RFW_STAGE_PRIO
-    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO); // experiment (EXPERIMENTS.md): the later stages of a frame win the issue arbitration over younger frames' primary rays
-#endif
+    __shared__ uint32_t s_stack[kTraceLdsRowsAny * kTraceBlock];
     // the queue is bucketed by light (shade pushes directional lights into the last region, positional lights into region light % 7): walk the buckets, each padded to whole wavefronts, so
     // the 64 rays of a wavefront start on neighbouring pixels AND aim at the same light
     uint32_t block = xcd_block(blockIdx.x);
@@ -544,7 +519,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
     {
         bool found = false;
         for (int kk = 0; kk < kShadowBuckets; kk++) {
-            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            const int k = kShadowBuckets - 1 - kk;
             if ((cam.flags & kFlagPacketShadowFar) && bucket_far_first(cam, (uint32_t)k)) continue; // (those went as packets: launch_shadow)
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
@@ -569,8 +544,7 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
         // floors), so their occluder search starts at the far end (measured on the bench scene's real shadow queue: 21.6 -> 12.1 nodes per
         // ray; rays towards the area lights get up to 15 % longer that way and keep the near-to-far order).  shade files every directional
         // light's rays under the last bucket, so the bucket tells the kind of light.
-        const bool far_first = RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional)
-                                                                                                 : (cam.flags & kFlagFarFirstPositional) != 0u); // option "shadow_order" overrides the default per light kind
+        const bool far_first = bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional) : (cam.flags & kFlagFarFirstPositional) != 0u; // option "shadow_order" overrides the default per light kind
         const bool occluded = far_first ? traverse<true, COUNT, true>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_base, tc)
                                         : traverse<true, COUNT, false>(sv, O, D, 0.001f, t, hu, hv, hi, ht, s_stack, threadIdx.x, spill_base, tc);
         if (!occluded) {
@@ -593,14 +567,14 @@ __global__ __launch_bounds__(kTraceBlock, RFW_TRACE_WAVES_ANY) void k_shadow(con
 // light.  One instantiation per visiting order, each launch walking the buckets of its order (as the streaming flavour below).
 RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket);
 template <bool COUNT, bool FAR>
-__global__ __launch_bounds__(kTraceBlock, RFW_PACKET_WAVES) void k_shadow_packet(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, kPacketWaves) void k_shadow_packet(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     uint32_t block = xcd_block(blockIdx.x);
     uint32_t bucket = 0, count = 0;
     {
         bool found = false;
         for (int kk = 0; kk < kShadowBuckets; kk++) {
-            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            const int k = kShadowBuckets - 1 - kk;
             if (bucket_far_first(cam, (uint32_t)k) != FAR) continue;
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + kTraceBlock - 1) / kTraceBlock;
@@ -672,19 +646,19 @@ struct ShadowStream {
 // registers into vector lanes.  Each launch walks the buckets of its own order only.
 RFW_DI bool bucket_far_first(const CameraParams& cam, const uint32_t bucket)
 {
-    return RFW_SHADOW_FAR_FIRST && (bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional) : (cam.flags & kFlagFarFirstPositional) != 0u);
+    return bucket == (uint32_t)kShadowBuckets - 1u ? !(cam.flags & kFlagNearFirstDirectional) : (cam.flags & kFlagFarFirstPositional) != 0u;
 }
 template <bool COUNT, bool FAR>
-__global__ __launch_bounds__(kTraceBlock, RFW_STREAM_WAVES_ANY) void k_shadow_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
+__global__ __launch_bounds__(kTraceBlock, kStreamWavesAny) void k_shadow_stream(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
-    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRowsAny * kTraceBlock];
     const uint32_t run = cam.stream_run * kTraceBlock;
     uint32_t block = xcd_run(blockIdx.x, 64u / cam.stream_run);
     uint32_t bucket = 0, count = 0;
     {
         bool found = false;
         for (int kk = 0; kk < kShadowBuckets; kk++) {
-            const int k = RFW_SHADOW_ORDER_REV ? kShadowBuckets - 1 - kk : kk;
+            const int k = kShadowBuckets - 1 - kk;
             if (bucket_far_first(cam, (uint32_t)k) != FAR) continue;
             const uint32_t c = sc.counters->shadow[bounce][k];
             const uint32_t nb = (c + run - 1u) / run;
@@ -713,9 +687,6 @@ template <bool BATCH, int kShadeBlock>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, const SceneDev sc, const PathDev p, const uint32_t bounce)
 {
     static_assert(kShadeBlock >= 128 && 8 * (kShadeBlock / 64) <= 64, "k_shade: the extension-ray filing needs a second wavefront and at most 64 (octant, wavefront) counts");
-#if RFW_STAGE_PRIO
-    __builtin_amdgcn_s_setprio(RFW_STAGE_PRIO);
-#endif
     const uint32_t idx = blockIdx.x * kShadeBlock + threadIdx.x;
     const uint32_t count = bounce == 0 ? p.capacity : sc.counters->ext[bounce - 1];
     if (blockIdx.x * kShadeBlock >= count) return;
@@ -894,17 +865,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                                     sh_e = contribution;
                                     sh_slot = slot;
                                     push_shadow = true;
-#if RFW_SHADOW_BUCKETS == 16
-                                    {
-                                        const float ax = gl_abs(gN.x), ay = gl_abs(gN.y), az = gl_abs(gN.z);
-                                        const int cls = (ay >= ax && ay >= az) ? (gN.y > 0.0f ? 1 : 2) : (ax >= az ? 0 : 3);
-                                        light_bucket = (picked & 3) | (cls << 2);
-                                    }
-#else
                                     // directional lights share the LAST bucket (their rays are traced far to near, k_shadow), the positional lights
                                     // are dealt over the other seven: the bucket tells the kind of light however many lights there are
                                     light_bucket = picked >= lc - (int)cam.directional_light_count ? kShadowBuckets - 1 : (int)((uint32_t)picked % (uint32_t)(kShadowBuckets - 1));
-#endif
                                 }
                             }
                         }
@@ -1120,7 +1083,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(const SceneDev sc
                                                                 const float t_min, const float t_max, const uint64_t n, rfw_hip_hit* __restrict__ hits,
                                                                 uint32_t* __restrict__ depth)
 {
-    __shared__ uint32_t s_stack[(kStackLds + (RFW_RAY_IN_LDS ? 6 : 0)) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     if (idx >= n) return;
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
@@ -1149,7 +1112,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_any(const SceneDev sc, co
                                                             const float t_min, const float* __restrict__ t_max, const uint64_t n,
                                                             uint8_t* __restrict__ occluded, uint32_t* __restrict__ depth)
 {
-    __shared__ uint32_t s_stack[(RFW_ANY_PARK ? kStackLdsAny + 6 : kStackLds) * kTraceBlock];
+    __shared__ uint32_t s_stack[kTraceLdsRowsAny * kTraceBlock];
     const uint64_t idx = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     if (idx >= n) return;
     const f3 O = mk3(origins[3 * idx], origins[3 * idx + 1], origins[3 * idx + 2]);
@@ -1302,8 +1265,7 @@ void launch_shadow(hipStream_t s, const CameraParams& cam_in, const SceneDev& sc
     // streaming pays where a wavefront's rays differ in length and direction: the shadow rays of the bounces.  The camera paths' own shadow rays
     // (bounce 0) start on neighbouring pixels towards one light and stay one ray per lane (measured: -16 % when they stream too with the nested
     // loops of rounds 3-4; break-even, 8012-8080 against 8059-8115 Mrays/s, with the flat ones of round 5)
-    static const bool kStreamShadow0 = getenv("RFW_STREAM_SHADOW0") != nullptr; // (experiment switch: the camera paths' shadow rays stream too)
-    if (cam.stream_run && (bounce >= 1u || kStreamShadow0)) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
+    if (cam.stream_run && bounce >= 1u) { // (a batch needs nothing special here: the queue entry carries the accumulator slot)
         const dim3 grid((ceil_div(p.capacity, kTraceBlock * cam.stream_run) + kShadowBuckets + 511u) & ~511u);
         // the two orders' launches follow each other on the stream (no rays of the other kind: the blocks return at once)
         if (count) {
@@ -1347,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src4
 }
 // Issue-rate probe (rfw_hip_issue_probe): streams of vector instructions, 8 wavefronts per SIMD on every CU.
 //   MIX 0 = v_fma_f32 alone (the instruction the guide's FP32 peak is quoted on): 32 per trip;
-//   MIX 1 = one child of the PER-LANE node test of traverse_body.inc, instruction for instruction, twice per trip: 6 byte -> float
+//   MIX 1 = one child of the PER-LANE node test of traverse_node.inc, instruction for instruction, twice per trip: 6 byte -> float
 //           conversions, 3 packed FMAs, max3, min3, min, two compares = 14, i.e. 28 per trip (round 4 counted 32: ADVICE r04);
 //   MIX 2 = one node step of the PACKET kernel (traverse_packet.h, slab4 + pushes): per child 6 v_fma_f32 with the plane as a scalar
 //           operand, v_max3, v_min3, v_min, v_max and ONE v_cmp into a scalar register pair = 11, four children = 44 vector instructions per

@@ -2,6 +2,7 @@
 // bottom-up box fit (agent-scope release/acquire hand-off between the two children of a node) -> every even-depth
 // internal node becomes one 4-wide Node4 whose children are its grandchildren.  One primitive per leaf.
 #include "lbvh.h"
+#include "env_switches.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -485,10 +486,6 @@ hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* work
     const Layout L = make_layout(n, cub_temp_bytes(n));
     if (L.total > workspace_bytes) return hipErrorInvalidValue;
     char* w = static_cast<char*>(workspace);
-    {   // test hook: nothing may depend on what the workspace held before
-        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
-        if (poison) (void)hipMemsetAsync(workspace, 0xCD, L.total, s);
-    }
     uint32_t* bounds = (uint32_t*)(w + L.bounds);
     uint32_t* keys_in = (uint32_t*)(w + L.keys_in);
     uint32_t* keys_out = (uint32_t*)(w + L.keys_out);
@@ -511,7 +508,7 @@ hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* work
     e = hipMemsetAsync(flags, 0, (size_t)n * 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks(n - 1)), dim3(kBlock), 0, s, keys_out, n, left, right, parent);
-    static const bool fenced = getenv("RFW_LBVH_FENCED") != nullptr && atoi(getenv("RFW_LBVH_FENCED")) != 0;
+    const bool fenced = env_switches().lbvh_fenced;
     if (fenced) hipLaunchKernelGGL(k_fit<true>, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
     else hipLaunchKernelGGL(k_fit<false>, dim3(blocks(n)), dim3(kBlock), 0, s, boxes, order_out, n, left, right, parent, flags, nbox);
     hipLaunchKernelGGL(k_flag_even_depth, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n - 1, parent, flag4);

@@ -23,6 +23,7 @@
 // The order of primitives inside a leaf depends on atomics and is not reproducible run to run; ray results do not depend on
 // the tree (padded boxes, exact-tie rule), so images are still bit-identical to the oracle.
 #include "sah_build.h"
+#include "env_switches.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -1309,10 +1310,6 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     if (L.total > workspace_bytes) return hipErrorInvalidValue;
     max_leaf = max_leaf < 1 ? 1 : (max_leaf > kMaxLeafTris ? kMaxLeafTris : max_leaf);
     char* w = static_cast<char*>(workspace);
-    {   // test hook: nothing may depend on what the workspace held before (tests/test_gpu_builders.py poisons it)
-        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
-        if (poison) (void)hipMemsetAsync(workspace, 0xCD, L.total, s);
-    }
     Counters* ctr = (Counters*)(w + L.ctr);
     SNode* nodes = (SNode*)(w + L.nodes);
     uint32_t* order[2] = {(uint32_t*)(w + L.order[0]), (uint32_t*)(w + L.order[1])};
@@ -1341,7 +1338,7 @@ hipError_t sah_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* works
     const uint32_t bin_groups = blocks(n); // workgroups of k_bin
     auto level_replicas = [&](int l) { return std::max(1u, std::min(32u, bin_groups / (8u * level_ub(l)))); };
     hipLaunchKernelGGL(k_root_node, dim3(1), dim3(64), 0, s, n, ctr, nodes, active[0], small, bin_slot, stamp, bins[0], level_replicas(0), small_cap);
-    static const bool dbg = getenv("RFW_SAH_DEBUG") != nullptr;
+    const bool dbg = env_switches().build_trace;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto msf = [](auto a, auto b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
     if (dbg) (void)hipStreamSynchronize(s);
@@ -1416,10 +1413,6 @@ hipError_t sah_build_forest(hipStream_t s, const DevBox* boxes, uint32_t n, cons
     if (sah_forest_workspace_bytes(n, n_trees) > workspace_bytes) return hipErrorInvalidValue;
     max_leaf = max_leaf < 1 ? 1 : (max_leaf > kMaxLeafTris ? kMaxLeafTris : max_leaf);
     char* w = static_cast<char*>(workspace);
-    {
-        static const bool poison = getenv("RFW_POISON_WORKSPACE") != nullptr;
-        if (poison) (void)hipMemsetAsync(workspace, 0xCD, sah_forest_workspace_bytes(n, n_trees), s);
-    }
     Counters* ctr = (Counters*)(w + L.ctr);
     SNode* nodes = (SNode*)(w + L.nodes);
     uint32_t* order[2] = {(uint32_t*)(w + L.order[0]), (uint32_t*)(w + L.order[1])};

@@ -15,71 +15,26 @@
 #include "device_math.h"
 #include "device_types.h"
 
-#ifndef RFW_ANY_PARK
-#define RFW_ANY_PARK 1 // any hit parks its ray too, over a 12-row stack (measured: no spills at 8 waves per SIMD, +0.6 %)
-#endif
-#ifndef RFW_POP_DS_READ
-#define RFW_POP_DS_READ 1 // bit 0: any hit, bit 1: closest hit — pops read LDS with ds_read_b32 instead of the flat load the compiler merges the two stack homes into
-#endif
-
-#ifndef RFW_SCALAR_NODES
-#define RFW_SCALAR_NODES 0
-#endif
-// Round 4: a lane reads the copy of the tree made for ITS ray's octant (device_types.h, make_octant_node): the planes it enters and leaves a
-// box through are in fixed words (no per-plane selects), and the children are stored front to back along the octant's diagonal, so the hit
-// ones go on the stack in the stored order — no keys, no sorting network (tools/probes/packet_model.cpp: 20.5 instead of 20.4 node visits
-// per camera ray with the static order).  0 = round 3's visit: plain nodes, children ordered by entry distance.
-#ifndef RFW_ANY_LEAF_GATE
-#define RFW_ANY_LEAF_GATE 1 // any hit: a lane that holds a leaf waits for the next even trip of the loop, which batches the triangle tests (round 1; re-measured with the static order: see EXPERIMENTS.md)
-#endif
-#ifndef RFW_ANY_LEAF_PERIOD
-#define RFW_ANY_LEAF_PERIOD 2 // ... every how many trips the waiting leaves are tested (round 5, nested loop: 3 -> k_shadow 0.278 -> 0.285 ms, 4 -> 0.295; flat loop: 1 -> frame -2 %, 3 -> +0.4 % = noise; waiting for 8 / 16 / 24 lanes at leaves instead, as the streaming kernels do: 0.329 / 0.367 / 0.408)
-#endif
-#ifndef RFW_STATIC_ORDER
-#define RFW_STATIC_ORDER 1
-#endif
-#ifndef RFW_SLAB_ONE_COMPARE
-#define RFW_SLAB_ONE_COMPARE 1 // min(tf, t) >= max(tn, 0) instead of two compares and a scalar AND per child (degenerate directions are turned away at the entry)
-#endif
-
-#ifndef RFW_IDENTITY_FAST
-#define RFW_IDENTITY_FAST 1 // an instance whose inverse matrix is exactly the identity is entered without the matrix product (traverse_body.inc)
-#endif
-// Shape of the traversal loop (traverse_body.inc), per flavour: 0 = the nested form of rounds 1-4 (if / else-if / else with `continue`, an instance
-// entered in the TLAS-leaf branch and left in front of the pop, an occluded ray returns from inside the packet loop); 1 = ONE block where the
-// ray changes space and one way out of the loop; 2 = flat: no else-branches, no continue, no divergent exit, all state in `cur`.  Measured per kind
-// (EXPERIMENTS.md, round 5): any hit and both streaming kinds flat; the plain closest-hit loop (camera rays one per lane: scenes beyond the packets'
-// range, latency-bound in HBM; extension rays when nothing streams) as in round 4 — both other shapes cost it 15-20 % there
-#ifndef RFW_MODE_ANY
-#define RFW_MODE_ANY 2
-#endif
-#ifndef RFW_MODE_CLOSEST
-#define RFW_MODE_CLOSEST 0
-#endif
-#ifndef RFW_MODE_STREAM_ANY
-#define RFW_MODE_STREAM_ANY 2
-#endif
-#ifndef RFW_MODE_STREAM_CLOSEST
-#define RFW_MODE_STREAM_CLOSEST 2
-#endif
-#ifndef RFW_TRI_BRANCHFREE
-#define RFW_TRI_BRANCHFREE 1 // the leaf triangle test without its early outs (traverse_body.inc; round 5: k_extend 1.30 -> 1.195 ms per frame, path traced +4.6 %, the headline unchanged)
-#endif
-#ifndef RFW_SPILL_COLUMN_LAZY
-#define RFW_SPILL_COLUMN_LAZY 1 // any hit (64 registers at 8 waves per SIMD): the HBM spill column's address is formed where it is used (0: hoisted out of the loop — a register pair that went to scratch)
-#endif
-#ifndef RFW_RAY_IN_LDS
-#define RFW_RAY_IN_LDS 1 // closest hit parks the world-space ray in LDS (measured: no spills at 6 waves per SIMD, +0.9 %)
-#endif
+// What ships (every alternative measured in rounds 1-5 is a row of EXPERIMENTS.md and a patch under experiments/traversal_variants/):
+//   * a lane reads the copy of the tree made for ITS ray's octant (device_types.h, make_octant_node): the planes it enters and leaves a box
+//     through are in fixed words (no per-plane selects), the children are stored front to back along the octant's diagonal, so the hit ones
+//     go on the stack in the stored order — no keys, no sorting network;
+//   * the slab test is ONE compare per child, min(tf, t) >= max(tn, 0) (degenerate directions are turned away at the entry);
+//   * the leaf's triangle test has no early outs (traverse_leaf.inc);
+//   * an instance whose inverse matrix is exactly the identity is entered without the matrix product;
+//   * the world-space ray is parked in LDS above the lane's stack column (6 words) and fetched back when an instance is entered or left;
+//   * pops of the any-hit loop read LDS with ds_read_b32 (the closest-hit loop keeps the flat load the compiler merges the two stack homes into);
+//   * the loop's SHAPE per kind of ray: any hit and both streaming kinds FLAT (traverse_flat.inc), the plain closest hit NESTED (traverse_nested.inc).
 namespace rfwhip {
 
 constexpr int kTraceBlock = 64;   // threads per workgroup of the trace kernels (one wavefront)
 constexpr int kStackLds = 16;     // stack entries per lane kept in LDS
-#ifndef RFW_STACK_LDS_ANY
-#define RFW_STACK_LDS_ANY 12
-#endif
-constexpr int kStackLdsAny = RFW_STACK_LDS_ANY;  // the same for any hit when its ray is parked in LDS too (RFW_ANY_PARK): 18 rows = 4.5 KB per wavefront
+constexpr int kStackLdsAny = 12;   // the same for any hit (its ray is parked in LDS too: 18 rows = 4.5 KB per wavefront; measured: no spills at 8 waves per SIMD)
 constexpr int kStackSpill = 48;   // further entries per lane in HBM (rarely touched)
+// any hit: a lane that holds a leaf waits for the next even trip of the loop, which batches the triangle tests (round 1; periods 1 / 3 / 4 and
+// waiting for 8 / 16 / 24 lanes at leaves were measured in round 5: EXPERIMENTS.md)
+constexpr uint32_t kAnyLeafPeriod = 2;
+constexpr int kTraceLdsRows = kStackLds + 6, kTraceLdsRowsAny = kStackLdsAny + 6; // LDS words per lane of a closest-hit / an any-hit trace kernel: stack + parked ray
 
 struct SceneView {
     const Node4Q* tlas_nodes;
@@ -87,7 +42,7 @@ struct SceneView {
     const InstanceXform* instances;
     const Node4Q* blas_nodes;
     // the per-octant copies of both trees (make_octant_node: entry / exit planes picked, children front to back), copy `oct` of node i at
-    // [oct * stride + i]: what the traversal below reads (RFW_STATIC_ORDER)
+    // [oct * stride + i]: what the traversal below reads
     const Node4Q* tlas_oct;
     const Node4Q* blas_oct;
     uint32_t tlas_oct_stride, blas_oct_stride;
@@ -111,12 +66,8 @@ RFW_DI uint32_t octant_bits(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (i
 // node array of a space for a ray with reciprocal direction `inv`: the TLAS, or the BLAS region `node_base` of an instance
 RFW_DI const Node4Q* space_nodes(const SceneView& sc, const bool blas, const uint32_t node_base, const f3 inv)
 {
-#if RFW_STATIC_ORDER
     const uint32_t oct = octant_bits(inv);
     return blas ? sc.blas_oct + (size_t)oct * sc.blas_oct_stride + node_base : sc.tlas_oct + (size_t)oct * sc.tlas_oct_stride;
-#else
-    return blas ? sc.blas_nodes + node_base : sc.tlas_nodes;
-#endif
 }
 
 struct TravCounters {
@@ -136,36 +87,26 @@ template <bool ANY_HIT, bool COUNT, bool FAR_FIRST = false>
 RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_min, float& t, float& hu, float& hv, int32_t& hit_inst,
                      int32_t& hit_tri, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_base, TravCounters& tc)
 {
-    constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds; // LDS stack rows of this kernel flavour
-    constexpr bool kPark = RFW_RAY_IN_LDS && (!ANY_HIT || RFW_ANY_PARK);
+    constexpr int kStack = ANY_HIT ? kStackLdsAny : kStackLds; // LDS stack rows of this kernel flavour
     f3 o = O, d = D;
-#if RFW_RAY_IN_LDS
-    // closest hit: the world-space ray is parked in LDS (6 words above the lane's stack column) and fetched back when an instance is
-    // entered or left, so it does not occupy six registers through the whole loop (the closest-hit kernels spill at 6 waves per SIMD)
-    if (kPark) {
+    // the world-space ray is parked in LDS (6 words above the lane's stack column) and fetched back when an instance is entered or left, so
+    // it does not occupy six registers through the whole loop (the closest-hit kernels spill at 6 waves per SIMD, the any-hit ones at 8)
+    {
         uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         park[0] = fbits(O.x); park[kTraceBlock] = fbits(O.y); park[2 * kTraceBlock] = fbits(O.z);
         park[3 * kTraceBlock] = fbits(D.x); park[4 * kTraceBlock] = fbits(D.y); park[5 * kTraceBlock] = fbits(D.z);
     }
     auto world_o = [&]() -> f3 {
-        if (!kPark) return O;
         const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[0]), bitsf(park[kTraceBlock]), bitsf(park[2 * kTraceBlock]));
     };
     auto world_d = [&]() -> f3 {
-        if (!kPark) return D;
         const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[3 * kTraceBlock]), bitsf(park[4 * kTraceBlock]), bitsf(park[5 * kTraceBlock]));
     };
-#else
-    auto world_o = [&]() -> f3 { return O; };
-    auto world_d = [&]() -> f3 { return D; };
-#endif
-#if RFW_SLAB_ONE_COMPARE
     // the single compare of the slab test takes max(tn, 0), and min / max IGNORE NaNs: a direction of exact zeros (or with a NaN) would enter
     // every box.  Such a ray hits nothing
     if (!((D.x == D.x) && (D.y == D.y) && (D.z == D.z) && (D.x != 0.0f || D.y != 0.0f || D.z != 0.0f))) return false;
-#endif
     f3 inv = slab_inv(d);
     int sp = 0;
     int blas_sp = -1;          // stack height at BLAS entry; -1 = currently in the TLAS
@@ -177,13 +118,13 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
     // pops of the any-hit kernel read LDS with ds_read_b32 (measured +0.7 % frame rate); the closest-hit kernels keep the flat load the
     // compiler builds, because every other formulation of their pop tried (ds_read, top of stack in a register) changed their loop nest
     // for the worse (k_primary 0.335 -> 0.39 ms)
-    constexpr bool kDsPop = ((RFW_POP_DS_READ >> (ANY_HIT ? 0 : 1)) & 1) != 0;
+    constexpr bool kDsPop = ANY_HIT;
     // A lane's column of the HBM spill rows = spill_base (wave-uniform: lane 0's column) + its lane.  Formed where it is used, behind a
     // barrier the optimiser cannot look through: hoisted out of the loop the 64-bit address of the column is a register pair that lives
     // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
     auto spill_slot = [&]() -> uint32_t {
         uint32_t l = lane_slot;
-        if (RFW_SPILL_COLUMN_LAZY && ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
+        if (ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
         return spill_base + l;
     };
     auto push = [&](uint32_t v) {
@@ -215,59 +156,28 @@ RFW_DI bool traverse(const SceneView& sc, const f3 O, const f3 D, const float t_
         return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
     };
 
-#define RFW_TRAV_TOP
-#define RFW_TRAV_LEAF_GATE if (RFW_ANY_LEAF_GATE && ANY_HIT && (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) != 0u) continue;
-#define RFW_TRAV_EXHAUSTED break;
-#define RFW_TRAV_TLAS_GATE
-    // (the body is included once per kind of ray so that each can have the loop shape that measured best for it: RFW_MODE_*)
+    // (the loop is included once per kind of ray so that each has the shape that measured best for it)
     if constexpr (ANY_HIT) {
-#define RFW_TRAV_MODE RFW_MODE_ANY
-#if RFW_TRAV_MODE == 2
+#define RFW_TRAV_TOP
 #define RFW_TRAV_OCCLUDED occ_ = 1u; next_ = kDoneRef; break;
-#define RFW_TRAV_AFTER_LEAF
 #define RFW_TRAV_FLAT_WHILE __ballot(cur != kDoneRef) != 0ull
-#define RFW_TRAV_LEAF_TRIP (!RFW_ANY_LEAF_GATE || (iteration % (uint32_t)RFW_ANY_LEAF_PERIOD) == 0u)
+#define RFW_TRAV_LEAF_TRIP ((iteration % kAnyLeafPeriod) == 0u)
 #define RFW_TRAV_TLAS_TRIP true
-#include "traverse_body.inc"
+#include "traverse_flat.inc"
+#undef RFW_TRAV_TOP
+#undef RFW_TRAV_OCCLUDED
 #undef RFW_TRAV_FLAT_WHILE
 #undef RFW_TRAV_LEAF_TRIP
 #undef RFW_TRAV_TLAS_TRIP
         return occ_ != 0u;
-#elif RFW_TRAV_MODE == 1
-        bool occluded = false;
-#define RFW_TRAV_OCCLUDED occluded = true; break;
-#define RFW_TRAV_AFTER_LEAF if (occluded) break;
-#include "traverse_body.inc"
-        return occluded;
-#else
-#define RFW_TRAV_OCCLUDED return true;
-#define RFW_TRAV_AFTER_LEAF
-#include "traverse_body.inc"
-        return false;
-#endif
-#undef RFW_TRAV_OCCLUDED
-#undef RFW_TRAV_AFTER_LEAF
-#undef RFW_TRAV_MODE
     } else {
-#define RFW_TRAV_MODE RFW_MODE_CLOSEST
 #define RFW_TRAV_OCCLUDED
-#define RFW_TRAV_AFTER_LEAF
-#define RFW_TRAV_FLAT_WHILE __ballot(cur != kDoneRef) != 0ull
-#define RFW_TRAV_LEAF_TRIP true
-#define RFW_TRAV_TLAS_TRIP true
-#include "traverse_body.inc"
-#undef RFW_TRAV_FLAT_WHILE
-#undef RFW_TRAV_LEAF_TRIP
-#undef RFW_TRAV_TLAS_TRIP
+#define RFW_TRAV_EXHAUSTED break;
+#include "traverse_nested.inc"
 #undef RFW_TRAV_OCCLUDED
-#undef RFW_TRAV_AFTER_LEAF
-#undef RFW_TRAV_MODE
+#undef RFW_TRAV_EXHAUSTED
         return false;
     }
-#undef RFW_TRAV_TOP
-#undef RFW_TRAV_EXHAUSTED
-#undef RFW_TRAV_LEAF_GATE
-#undef RFW_TRAV_TLAS_GATE
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -284,19 +194,16 @@ template <bool ANY_HIT, bool COUNT, bool FAR_FIRST, class Stream>
 RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refill, const uint32_t leaf_gate, uint32_t* lds_stack, const uint32_t lane_slot, const uint32_t spill_base,
                             TravCounters& tc)
 {
-    constexpr int kStack = (ANY_HIT && RFW_ANY_PARK) ? kStackLdsAny : kStackLds;
-    constexpr bool kPark = RFW_RAY_IN_LDS && (!ANY_HIT || RFW_ANY_PARK);
-    f3 O = mk3(0.0f), D = mk3(0.0f), o = O, d = D;
+    constexpr int kStack = ANY_HIT ? kStackLdsAny : kStackLds;
+    f3 o = mk3(0.0f), d = o;
     const float t_min = Stream::kTMin; // (the same for every ray of a queue: not a register per lane)
     float t = 0.0f, hu = 0.0f, hv = 0.0f;
     int32_t hit_inst = -1, hit_tri = -1;
     auto world_o = [&]() -> f3 {
-        if (!kPark) return O;
         const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[0]), bitsf(park[kTraceBlock]), bitsf(park[2 * kTraceBlock]));
     };
     auto world_d = [&]() -> f3 {
-        if (!kPark) return D;
         const uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;
         return mk3(bitsf(park[3 * kTraceBlock]), bitsf(park[4 * kTraceBlock]), bitsf(park[5 * kTraceBlock]));
     };
@@ -305,15 +212,15 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
     int blas_sp = -1;
     int32_t cur_inst = -1;
     uint32_t tri_base = 0;
-    uint32_t cur = 0;
+    uint32_t cur = 0xfffffffdu; // kIdleRef (traverse_flat.inc): the lane holds no ray yet
     const Node4Q* nodes = sc.tlas_nodes; // (set with every ray a lane takes)
-    constexpr bool kDsPop = ((RFW_POP_DS_READ >> (ANY_HIT ? 0 : 1)) & 1) != 0;
+    constexpr bool kDsPop = ANY_HIT;
     // A lane's column of the HBM spill rows = spill_base (wave-uniform: lane 0's column) + its lane.  Formed where it is used, behind a
     // barrier the optimiser cannot look through: hoisted out of the loop the 64-bit address of the column is a register pair that lives
     // through the whole traversal — at 8 waves per SIMD it went to scratch memory — for a path almost no ray takes.
     auto spill_slot = [&]() -> uint32_t {
         uint32_t l = lane_slot;
-        if (RFW_SPILL_COLUMN_LAZY && ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
+        if (ANY_HIT) asm volatile("" : "+v"(l)); // (closest hit has the registers: hoisted it is 4 ... 12 % faster, measured)
         return spill_base + l;
     };
     auto push = [&](uint32_t v) {
@@ -338,53 +245,14 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
         if (sp < kStack) return lds_stack[sp * kTraceBlock + lane_slot];
         return sc.spill[(size_t)(sp - kStack) * sc.spill_stride + spill_slot()];
     };
-    bool have = false, pending = false, occluded = false;
     const uint64_t everyone = __ballot(1);
     // Leaves wait for company: the packet loop (and the entry into an instance) costs a wavefront the same with 3 active lanes as with 40, and
     // with refilled lanes at every depth some lane holds a leaf in almost every trip.  A lane at a leaf sits out until `leaf_gate` lanes
     // are, or until no lane has a node to test.
     bool do_leaves = true;
-#define RFW_STREAM_TOP_NESTED                                                                                                         \
-    {                                                                                                                                 \
-        /* `iteration` counts every trip of the WAVEFRONT here (idle lanes included): the loop provably ends, which also keeps the */ \
-        /* compiler from reasoning about a lane that spins without side effects; a run that does not end raises the overflow flag */  \
-        if (iteration > (1u << 20)) { *sc.overflow_flag = 1u; break; }                                                                \
-        const uint64_t idle = __ballot(!have);                                                                                        \
-        if (idle != 0ull) {                                                                                                           \
-            const bool more = st.more();                                                                                              \
-            if (!more && idle == everyone) break;                                                                                     \
-            if (more && (uint32_t)__popcll(idle) >= refill) {                                                                         \
-                if (!have) {                                                                                                          \
-                    if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);                                                   \
-                    pending = false;                                                                                                  \
-                    have = st.fetch(idle, o, d, t);                                                                            \
-                    if (have) {                                                                                                       \
-                        /* the fetched ray lands in the traversal's own registers and is parked at once: a second copy of it (O, D) waiting */ \
-                        /* for the park went to scratch memory at 8 waves per SIMD */                                                  \
-                        if (kPark) {                                                                                                  \
-                            uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;                                            \
-                            park[0] = fbits(o.x); park[kTraceBlock] = fbits(o.y); park[2 * kTraceBlock] = fbits(o.z);                 \
-                            park[3 * kTraceBlock] = fbits(d.x); park[4 * kTraceBlock] = fbits(d.y); park[5 * kTraceBlock] = fbits(d.z); \
-                        } else { O = o; D = d; }                                                                                      \
-                        inv = slab_inv(d);                                                                                            \
-                        sp = 0; blas_sp = -1; cur_inst = -1; tri_base = 0; cur = 0; nodes = space_nodes(sc, false, 0u, inv);          \
-                        hu = 0.0f; hv = 0.0f; hit_inst = -1; hit_tri = -1; occluded = false;                                          \
-                        /* a degenerate direction hits nothing (see traverse()): finished before it starts */                          \
-                        if (RFW_SLAB_ONE_COMPARE && !((d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f))) { have = false; pending = true; } \
-                    }                                                                                                                 \
-                }                                                                                                                     \
-                st.advance(idle);                                                                                                     \
-            }                                                                                                                         \
-        }                                                                                                                             \
-        {                                                                                                                             \
-            const uint64_t busy = __ballot(have), at_leaf = __ballot(have && (cur & kLeafBit) != 0u);                                  \
-            do_leaves = at_leaf == busy || (uint32_t)__popcll(at_leaf) >= leaf_gate;                                                  \
-        }                                                                                                                             \
-        if (!have) continue;                                                                                                          \
-    }
-// The same supply of rays for the FLAT loop (RFW_MODE_STREAM_* = 2, traverse_body.inc): a lane's state is `cur` alone — kIdleRef: no ray,
-// kDoneRef: a finished ray waiting to be committed, anything else: at work — so `have`, `pending` and `occluded` are no flags that live
-// across the loop's branches (each an SGPR pair merged with three scalar instructions at every join)
+// The supply of rays at the top of every trip of the flat loop (traverse_flat.inc): a lane's state is `cur` alone — kIdleRef: no ray,
+// kDoneRef: a finished ray waiting to be committed, anything else: at work — no flags that live across the loop's
+// branches (each would be an SGPR pair merged with three scalar instructions at every join)
 #define RFW_STREAM_TOP_FLAT                                                                                                           \
     if (iteration > (1u << 20)) { *sc.overflow_flag = 1u; break; }                                                                    \
     {                                                                                                                                 \
@@ -399,16 +267,16 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
                     const bool got_ = st.fetch(idle, o, d, t);                                                                        \
                     cur = kIdleRef;                                                                                                   \
                     if (got_) {                                                                                                       \
-                        if (kPark) {                                                                                                  \
+                        {   /* the fetched ray lands in the traversal's own registers and is parked at once */                         \
                             uint32_t* park = lds_stack + kStack * kTraceBlock + lane_slot;                                            \
                             park[0] = fbits(o.x); park[kTraceBlock] = fbits(o.y); park[2 * kTraceBlock] = fbits(o.z);                 \
                             park[3 * kTraceBlock] = fbits(d.x); park[4 * kTraceBlock] = fbits(d.y); park[5 * kTraceBlock] = fbits(d.z); \
-                        } else { O = o; D = d; }                                                                                      \
+                        }                                                                                                             \
                         inv = slab_inv(d);                                                                                            \
                         sp = 0; blas_sp = -1; cur_inst = -1; tri_base = 0; nodes = space_nodes(sc, false, 0u, inv);                   \
                         hu = 0.0f; hv = 0.0f; hit_inst = -1; hit_tri = -1; occ_ = 0u;                                                 \
                         /* a degenerate direction hits nothing (see traverse()): finished before it starts */                          \
-                        const bool fine_ = !RFW_SLAB_ONE_COMPARE || ((d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f)); \
+                        const bool fine_ = ((d.x == d.x) && (d.y == d.y) && (d.z == d.z) && (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f)); \
                         cur = fine_ ? 0u : kDoneRef;                                                                                  \
                     }                                                                                                                 \
                 }                                                                                                                     \
@@ -421,69 +289,26 @@ RFW_DI void traverse_stream(const SceneView& sc, Stream& st, const uint32_t refi
         const uint64_t busy = __ballot(have_), at_leaf = __ballot(have_ & ((int32_t)cur < -3));                                       \
         do_leaves = at_leaf == busy || (uint32_t)__popcll(at_leaf) >= leaf_gate;                                                      \
     }
-#define RFW_TRAV_EXHAUSTED have = false; pending = true; continue;
+#define RFW_TRAV_TOP RFW_STREAM_TOP_FLAT
+#define RFW_TRAV_FLAT_WHILE true
+#define RFW_TRAV_LEAF_TRIP do_leaves
+#define RFW_TRAV_TLAS_TRIP do_leaves
     if constexpr (ANY_HIT) {
-#define RFW_TRAV_MODE RFW_MODE_STREAM_ANY
-#if RFW_TRAV_MODE == 2
-        cur = 0xfffffffdu; // kIdleRef
-#define RFW_TRAV_TOP RFW_STREAM_TOP_FLAT
 #define RFW_TRAV_OCCLUDED occ_ = 1u; next_ = kDoneRef; break;
-#define RFW_TRAV_AFTER_LEAF
-#define RFW_TRAV_FLAT_WHILE true
-#define RFW_TRAV_LEAF_TRIP do_leaves
-#define RFW_TRAV_TLAS_TRIP do_leaves
-#include "traverse_body.inc"
+#include "traverse_flat.inc"
+#undef RFW_TRAV_OCCLUDED
         if (cur == kDoneRef) st.commit(occ_ != 0u, t, hu, hv, hit_inst, hit_tri);
-#undef RFW_TRAV_FLAT_WHILE
-#undef RFW_TRAV_LEAF_TRIP
-#undef RFW_TRAV_TLAS_TRIP
-#else
-#define RFW_TRAV_TOP RFW_STREAM_TOP_NESTED
-#define RFW_TRAV_LEAF_GATE if (!do_leaves) continue;
-#define RFW_TRAV_TLAS_GATE if (!do_leaves) continue;
-#define RFW_TRAV_OCCLUDED occluded = true; break;
-#define RFW_TRAV_AFTER_LEAF if (occluded) { have = false; pending = true; continue; }
-#include "traverse_body.inc"
-        if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);
-#undef RFW_TRAV_LEAF_GATE
-#undef RFW_TRAV_TLAS_GATE
-#endif
-#undef RFW_TRAV_TOP
-#undef RFW_TRAV_OCCLUDED
-#undef RFW_TRAV_AFTER_LEAF
-#undef RFW_TRAV_MODE
     } else {
-#define RFW_TRAV_MODE RFW_MODE_STREAM_CLOSEST
-#if RFW_TRAV_MODE == 2
-        cur = 0xfffffffdu; // kIdleRef
-#define RFW_TRAV_TOP RFW_STREAM_TOP_FLAT
 #define RFW_TRAV_OCCLUDED
-#define RFW_TRAV_AFTER_LEAF
-#define RFW_TRAV_FLAT_WHILE true
-#define RFW_TRAV_LEAF_TRIP do_leaves
-#define RFW_TRAV_TLAS_TRIP do_leaves
-#include "traverse_body.inc"
+#include "traverse_flat.inc"
+#undef RFW_TRAV_OCCLUDED
         if (cur == kDoneRef) st.commit(false, t, hu, hv, hit_inst, hit_tri);
+    }
+#undef RFW_TRAV_TOP
 #undef RFW_TRAV_FLAT_WHILE
 #undef RFW_TRAV_LEAF_TRIP
 #undef RFW_TRAV_TLAS_TRIP
-#else
-#define RFW_TRAV_TOP RFW_STREAM_TOP_NESTED
-#define RFW_TRAV_LEAF_GATE if (!do_leaves) continue;
-#define RFW_TRAV_TLAS_GATE if (!do_leaves) continue;
-#define RFW_TRAV_OCCLUDED
-#define RFW_TRAV_AFTER_LEAF
-#include "traverse_body.inc"
-        if (pending) st.commit(occluded, t, hu, hv, hit_inst, hit_tri);
-#undef RFW_TRAV_LEAF_GATE
-#undef RFW_TRAV_TLAS_GATE
-#endif
-#undef RFW_TRAV_TOP
-#undef RFW_TRAV_OCCLUDED
-#undef RFW_TRAV_AFTER_LEAF
-#undef RFW_TRAV_MODE
-    }
-#undef RFW_TRAV_EXHAUSTED
+#undef RFW_STREAM_TOP_FLAT
 }
 
 } // namespace rfwhip

@@ -68,16 +68,7 @@ RFW_DI uint32_t octant_of(const f3 inv) { return (inv.x < 0.0f ? 1u : 0u) | (inv
 // lanes that are not part of the packet from the votes.  An empty slot holds the box (+inf, -inf): its entry distance is +inf for every
 // ray, so it needs no test of its own.
 // a: nx[4] ny[4] nz[4] fx[4]   b: fy[4] fz[4] child[4] pad[4]  (the 128-B node, in scalar registers)
-// m[i] = lanes whose ray enters child i before t (6 fma + max3 + min3 + min + 2 compares per child)
-#ifndef RFW_PACKET_DIRECT_NEAR
-#define RFW_PACKET_DIRECT_NEAR 1
-#endif
-#ifndef RFW_PACKET_ONE_COMPARE
-#define RFW_PACKET_ONE_COMPARE 1
-#endif
-#ifndef RFW_PACKET_NAN_MASK
-#define RFW_PACKET_NAN_MASK 1 // closest hit: the lanes outside the packet carry a NaN ray (they fail every compare) instead of being masked out of every vote
-#endif
+// m[i] = lanes whose ray enters child i before t (6 fma + max3 + max + min3 + min + 1 compare per child)
 template <bool MASK> RFW_DI void slab4(const su16 a, const su16 b, const SlabRay& r, const float t, const uint64_t packet, uint64_t (&m)[4])
 {
 #pragma unroll
@@ -87,12 +78,8 @@ template <bool MASK> RFW_DI void slab4(const su16 a, const su16 b, const SlabRay
                                          __builtin_fmaf(bitsf(a[8 + i]), r.inv.z, r.bn.z));
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bitsf(a[12 + i]), r.inv.x, r.bf.x), __builtin_fmaf(bitsf(b[i]), r.inv.y, r.bf.y)),
                                          __builtin_fmaf(bitsf(b[4 + i]), r.inv.z, r.bf.z));
-#if RFW_PACKET_ONE_COMPARE
         // min(tf, t) >= max(tn, 0)  <=>  min(tf, t) >= tn  &&  tf >= 0  (t >= 0): one vector max instead of a compare and a scalar AND
         m[i] = ballot64(__builtin_fminf(tf, t) >= __builtin_fmaxf(tn, 0.0f));
-#else
-        m[i] = ballot64(__builtin_fminf(tf, t) >= tn) & ballot64(tf >= 0.0f);
-#endif
         if (MASK) m[i] &= packet;
     }
 }
@@ -141,7 +128,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                 const float4 r1 = make_float4(bitsf(xf[4]), bitsf(xf[5]), bitsf(xf[6]), bitsf(xf[7]));
                 const float4 r2 = make_float4(bitsf(xf[8]), bitsf(xf[9]), bitsf(xf[10]), bitsf(xf[11]));
                 // ray into object space with the inverse instance matrix; direction NOT renormalised (ray_gen.comp:340-341)
-                if (RFW_IDENTITY_FAST && (xf[14] & kInstanceIdentity)) { // (wave-uniform: traverse_body.inc)
+                if (xf[14] & kInstanceIdentity) { // (wave-uniform: traverse_flat.inc)
                     o = mk3(O.x + 0.0f, O.y + 0.0f, O.z + 0.0f);
                     d = mk3(D.x + 0.0f, D.y + 0.0f, D.z + 0.0f);
                 } else {
@@ -160,7 +147,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                 cur = 0u;
             }
             SlabRay r = slab_ray(o, d);
-            constexpr bool kNanMask = RFW_PACKET_NAN_MASK && !ANY_HIT; // (any hit: the packet shrinks inside the loop as rays find their occluders)
+            constexpr bool kNanMask = !ANY_HIT; // closest hit: the lanes outside the packet carry a ray that fails every compare instead of being masked out of every vote (any hit: the packet shrinks inside the loop as rays find their occluders)
             // a lane outside the packet leaves every box at -inf, before it could enter it: min(-inf, t) >= max(tn, 0) is false whatever tn is.
             // Its reciprocal direction is +-1 with the OCTANT's signs, so that the far plane of an EMPTY slot — -inf on an axis the octant
             // travels up, +inf on one it travels down — times it is -inf as well: with +1 throughout, (+inf) * 1 + (-inf) was a NaN, min / max
@@ -214,7 +201,6 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     // overwritten; the pushes themselves stay unconditional: as the else-branch of this test they made the compiler keep two
                     // copies of the stack register and move one into the other on every trip)
                     if (__builtin_expect(sp + 4u > kPacketStack, 0)) { *sc.overflow_flag = 1u; sp = kPacketStack - 4u; }
-#if RFW_PACKET_DIRECT_NEAR
                     // ... except the one that would come straight back: when the first child of the visiting order is hit it IS the next node
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
@@ -225,15 +211,6 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     constexpr int kFirst = (ANY_HIT && FAR_FIRST) ? 3 : 0;
                     if (m[kFirst] != 0ull) cur = c[kFirst];
                     else pop();
-#else
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int i = (ANY_HIT && FAR_FIRST) ? j : 3 - j;
-                        lane_write(stack, c[i], sp);
-                        asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, 0" : "+s"(sp) : "s"(m[i]) : "scc"); // sp += (m[i] != 0), on the scalar unit (the compiler converts the bool on the vector unit)
-                    }
-                    pop();
-#endif
                 }
                 if (cur == kInvalidRef) { // the space is exhausted
                     if (in_blas) leave = true;
@@ -249,8 +226,7 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                     for (uint32_t k = 0; k < count; k++) {
                         const su4 q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
                         const f3 v0 = mk3(bitsf(q0.x), bitsf(q0.y), bitsf(q0.z)), edge1 = mk3(bitsf(q1.x), bitsf(q1.y), bitsf(q1.z)), edge2 = mk3(bitsf(q2.x), bitsf(q2.y), bitsf(q2.z));
-#if RFW_TRI_BRANCHFREE
-                        // (without the early outs: traverse_body.inc)
+                        // (without the early outs: traverse_leaf.inc)
                         const f3 h = cross(d, edge2);
                         const float a = dot(edge1, h);
                         const float f = 1.0f / a;
@@ -272,32 +248,6 @@ RFW_DI void traverse_packet(const SceneView& sc, const PacketNode* __restrict__ 
                             hit_inst = take ? cur_inst : hit_inst;
                             hit_tri = take ? prim : hit_tri;
                         }
-#else
-                        const f3 h = cross(d, edge2);
-                        const float a = dot(edge1, h);
-                        if (a > -0.0001f && a < 0.0001f) continue;
-                        const float f = 1.0f / a;
-                        const f3 s = o - v0;
-                        const float u = f * dot(s, h);
-                        if (u < 0.0f || u > 1.0f) continue;
-                        const f3 q = cross(s, edge1);
-                        const float v = f * dot(d, q);
-                        if (v < 0.0f || (u + v) > 1.0f) continue;
-                        const float tt = f * dot(edge2, q);
-                        if (ANY_HIT) {
-                            if (tt > t_min && tt < t) occluded = true;
-                        } else {
-                            const int32_t prim = (int32_t)q0.w;
-                            const bool lower = (cur_inst < hit_inst) || (cur_inst == hit_inst && prim < hit_tri);
-                            if (tt > t_min && (tt < t || (tt == t && hit_inst >= 0 && lower))) {
-                                t = tt;
-                                hu = u * bitsf(q1.w);
-                                hv = v * bitsf(q1.w);
-                                hit_inst = cur_inst;
-                                hit_tri = prim;
-                            }
-                        }
-#endif
                     }
                 }
                 if (ANY_HIT) {

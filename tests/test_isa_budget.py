@@ -47,10 +47,11 @@ def test_trace_kernels_fit_their_occupancy(listing):
     _, _, ks = listing
     budget = {8: 64, 7: 72, 6: 85, 5: 102}  # VGPRs per lane at that many waves per SIMD (512 / waves, granule 8)
     src = open(os.path.join(ROOT, "rfw-rs_amd", "csrc", "kernels.hip")).read()
-    waves = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (RFW_\w*WAVES\w*) (\d+)", src)}
-    want = {"k_shadow<": waves["RFW_TRACE_WAVES_ANY"], "k_shadow_stream<": waves["RFW_STREAM_WAVES_ANY"], "k_shadow_packet<": waves["RFW_PACKET_WAVES"],
-            "k_primary_packet<": waves["RFW_PACKET_WAVES"], "k_primary<": waves["RFW_TRACE_WAVES"], "k_extend<": waves["RFW_TRACE_WAVES"],
-            "k_extend_stream<": waves["RFW_STREAM_WAVES"]}
+    decl = re.search(r"constexpr int (kTraceWaves = \d+(?:, k\w+Waves\w* = \d+)+);", src).group(1)  # the waves per SIMD each kind of kernel is compiled for
+    waves = {m.group(1): int(m.group(2)) for m in re.finditer(r"(k\w+) = (\d+)", decl)}
+    want = {"k_shadow<": waves["kTraceWavesAny"], "k_shadow_stream<": waves["kStreamWavesAny"], "k_shadow_packet<": waves["kPacketWaves"],
+            "k_primary_packet<": waves["kPacketWaves"], "k_primary<": waves["kTraceWaves"], "k_extend<": waves["kTraceWaves"],
+            "k_extend_stream<": waves["kStreamWaves"]}
     for name, k in ks.items():
         for prefix, w in want.items():
             if name.startswith(prefix):
@@ -58,20 +59,11 @@ def test_trace_kernels_fit_their_occupancy(listing):
 
 
 def test_flat_loops_keep_their_scalar_share(listing):
-    """Static scalar instruction counts of the kernels whose loops are flat (RFW_MODE_* = 2, traverse_body.inc), against bounds half way
+    """Static scalar instruction counts of the kernels whose loops are flat (traverse_flat.inc), against bounds half way
     between what the flat and the nested forms compile to (round 5, ROCm 7.2: k_shadow 803 / 923, k_shadow_stream 646 / 876,
     k_extend_stream 423 / 549).  A tripwire for the source and for the compiler, not a performance claim."""
     _, _, ks = listing
-    src = open(os.path.join(ROOT, "rfw-rs_amd", "csrc", "traverse.h")).read()
-    mode = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (RFW_MODE_\w+) (\d)", src)}
-    want = {}
-    if mode["RFW_MODE_ANY"] == 2:
-        want["k_shadow<false, false>"] = 865
-    if mode["RFW_MODE_STREAM_ANY"] == 2:
-        want["k_shadow_stream<false, false>"] = 760
-    if mode["RFW_MODE_STREAM_CLOSEST"] == 2:
-        want["k_extend_stream<false>"] = 485
-    assert want, mode
+    want = {"k_shadow<false, false>": 865, "k_shadow_stream<false, false>": 760, "k_extend_stream<false>": 485}
     for name, bound in want.items():
         assert name in ks, (name, sorted(ks)[:8])
         assert ks[name]["salu"] <= bound, (name, ks[name]["salu"], bound)
