@@ -170,6 +170,10 @@ def main():
                     help="copy every finished frame to (pinned) host memory inside the timed region (the PCIe-inclusive rate of DESIGN.md; never the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--mode-frames", type=int, default=48, help="frames per secondary mode")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="the headline run (atrium1m, max path length 1, one GPU) also runs BASELINE.json's other single-GPU configurations — C2, C3 and the "
+                         "path-traced C4 — as short child runs of this script, each with its own oracle check, and reports them in config.modes; this skips them")
+    ap.add_argument("--baseline-steps", type=int, default=120, help="timed frames of each of those child runs")
     args = ap.parse_args()
 
     # ---- who runs the ranks.  `--gpus N` is the number of ranks, whoever starts them:
@@ -277,7 +281,7 @@ def main():
             # each instance launches on its own HIP stream; torch wraps THAT stream (no second stream is created), so RCCL's
             # all-gather is ordered against the kernels
             st = torch.cuda.ExternalStream(be.stream_handle(), device=dev)
-            for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays", "stream_run", "stream_refill", "stream_leaf_gate", "shade_group"):  # A/B experiments: RFW_<OPTION>=value
+            for key in ("sah_max_leaf", "sah_trav_cost", "sort_extension_rays", "stream_run", "stream_refill", "stream_leaf_gate", "shade_group", "stage_chain", "tlas_fused"):  # A/B experiments: RFW_<OPTION>=value
                 if os.environ.get("RFW_" + key.upper()):
                     be.set_option(key, float(os.environ["RFW_" + key.upper()]))
             if world > 1 or args.emulate_shard:
@@ -716,12 +720,55 @@ def main():
                     res[name] = {"frame": int(vi) if name == "first" else args.steps - 1, "bit_identical": same, "rel_l2": rel}
                 res["all"] = all(v["bit_identical"] for v in res.values())
                 out["config"]["timed_frame_equals_oracle"] = res
+        if (single and not args.no_baseline_configs and not args.no_modes and args.workload == "atrium1m" and args.max_path_length == 1
+                and (w, h) == (1920, 1080) and not args.identical_frames and not args.readback):
+            for b in bes:   # (the children get the whole device)
+                b.close()
+            bes = []
+            out["config"]["modes"].update(baseline_configs(args))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     for b in bes:
         b.close()
+
+
+def baseline_configs(args):
+    """BASELINE.json's other single-GPU configurations, each as a short run of this script in a child process (started after this process is
+    done with the device; nothing is exec'ed): C2 (Sponza-class, 262 k triangles, primary + shadow), C3 (C2 + 10 000 animated instances, the
+    TLAS rebuilt every frame) and C4 as BASELINE.json words it (the 1 M-triangle scene path traced with NEE, max path length 3; 4 spp per call as
+    one of its modes).  Every child checks its own first and last timed frame against the oracle and times the oracle on its own workload."""
+    import subprocess
+    rows = {}
+    todo = (("BASELINE config 2 (Sponza-class 262 k triangles, primary+shadow, static BVH)", ["--workload", "atrium262k"], False),
+            ("BASELINE config 3 (config 2 + 10 000 animated instances, TLAS rebuilt every frame)", ["--workload", "spheres10k"], False),
+            ("BASELINE config 4 (~1 M triangles path traced with NEE, max path length 3)", ["--workload", "atrium1m", "--max-path-length", "3"], True))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for name, extra, with_modes in todo:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.baseline_steps), "--warmup", "20", "--no-baseline-configs",
+               "--cpu-seconds", "3", "--mode-frames", "32"] + extra + ([] if with_modes else ["--no-modes"]) + (["--procedural"] if args.procedural else [])
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                rows[name] = {"error": f"child exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
+                continue
+            d = json.loads(line[-1])
+        except Exception as e:  # a child that fails costs its row, not the headline
+            rows[name] = {"error": repr(e)[:300]}
+            continue
+        c = d["config"]
+        row = {"Mrays_per_s": d["value"], "ms_per_frame": d["ms_per_step"], "frames": d["steps"], "workload": c["workload"], "mode": c["mode"],
+               "rays_per_frame": c["rays_per_frame"], "timed_frame_equals_oracle": c.get("timed_frame_equals_oracle"),
+               "cpu_baseline_Mrays_per_s": (d.get("cpu_baseline") or {}).get("value"), "cpu_baseline_cores": (d.get("cpu_baseline") or {}).get("cores"),
+               "per_frame_synchronize_ms": c.get("per_frame_synchronize_ms"), "child_seconds": round(time.time() - t0, 1),
+               "command": "python3 bench.py " + " ".join(cmd[2:])}
+        if with_modes:
+            row["modes"] = {k: v["Mrays_per_s"] for k, v in c.get("modes", {}).items() if not v.get("is_value")}
+        rows[name] = row
+    return rows
 
 
 def latest_profile(pattern):

@@ -78,8 +78,8 @@ int alloc_paths(Instance* I)
     HIP_TRY(I, hipMemsetAsync(I->d_frame_out.ptr, 0, px * sizeof(float4), I->stream));
     // per-thread overflow slots: launch grids are padded (XCD tiling, shadow buckets), so leave a margin per sub-shard
     HIP_TRY(I, I->d_spill.ensure((size_t)kStackSpill * I->substreams * ((size_t)I->cap_v * I->max_batch + kSpillMargin)));
-    HIP_TRY(I, I->d_counters.ensure(kMaxSub));
-    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, kMaxSub * sizeof(QueueCounters), I->stream));
+    HIP_TRY(I, I->d_counters.ensure(2 * kMaxSub));
+    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, 2 * kMaxSub * sizeof(QueueCounters), I->stream));
     I->sample_count = 0;
     return RFW_HIP_OK;
 }
@@ -120,7 +120,8 @@ SceneDev scene_dev(Instance* I)
     s.spill_stride = spill_stride(I);
     s.spill_rows = std::min<uint32_t>(scene_of(I)->spill_rows, (uint32_t)kStackSpill);
     s.overflow_flag = I->overflow_dev;
-    s.counters = I->d_counters.ptr;
+    s.counters = I->d_counters.ptr + (size_t)I->counter_phase * kMaxSub; // (the latest frame's block)
+    s.counters_next = nullptr;
     return s;
 }
 
@@ -230,7 +231,8 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
     const uint32_t bounces = std::min<uint32_t>(I->max_path_length, kMaxBounces);
 
     if (tm) (void)hipEventRecord(I->events[EV_FRAME0], main);
-    HIP_TRY(I, hipMemsetAsync(I->d_counters.ptr, 0, S * sizeof(QueueCounters), main));
+    // queue counters: this frame takes the block the previous frame's k_primary cleared (alloc_paths cleared both), and clears the other
+    I->counter_phase ^= 1u;
     // The frame's tiles are dealt to S sub-shards, each with its own queues, counters and accumulator slab, each traced on its
     // own stream: the long tail of one sub-shard's trace kernel (the slowest wavefront bounds a launch) overlaps the other
     // sub-shards' kernels.  Fork from / join into the caller's stream with events.
@@ -243,7 +245,8 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
         st[s] = S > 1 ? I->sub[s] : main;
         if (S > 1) HIP_TRY(I, hipStreamWaitEvent(st[s], I->ev_fork, 0));
         sc[s] = scene_dev(I);
-        sc[s].counters = I->d_counters.ptr + s;
+        sc[s].counters = I->d_counters.ptr + (size_t)I->counter_phase * kMaxSub + s;
+        sc[s].counters_next = I->d_counters.ptr + (size_t)(I->counter_phase ^ 1u) * kMaxSub + s;
         sc[s].spill = I->d_spill.ptr + (size_t)s * (I->cap_v + kSpillMargin);
         p[s] = path_dev(I, s);
         cam[s] = camera_params(I, view, s);
@@ -268,10 +271,29 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
             v.p1[0] = views[f].p1.x; v.p1[1] = views[f].p1.y; v.p1[2] = views[f].p1.z; v.pad2 = 0.0f;
         }
     }
+    // option "stage_chain": this frame's kernel of kind `kind` (0 camera rays, 1 the camera paths' shadow rays) waits for the same kernel of the
+    // frame issued `lag` frames earlier, whatever slot that one runs on
+    Instance* const OW = scene_of(I);
+    auto chain_wait = [&](int kind, hipStream_t on) -> int {
+        const int lag = (OW->stage_chain >> (8 * kind)) & 0xff;
+        if (lag <= 0 || S > 1 || OW->slots.empty()) return RFW_HIP_OK;
+        if (OW->chain_index[kind] >= (uint64_t)lag && lag <= 16) HIP_TRY(I, hipStreamWaitEvent(on, OW->chain_ev[kind][(OW->chain_index[kind] - (uint64_t)lag) % 16], 0));
+        return RFW_HIP_OK;
+    };
+    auto chain_record = [&](int kind, hipStream_t on) -> int {
+        const int lag = (OW->stage_chain >> (8 * kind)) & 0xff;
+        if (lag <= 0 || S > 1 || OW->slots.empty()) return RFW_HIP_OK;
+        hipEvent_t& ev = OW->chain_ev[kind][OW->chain_index[kind] % 16];
+        if (!ev) HIP_TRY(I, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(I, hipEventRecord(ev, on));
+        OW->chain_index[kind]++;
+        return RFW_HIP_OK;
+    };
     for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back; stage by stage across the sub-shards
         for (uint32_t s = 0; s < S; s++) {
             hipEvent_t* ev = ring_events(I, slot, s);
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
+            if (b == 0) { const int cw = chain_wait(0, st[s]); if (cw) return cw; }
             if (b == 0 && k > 1) launch_primary_batch(st[s], cam[s], bv, sc[s], p[s], count);
             else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
             else {
@@ -294,6 +316,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
                 }
                 launch_extend(st[s], cam[s], sc[s], p[s], b, count, order);
             }
+            if (b == 0) { const int cr = chain_record(0, st[s]); if (cr) return cr; }
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 1)], st[s]);
         }
         for (uint32_t s = 0; s < S; s++) {
@@ -306,7 +329,9 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
             for (uint32_t s = 0; s < S; s++) {
                 hipEvent_t* ev = ring_events(I, slot, s);
                 if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 0)], st[s]);
+                if (b == 0) { const int cw = chain_wait(1, st[s]); if (cw) return cw; }
                 launch_shadow(st[s], cam[s], sc[s], p[s], b, count);
+                if (b == 0) { const int cr = chain_record(1, st[s]); if (cr) return cr; }
                 if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 1)], st[s]);
             }
     }
@@ -509,11 +534,14 @@ void rfw_hip_destroy(void* inst)
         if (I->tables_ready) (void)hipEventDestroy(I->tables_ready);
         if (I->upload_stream) (void)hipStreamDestroy(I->upload_stream);
         I->d_spill.release(); I->d_counters.release(); I->d_tex_data.release(); I->d_tex_desc.release(); I->d_blue_noise.release();
-        I->d_valid_gids.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
+        I->d_valid_gids.release(); I->d_stage_dev.release(); I->d_tlas_order.release(); I->d_node_count.release(); I->d_inst_boxes.release(); I->d_mesh_local.release();
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
+        for (auto& row : I->chain_ev)
+            for (hipEvent_t& ev : row)
+                if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         for (auto& ev : I->ev_build)
             if (ev) (void)hipEventDestroy(ev);
         if (I->records_stream) (void)hipStreamSynchronize(I->records_stream);
@@ -684,6 +712,8 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         if ((int)value != 0 && (int)value != 256 && (int)value != 512) return fail(I, RFW_HIP_E_INVALID, "set_option: shade_group is 0, 256 or 512");
         I->shade_group = (int)value;
     }
+    else if (k == "stage_chain") I->stage_chain = std::max(0, (int)value) & 0xffff; // (api_internal.h) lag of the camera-ray chain | lag of the shadow-ray chain << 8; 0 = off
+    else if (k == "tlas_fused") I->tlas_fused = value != 0.0; // 0: every instance update through the launch chain (lbvh_build) whatever the instance count
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)
         if (value < 0 || value > 2) return fail(I, RFW_HIP_E_INVALID, "set_option: gather_format is 0, 1 or 2");
@@ -890,7 +920,7 @@ int rfw_hip_get_frame_stats(void* inst, rfw_hip_frame_stats* out)
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
     QueueCounters qc[kMaxSub];
-    HIP_TRY(I, hipMemcpy(qc, I->d_counters.ptr, I->substreams * sizeof(QueueCounters), hipMemcpyDeviceToHost));
+    HIP_TRY(I, hipMemcpy(qc, I->d_counters.ptr + (size_t)I->counter_phase * kMaxSub, I->substreams * sizeof(QueueCounters), hipMemcpyDeviceToHost));
     CHECK_OVERFLOW(I);
     const uint32_t nb = I->last_bounces;
     out->primary_rays = nb ? I->local_pixels : 0;

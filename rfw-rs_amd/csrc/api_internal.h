@@ -342,6 +342,8 @@ struct Instance {
     DevBuf<uint8_t> d_blue_noise; // the blue-noise sampler's tables as bytes (rfw_hip_set_blue_noise)
     bool has_blue_noise = false;
     DevBuf<uint32_t> d_valid_gids, d_tlas_order, d_node_count;
+    DevBuf<char> d_stage_dev;  // the fused TLAS path: the pinned staging block [matrices | mesh_of | valid_gids | mesh_local] as ONE device copy
+    bool tlas_fused = true;    // option "tlas_fused" (owner): up to kTlasFusedMax instances, no skinned copies -> one copy + two launches per instance update (0: the chain of round 5)
     DevBuf<DevBox> d_inst_boxes, d_mesh_local, d_tri_boxes;
     DevBuf<char> d_lbvh_ws;
     DevBuf<uint32_t> d_blas_order;
@@ -359,7 +361,8 @@ struct Instance {
     DevBuf<uint32_t> d_mesh_node_counts;
     DevBuf<ForestTree> d_forest; // (first, count, node region) of every mesh of a full build: sah_build_forest
     DevBuf<uint32_t> d_refit_parent, d_refit_nint, d_refit_arrive; // per raw node of the skinned copies
-    DevBuf<QueueCounters> d_counters;
+    DevBuf<QueueCounters> d_counters;        // a ring of two blocks of kMaxSub: the frame being issued uses block `counter_phase`, its k_primary clears the other for the next one
+    uint32_t counter_phase = 0;
     // traversal stack overflow: a word of pinned host memory the kernels set (device-visible mapping), so every later call can report
     // RFW_HIP_E_STATE without a read-back; cleared when synchronize() rebuilds the trees
     uint32_t* overflow_host = nullptr;
@@ -384,7 +387,7 @@ struct Instance {
     uint64_t hole_tris = 0;                   // triangles' worth of regions abandoned since the last full build
     bool layout_valid = false;                // a full device build has laid the buffers out; cleared by anything the incremental path does not cover
     bool node_counts_stale = false;           // n_blas_nodes is re-read lazily (get_scene_stats) after an incremental build
-    uint32_t incremental_builds = 0, full_builds = 0, heads_first_builds = 0;
+    uint32_t incremental_builds = 0, full_builds = 0, heads_first_builds = 0, tlas_fused_builds = 0;
     bool packet_auto = true; // option "packet_trace" / RFW_PACKET_TRACE not set: packets only below kPacketAutoMaxTriangles
     PinnedRing pins;
     uint64_t n_instances = 0, n_valid_instances = 0, n_tris = 0, n_blas_nodes = 0, n_tlas_nodes = 0; // (n_tris: stored primitives, duplicates included)
@@ -413,6 +416,13 @@ struct Instance {
     // extension rays traced in spatial order (option "sort_extension_rays"): (key, queue index) pairs, sorted with hipCUB on the frame's stream
     DevBuf<uint32_t> d_sort_keys[2], d_sort_vals[2];
     DevBuf<char> d_sort_ws;
+    // option "stage_chain" (owner only): kernels of one KIND from different frame slots are chained by events — the k-th frame's k_primary
+    // starts when the (k - lag)-th frame's has ended (likewise k_shadow: lag in bits 8..15) — so that the chip runs a MIX of stages instead of
+    // every slot's camera rays at once (the packet kernel waits on scalar loads, the any-hit kernel issues vector work: together they fill
+    // what either leaves idle).  0 = off
+    int stage_chain = 0;
+    hipEvent_t chain_ev[2][16] = {};
+    uint64_t chain_index[2] = {0, 0};
     int shade_group = 0; // option "shade_group": threads per k_shade workgroup — 0 = 256 where frames overlap (several frame slots, one frame per call), 512 otherwise; or 256 / 512
     int sort_extension_rays = 2; // 0 never, 1 always, 2 only where it pays: batches of frames / samples (see do_render)
     void* external_slab = nullptr;

@@ -247,7 +247,7 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     if (w == "build_counters") { // host-side: full builds, incremental builds, full builds that sent the 48-B heads first, meshes registered with the runtime
         uint32_t pinned = 0;
         for (auto& kv : I->meshes) pinned += kv.second.pinned ? 1u : 0u;
-        const uint32_t v[4] = {I->full_builds, I->incremental_builds, I->heads_first_builds, pinned};
+        const uint32_t v[5] = {I->full_builds, I->incremental_builds, I->heads_first_builds, pinned, I->tlas_fused_builds}; // ([4]: instance updates through the fused TLAS path)
         const uint64_t n = std::min<uint64_t>(bytes, sizeof(v));
         std::memcpy(dst, v, n);
         if (written) *written = n;
@@ -273,7 +273,11 @@ int rfw_hip_debug_read(void* inst, const char* what, void* dst, uint64_t bytes, 
     else if (w == "sh_o") { src = I->d_sh_o.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
     else if (w == "sh_d") { src = I->d_sh_d.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
     else if (w == "sh_e") { src = I->d_sh_e.ptr; avail = q * kShadowBuckets; } // bucket b at element b * capacity
-    else if (w == "counters") { src = I->d_counters.ptr; avail = sizeof(QueueCounters); }
+    else if (w == "counters") { src = I->d_counters.ptr + (size_t)I->counter_phase * kMaxSub; avail = sizeof(QueueCounters); }
+    else if (w == "tlas_raw") { src = I->d_tlas_raw.ptr; avail = (uint64_t)I->d_tlas_raw.cap * sizeof(Node4); }         // the device-built TLAS before quantisation (entries past the node count are stale)
+    else if (w == "tlas_nodes") { src = I->d_tlas_nodes.ptr; avail = (uint64_t)I->d_tlas_nodes.cap * sizeof(Node4Q); }
+    else if (w == "tlas_oct") { src = I->d_tlas_oct.ptr; avail = (uint64_t)I->d_tlas_oct.cap * sizeof(Node4Q); }        // eight copies, stride = capacity / 8
+    else if (w == "tlas_prims") { src = I->d_tlas_prims.ptr; avail = (uint64_t)I->n_valid_instances * 4; }
     else if (w == "xforms") { src = I->d_xforms.ptr; avail = I->n_instances * sizeof(InstanceXform); }
     else if (w == "normals") { src = I->d_normals.ptr; avail = I->n_instances * sizeof(InstanceNormal); }
     else if (w == "blas_raw") { src = I->d_blas_raw.ptr; avail = (uint64_t)I->d_blas_raw.cap * sizeof(Node4); }       // device builders: f32 nodes before quantisation

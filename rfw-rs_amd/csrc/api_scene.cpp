@@ -829,6 +829,30 @@ int build_instances(Instance* I, Instance* T)
     HIP_TRY(I, T->d_tlas_raw.ensure(std::max<size_t>(n_valid, 1)));
     HIP_TRY(I, T->d_node_count.ensure(1));
     hipStream_t s = T->stream;
+    // Up to kTlasFusedMax live instances and no skinned copies (BASELINE config 3): the staging block goes up as ONE copy, the tree is built
+    // by ONE workgroup (lbvh.hip, k_tlas_fused), nodes are quantised / copied per octant and the instance descriptors made by one more launch —
+    // 3 API calls where the chain below takes 27, and the host thread that issues them was what bound that configuration
+    if (I->tlas_on_device && I->tlas_fused && I->derived.empty() && n_valid >= 2 && n_valid <= kTlasFusedMax) {
+        HIP_TRY(I, T->d_stage_dev.ensure(total));
+        HIP_TRY(I, T->d_inst_boxes.ensure(n_valid));
+        if ((rc = ensure_lbvh_ws(T, n_valid))) return rc;
+        HIP_TRY(I, hipMemcpyAsync(T->d_stage_dev.ptr, st, off_joints, hipMemcpyHostToDevice, s));
+        const rfw_mat4* d_mats = reinterpret_cast<const rfw_mat4*>(T->d_stage_dev.ptr + off_mats);
+        const uint32_t* d_mesh_of = reinterpret_cast<const uint32_t*>(T->d_stage_dev.ptr + off_meshof);
+        const uint32_t* d_valid = reinterpret_cast<const uint32_t*>(T->d_stage_dev.ptr + off_valid);
+        const DevBox* d_local = reinterpret_cast<const DevBox*>(T->d_stage_dev.ptr + off_local);
+        HIP_TRY(I, tlas_build_fused(s, d_mats, d_mesh_of, d_local, d_valid, n_valid, T->d_lbvh_ws.ptr, T->d_lbvh_ws.cap, T->d_inst_boxes.ptr, T->d_tlas_raw.ptr,
+                                    T->d_tlas_prims.ptr, T->d_node_count.ptr));
+        launch_tlas_finish(s, T->d_tlas_raw.ptr, T->d_tlas_nodes.ptr, copies_of(T->d_tlas_wide, T->d_tlas_oct), n_valid, T->d_node_count.ptr, d_mats, d_mesh_of,
+                           I->d_mesh_records.ptr, (uint32_t)n_all, T->d_xforms.ptr, T->d_normals.ptr);
+        HIP_TRY(I, hipGetLastError());
+        T->n_tlas_nodes = 0; // read back lazily (get_scene_stats)
+        HIP_TRY(I, hipEventRecord(T->stage_event[T->stage_next], s));
+        T->stage_pending[T->stage_next] = true;
+        T->stage_next = (T->stage_next + 1) % Instance::kStages;
+        I->tlas_fused_builds++;
+        return RFW_HIP_OK;
+    }
     if (n_all) {
         HIP_TRY(I, hipMemcpyAsync(T->d_matrices.ptr, mats, n_all * sizeof(rfw_mat4), hipMemcpyHostToDevice, s));
         HIP_TRY(I, hipMemcpyAsync(T->d_mesh_of_instance.ptr, mesh_of, n_all * 4, hipMemcpyHostToDevice, s));

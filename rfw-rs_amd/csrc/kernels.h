@@ -40,6 +40,10 @@ struct SceneDev {
     uint32_t spill_rows;        // <= kStackSpill
     uint32_t* overflow_flag;    // pinned host word, device-visible
     QueueCounters* counters;
+    // the counter block of the NEXT frame on this instance's stream (the other half of a ring of two): k_primary clears it, so that no frame starts
+    // with a clear of its own — a 512-byte fill is a dispatch like any other, and with frames in flight it queued behind the trace kernels'
+    // wavefronts for up to 0.76 ms before its frame's first kernel could start (kernel timeline, round 5)
+    QueueCounters* counters_next;
 };
 
 // Wavefront state, structure-of-arrays of 16-B elements (the reference's 64-B AoS PathState, structs.glsl:4-9, split):
@@ -79,6 +83,9 @@ struct OctantCopies {
 // out[i] = quantised in[i] and its octant copies at oc[first + i], i < n.  `live` (nullable): the tree's node count ON THE DEVICE — slots behind
 // it are skipped (regions are sized for the worst case, one node per primitive)
 void launch_quantize_nodes(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live = nullptr);
+// behind tlas_build_fused (lbvh.h): quantised nodes + their per-octant copies (the first *live of n_nodes_max) and the instance descriptors, one launch
+void launch_tlas_finish(hipStream_t s, const Node4* raw, Node4Q* out, const OctantCopies& oc, uint32_t n_nodes_max, const uint32_t* live, const rfw_mat4* matrices,
+                        const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n_instances, InstanceXform* xf, InstanceNormal* nm);
 void launch_expand_nodes(hipStream_t s, const Node4Q* in, const OctantCopies& oc, uint32_t first, uint32_t n, const uint32_t* live = nullptr); // the copies of already quantised nodes
 // the same for slots [0, n) holding SEVERAL trees: record k's tree lives at recs[k].node_base and has counts[k] nodes (both on the device)
 void launch_quantize_regions(hipStream_t s, const Node4* in, Node4Q* out, const OctantCopies& oc, uint32_t n, const MeshRecord* recs, const uint32_t* counts, uint32_t n_recs);

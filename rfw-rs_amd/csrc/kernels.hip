@@ -90,6 +90,14 @@ RFW_DI SceneView scene_view(const SceneDev& sc)
     return v;
 }
 
+// the first workgroup of a frame's first kernel clears the counter block the NEXT frame of this stream will use (SceneDev::counters_next)
+RFW_DI void clear_next_counters(const SceneDev& sc)
+{
+    static_assert(sizeof(QueueCounters) % 8 == 0, "QueueCounters is cleared in 8-byte words");
+    if (blockIdx.x != 0 || !sc.counters_next) return;
+    unsigned long long* z = reinterpret_cast<unsigned long long*>(sc.counters_next);
+    for (uint32_t i = threadIdx.x; i < sizeof(QueueCounters) / 8u; i += kTraceBlock) z[i] = 0ull;
+}
 template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCounters& tc, const int kind)
 {
     if (!COUNT) return;
@@ -122,12 +130,9 @@ template <bool COUNT> RFW_DI void flush_counters(QueueCounters* qc, const TravCo
 
 // ---------------------------------------------------------------- instance descriptors (gpu-rt/src/lib.rs:1589-1615)
 // matrix -> inverse (explicit cofactor expansion, every term left to right) and normal = transpose(inverse)
-__global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
-                                    const MeshRecord* __restrict__ meshes, uint32_t n, InstanceXform* __restrict__ xf,
-                                    InstanceNormal* __restrict__ nm)
+RFW_DI void prepare_instance(const uint32_t i, const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                             const MeshRecord* __restrict__ meshes, InstanceXform* __restrict__ xf, InstanceNormal* __restrict__ nm)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     float m[16], inv[16];
     bool zero = true;
     for (int k = 0; k < 16; k++) {
@@ -180,6 +185,13 @@ __global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const
     x.mesh = mesh;
     xf[i] = x;
     nm[i] = nn;
+}
+__global__ void k_prepare_instances(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                                    const MeshRecord* __restrict__ meshes, uint32_t n, InstanceXform* __restrict__ xf,
+                                    InstanceNormal* __restrict__ nm)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) prepare_instance(i, matrices, mesh_of_instance, meshes, xf, nm);
 }
 
 // ---------------------------------------------------------------- ray_gen.comp:72-91 == shade.comp:530-545
@@ -262,6 +274,7 @@ RFW_DI uint32_t xcd_run(const uint32_t b, const uint32_t per_tile)
 // ---------------------------------------------------------------- ray_gen.comp:39-70
 template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_primary(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
+    clear_next_counters(sc);
     __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
@@ -292,6 +305,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kTraceWaves) voi
 // same triangle tests, same image; no LDS.
 template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kPacketWaves) void k_primary_packet(const CameraParams cam, const SceneDev sc, const PathDev p)
 {
+    clear_next_counters(sc);
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     TravCounters tc{0, 0, 0};
@@ -324,6 +338,7 @@ template <bool COUNT> __global__ __launch_bounds__(kTraceBlock, kPacketWaves) vo
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_primary_batch(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
 {
+    clear_next_counters(sc);
     __shared__ uint32_t s_stack[kTraceLdsRows * kTraceBlock];
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
@@ -363,6 +378,7 @@ __global__ __launch_bounds__(kTraceBlock, kTraceWaves) void k_primary_batch(cons
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, kPacketWaves) void k_primary_batch_packet(const CameraParams cam, const BatchViews views, const SceneDev sc, const PathDev p)
 {
+    clear_next_counters(sc);
     const uint32_t block = xcd_block(blockIdx.x);
     const uint32_t idx = block * kTraceBlock + threadIdx.x;
     const uint32_t f = (block * kTraceBlock) / cam.frame_capacity;
@@ -1174,6 +1190,30 @@ __global__ void k_expand_regions(const Node4Q* __restrict__ in, PacketNode* __re
     }
 }
 
+// What follows the fused TLAS build (lbvh.hip, k_tlas_fused) in ONE launch: the first `expand_blocks` workgroups quantise the 4-wide nodes and
+// write their eight per-octant copies (k_quantize_nodes + k_expand_nodes: one thread per (node, octant); the quantisation is a few operations,
+// done by all eight), the other workgroups make the instance descriptors (k_prepare_instances).  With the one copy of the staging block in
+// front of them a frame's whole instance update is three API calls where it was 27.
+__global__ __launch_bounds__(256) void k_tlas_finish(const Node4* __restrict__ raw, Node4Q* __restrict__ out, PacketNode* __restrict__ wide, Node4Q* __restrict__ octq,
+                                                     const uint32_t wide_stride, const uint32_t n_nodes_max, const uint32_t* __restrict__ live, const uint32_t expand_blocks,
+                                                     const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance, const MeshRecord* __restrict__ meshes,
+                                                     const uint32_t n_instances, InstanceXform* __restrict__ xf, InstanceNormal* __restrict__ nm)
+{
+    if (blockIdx.x < expand_blocks) {
+        const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t i = g >> 3, oct = g & 7u;
+        if (i < n_nodes_max && i < *live) {
+            const Node4Q q = quantize_node(raw[i]);
+            if (oct == 0u) out[i] = q;
+            if (wide) wide[(size_t)oct * wide_stride + i] = make_packet_node(q, oct);
+            if (octq) octq[(size_t)oct * wide_stride + i] = make_octant_node(q, oct);
+        }
+    } else {
+        const uint32_t i = (blockIdx.x - expand_blocks) * 256u + threadIdx.x;
+        if (i < n_instances) prepare_instance(i, matrices, mesh_of_instance, meshes, xf, nm);
+    }
+}
+
 // ---------------------------------------------------------------- launch wrappers
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static SrgbSteps make_steps(const float* steps255)
@@ -1189,6 +1229,14 @@ void launch_prepare_instances(hipStream_t s, const rfw_mat4* matrices, const uin
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_prepare_instances, dim3(ceil_div(n, 64)), dim3(64), 0, s, matrices, mesh_of_instance, meshes, n, xf, nm);
+}
+void launch_tlas_finish(hipStream_t s, const Node4* raw, Node4Q* out, const OctantCopies& oc, uint32_t n_nodes_max, const uint32_t* live, const rfw_mat4* matrices,
+                        const uint32_t* mesh_of_instance, const MeshRecord* meshes, uint32_t n_instances, InstanceXform* xf, InstanceNormal* nm)
+{
+    const uint32_t expand_blocks = ceil_div((uint64_t)n_nodes_max * 8u, 256), prepare_blocks = ceil_div(n_instances, 256);
+    if (expand_blocks + prepare_blocks == 0u) return;
+    hipLaunchKernelGGL(k_tlas_finish, dim3(expand_blocks + prepare_blocks), dim3(256), 0, s, raw, out, oc.wide, oc.quant, oc.stride, n_nodes_max, live, expand_blocks, matrices,
+                       mesh_of_instance, meshes, n_instances, xf, nm);
 }
 void launch_primary(hipStream_t s, const CameraParams& cam, const SceneDev& sc, const PathDev& p, bool count)
 {

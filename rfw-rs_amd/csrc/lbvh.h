@@ -30,6 +30,13 @@ size_t lbvh_workspace_bytes(uint32_t n);
 hipError_t lbvh_build(hipStream_t stream, const DevBox* boxes, uint32_t n, void* workspace, size_t workspace_bytes, Node4* nodes_out,
                       uint32_t* prim_order_out, uint32_t* node_count_out /* device, optional */);
 
+// The TLAS of up to kTlasFusedMax instances in ONE launch (one workgroup: lbvh.hip, k_tlas_fused): instance boxes -> Morton sort -> hierarchy
+// -> fit -> 4-wide nodes, and tlas_prims[k] = valid_gids[leaf order k].  The same tree, node for node, as launch_instance_boxes + lbvh_build +
+// launch_gather_u32.  inst_boxes: room for n; workspace: lbvh_workspace_bytes(n).  hipErrorInvalidValue when n is outside [2, kTlasFusedMax].
+constexpr uint32_t kTlasFusedMax = 16384;
+hipError_t tlas_build_fused(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const DevBox* mesh_local_boxes, const uint32_t* valid_gids,
+                            uint32_t n, void* workspace, size_t workspace_bytes, DevBox* inst_boxes, Node4* nodes_out, uint32_t* tlas_prims, uint32_t* node_count_out);
+
 // Stress test of lbvh_build's fence-free bottom-up fit: `iterations` times n jittered boxes -> tree -> exact structural check, all on the
 // stream (no host round trip).  nodes / order / seen: room for n; node_count: 1 word; result: 2 words, zeroed by the caller
 // ([0] += mismatches, [1] += child boxes checked).

@@ -94,25 +94,33 @@ __device__ inline uint32_t expand10(uint32_t v)
     return v;
 }
 
-__global__ void k_morton(const DevBox* __restrict__ boxes, uint32_t n, const uint32_t* __restrict__ bounds, uint32_t* keys, uint32_t* vals)
+// 30-bit Morton key of a box's centre inside the bounds of all centres (lo / hi per axis)
+__device__ inline uint32_t morton_key(const DevBox& box, const float* lo3, const float* hi3)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
     uint32_t q[3];
     for (int a = 0; a < 3; a++) {
-        const float lo = f_unorder(bounds[a]), hi = f_unorder(bounds[3 + a]);
-        const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+        const float lo = lo3[a], hi = hi3[a];
+        const float c = 0.5f * (box.lo[a] + box.hi[a]);
         const float ext = hi - lo;
         float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
         t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
         q[a] = (uint32_t)t;
     }
-    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    return (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+}
+__global__ void k_morton(const DevBox* __restrict__ boxes, uint32_t n, const uint32_t* __restrict__ bounds, uint32_t* keys, uint32_t* vals)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = f_unorder(bounds[a]); hi[a] = f_unorder(bounds[3 + a]); }
+    keys[i] = morton_key(boxes[i], lo, hi);
     vals[i] = i;
 }
 
-// longest common prefix of keys i and j (ties broken by index), -1 outside the array
-__device__ inline int delta(const uint32_t* __restrict__ keys, int n, int i, int j)
+// longest common prefix of keys i and j (ties broken by index), -1 outside the array.  `Keys`: anything indexable that yields the sorted 30-bit
+// keys — the sorted array in memory (k_hierarchy) or the high words of the (key, index) pairs the fused TLAS build sorts in LDS
+template <class Keys> __device__ inline int delta(const Keys& keys, int n, int i, int j)
 {
     if (j < 0 || j >= n) return -1;
     const uint32_t a = keys[i], b = keys[j];
@@ -121,11 +129,8 @@ __device__ inline int delta(const uint32_t* __restrict__ keys, int n, int i, int
 }
 
 // child encoding in left/right: >= 0 internal node index, < 0 leaf ~index
-__global__ void k_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, int32_t* left, int32_t* right, uint32_t* parent)
+template <class Keys> __device__ inline void hierarchy_node(const Keys& keys, const int ni, const int i, int32_t* left, int32_t* right, uint32_t* parent)
 {
-    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
-    const int ni = (int)n;
-    if (i >= ni - 1) return;
     const int d = (delta(keys, ni, i, i + 1) - delta(keys, ni, i, i - 1)) >= 0 ? 1 : -1;
     const int dmin = delta(keys, ni, i, i - d);
     int lmax = 2;
@@ -150,6 +155,12 @@ __global__ void k_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, int32
     parent[right_leaf ? (ni - 1 + gamma + 1) : gamma + 1] = (uint32_t)i;
     if (i == 0) parent[0] = 0xffffffffu;
 }
+__global__ void k_hierarchy(const uint32_t* __restrict__ keys, uint32_t n, int32_t* left, int32_t* right, uint32_t* parent)
+{
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= (int)n - 1) return;
+    hierarchy_node(keys, (int)n, i, left, right, parent);
+}
 
 __device__ inline uint32_t node_slot(int32_t child, uint32_t n) { return child < 0 ? (n - 1 + (uint32_t)(~child)) : (uint32_t)child; }
 
@@ -163,12 +174,9 @@ __device__ inline uint32_t node_slot(int32_t child, uint32_t n) { return child <
 // step: 9.4 instead of 4.8 ms for 1 M primitives).  The known-good fallback should the fence-free form ever fail
 // rfw_hip_debug_lbvh_stress (tests/test_gpu_api.py::test_fence_free_tlas_fit_survives_ten_thousand_rebuilds) on some driver or firmware.
 template <bool FENCED>
-__global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n, const int32_t* __restrict__ left,
-                      const int32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* flags, DevBox* nbox)
+__device__ inline void fit_climb(DevBox b, const uint32_t i, const uint32_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                 const uint32_t* __restrict__ parent, uint32_t* flags, DevBox* nbox)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    DevBox b = boxes[order[i]];
     uint32_t me = n - 1 + i;
     uint32_t node = parent[me];
     for (;;) {
@@ -201,25 +209,36 @@ __global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restri
         node = parent[node];
     }
 }
-
-// internal nodes at even depth become Node4s
-__global__ void k_flag_even_depth(uint32_t n_internal, const uint32_t* __restrict__ parent, uint32_t* flag4)
+template <bool FENCED>
+__global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n, const int32_t* __restrict__ left,
+                      const int32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* flags, DevBox* nbox)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_internal) return;
+    if (i >= n) return;
+    fit_climb<FENCED>(boxes[order[i]], i, n, left, right, parent, flags, nbox);
+}
+
+// internal nodes at even depth become Node4s
+__device__ inline uint32_t even_depth(const uint32_t i, const uint32_t* __restrict__ parent)
+{
     uint32_t depth = 0, p = parent[i];
     while (p != 0xffffffffu) {
         depth++;
         p = parent[p];
     }
-    flag4[i] = (depth & 1u) ? 0u : 1u;
+    return (depth & 1u) ? 0u : 1u;
 }
-
-__global__ void k_emit4(uint32_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right, const uint32_t* __restrict__ flag4,
-                        const uint32_t* __restrict__ idx4, const DevBox* __restrict__ nbox, Node4* __restrict__ nodes, uint32_t* node_count_out)
+__global__ void k_flag_even_depth(uint32_t n_internal, const uint32_t* __restrict__ parent, uint32_t* flag4)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n - 1) return;
+    if (i >= n_internal) return;
+    flag4[i] = even_depth(i, parent);
+}
+
+__device__ inline void emit4_node(const uint32_t i, const uint32_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                  const uint32_t* __restrict__ flag4, const uint32_t* __restrict__ idx4, const DevBox* __restrict__ nbox, Node4* __restrict__ nodes,
+                                  uint32_t* node_count_out)
+{
     if (i == n - 2 && node_count_out) *node_count_out = idx4[i] + flag4[i];
     if (!flag4[i]) return;
     int32_t kids[4];
@@ -248,6 +267,13 @@ __global__ void k_emit4(uint32_t n, const int32_t* __restrict__ left, const int3
     }
     nodes[idx4[i]] = out;
 }
+__global__ void k_emit4(uint32_t n, const int32_t* __restrict__ left, const int32_t* __restrict__ right, const uint32_t* __restrict__ flag4,
+                        const uint32_t* __restrict__ idx4, const DevBox* __restrict__ nbox, Node4* __restrict__ nodes, uint32_t* node_count_out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    emit4_node(i, n, left, right, flag4, idx4, nbox, nodes, node_count_out);
+}
 
 // n == 0 / n == 1: a root with no / one leaf child
 __global__ void k_tiny_tree(const DevBox* __restrict__ boxes, uint32_t n, Node4* nodes, uint32_t* order, uint32_t* node_count_out)
@@ -269,12 +295,9 @@ __global__ void k_tiny_tree(const DevBox* __restrict__ boxes, uint32_t n, Node4*
     if (node_count_out) *node_count_out = 1;
 }
 
-__global__ void k_instance_boxes(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
-                                 const DevBox* __restrict__ mesh_local, const uint32_t* __restrict__ valid_gids, uint32_t n, DevBox* out)
+__device__ inline DevBox instance_box(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance, const DevBox* __restrict__ mesh_local,
+                                      const uint32_t gid)
 {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t gid = valid_gids[k];
     const float* m = matrices[gid].m;
     const DevBox lb = mesh_local[mesh_of_instance[gid]];
     DevBox b;
@@ -292,7 +315,14 @@ __global__ void k_instance_boxes(const rfw_mat4* __restrict__ matrices, const ui
         b.hi[a] += e;
     }
     b.lo[3] = 0.0f; b.hi[3] = 0.0f;
-    out[k] = b;
+    return b;
+}
+__global__ void k_instance_boxes(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                                 const DevBox* __restrict__ mesh_local, const uint32_t* __restrict__ valid_gids, uint32_t n, DevBox* out)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    out[k] = instance_box(matrices, mesh_of_instance, mesh_local, valid_gids[k]);
 }
 
 __global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ order, uint32_t n, uint32_t* dst)
@@ -457,6 +487,110 @@ __global__ void k_bounds_store(const uint32_t* scratch, DevBox* out)
     }
 }
 
+
+// ---------------------------------------------------------------- the whole TLAS build as ONE workgroup
+// A scene whose instances move every frame rebuilds its TLAS every frame (the reference: on the CPU, backends/gpu-rt/src/lib.rs:1576-1615).
+// lbvh_build is a chain of 17 launches, each a few microseconds of work for 10 000 instances: as a dependent chain 0.43 ms of launch gaps
+// per frame, and the HOST thread that issues them was what bound BASELINE config 3 (round 5: 6366 Mrays/s where the kernels allow 7300).
+// For up to kTlasFusedMax instances one workgroup of 1024 threads does every step — instance boxes, bounds of the centres, Morton keys, the
+// sort (bitonic, in LDS, on (key, index) pairs: the order a stable radix sort of the keys gives), Karras' hierarchy, the bottom-up fit, the
+// 4-wide collapse — with workgroup barriers where the chain had launches.  Same arithmetic, same tree, node for node
+// (tests/test_gpu_api.py::test_fused_tlas_build_equals_the_chain).
+constexpr uint32_t kFusedThreads = 1024;
+struct LdsKeys { // the sorted 30-bit keys = the high words of the sorted pairs
+    const unsigned long long* pairs;
+    __device__ uint32_t operator[](const int i) const { return (uint32_t)(pairs[i] >> 32); }
+};
+__global__ __launch_bounds__(kFusedThreads) void k_tlas_fused(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
+                                                               const DevBox* __restrict__ mesh_local, const uint32_t* __restrict__ valid_gids, const uint32_t n,
+                                                               DevBox* inst_boxes, int32_t* left, int32_t* right, uint32_t* parent, uint32_t* flags, DevBox* nbox,
+                                                               uint32_t* flag4, uint32_t* idx4, Node4* __restrict__ nodes_out, uint32_t* __restrict__ tlas_prims,
+                                                               uint32_t* node_count_out)
+{
+    __shared__ unsigned long long s_pairs[kTlasFusedMax]; // 128 KB of the CU's 160
+    __shared__ float s_red[2][3][kFusedThreads / 64];
+    __shared__ float s_bounds[2][3];
+    __shared__ uint32_t s_scan[kFusedThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // ---- instance boxes, the arrival counters of the fit, the bounds of the boxes' centres
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k = tid; k < n; k += kFusedThreads) {
+        const DevBox b = instance_box(matrices, mesh_of_instance, mesh_local, valid_gids[k]);
+        inst_boxes[k] = b;
+        flags[k] = 0u;
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (b.lo[a] + b.hi[a]);
+            lo[a] = fminf(lo[a], c);
+            hi[a] = fmaxf(hi[a], c);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], __shfl_down(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off));
+        }
+    if (lane == 0)
+        for (int a = 0; a < 3; a++) { s_red[0][a][wave] = lo[a]; s_red[1][a][wave] = hi[a]; }
+    __syncthreads();
+    if (tid < 6) {
+        const int a = (int)tid % 3, which = (int)tid / 3;
+        float v = s_red[which][a][0];
+        for (uint32_t w = 1; w < kFusedThreads / 64; w++) v = which ? fmaxf(v, s_red[1][a][w]) : fminf(v, s_red[0][a][w]);
+        s_bounds[which][a] = v;
+    }
+    __syncthreads();
+    // ---- (Morton key, index) pairs, padded with the largest pair to a power of two, sorted in LDS
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    {
+        const float blo[3] = {s_bounds[0][0], s_bounds[0][1], s_bounds[0][2]}, bhi[3] = {s_bounds[1][0], s_bounds[1][1], s_bounds[1][2]};
+        for (uint32_t k = tid; k < m; k += kFusedThreads)
+            s_pairs[k] = k < n ? ((unsigned long long)morton_key(inst_boxes[k], blo, bhi) << 32) | k : ~0ull; // (this thread wrote inst_boxes[k] itself)
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (m >> 1); t += kFusedThreads) {
+                const uint32_t i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u)), j = i | stride;
+                const unsigned long long a = s_pairs[i], b = s_pairs[j];
+                const bool up = (i & size) == 0u;
+                if ((a > b) == up) { s_pairs[i] = b; s_pairs[j] = a; }
+            }
+            __syncthreads();
+        }
+    // ---- the instance ids in leaf order; Karras' hierarchy over the sorted keys
+    const LdsKeys keys{s_pairs};
+    for (uint32_t k = tid; k < n; k += kFusedThreads) tlas_prims[k] = valid_gids[(uint32_t)s_pairs[k]];
+    for (uint32_t i = tid; i + 1 < n; i += kFusedThreads) hierarchy_node(keys, (int)n, (int)i, left, right, parent);
+    __syncthreads(); // (workgroup-scope release / acquire: the stores above are visible to every wave of this workgroup)
+    // ---- bottom-up fit (the hand-off of lbvh_build's fence-free k_fit, between the waves of one workgroup here), 4-wide collapse
+    for (uint32_t i = tid; i < n; i += kFusedThreads) fit_climb<false>(inst_boxes[(uint32_t)s_pairs[i]], i, n, left, right, parent, flags, nbox);
+    // flag4[i] = internal node i lies at even depth; idx4 = its exclusive prefix sum (a thread owns 16 consecutive nodes)
+    constexpr uint32_t kPer = kTlasFusedMax / kFusedThreads;
+    uint32_t mine[kPer], sum = 0;
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t i = tid * kPer + q;
+        mine[q] = i + 1 < n ? even_depth(i, parent) : 0u;
+        sum += mine[q];
+    }
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads(); // (also: every box of the fit has been published)
+    uint32_t before = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) before += s_scan[w];
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t i = tid * kPer + q;
+        if (i + 1 < n) { flag4[i] = mine[q]; idx4[i] = before; }
+        before += mine[q];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i + 1 < n; i += kFusedThreads) emit4_node(i, n, left, right, flag4, idx4, nbox, nodes_out, node_count_out);
+}
+
 inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 } // namespace
@@ -516,6 +650,19 @@ hipError_t lbvh_build(hipStream_t s, const DevBox* boxes, uint32_t n, void* work
     e = hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag4, idx4, (int)(n - 1), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit4, dim3(blocks(n - 1)), dim3(kBlock), 0, s, n, left, right, flag4, idx4, nbox, nodes_out, node_count_out);
+    return hipGetLastError();
+}
+
+hipError_t tlas_build_fused(hipStream_t s, const rfw_mat4* matrices, const uint32_t* mesh_of_instance, const DevBox* mesh_local_boxes, const uint32_t* valid_gids,
+                            uint32_t n, void* workspace, size_t workspace_bytes, DevBox* inst_boxes, Node4* nodes_out, uint32_t* tlas_prims, uint32_t* node_count_out)
+{
+    if (n < 2 || n > kTlasFusedMax) return hipErrorInvalidValue;
+    const Layout L = make_layout(n, 0);
+    if (L.total > workspace_bytes) return hipErrorInvalidValue;
+    char* w = static_cast<char*>(workspace);
+    hipLaunchKernelGGL(k_tlas_fused, dim3(1), dim3(kFusedThreads), 0, s, matrices, mesh_of_instance, mesh_local_boxes, valid_gids, n, inst_boxes, (int32_t*)(w + L.left),
+                       (int32_t*)(w + L.right), (uint32_t*)(w + L.parent), (uint32_t*)(w + L.flags), (DevBox*)(w + L.nbox), (uint32_t*)(w + L.flag4), (uint32_t*)(w + L.idx4),
+                       nodes_out, tlas_prims, node_count_out);
     return hipGetLastError();
 }
 

@@ -699,3 +699,54 @@ def test_backends_one_after_the_other_in_one_process():
                     be.render(view); orc.render(view)
                 assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), (rep, builder, fif, tris, inst)
                 be.close()
+
+
+@pytest.mark.parametrize("n_inst", [2, 3, 17, 1000, 10000])
+def test_fused_tlas_build_equals_the_chain(n_inst):
+    """up to 16 384 instances the per-frame TLAS is built by ONE workgroup (csrc/lbvh.hip, k_tlas_fused) and finished by one more
+    launch (k_tlas_finish), instead of the chain of 23 launches (option tlas_fused = 0 keeps the chain).  Same arithmetic, so the same tree: the
+    4-wide nodes before and after quantisation, every per-octant copy and the leaf order are compared byte for byte, over several frames of an
+    animation, and both equal the oracle's image."""
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    w, h = 96, 64
+    if n_inst >= 1000:
+        side = int(round(n_inst ** 0.5))
+        scene = Scene().build("cornell")
+        scene.build("spheres", side, side, 0.28)          # + side x side animated icosphere instances
+    else:
+        scene = Scene().build("soup", 900, n_inst, 0.0, 21)
+    scene.set_aspect(w / h)
+    view = scene.view(w, h)
+    fused, chain = HipBackend.init(w, h, 1.0), HipBackend.init(w, h, 1.0)
+    chain.set_option("tlas_fused", 0)
+    orc = Oracle(w, h, threads=8)
+    for frame in range(3):
+        if n_inst >= 1000:
+            scene.animate(frame / 7.0)
+        for be in (fused, chain):
+            scene.mark_all_changed()
+            scene.sync(be)
+        scene.mark_all_changed(); scene.sync(orc)
+        nf, nc = fused.scene_stats()["tlas_nodes"], chain.scene_stats()["tlas_nodes"]
+        assert nf == nc and nf >= 1
+        n_valid = fused.scene_stats()["instances"]
+        for what, item in (("tlas_raw", 128), ("tlas_nodes", 64)):
+            a, b = fused.debug_read(what, nf * item), chain.debug_read(what, nf * item)
+            assert len(a) == nf * item and np.array_equal(a, b), (frame, what, np.argwhere(a != b)[:4])
+        a, b = fused.debug_read("tlas_prims", 4 * n_valid), chain.debug_read("tlas_prims", 4 * n_valid)
+        assert len(a) > 0 and np.array_equal(a, b), (frame, "tlas_prims")
+        fo, co = fused.debug_read("tlas_oct", 1 << 30), chain.debug_read("tlas_oct", 1 << 30)
+        fo, co = fo.reshape(8, -1), co.reshape(8, -1)          # (the strides may differ: each follows its own allocation)
+        assert np.array_equal(fo[:, : nf * 64], co[:, : nf * 64]), (frame, "tlas_oct")
+        orc.reset()
+        for be in (fused, chain):
+            be.reset_accumulation()
+            be.render(view)
+        orc.render(view)
+        assert np.array_equal(fused.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), frame
+        assert np.array_equal(chain.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), frame
+    cf = fused.debug_read("build_counters", 20).view(np.uint32)
+    cc = chain.debug_read("build_counters", 20).view(np.uint32)
+    assert cf[4] >= 3 and cc[4] == 0, (cf, cc)          # the fused path did run — and only where it was asked to
+    fused.close(); chain.close()
