@@ -11,8 +11,10 @@ strictly one frame at a time, and frames traced 8 per launch through the rfw_hip
 frame of the timed region are read back and compared, bit for bit, with the CPU oracle's frames of the same views at the same
 resolution (`config.timed_frame_equals_oracle`); the oracle's time for those frames is the `cpu_baseline`.
 
-N > 1: the frame is sharded by 64x64 tiles across ranks, batches of 8 frames (8 different views) are traced per launch and the ranks'
-slabs are all-gathered once per batch (RCCL over xGMI; strong scaling: the frame is fixed)."""
+N > 1: the frame is sharded by 64x64 tiles across ranks; `value` is north_star's protocol — one render() and ONE all-gather of the
+framebuffer per frame (RCCL over xGMI; strong scaling: the frame is fixed), 8 (N = 2) or 12 renderer instances in flight.  Batches of 8
+frames traced per launch with one exchange per batch (the rfw_hip_render_batch extension) are measured after the timed region and reported
+as a row of config.modes."""
 import argparse
 import contextlib
 import ctypes
@@ -146,8 +148,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frame slots (N = 1) / renderer instances (N > 1) used round-robin; 1 = strictly one frame at a time")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames traced per rfw_hip_render_batch call.  Default 1 at N = 1 (one trait call per frame: the headline) and 8 at N > 1 "
-                         "(one all-gather per batch)")
+                    help="frames traced per rfw_hip_render_batch call.  Default 1 at every N: one trait call per frame and, at N > 1, ONE exchange of the "
+                         "framebuffer per frame (north_star's protocol: that is the `value`); at N > 1 batches of 8 — one exchange per batch — are measured "
+                         "after the timed region and reported as a row of config.modes")
     ap.add_argument("--procedural", action="store_true",
                     help="hand the generated scene to the backend directly; default: write it as a binary glTF 2.0 file (host/gltf_export.cpp) and "
                          "run on what the glTF importer (host/gltf.cpp) reads back — the configurations of BASELINE.json are glTF scenes")
@@ -255,7 +258,7 @@ def main():
     views = [base_view] * N_VIEWS if (args.identical_frames or animated) else dolly_views(base_view, N_VIEWS, 0.005)
 
     single = world == 1 and not args.emulate_shard
-    B = args.batch if args.batch > 0 else (1 if single else 8)
+    B = args.batch if args.batch > 0 else 1
     if animated:
         B = 1
     # (C3: a frame's chain is longer — instance upload, TLAS rebuild, then the trace — and 16 slots, the most an instance takes, hide it best:
@@ -302,20 +305,23 @@ def main():
     t0 = time.time()
     inst = make_instances(F, B, use_slots)
     sync_s = (time.time() - t0) / len(inst)
-    if p2p:
-        # every rank's 256-byte handle to every rank, once; after that the ranks only meet in their peers' flag words
-        for be_, _, _ in inst:
-            hds = [None] * world
-            dist.all_gather_object(hds, be_.p2p_export())
-            be_.p2p_connect(hds)
-        dist.barrier()
-    elif native:
-        # the communicators live inside the library (librccl; one per instance, i.e. per frame / batch in flight): rank 0's unique ids
-        # travel through torch's store once, after that torch.distributed is only used for the barrier around the timed region
-        uids = [[HipBackend.comm_unique_id() for _ in inst] if rank == 0 else None]
-        dist.broadcast_object_list(uids, src=0)
-        for (be_, _, _), uid in zip(inst, uids[0]):
-            be_.comm_init(uid, rank, world)
+    def connect(insts):
+        if p2p:
+            # every rank's 256-byte handle to every rank, once; after that the ranks only meet in their peers' flag words
+            for be_, _, _ in insts:
+                hds = [None] * world
+                dist.all_gather_object(hds, be_.p2p_export())
+                be_.p2p_connect(hds)
+            dist.barrier()
+        elif native:
+            # the communicators live inside the library (librccl; one per instance, i.e. per frame / batch in flight): rank 0's unique ids
+            # travel through torch's store once, after that torch.distributed is only used for the barrier around the timed region
+            uids = [[HipBackend.comm_unique_id() for _ in insts] if rank == 0 else None]
+            dist.broadcast_object_list(uids, src=0)
+            for (be_, _, _), uid in zip(insts, uids[0]):
+                be_.comm_init(uid, rank, world)
+
+    connect(inst)
     bes = [i[0] for i in inst]
     be = bes[0]
     sstats = be.scene_stats()
@@ -524,6 +530,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    # ---- N > 1: the same frames in batches of 8 — ONE exchange per batch instead of one per frame — as a secondary mode (north_star's protocol,
+    # one exchange per frame, is the `value` above)
+    batch_mode = None
+    if world > 1 and B == 1 and not args.no_modes and not animated and not args.emulate_shard and not args.readback:
+        for b_ in bes:
+            b_.close()
+        headline_setup = (B, F, use_slots)
+        B, F = 8, 3
+        use_slots = native and os.environ.get("RFW_BENCH_INSTANCES") is None
+        inst = make_instances(F, B, use_slots)
+        connect(inst)
+        bes = [i[0] for i in inst]
+        state.update({"issued": 0, "pending": [], "k": 0, "last": None})
+        nfb = max(args.mode_frames - args.mode_frames % B, 2 * B)
+        for i in range(2 * B):
+            step(i)
+        flush()
+        for b_ in bes:
+            b_.device_synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_b = time.perf_counter()
+        for i in range(nfb):
+            step(i)
+        flush()
+        for b_ in bes:
+            b_.device_synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el_b = time.perf_counter() - t_b
+        t = torch.tensor([el_b], dtype=torch.float64, device="cuda" if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_b = float(t[0])
+        batch_mode = {"Mrays_per_s": round(sum(view_rays(i) for i in range(nfb)) / el_b / 1e6, 1), "ms_per_frame": round(el_b / nfb * 1e3, 4), "frames": nfb,
+                      "exchanges": nfb // B, "note": "extension call rfw_hip_render_batch: 8 frames traced per launch, ONE exchange of their 8 framebuffers"}
+        B, F, use_slots = headline_setup  # (what the headline ran with: the line below describes THAT)
     # host cost of the per-frame scene update (animate + set_3d_instances + synchronize) without back-pressure
     host_sync_ms = None
     if animated:
@@ -548,6 +590,10 @@ def main():
     iso = None
     if rank == 0:
         modes[headline_mode] = {"Mrays_per_s": round(value, 1), "ms_per_frame": round(ms_step, 4), "frames": args.steps, "is_value": True}
+        if world > 1 and B == 1:
+            modes[headline_mode]["exchanges"] = args.steps  # one per frame
+        if batch_mode:
+            modes["render_batch of 8, 3 batches in flight: one exchange per batch (extension call)"] = batch_mode
     if single and not args.no_modes and not animated:
         if F == 1 and B == 1:
             iso = bes[0].drain_timing()  # the timed region itself was one frame at a time: its own per-kernel events

@@ -261,6 +261,12 @@ RFW_HIP_API int rfw_hip_assemble_frame(void* instance, const void* gathered_devi
 RFW_HIP_API int rfw_hip_comm_unique_id(void* out128);
 RFW_HIP_API int rfw_hip_comm_init(void* instance, const void* id128, uint32_t rank, uint32_t world);
 RFW_HIP_API int rfw_hip_comm_destroy(void* instance);
+/* TEST TRANSPORT.  `world` instances of ONE process on ONE device, created with options.rank = 0 .. world - 1, join the hub `hub_key` instead of
+ * a communicator: their render() calls then exchange tiles as with rfw_hip_comm_init — same packing, same per-slot gather buffers, same
+ * ordering of the frame slots' collectives, same de-tiling — but the bytes are moved by device copies the LAST rank to call enqueues.  Every
+ * rank must call render() for a frame before anyone waits for that frame; a rank that never does shows up as RFW_HIP_E_DEVICE ("a peer's
+ * flag did not arrive", option p2p_timeout_ms) from the others' reads.  rfw_hip_comm_destroy leaves the hub.  No RCCL is involved. */
+RFW_HIP_API int rfw_hip_comm_init_loopback(void* instance, uint64_t hub_key, uint32_t rank, uint32_t world);
 
 /* The same exchange WITHOUT a collective library (SURVEY.md §8e's alternative): every rank stores its tiles straight into its peers'
  * receive buffers over xGMI.  xGMI is point to point, so the 7 links of a GPU carry the 7 peers' tiles side by side, where a ring

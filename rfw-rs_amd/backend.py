@@ -25,7 +25,7 @@ EXPORTS = [
     "rfw_hip_shard_info", "rfw_hip_set_slab_output", "rfw_hip_assemble_frame", "rfw_hip_intersect", "rfw_hip_occludes", "rfw_hip_debug_occludes_depth",
     "rfw_hip_debug_read", "rfw_hip_bandwidth_probe", "rfw_hip_depth_test", "rfw_hip_render_batch", "rfw_hip_assemble_batch",
     "rfw_hip_read_framebuffer_at", "rfw_hip_read_accumulator_at", "rfw_hip_host_alloc", "rfw_hip_host_free", "rfw_hip_download_frame",
-    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_destroy", "rfw_hip_p2p_export", "rfw_hip_p2p_connect", "rfw_hip_p2p_disconnect", "rfw_hip_intersect4", "rfw_hip_occludes4", "rfw_hip_debug_lbvh_stress", "rfw_hip_issue_probe",
+    "rfw_hip_wait_downloads", "rfw_hip_wait_download", "rfw_hip_srgb_steps", "rfw_hip_render_samples", "rfw_hip_set_blue_noise", "rfw_hip_debug_eval_shading", "rfw_hip_comm_unique_id", "rfw_hip_comm_init", "rfw_hip_comm_init_loopback", "rfw_hip_comm_destroy", "rfw_hip_p2p_export", "rfw_hip_p2p_connect", "rfw_hip_p2p_disconnect", "rfw_hip_intersect4", "rfw_hip_occludes4", "rfw_hip_debug_lbvh_stress", "rfw_hip_issue_probe",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def hip_lib():
         l.rfw_hip_comm_unique_id.argtypes = [vp]
         l.rfw_hip_comm_init.argtypes = [vp, vp, u32, u32]
         l.rfw_hip_comm_destroy.argtypes = [vp]
+        l.rfw_hip_comm_init_loopback.argtypes = [vp, C.c_uint64, u32, u32]
         l.rfw_hip_p2p_export.argtypes = [vp, vp]
         l.rfw_hip_p2p_connect.argtypes = [vp, vp]
         l.rfw_hip_p2p_disconnect.argtypes = [vp]
@@ -290,6 +291,11 @@ class HipBackend:
         """Collective: the instance gets its own RCCL communicator; render() then gathers and assembles the frame itself."""
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._l.rfw_hip_comm_init(self._h, buf, rank, world))
+
+    def comm_init_loopback(self, hub_key, rank, world):
+        """TEST TRANSPORT: the instances of one process (one per rank, one device) exchange their tiles through hub `hub_key` instead of a
+        communicator — everything around the collective runs as with comm_init (include/rfw_hip.h)."""
+        self._check(self._l.rfw_hip_comm_init_loopback(self._h, hub_key, rank, world))
 
     def comm_destroy(self):
         self._check(self._l.rfw_hip_comm_destroy(self._h))

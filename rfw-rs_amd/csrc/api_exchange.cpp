@@ -63,8 +63,8 @@ int assemble_gathered(Instance* I, hipStream_t s, const void* gathered, uint32_t
     return RFW_HIP_OK;
 }
 // does this instance receive other ranks' tiles in the gather format (whoever moves them)?
-bool gathers_tiles(const Instance* I) { return scene_of(I)->comm != nullptr || I->external_slab != nullptr || scene_of(I)->p2p.connected; }
-bool p2p_timed_out(const Instance* I) { return scene_of(I)->p2p.connected && I->overflow_host && ((volatile const uint32_t*)I->overflow_host)[1] != 0u; }
+bool gathers_tiles(const Instance* I) { return scene_of(I)->comm != nullptr || scene_of(I)->loop != nullptr || I->external_slab != nullptr || scene_of(I)->p2p.connected; }
+bool p2p_timed_out(const Instance* I) { return (scene_of(I)->p2p.connected || scene_of(I)->loop) && I->overflow_host && ((volatile const uint32_t*)I->overflow_host)[1] != 0u; }
 // The frame's exchange by stores into the peers' buffers (include/rfw_hip.h, rfw_hip_p2p_*).  Destinations: the presenting rank, or all.
 int p2p_exchange(Instance* I, hipStream_t s, uint32_t frames)
 {
@@ -117,7 +117,7 @@ int gathered_arrived(Instance* I, hipStream_t s, const void* gathered, uint32_t 
 int ensure_assembled(Instance* I)
 {
     if (I->frame_elsewhere) return fail(I, RFW_HIP_E_STATE, "this rank sent its tiles to the presenting rank (present_rank): the frame exists there only");
-    if (p2p_timed_out(I)) return fail(I, RFW_HIP_E_DEVICE, "p2p exchange: a peer's flag did not arrive within p2p_timeout_ms (the frame is incomplete)");
+    if (p2p_timed_out(I)) return fail(I, RFW_HIP_E_DEVICE, "exchange: a peer's flag did not arrive within p2p_timeout_ms (a rank did not take part: the frame is incomplete)");
     if (!I->deferred.gathered) return RFW_HIP_OK;
     return assemble_gathered(I, I->stream, I->deferred.gathered, I->deferred.k, I->deferred.samples);
 }
@@ -172,6 +172,14 @@ int rfw_hip_comm_init(void* inst, const void* id128, uint32_t rank, uint32_t wor
 int rfw_hip_comm_destroy(void* inst)
 {
     LOCK(inst);
+    if (I->loop) {
+        HIP_TRY(I, hipSetDevice(I->device));
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        for (Instance* c : I->slots) HIP_TRY(I, hipStreamSynchronize(c->stream));
+        loop_leave(I);
+        I->acc_source = nullptr;
+        return RFW_HIP_OK;
+    }
     if (!I->comm) return RFW_HIP_OK;
     HIP_TRY(I, hipSetDevice(I->device));
     HIP_TRY(I, hipStreamSynchronize(I->stream));
@@ -182,6 +190,137 @@ int rfw_hip_comm_destroy(void* inst)
     return RFW_HIP_OK;
 }
 
+} // extern "C"
+
+// ---- the loop-back transport (rfw_hip_comm_init_loopback): W instances of ONE process, one per rank, exchange their tiles through a hub
+// instead of a communicator.  It exists so that everything around the collective — the packing, the per-slot gather buffers, the event chain
+// that orders the slots' collectives (comm_chain), de-tiling on the presenting rank, a rank that never arrives — runs where there is one
+// GPU and no second process.  Semantics of ncclAllGather on a stream: the call returns at once; what follows it on the
+// caller's stream runs when every rank's contribution is in every rank's receive buffer.  Here: the caller records "my tiles are packed",
+// enqueues a wait for its own flag word, and the LAST rank to arrive (host side) enqueues the W x W copies on the hub's stream behind
+// every rank's event, then sets every rank's flag.
+namespace rfwapi {
+struct LoopHub {
+    std::mutex mu;
+    uint32_t world = 0, n_slots = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* flags = nullptr; // [slot][rank]: gathers completed
+    std::vector<Instance*> owner; // per rank (nullptr: not joined / left)
+    struct Call { Instance* inst; uint64_t words; };
+    std::vector<std::vector<Call>> pending; // [slot]
+    std::vector<uint32_t> done;             // [slot]
+};
+static std::mutex g_hubs_mu;
+static std::map<uint64_t, LoopHub*> g_hubs;
+
+int loop_all_gather(Instance* I, hipStream_t s, uint64_t n_words)
+{
+    Instance* C = scene_of(I);
+    LoopHub* H = C->loop;
+    const uint32_t slot = I->slot_index;
+    if (slot >= H->n_slots) return fail(I, RFW_HIP_E_STATE, "loop-back exchange: this instance has more frame slots than the hub was made for");
+    if (!I->loop_sent) HIP_TRY(I, hipEventCreateWithFlags(&I->loop_sent, hipEventDisableTiming));
+    HIP_TRY(I, hipEventRecord(I->loop_sent, s)); // (behind pack_slabs)
+    const uint32_t want = ++I->loop_seq;
+    launch_p2p_wait(s, H->flags + (size_t)slot * H->world, I->rank, 1u, want, C->p2p.timeout_ticks, I->overflow_dev + 1);
+    std::lock_guard<std::mutex> g(H->mu);
+    auto& calls = H->pending[slot];
+    for (const auto& c : calls)
+        if (c.inst->rank == I->rank) return fail(I, RFW_HIP_E_STATE, "loop-back exchange: this rank joined the slot's gather twice before the others arrived");
+    calls.push_back({I, n_words});
+    if (calls.size() < H->world) return RFW_HIP_OK;
+    // the last rank of this gather: move everything, on the hub's stream, behind every rank's packing
+    for (const auto& c : calls) {
+        if (c.words != n_words) { calls.clear(); return fail(I, RFW_HIP_E_STATE, "loop-back exchange: the ranks contribute slabs of different sizes"); }
+        HIP_TRY(I, hipStreamWaitEvent(H->stream, c.inst->loop_sent, 0));
+    }
+    for (const auto& dst : calls)
+        for (const auto& src : calls)
+            HIP_TRY(I, hipMemcpyAsync(dst.inst->d_recv.ptr + (size_t)src.inst->rank * n_words, src.inst->d_send.ptr, n_words * sizeof(float), hipMemcpyDeviceToDevice, H->stream));
+    P2PTargets t;
+    for (uint32_t r = 0; r < H->world; r++) t.p[r] = H->flags + (size_t)slot * H->world + r;
+    launch_p2p_signal(H->stream, t, H->world, ++H->done[slot]);
+    HIP_TRY(I, hipGetLastError());
+    calls.clear();
+    return RFW_HIP_OK;
+}
+void loop_leave(Instance* owner)
+{
+    LoopHub* H = owner->loop;
+    if (!H) return;
+    owner->loop = nullptr;
+    bool last = true;
+    {
+        std::lock_guard<std::mutex> g(H->mu);
+        H->owner[owner->rank] = nullptr;
+        for (auto& calls : H->pending) // a gather this rank had joined and the others had not: it will never complete
+            calls.erase(std::remove_if(calls.begin(), calls.end(), [&](const LoopHub::Call& c) { return scene_of(c.inst) == owner; }), calls.end());
+        for (Instance* o : H->owner) last = last && o == nullptr;
+    }
+    if (!last) return;
+    std::lock_guard<std::mutex> g(g_hubs_mu);
+    for (auto it = g_hubs.begin(); it != g_hubs.end(); ++it)
+        if (it->second == H) { g_hubs.erase(it); break; }
+    (void)hipSetDevice(H->device);
+    if (H->stream) { (void)hipStreamSynchronize(H->stream); (void)hipStreamDestroy(H->stream); }
+    if (H->flags) (void)hipFree(H->flags);
+    delete H;
+}
+} // namespace rfwapi
+
+extern "C" {
+int rfw_hip_comm_init_loopback(void* inst, uint64_t hub_key, uint32_t rank, uint32_t world)
+{
+    LOCK(inst);
+    if (world == 0 || world > 16 || rank >= world) return fail(I, RFW_HIP_E_INVALID, "comm_init_loopback: bad arguments (1 <= world <= 16, rank < world)");
+    if (rank != I->rank || world != I->world) return fail(I, RFW_HIP_E_INVALID, "comm_init_loopback: rank / world differ from the shard this instance was created with (rfw_hip_options.rank / world)");
+    if (I->substreams > 1) return fail(I, RFW_HIP_E_STATE, "comm_init_loopback: an instance with sub-streams cannot exchange through a hub");
+    if (I->comm || I->loop || I->p2p.data) return fail(I, RFW_HIP_E_STATE, "comm_init_loopback: this instance already has an exchange");
+    HIP_TRY(I, hipSetDevice(I->device));
+    LoopHub* H = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_hubs_mu);
+        auto it = g_hubs.find(hub_key);
+        if (it == g_hubs.end()) {
+            H = new LoopHub();
+            H->world = world; H->n_slots = (uint32_t)I->slots.size() + 1u; H->device = I->device;
+            H->owner.assign(world, nullptr); H->pending.resize(H->n_slots); H->done.assign(H->n_slots, 0u);
+            const size_t fb = (size_t)H->n_slots * world * sizeof(uint32_t);
+            hipError_t e = hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking);
+            if (e == hipSuccess && hipExtMallocWithFlags((void**)&H->flags, fb, hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                e = hipMalloc((void**)&H->flags, fb);
+            }
+            if (e == hipSuccess) e = hipMemset(H->flags, 0, fb);
+            if (e != hipSuccess) {
+                if (H->stream) (void)hipStreamDestroy(H->stream);
+                if (H->flags) (void)hipFree(H->flags);
+                delete H;
+                return fail(I, RFW_HIP_E_DEVICE, std::string("comm_init_loopback: ") + hipGetErrorString(e));
+            }
+            g_hubs[hub_key] = H;
+        } else H = it->second;
+    }
+    std::lock_guard<std::mutex> g(H->mu);
+    if (H->world != world || H->device != I->device || H->n_slots != I->slots.size() + 1u)
+        return fail(I, RFW_HIP_E_INVALID, "comm_init_loopback: the hub was made for another world size, device or number of frame slots");
+    if (H->owner[rank]) return fail(I, RFW_HIP_E_STATE, "comm_init_loopback: this rank of the hub is taken");
+    const size_t n = (size_t)I->capacity * I->max_batch * 3u; // (room for the widest format: the option may still change)
+    for (uint32_t k = 0; k <= I->slots.size(); k++) { // as rfw_hip_comm_init: every slot gathers into buffers of its own
+        Instance* c = slot_ptr(I, k);
+        HIP_TRY(I, c->d_send.ensure(n));
+        HIP_TRY(I, c->d_recv.ensure(n * world));
+        HIP_TRY(I, hipMemsetAsync(c->d_recv.ptr, 0, n * world * sizeof(float), c->stream));
+        c->sample_count = 0;
+        c->loop_seq = 0;
+    }
+    if (!I->slots.empty() && !I->comm_chain) HIP_TRY(I, hipEventCreateWithFlags(&I->comm_chain, hipEventDisableTiming));
+    I->comm_chain_pending = false;
+    H->owner[rank] = I;
+    I->loop = H;
+    return RFW_HIP_OK;
+}
 } // extern "C"
 
 // ---- the exchange by peer stores

@@ -347,13 +347,18 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
     I->sample_count += samples ? k : 1;
     const uint32_t frames_out = samples ? 1u : k; // images this call leaves behind
     if (tm) (void)hipEventRecord(I->events[kEvBlit], main);
-    if (Instance* C = scene_of(I); C->comm) {
+    if (Instance* C = scene_of(I); C->comm || C->loop) {
         // the frame's ONE collective, issued by the library itself: this rank's slab(s) -> all ranks (RCCL over xGMI) -> de-tile
         const uint64_t n_send = slab_words(I) * frames_out; // 4-byte words, whatever they hold
         pack_slabs(I, main, I->d_send.ptr, frames_out);
         if (C->comm_chain && C->comm_chain_pending) HIP_TRY(I, hipStreamWaitEvent(main, C->comm_chain, 0)); // behind the previous slot's collective
-        const ncclResult_t nr = g_rccl.all_gather(I->d_send.ptr, I->d_recv.ptr, n_send, ncclFloat, C->comm, main);
-        if (nr != ncclSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("ncclAllGather: ") + g_rccl.error_string(nr));
+        if (C->loop) { // (the test transport: same buffers, same ordering around it)
+            const int lrc = loop_all_gather(I, main, n_send);
+            if (lrc != RFW_HIP_OK) return lrc;
+        } else {
+            const ncclResult_t nr = g_rccl.all_gather(I->d_send.ptr, I->d_recv.ptr, n_send, ncclFloat, C->comm, main);
+            if (nr != ncclSuccess) return fail(I, RFW_HIP_E_DEVICE, std::string("ncclAllGather: ") + g_rccl.error_string(nr));
+        }
         if (C->comm_chain) { HIP_TRY(I, hipEventRecord(C->comm_chain, main)); C->comm_chain_pending = true; }
         const int arc = gathered_arrived(I, main, I->d_recv.ptr, frames_out); // gathered = [rank][frame][slab]
         if (arc != RFW_HIP_OK) return arc;
@@ -418,7 +423,7 @@ void* rfw_hip_create(uint32_t width, uint32_t height, double /*scale*/, const rf
         if (o->builder) I->builder = o->builder;
         I->flags = o->flags & 15u; // the public RFW_HIP_FLAG_* bits; the others are internal (set_option)
         if (o->streams) I->substreams = std::min<uint32_t>(o->streams, kMaxSub);
-        if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 16u);
+        if (o->struct_size >= offsetof(rfw_hip_options, frames_in_flight) + sizeof(uint32_t)) n_slots = std::min<uint32_t>(std::max<uint32_t>(o->frames_in_flight, 1u), 24u);
         if (o->struct_size >= offsetof(rfw_hip_options, max_batch) + sizeof(uint32_t)) I->max_batch = std::min<uint32_t>(std::max<uint32_t>(o->max_batch, 1u), (uint32_t)kMaxBatch);
     }
     {
@@ -538,6 +543,8 @@ void rfw_hip_destroy(void* inst)
         I->d_tri_boxes.release(); I->d_lbvh_ws.release(); I->d_blas_order.release();
         I->d_q_o.release(); I->d_q_d.release(); I->d_q_t.release(); I->d_q_h.release(); I->d_q_depth.release(); I->d_q_r.release();
         if (I->comm) { (void)g_rccl.comm_destroy(I->comm); I->comm = nullptr; }
+        if (I->loop) loop_leave(I);
+        if (I->loop_sent) { (void)hipEventDestroy(I->loop_sent); I->loop_sent = nullptr; }
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
         for (auto& row : I->chain_ev)
             for (hipEvent_t& ev : row)
@@ -663,7 +670,7 @@ int rfw_hip_resize(void* inst, uint32_t w, uint32_t h, double)
     // a gathered frame not de-tiled yet belongs to the old size (and d_recv may move below): forget it (each slot passes here for itself)
     I->deferred = Instance::Deferred(); I->acc_source = nullptr; I->presented_valid = false;
     const int arc = alloc_paths(I); // also restarts accumulation (gpu-rt/src/lib.rs:1809)
-    if (arc == RFW_HIP_OK && scene_of(I)->comm) { // the gather buffers follow the slab size
+    if (arc == RFW_HIP_OK && (scene_of(I)->comm || scene_of(I)->loop)) { // the gather buffers follow the slab size
         const size_t n = (size_t)I->capacity * I->max_batch * 3u;
         HIP_TRY(I, I->d_send.ensure(n));
         HIP_TRY(I, I->d_recv.ensure(n * I->world));

@@ -81,6 +81,9 @@ struct Rccl {
     }
 };
 extern Rccl g_rccl;        // (api_exchange.cpp)
+struct Instance;
+int loop_all_gather(Instance* I, hipStream_t s, uint64_t n_words); // (api_exchange.cpp) what ncclAllGather does for a communicator, for a loop-back hub
+void loop_leave(Instance* owner);
 extern std::mutex g_rccl_mu;
 
 template <typename T> struct DevBuf {
@@ -444,6 +447,9 @@ struct Instance {
     bool comm_chain_pending = false;
     // the exchange without a collective library (rfw_hip_p2p_*): receive buffers [slot][rank][frame][slab] and flag words
     // [slot][arrived | credit][rank] of THIS rank, and where the peers' are mapped.  Lives in the owner; a slot knows its index.
+    struct LoopHub* loop = nullptr;  // rfw_hip_comm_init_loopback (owner): the test transport that stands in for the communicator
+    uint32_t loop_seq = 0;           // per slot: gathers this slot has joined
+    hipEvent_t loop_sent = nullptr;  // per slot: its packed tiles are in d_send
     struct P2P {
         bool connected = false;
         uint32_t* data = nullptr;   // hipMalloc: 4-byte words

@@ -1,6 +1,8 @@
 """Parity proper: the HIP path through the C ABI against the oracle on the same seeded inputs.
 Ray queries (ids, t, u, v) must be bit-exact; accumulated radiance must match to <= 1e-4 relative L2
 (north_star tolerance) — the arithmetic contract actually yields identical bits, which is asserted too."""
+import os
+
 import numpy as np
 import pytest
 
@@ -286,7 +288,11 @@ def test_bench_two_ranks_on_one_gpu_gloo_hook(gather_format):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rays_per_frame"] >= 320 * 200
-    assert out["config"]["frames_per_batch"] == 8 and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
+    # the value is north_star's protocol — one exchange per FRAME; batches of 8 (one exchange per batch) are a row of config.modes
+    assert out["config"]["frames_per_batch"] == 1 and out["config"]["sharded_frame_equals_single_gpu_frame"] is True
+    rows = out["config"]["modes"]
+    assert any(v.get("is_value") and v.get("exchanges") == 3 for v in rows.values()), rows
+    assert any("render_batch of 8" in k and v["exchanges"] * 8 == v["frames"] and v["Mrays_per_s"] > 0 for k, v in rows.items()), rows
     assert out["config"]["gather_format"] == gather_format
     assert out["config"]["gather_bytes_per_frame"] == {"f32": 12, "f16": 6, "bgra8": 4}[gather_format] * 320 * 200
     assert "distinct" in out["config"]["views"] or "cycled" in out["config"]["views"]
@@ -963,3 +969,17 @@ def test_texture_array_normalisation_matches_oracle(tmp_path, size, array):
     assert ra[..., :3].max() > 0 and ra[60:, :, :3].std() > 1e-3      # the textured floor is in view
     assert np.array_equal(ga.view(np.uint32), ra.view(np.uint32))
     be.close()
+
+
+@pytest.mark.parametrize("fmt,present_rank", [(0, -1), (1, 0), (2, 0), (2, -1)])
+def test_library_exchange_through_the_loopback_hub(fmt, present_rank):
+    """the exchange INSIDE the library (render() packs, gathers, de-tiles: what `bench.py --collective native` runs over RCCL
+    on a multi-GPU node) cannot be rehearsed with world > 1 on one device through RCCL itself.  rfw_hip_comm_init_loopback stands in for the
+    communicator only (tests/loopback_ranks.py: three ranks in one process, three frame slots each, six frames in flight, every gather format,
+    a rank that never arrives).  In a process of its own: like several NCCL ranks driven by one process, every stream involved needs a
+    hardware queue of its own (a rank's wait must not sit in front of the copies it waits for), and the runtime reads GPU_MAX_HW_QUEUES once."""
+    import subprocess, sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="24")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback_ranks.py"), str(fmt), str(present_rank)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "LOOPBACK OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -12,15 +12,16 @@
 # device (torch's collective through the gloo hook, the peer-store exchange through real IPC handles — also with the fall-back kind of flag
 # memory forced, RFW_P2P_FLAGS_FINEGRAINED=1) on a small frame, and it FAILS LOUDLY (exit 1, the failing pairs named) unless every run exits 0
 # with config.sharded_frame_equals_single_gpu_frame true.  `native` (RCCL inside the library) cannot be rehearsed this way — RCCL refuses two
-# ranks on one device; tests/test_gpu_api.py runs it with a one-rank communicator.
+# ranks on one device: everything AROUND its ncclAllGather call runs with three ranks of one process through the library's loop-back hub
+# (tests/test_gpu_parity.py::test_library_exchange_through_the_loopback_hub), the call itself with a one-rank communicator (tests/test_gpu_api.py).
 if [ "$1" = "--dry" ]; then
   R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/scale_dry; mkdir -p "$OUT"; cd "$R" || exit 1
   export HSA_ENABLE_IPC_MODE_LEGACY=0 RFW_BENCH_DIST_BACKEND=gloo
   PORT=29710; FAILED=""
-  for v in torch:bgra8 torch:f16 torch:f32 p2p:bgra8 p2p:f16 p2p:f32 p2p:bgra8:finegrained-flags p2p:f32:cached-data torch:bgra8:latency p2p:bgra8:latency; do
+  for v in torch:bgra8 torch:f16 torch:f32 p2p:bgra8 p2p:f16 p2p:f32 p2p:bgra8:finegrained-flags p2p:f32:cached-data torch:bgra8:batched p2p:bgra8:batched; do
     coll=${v%%:*}; rest=${v#*:}; fmt=${rest%%:*}; extra=""
     case "$v" in *finegrained-flags) extra="RFW_P2P_FLAGS_FINEGRAINED=1";; *cached-data) extra="RFW_P2P_DATA_CACHED=1";; esac
-    barg=""; case "$v" in *latency) barg="--batch 1";; esac
+    barg=""; case "$v" in *batched) barg="--batch 8";; esac   # (default: one exchange per FRAME, north_star's protocol; batched: one per 8 frames)
     PORT=$((PORT + 1)); f=$OUT/dry_${v//:/_}.json
     env $extra timeout 600 python3 bench.py --gpus 2 \
       --steps 12 --warmup 4 --workload cornell --width 320 --height 200 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $barg > "$f" 2> "${f%.json}.err"
@@ -35,8 +36,9 @@ TAG=${1:-scale}
 STEPS=${2:-240}
 GPUS=${GPUS:-"1 2 4 8"}
 VARIANTS=${VARIANTS:-"torch:bgra8 torch:f16 torch:f32 native:bgra8 native:f32 p2p:bgra8 p2p:f16 p2p:f32"}
-# the same exchange per FRAME instead of per batch of 8 (bench.py --batch 1): what an interactive render() loop sees
-LATENCY_VARIANTS=${LATENCY_VARIANTS:-"native:bgra8 p2p:bgra8"}
+# every row above exchanges the framebuffer once per FRAME (north_star's protocol, bench.py's default).  The same with 8 frames traced per launch
+# and ONE exchange per batch (bench.py --batch 8, the rfw_hip_render_batch extension):
+BATCH_VARIANTS=${BATCH_VARIANTS:-"native:bgra8 p2p:bgra8"}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -46,23 +48,23 @@ HAVE=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 PORT=29610
 ROWS=$OUT/rows.txt
 : > "$ROWS"
-run() { # n collective format [latency]
-  local n=$1 coll=$2 fmt=$3 lat=$4 f=$OUT/scale_n${1}_${2}_${3}${4:+_latency}.json
+run() { # n collective format [batched]
+  local n=$1 coll=$2 fmt=$3 lat=$4 f=$OUT/scale_n${1}_${2}_${3}${4:+_batched}.json
   local extra=""
-  [ -n "$lat" ] && extra="--batch 1"   # latency mode: one render() per frame over frame slots, one exchange per FRAME (an interactive caller cannot batch 8 frames)
+  [ -n "$lat" ] && extra="--batch 8"   # 8 frames per launch, one exchange per batch
   if [ "$n" -eq 1 ]; then
     python3 bench.py --gpus 1 --steps "$STEPS" --warmup 24 --no-cpu-baseline --no-modes > "$f" 2> "${f%.json}.err"
   else
     python3 bench.py --gpus "$n" \
       --steps "$STEPS" --warmup 24 --no-cpu-baseline --collective "$coll" --gather-format "$fmt" $extra > "$f" 2> "${f%.json}.err"
   fi
-  echo "$n $coll ${fmt}${lat:+(one-frame-per-exchange)} $f" >> "$ROWS"
+  echo "$n $coll ${fmt}${lat:+(one-exchange-per-8-frames)} $f" >> "$ROWS"
 }
 for n in $GPUS; do
   if [ "$n" -gt "$HAVE" ] && [ -z "$RFW_BENCH_DIST_BACKEND" ]; then echo "skipping N = $n: this box has $HAVE GPU(s)"; continue; fi
   if [ "$n" -eq 1 ]; then run 1 - -; continue; fi
   for v in $VARIANTS; do run "$n" "${v%%:*}" "${v##*:}"; done
-  for v in $LATENCY_VARIANTS; do run "$n" "${v%%:*}" "${v##*:}" latency; done
+  for v in $BATCH_VARIANTS; do run "$n" "${v%%:*}" "${v##*:}" batched; done
 done
 python3 - "$ROWS" > "$OUT/scale.md" <<'PY'
 import json, sys
