@@ -22,6 +22,7 @@ void read_env_switches()
     if (const char* v = getenv("RFW_PACKET_AUTO_MAX_TRIANGLES")) e.packet_auto_max_triangles = strtoull(v, nullptr, 10);
     if (const char* v = getenv("RFW_SPATIAL_SPLITS")) { e.has_spatial_splits = true; e.spatial_splits = (float)std::max(0.0, atof(v)); }
     if (const char* v = getenv("RFW_PACKET_TRACE")) e.packet_trace = std::max(0, atoi(v));
+    if (const char* v = getenv("RFW_NODE_ORDER")) e.node_order = std::max(0, atoi(v));
     g_env = e;
 }
 } // namespace rfwhip
@@ -271,29 +272,10 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
             v.p1[0] = views[f].p1.x; v.p1[1] = views[f].p1.y; v.p1[2] = views[f].p1.z; v.pad2 = 0.0f;
         }
     }
-    // option "stage_chain": this frame's kernel of kind `kind` (0 camera rays, 1 the camera paths' shadow rays) waits for the same kernel of the
-    // frame issued `lag` frames earlier, whatever slot that one runs on
-    Instance* const OW = scene_of(I);
-    auto chain_wait = [&](int kind, hipStream_t on) -> int {
-        const int lag = (OW->stage_chain >> (8 * kind)) & 0xff;
-        if (lag <= 0 || S > 1 || OW->slots.empty()) return RFW_HIP_OK;
-        if (OW->chain_index[kind] >= (uint64_t)lag && lag <= 16) HIP_TRY(I, hipStreamWaitEvent(on, OW->chain_ev[kind][(OW->chain_index[kind] - (uint64_t)lag) % 16], 0));
-        return RFW_HIP_OK;
-    };
-    auto chain_record = [&](int kind, hipStream_t on) -> int {
-        const int lag = (OW->stage_chain >> (8 * kind)) & 0xff;
-        if (lag <= 0 || S > 1 || OW->slots.empty()) return RFW_HIP_OK;
-        hipEvent_t& ev = OW->chain_ev[kind][OW->chain_index[kind] % 16];
-        if (!ev) HIP_TRY(I, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(I, hipEventRecord(ev, on));
-        OW->chain_index[kind]++;
-        return RFW_HIP_OK;
-    };
     for (uint32_t b = 0; b < bounces; b++) { // gpu-rt/src/lib.rs:1708-1728 without the read-back; stage by stage across the sub-shards
         for (uint32_t s = 0; s < S; s++) {
             hipEvent_t* ev = ring_events(I, slot, s);
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 0)], st[s]);
-            if (b == 0) { const int cw = chain_wait(0, st[s]); if (cw) return cw; }
             if (b == 0 && k > 1) launch_primary_batch(st[s], cam[s], bv, sc[s], p[s], count);
             else if (b == 0) launch_primary(st[s], cam[s], sc[s], p[s], count);
             else {
@@ -316,7 +298,6 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
                 }
                 launch_extend(st[s], cam[s], sc[s], p[s], b, count, order);
             }
-            if (b == 0) { const int cr = chain_record(0, st[s]); if (cr) return cr; }
             if (tm) (void)hipEventRecord(ev[ev_index(b, 0, 1)], st[s]);
         }
         for (uint32_t s = 0; s < S; s++) {
@@ -329,9 +310,7 @@ int do_render(Instance* I, const rfw_camera_view_3d* views, uint32_t k, bool sam
             for (uint32_t s = 0; s < S; s++) {
                 hipEvent_t* ev = ring_events(I, slot, s);
                 if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 0)], st[s]);
-                if (b == 0) { const int cw = chain_wait(1, st[s]); if (cw) return cw; }
                 launch_shadow(st[s], cam[s], sc[s], p[s], b, count);
-                if (b == 0) { const int cr = chain_record(1, st[s]); if (cr) return cr; }
                 if (tm) (void)hipEventRecord(ev[ev_index(b, 2, 1)], st[s]);
             }
     }
@@ -546,9 +525,6 @@ void rfw_hip_destroy(void* inst)
         if (I->loop) loop_leave(I);
         if (I->loop_sent) { (void)hipEventDestroy(I->loop_sent); I->loop_sent = nullptr; }
         if (I->comm_chain) (void)hipEventDestroy(I->comm_chain);
-        for (auto& row : I->chain_ev)
-            for (hipEvent_t& ev : row)
-                if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         for (auto& ev : I->ev_build)
             if (ev) (void)hipEventDestroy(ev);
         if (I->records_stream) (void)hipStreamSynchronize(I->records_stream);
@@ -719,7 +695,6 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         if ((int)value != 0 && (int)value != 256 && (int)value != 512) return fail(I, RFW_HIP_E_INVALID, "set_option: shade_group is 0, 256 or 512");
         I->shade_group = (int)value;
     }
-    else if (k == "stage_chain") I->stage_chain = std::max(0, (int)value) & 0xffff; // (api_internal.h) lag of the camera-ray chain | lag of the shadow-ray chain << 8; 0 = off
     else if (k == "tlas_fused") I->tlas_fused = value != 0.0; // 0: every instance update through the launch chain (lbvh_build) whatever the instance count
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)

@@ -419,13 +419,6 @@ struct Instance {
     // extension rays traced in spatial order (option "sort_extension_rays"): (key, queue index) pairs, sorted with hipCUB on the frame's stream
     DevBuf<uint32_t> d_sort_keys[2], d_sort_vals[2];
     DevBuf<char> d_sort_ws;
-    // option "stage_chain" (owner only): kernels of one KIND from different frame slots are chained by events — the k-th frame's k_primary
-    // starts when the (k - lag)-th frame's has ended (likewise k_shadow: lag in bits 8..15) — so that the chip runs a MIX of stages instead of
-    // every slot's camera rays at once (the packet kernel waits on scalar loads, the any-hit kernel issues vector work: together they fill
-    // what either leaves idle).  0 = off
-    int stage_chain = 0;
-    hipEvent_t chain_ev[2][16] = {};
-    uint64_t chain_index[2] = {0, 0};
     int shade_group = 0; // option "shade_group": threads per k_shade workgroup — 0 = 256 where frames overlap (several frame slots, one frame per call), 512 otherwise; or 256 / 512
     int sort_extension_rays = 2; // 0 never, 1 always, 2 only where it pays: batches of frames / samples (see do_render)
     void* external_slab = nullptr;

@@ -495,6 +495,58 @@ int build_blas_device_full(Instance* I)
         }
         I->build_from_heads = false;
     }
+    if (env_switches().node_order && n_static) {
+        // EXPERIMENT (round 6): the builders number the 4-wide nodes in arrival order; renumber every static tree on the host —
+        // 1: depth-first (a node, then the subtree of its first child, ...), 2: treelets of up to 32 nodes (breadth-first inside a treelet,
+        // treelets depth-first) — and measure what the caches make of it beyond their reach (bench.py --workload atrium32m)
+        HIP_TRY(I, hipStreamSynchronize(I->stream));
+        std::vector<uint32_t> cnt(n_static, 0u);
+        HIP_TRY(I, hipMemcpy(cnt.data(), I->d_mesh_node_counts.ptr, n_static * 4, hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < n_static; q++) {
+            const uint32_t n = cnt[q];
+            if (n < 2) continue;
+            Node4* dev = I->d_blas_raw.ptr + (I->mesh_records[q].node_base - I->raw_node_origin);
+            std::vector<Node4> in(n), out(n);
+            HIP_TRY(I, hipMemcpy(in.data(), dev, (size_t)n * sizeof(Node4), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> order; // order[new] = old
+            order.reserve(n);
+            auto interior = [&](uint32_t c) { return c != kInvalidRef && !(c & kLeafBit); };
+            if (env_switches().node_order == 1) {
+                std::vector<uint32_t> stack{0u};
+                while (!stack.empty()) {
+                    const uint32_t v = stack.back(); stack.pop_back();
+                    order.push_back(v);
+                    for (int k = 3; k >= 0; k--) if (interior(in[v].child[k])) stack.push_back(in[v].child[k]);
+                }
+            } else {
+                std::vector<uint32_t> roots{0u}; // treelet roots, depth-first (a stack)
+                while (!roots.empty()) {
+                    const uint32_t r = roots.back(); roots.pop_back();
+                    std::vector<uint32_t> fifo{r};
+                    size_t head = 0;
+                    std::vector<uint32_t> spill;
+                    while (head < fifo.size()) {
+                        const uint32_t v = fifo[head++];
+                        order.push_back(v);
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t c = in[v].child[k];
+                            if (!interior(c)) continue;
+                            if (fifo.size() < 32) fifo.push_back(c); else spill.push_back(c);
+                        }
+                    }
+                    for (size_t k = spill.size(); k-- > 0;) roots.push_back(spill[k]);
+                }
+            }
+            if (order.size() != n) return fail(I, RFW_HIP_E_STATE, "RFW_NODE_ORDER: the tree does not reach every node of its region");
+            std::vector<uint32_t> where(n);
+            for (uint32_t k = 0; k < n; k++) where[order[k]] = k;
+            for (uint32_t k = 0; k < n; k++) {
+                out[k] = in[order[k]];
+                for (int c = 0; c < 4; c++) if (interior(out[k].child[c])) out[k].child[c] = where[out[k].child[c]];
+            }
+            HIP_TRY(I, hipMemcpy(dev, out.data(), (size_t)n * sizeof(Node4), hipMemcpyHostToDevice));
+        }
+    }
     if ((rc = upload(I, I->d_mesh_records, I->mesh_records.data(), I->mesh_records.size()))) return rc;
     // all static regions in one launch; the slots behind a tree's last node are skipped (the builders left the node counts on the device)
     launch_quantize_regions(I->stream, I->d_blas_raw.ptr, I->d_blas_nodes.ptr, copies_of(I->d_blas_wide, I->d_blas_oct), static_nodes, I->d_mesh_records.ptr,

@@ -14,6 +14,7 @@ struct EnvSwitches {
     uint64_t packet_auto_max_triangles = 0; // RFW_PACKET_AUTO_MAX_TRIANGLES (tests): moves kPacketAutoMaxTriangles; 0 = not set
     bool has_spatial_splits = false;        // RFW_SPATIAL_SPLITS: the default of option "spatial_splits"
     float spatial_splits = 0.0f;
+    int node_order = 0;                     // RFW_NODE_ORDER (experiment, round 6): static BLAS nodes renumbered on the host after a full build — 1 depth-first, 2 treelets of <= 32 nodes
     int packet_trace = -1;                  // RFW_PACKET_TRACE: the default of option "packet_trace"; -1 = not set
 };
 const EnvSwitches& env_switches(); // (api_frame.cpp)
