@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 
 # Every frame slot / renderer instance launches on its own HIP stream, and the runtime deals streams to hardware queues (4 by
 # default): two streams on one queue serialise.  Ask for enough queues BEFORE the HIP runtime starts (it reads this once).
+# (main() chooses once it knows the configuration: 16 hardware queues, 24 where more than 16 streams are in use — N > 2, or C3's 20 frame slots)
 QUEUES_SET_BY_CALLER = "GPU_MAX_HW_QUEUES" in os.environ
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if int(os.environ.get("WORLD_SIZE", "1")) > 2 else "16")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured for a float4 copy)
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
@@ -194,6 +194,8 @@ def main():
     if args.gpus > 1 and env_world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks: refusing to report a number for a job of another size")
     world = args.gpus
+    if not QUEUES_SET_BY_CALLER:  # (before anything starts the HIP runtime)
+        os.environ["GPU_MAX_HW_QUEUES"] = "24" if (world > 2 or args.workload == "spheres10k") else "16"
     rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
     # RFW_BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets two ranks share one GPU (RCCL refuses duplicate devices) so the
@@ -264,10 +266,11 @@ def main():
     B = args.batch if args.batch > 0 else 1
     if animated:
         B = 1
-    # (C3: a frame's chain is longer — instance upload, TLAS rebuild, then the trace — and 16 slots, the most an instance takes, hide it best:
-    # measured 5000 / 4910 / 5080 / 5160 Mrays/s with 4 / 8 / 12 / 16 slots on one box)
+    # (C3: a frame's chain is longer — instance upload, TLAS rebuild, then the trace: measured 5000 / 4910 / 5080 / 5160 Mrays/s with 4 / 8 / 12 /
+    # 16 slots on one box in round 3; round 6, interleaved on one box, three runs each: 16 slots 6919-7071, 20 slots with 24 hardware queues
+    # 7099-7276; beyond 22 slots the streams outnumber the queues the hardware has and the rate collapses)
     # (static scenes, round 4: 8 / 12 / 16 slots give 7050 / 7096 / 7118 Mrays/s over 400 frames and 6560 / 6680 / 6730 over the driver's 20: 12 it is)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 16 if (animated and world == 1) else 12 if world == 1 else 8 if world <= 2 else 12)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (3 if B > 1 else 20 if (animated and world == 1) else 12 if world == 1 else 8 if world <= 2 else 12)
     # HOW the frames in flight are held.  One GPU: ONE renderer instance with F frame slots (rfw_hip_options.frames_in_flight: one scene
     # in HBM; path state, stream and TLAS per slot, so C3's per-frame instance updates pipeline too).  Sharded frame (N > 1): F instances
     # used round-robin, each with its own scene copy, because every frame in flight then needs its own all-gather buffers.

@@ -88,6 +88,14 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/bench_c4_20_steps.json 2> $OUT/ben
 if [ -z "$QUICK" ]; then
   python3 tools/probes/build_time.py 0 > $OUT/build_time.json 2> $OUT/build_time.err && cp $OUT/build_time.json profiles/${TAG}_build_time.json
 fi
+# kernel timelines (start / end of every kernel of the timed region): the driver's command, and C3 with its per-frame instance update
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_c4 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-modes > $OUT/tl_c4_line.json 2> $OUT/tl_c4.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_c3 -- python3 $R/bench.py --gpus 1 --workload spheres10k --steps 60 --warmup 24 --no-cpu-baseline --no-modes > $OUT/tl_c3_line.json 2> $OUT/tl_c3.err
+cd $R
+python3 tools/timeline.py $OUT/tl_c4 20 5 profiles/${TAG}_c4_20_steps_timeline.csv > profiles/${TAG}_c4_20_steps_timeline.json 2>> $OUT/tl_c4.err
+python3 tools/timeline.py $OUT/tl_c3 60 24 profiles/${TAG}_c3_timeline.csv > profiles/${TAG}_c3_timeline.json 2>> $OUT/tl_c3.err
+rm -rf $OUT/tl_c4 $OUT/tl_c3
 # gpurun only brings gpurun_out/ back: the condensed files ride along in it (copy them into profiles/ of the checkout afterwards)
 mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/
 ls -la profiles/ | tail -40

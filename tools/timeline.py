@@ -42,9 +42,11 @@ def main():
     total = max(r[1] for r in rows)
     ev = sorted([(r[0], 1) for r in rows if r[2].startswith("k_")] + [(r[1], -1) for r in rows if r[2].startswith("k_")])
     n, last, thin = 0, 0.0, 0.0
+    resident = {}  # kernels running at once -> ms
     for t, dlt in ev:
         if n < 4:
             thin += t - last
+        resident[n] = resident.get(n, 0.0) + (t - last)
         n += dlt
         last = t
     out = sys.argv[4] if len(sys.argv) > 4 else None
@@ -56,8 +58,11 @@ def main():
     by = {}
     for r in rows:
         by.setdefault(r[2], []).append(r[1] - r[0])
-    print({"frames": K, "gpu_ms": round(total, 3), "ms_per_frame": round(total / K, 4), "ms_with_fewer_than_4_kernels_running": round(thin, 3),
-           "resident_ms_mean_max": {k: [round(sum(v) / len(v), 3), round(max(v), 3)] for k, v in by.items()}})
+    import json
+    print(json.dumps({"frames": K, "gpu_ms": round(total, 3), "ms_per_frame": round(total / K, 4), "ms_with_fewer_than_4_kernels_running": round(thin, 3),
+                      "share_of_time_with_at_least_3_kernels_running": round(sum(v for k, v in resident.items() if k >= 3) / max(total, 1e-9), 3),
+                      "ms_by_kernels_running_at_once": {str(k): round(v, 3) for k, v in sorted(resident.items())},
+                      "resident_ms_mean_max": {k: [round(sum(v) / len(v), 3), round(max(v), 3)] for k, v in by.items()}}, indent=1))
 
 
 if __name__ == "__main__":
