@@ -15,7 +15,9 @@ namespace rfwhip {
 // child[i]: kInvalidRef = empty slot; bit31 set = leaf: (count-1) << 27 | first  (first: index into the
 // leaf-ordered triangle packets of the mesh, or into the TLAS instance-index list); else interior node index
 // (relative to the owning BVH's node base).
-struct Node4 {
+// (alignas(16) on the node and box types: struct copies then move as 16-byte accesses — with the natural alignment of 4 a 128-B node store
+// is 32 dword stores, each touching 64 lines per wavefront)
+struct alignas(16) Node4 {
     float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
     uint32_t child[4];
     uint32_t pad[4];
@@ -33,7 +35,7 @@ inline __host__ __device__ uint32_t make_leaf(uint32_t first, uint32_t count) { 
 // instead of 7.  The trace kernels are bound by the L1/TA data-return path (16 cycles per dwordx4 wave-instruction,
 // profiles/), so bytes per node visit are what matters.  plane = origin + q * scale, scale = a power of two per axis, stored as the
 // float itself (the kernels are instruction-bound: an exponent byte would cost a shift and a mask per axis and visit to unpack).
-struct Node4Q {
+struct alignas(16) Node4Q {
     float ox, oy, oz;
     float sx;           // scale of axis x
     uint32_t qlo[3];    // byte i of qlo[a] = quantised lower plane of child i on axis a
@@ -101,7 +103,7 @@ inline __host__ __device__ Node4Q quantize_node(const Node4& n)
 // [oct * stride + i] of the array.  Made from the quantised node: the boxes are the ones the 64-B node encodes, as floats (plane = origin +
 // q * scale, pushed outwards by an ulp for the rounding of the add): conservative like those, and no result depends on the boxes.
 // An empty slot gets the box (+inf, -inf) — every ray's entry distance is +inf, so it needs no test of its own — and keeps kInvalidRef.
-struct PacketNode {
+struct alignas(16) PacketNode {
     float nx[4], ny[4], nz[4], fx[4];
     float fy[4], fz[4];
     uint32_t child[4], pad[4];
@@ -186,7 +188,7 @@ struct TriPacket {
 static_assert(sizeof(TriPacket) == 48, "TriPacket");
 
 // Per-instance record used by traversal (64 B): rows of the inverse matrix + where the mesh's BLAS lives.
-struct InstanceXform {
+struct alignas(16) InstanceXform {
     float inv_r0[4], inv_r1[4], inv_r2[4]; // row i = (m[i], m[4+i], m[8+i], m[12+i]) of the column-major inverse
     uint32_t node_base;                    // first node of the mesh's BLAS in blas_nodes
     uint32_t tri_base;                     // first packet of the mesh in tri_packets
@@ -197,7 +199,7 @@ static_assert(sizeof(InstanceXform) == 64, "InstanceXform");
 constexpr uint32_t kInstanceIdentity = 2u;
 
 // Per-instance record used by shade (48 B): rows of the normal matrix transpose(inverse(M)).
-struct InstanceNormal {
+struct alignas(16) InstanceNormal {
     float n_r0[4], n_r1[4], n_r2[4];
 };
 

@@ -13,7 +13,7 @@
 namespace rfwhip {
 
 // primitive bounds on the device: lo.xyz / hi.xyz (w unused)
-struct DevBox {
+struct alignas(16) DevBox {
     float lo[4], hi[4];
 };
 

@@ -95,18 +95,23 @@ __device__ inline uint32_t expand10(uint32_t v)
 }
 
 // 30-bit Morton key of a box's centre inside the bounds of all centres (lo / hi per axis)
-__device__ inline uint32_t morton_key(const DevBox& box, const float* lo3, const float* hi3)
+__device__ inline uint32_t morton_key_of_centre(const float* centre, const float* lo3, const float* hi3)
 {
     uint32_t q[3];
     for (int a = 0; a < 3; a++) {
         const float lo = lo3[a], hi = hi3[a];
-        const float c = 0.5f * (box.lo[a] + box.hi[a]);
+        const float c = centre[a];
         const float ext = hi - lo;
         float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
         t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
         q[a] = (uint32_t)t;
     }
     return (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+}
+__device__ inline uint32_t morton_key(const DevBox& box, const float* lo3, const float* hi3)
+{
+    const float c[3] = {0.5f * (box.lo[0] + box.hi[0]), 0.5f * (box.lo[1] + box.hi[1]), 0.5f * (box.lo[2] + box.hi[2])};
+    return morton_key_of_centre(c, lo3, hi3);
 }
 __global__ void k_morton(const DevBox* __restrict__ boxes, uint32_t n, const uint32_t* __restrict__ bounds, uint32_t* keys, uint32_t* vals)
 {
@@ -219,6 +224,50 @@ __global__ void k_fit(const DevBox* __restrict__ boxes, const uint32_t* __restri
 }
 
 // internal nodes at even depth become Node4s
+// The same fit for ONE workgroup whose threads own several leaves each (k_tlas_fused).  One CU has ONE texture-address unit, and a
+// wave instruction whose 64 lanes touch 64 different lines keeps it busy for a few hundred cycles: with k_fit's six 4-byte stores and six
+// 4-byte loads per box the fit of 10 000 leaves took 0.3-0.4 ms of it (measured with cycle stamps per phase).  Here a box moves as two
+// 16-byte accesses, the arrival counters are LDS atomics, and — all waves sharing one CU and its L1 — the hand-off needs no cache-bypassing
+// accesses: a workgroup-scope release / acquire around the counter (the stores have left the wave before the counter is bumped).  A lane
+// that has handed its box over takes its next leaf in the same trip of the loop instead of waiting for the slowest climb of its wavefront.
+// Same boxes as k_fit's: min / max are exact and the order of arrival does not matter.
+__device__ inline void fit_leaves_of_thread(const DevBox* __restrict__ boxes, const uint32_t* leaf_box, uint32_t first, const uint32_t step, const uint32_t n,
+                                            const int32_t* __restrict__ left, const int32_t* __restrict__ right, const uint32_t* __restrict__ parent, uint32_t* arrivals, DevBox* nbox)
+{
+    uint32_t next = first, me = 0, node = 0xffffffffu;
+    bool climbing = false;
+    float4 blo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), bhi = blo;
+    for (;;) {
+        if (!climbing && next < n) {
+            const float4* src = reinterpret_cast<const float4*>(boxes + leaf_box[next]);
+            blo = src[0]; bhi = src[1];
+            me = n - 1 + next;
+            node = parent[me];
+            next += step;
+            climbing = true;
+        }
+        if (__ballot(climbing) == 0ull) break; // (wave-uniform: every lane has published its last box)
+        if (climbing) {
+            float4* dst = reinterpret_cast<float4*>(nbox + me);
+            dst[0] = blo; dst[1] = bhi;
+            if (node == 0xffffffffu) climbing = false; // the root
+            else {
+                const uint32_t old = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == 0u) climbing = false; // the second arrival at a node owns it
+                else {
+                    const uint32_t ls = node_slot(left[node], n), rs = node_slot(right[node], n);
+                    const float4* sib = reinterpret_cast<const float4*>(nbox + (ls == me ? rs : ls));
+                    const float4 slo = sib[0], shi = sib[1];
+                    blo = make_float4(fminf(blo.x, slo.x), fminf(blo.y, slo.y), fminf(blo.z, slo.z), 0.0f);
+                    bhi = make_float4(fmaxf(bhi.x, shi.x), fmaxf(bhi.y, shi.y), fmaxf(bhi.z, shi.z), 0.0f);
+                    me = node;
+                    node = parent[node];
+                }
+            }
+        }
+    }
+}
+
 __device__ inline uint32_t even_depth(const uint32_t i, const uint32_t* __restrict__ parent)
 {
     uint32_t depth = 0, p = parent[i];
@@ -497,31 +546,41 @@ __global__ void k_bounds_store(const uint32_t* scratch, DevBox* out)
 // 4-wide collapse — with workgroup barriers where the chain had launches.  Same arithmetic, same tree, node for node
 // (tests/test_gpu_api.py::test_fused_tlas_build_equals_the_chain).
 constexpr uint32_t kFusedThreads = 1024;
-struct LdsKeys { // the sorted 30-bit keys = the high words of the sorted pairs
-    const unsigned long long* pairs;
-    __device__ uint32_t operator[](const int i) const { return (uint32_t)(pairs[i] >> 32); }
-};
 __global__ __launch_bounds__(kFusedThreads) void k_tlas_fused(const rfw_mat4* __restrict__ matrices, const uint32_t* __restrict__ mesh_of_instance,
                                                                const DevBox* __restrict__ mesh_local, const uint32_t* __restrict__ valid_gids, const uint32_t n,
-                                                               DevBox* inst_boxes, int32_t* left, int32_t* right, uint32_t* parent, uint32_t* flags, DevBox* nbox,
+                                                               DevBox* inst_boxes, int32_t* left, int32_t* right, uint32_t* parent, DevBox* nbox,
                                                                uint32_t* flag4, uint32_t* idx4, Node4* __restrict__ nodes_out, uint32_t* __restrict__ tlas_prims,
                                                                uint32_t* node_count_out)
 {
-    __shared__ unsigned long long s_pairs[kTlasFusedMax]; // 128 KB of the CU's 160
+    // 128 KB of the CU's 160, used three ways one after the other: the (key, index) pairs while they are sorted; then the sorted keys
+    // (first half) and the sorted indices (second half) as 32-bit words; then — keys dead after the hierarchy, indices dead after the fit —
+    // the fit's arrival counters and the parents of the interior nodes.  One workgroup has 16 wavefronts to hide latency with where the
+    // chain's launches had thousands: everything that is walked (counters, parent chains, sorted keys) therefore lives in LDS.
+    __shared__ __attribute__((aligned(16))) unsigned long long s_pairs[kTlasFusedMax];
+    uint32_t* const s_lo = reinterpret_cast<uint32_t*>(s_pairs);
+    uint32_t* const s_hi = s_lo + kTlasFusedMax;
     __shared__ float s_red[2][3][kFusedThreads / 64];
     __shared__ float s_bounds[2][3];
     __shared__ uint32_t s_scan[kFusedThreads / 64];
+    __builtin_amdgcn_s_setprio(3); // a frame waits for this workgroup: it goes first where it shares its CU with other frames' trace wavefronts
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // ---- instance boxes, the arrival counters of the fit, the bounds of the boxes' centres
+    constexpr uint32_t kPer = kTlasFusedMax / kFusedThreads;
+    // ---- instance boxes, the bounds of the boxes' centres (a thread keeps its boxes' centres: the keys are made from them)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t k = tid; k < n; k += kFusedThreads) {
-        const DevBox b = instance_box(matrices, mesh_of_instance, mesh_local, valid_gids[k]);
-        inst_boxes[k] = b;
-        flags[k] = 0u;
-        for (int a = 0; a < 3; a++) {
-            const float c = 0.5f * (b.lo[a] + b.hi[a]);
-            lo[a] = fminf(lo[a], c);
-            hi[a] = fmaxf(hi[a], c);
+    float centre[kPer][3];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t k = tid + q * kFusedThreads;
+        for (int a = 0; a < 3; a++) centre[q][a] = 0.0f;
+        if (k < n) {
+            const DevBox b = instance_box(matrices, mesh_of_instance, mesh_local, valid_gids[k]);
+            inst_boxes[k] = b;
+            for (int a = 0; a < 3; a++) {
+                const float c = 0.5f * (b.lo[a] + b.hi[a]);
+                centre[q][a] = c;
+                lo[a] = fminf(lo[a], c);
+                hi[a] = fmaxf(hi[a], c);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1)
@@ -539,38 +598,103 @@ __global__ __launch_bounds__(kFusedThreads) void k_tlas_fused(const rfw_mat4* __
         s_bounds[which][a] = v;
     }
     __syncthreads();
-    // ---- (Morton key, index) pairs, padded with the largest pair to a power of two, sorted in LDS
-    uint32_t m = 2;
+    // ---- (Morton key, index) pairs, padded with the largest pair to a power of two, sorted in LDS: a bitonic network whose exchanges at
+    // distances below 16 happen in REGISTERS (a thread owns 16 consecutive pairs for those: one load and one store of its pairs stand for
+    // four — at the start ten — passes over LDS with a barrier each).  Pair e lives at word e ^ ((e >> 4) & 15): a thread's 16 consecutive
+    // pairs then lie in 16 different bank pairs across neighbouring lanes (unswizzled, all 64 lanes would hit the same two banks), and the
+    // passes at distance >= 16 stay conflict-free (the swizzle permutes inside aligned groups of 16).
+    uint32_t m = 16;
     while (m < n) m <<= 1;
+    auto phys = [](const uint32_t e) { return e ^ ((e >> 4) & 15u); };
     {
         const float blo[3] = {s_bounds[0][0], s_bounds[0][1], s_bounds[0][2]}, bhi[3] = {s_bounds[1][0], s_bounds[1][1], s_bounds[1][2]};
-        for (uint32_t k = tid; k < m; k += kFusedThreads)
-            s_pairs[k] = k < n ? ((unsigned long long)morton_key(inst_boxes[k], blo, bhi) << 32) | k : ~0ull; // (this thread wrote inst_boxes[k] itself)
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; q++) {
+            const uint32_t k = tid + q * kFusedThreads;
+            if (k < m) s_pairs[phys(k)] = k < n ? ((unsigned long long)morton_key_of_centre(centre[q], blo, bhi) << 32) | k : ~0ull;
+        }
     }
     __syncthreads();
-    for (uint32_t size = 2; size <= m; size <<= 1)
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (m >> 1); t += kFusedThreads) {
-                const uint32_t i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u)), j = i | stride;
-                const unsigned long long a = s_pairs[i], b = s_pairs[j];
-                const bool up = (i & size) == 0u;
-                if ((a > b) == up) { s_pairs[i] = b; s_pairs[j] = a; }
+    {
+        const uint32_t base = tid * kPer, rot = tid & 15u;
+        const bool mine_in = base < m;
+        unsigned long long r[kPer];
+        auto exchange = [&](const int i, const int j, const bool up) {
+            const bool sw = (r[i] > r[j]) == up;
+            const unsigned long long a_ = sw ? r[j] : r[i], b_ = sw ? r[i] : r[j];
+            r[i] = a_; r[j] = b_;
+        };
+        static_assert(kPer == 16, "the register passes below are written for 16 pairs per thread");
+        if (mine_in) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) r[q] = s_pairs[base + ((uint32_t)q ^ rot)];
+            // sizes 2 .. 16 entirely in registers
+#pragma unroll
+            for (int size = 2; size <= 16; size <<= 1)
+#pragma unroll
+                for (int stride = size >> 1; stride > 0; stride >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if ((q & stride) == 0) exchange(q, q | stride, size == 16 ? ((base & 16u) == 0u) : ((q & size) == 0));
+#pragma unroll
+            for (int q = 0; q < 16; q++) s_pairs[base + ((uint32_t)q ^ rot)] = r[q];
+        }
+        __syncthreads();
+        for (uint32_t size = 32; size <= m; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride >= 16u; stride >>= 1) {
+                for (uint32_t t = tid; t < (m >> 1); t += kFusedThreads) {
+                    const uint32_t i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u)), j = i | stride;
+                    const unsigned long long a = s_pairs[phys(i)], b = s_pairs[phys(j)];
+                    const bool up = (i & size) == 0u;
+                    if ((a > b) == up) { s_pairs[phys(i)] = b; s_pairs[phys(j)] = a; }
+                }
+                __syncthreads();
+            }
+            if (mine_in) {
+                const bool up = (base & size) == 0u;
+#pragma unroll
+                for (int q = 0; q < 16; q++) r[q] = s_pairs[base + ((uint32_t)q ^ rot)];
+#pragma unroll
+                for (int stride = 8; stride > 0; stride >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if ((q & stride) == 0) exchange(q, q | stride, up);
+#pragma unroll
+                for (int q = 0; q < 16; q++) s_pairs[base + ((uint32_t)q ^ rot)] = r[q];
             }
             __syncthreads();
         }
+    }
+    // ---- pairs -> sorted keys (s_lo) | sorted indices (s_hi), in place: every thread holds its pairs across the barrier
+    {
+        unsigned long long mine[kPer];
+        for (uint32_t q = 0; q < kPer; q++) mine[q] = tid + q * kFusedThreads < m ? s_pairs[phys(tid + q * kFusedThreads)] : 0ull;
+        __syncthreads();
+        for (uint32_t q = 0; q < kPer; q++) {
+            const uint32_t k = tid + q * kFusedThreads;
+            if (k < m) { s_lo[k] = (uint32_t)(mine[q] >> 32); s_hi[k] = (uint32_t)mine[q]; }
+        }
+    }
+    __syncthreads();
     // ---- the instance ids in leaf order; Karras' hierarchy over the sorted keys
-    const LdsKeys keys{s_pairs};
-    for (uint32_t k = tid; k < n; k += kFusedThreads) tlas_prims[k] = valid_gids[(uint32_t)s_pairs[k]];
+    const uint32_t* const keys = s_lo;
+    for (uint32_t k = tid; k < n; k += kFusedThreads) tlas_prims[k] = valid_gids[s_hi[k]];
     for (uint32_t i = tid; i + 1 < n; i += kFusedThreads) hierarchy_node(keys, (int)n, (int)i, left, right, parent);
-    __syncthreads(); // (workgroup-scope release / acquire: the stores above are visible to every wave of this workgroup)
-    // ---- bottom-up fit (the hand-off of lbvh_build's fence-free k_fit, between the waves of one workgroup here), 4-wide collapse
-    for (uint32_t i = tid; i < n; i += kFusedThreads) fit_climb<false>(inst_boxes[(uint32_t)s_pairs[i]], i, n, left, right, parent, flags, nbox);
-    // flag4[i] = internal node i lies at even depth; idx4 = its exclusive prefix sum (a thread owns 16 consecutive nodes)
-    constexpr uint32_t kPer = kTlasFusedMax / kFusedThreads;
+    __syncthreads(); // (workgroup-scope release / acquire: the stores above are visible to every wave of this workgroup; the keys are dead)
+    uint32_t* const arrivals = s_lo;
+    for (uint32_t k = tid; k < n; k += kFusedThreads) arrivals[k] = 0u;
+    __syncthreads();
+    // ---- bottom-up fit: the hand-off of lbvh_build's fence-free k_fit between the waves of one workgroup, its arrival counters in LDS
+    fit_leaves_of_thread(inst_boxes, s_hi, tid, kFusedThreads, n, left, right, parent, arrivals, nbox);
+    __syncthreads(); // (every box is published; the sorted indices are dead)
+    // ---- flag4[i] = interior node i lies at even depth (the parent chains are walked in LDS); idx4 = its exclusive prefix sum
+    uint32_t* const up = s_hi;
+    for (uint32_t i = tid; i + 1 < n; i += kFusedThreads) up[i] = parent[i];
+    __syncthreads();
     uint32_t mine[kPer], sum = 0;
-    for (uint32_t q = 0; q < kPer; q++) {
+    for (uint32_t q = 0; q < kPer; q++) { // (a thread owns 16 consecutive nodes)
         const uint32_t i = tid * kPer + q;
-        mine[q] = i + 1 < n ? even_depth(i, parent) : 0u;
+        mine[q] = i + 1 < n ? even_depth(i, up) : 0u;
         sum += mine[q];
     }
     uint32_t incl = sum;
@@ -579,7 +703,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_tlas_fused(const rfw_mat4* __
         if ((int)lane >= off) incl += v;
     }
     if (lane == 63) s_scan[wave] = incl;
-    __syncthreads(); // (also: every box of the fit has been published)
+    __syncthreads();
     uint32_t before = incl - sum;
     for (uint32_t w = 0; w < wave; w++) before += s_scan[w];
     for (uint32_t q = 0; q < kPer; q++) {
@@ -661,8 +785,8 @@ hipError_t tlas_build_fused(hipStream_t s, const rfw_mat4* matrices, const uint3
     if (L.total > workspace_bytes) return hipErrorInvalidValue;
     char* w = static_cast<char*>(workspace);
     hipLaunchKernelGGL(k_tlas_fused, dim3(1), dim3(kFusedThreads), 0, s, matrices, mesh_of_instance, mesh_local_boxes, valid_gids, n, inst_boxes, (int32_t*)(w + L.left),
-                       (int32_t*)(w + L.right), (uint32_t*)(w + L.parent), (uint32_t*)(w + L.flags), (DevBox*)(w + L.nbox), (uint32_t*)(w + L.flag4), (uint32_t*)(w + L.idx4),
-                       nodes_out, tlas_prims, node_count_out);
+                       (int32_t*)(w + L.right), (uint32_t*)(w + L.parent), (DevBox*)(w + L.nbox), (uint32_t*)(w + L.flag4), (uint32_t*)(w + L.idx4), nodes_out, tlas_prims,
+                       node_count_out);
     return hipGetLastError();
 }
 
