@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--no-baseline-configs", action="store_true",
                     help="the headline run (atrium1m, max path length 1, one GPU) also runs BASELINE.json's other single-GPU configurations — C2, C3 and the "
                          "path-traced C4 — as short child runs of this script, each with its own oracle check, and reports them in config.modes; this skips them")
-    ap.add_argument("--baseline-steps", type=int, default=120, help="timed frames of each of those child runs")
+    ap.add_argument("--baseline-steps", type=int, default=200, help="timed frames of each of those child runs")
     args = ap.parse_args()
 
     # ---- who runs the ranks.  `--gpus N` is the number of ranks, whoever starts them:

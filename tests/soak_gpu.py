@@ -9,7 +9,8 @@ slot's, visible only in a process whose earlier backends had dirtied the recycle
 test_backends_one_after_the_other_in_one_process).  After the fix 300 + 2 + 60: 0 mismatches.  A failing configuration now names its failed checks.
 Round 5 (spatial splits, the triangle test without early outs): every fourth configuration an atrium with split walls under a random threshold;
 at the end of the round (flat traversal loops, streaming ones too; k_shade in workgroups of 256 or 512) streaming runs / refills and the shade
-group are random too."""
+group are random too.
+Round 6 (queue counters in a ring, the TLAS in one workgroup, 16-byte aligned node types): the TLAS path is random too."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,6 +34,7 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     mb = int(rng.choice([0, 5]))
     be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif, max_batch=mb)
     be.set_option("spatial_splits", float(rng.choice([0.0, 8e-5, 1e-6])))
+    be.set_option("tlas_fused", int(rng.choice([0, 1, 1])))   # round 6: the one-workgroup TLAS build (2 ... 16 384 instances) or the launch chain
     orc = Oracle(w, h, threads=8, max_path_length=3)
     # round 2: the blue-noise sampler with seeded tables, extension rays in sorted order, a material edit with a `changed` bit
     bn = int(rng.integers(0, 3))
