@@ -202,6 +202,14 @@ def main():
     # N > 1 code path can be exercised on a 1-GPU box; slabs are then staged through host memory.  Default: nccl (= RCCL).
     dist_backend = os.environ.get("RFW_BENCH_DIST_BACKEND", "nccl")
 
+    # BASELINE.json's other single-GPU configurations as child runs (baseline_configs), BEFORE this process starts the HIP runtime: a second
+    # process beside one that holds its 16 hardware queues — even idle ones — oversubscribes the device's queues and runs 5-13 % slower
+    # (measured: C3 as a child of an initialised parent 5690, alone 6568 Mrays/s on the same box)
+    baseline_rows = {}
+    if (world == 1 and not args.emulate_shard and not args.no_baseline_configs and not args.no_modes and not args.rendezvous_only and args.workload == "atrium1m"
+            and args.max_path_length == 1 and (args.width, args.height) == (1920, 1080) and not args.identical_frames and not args.readback):
+        baseline_rows = baseline_configs(args)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -574,18 +582,22 @@ def main():
         B, F, use_slots = headline_setup  # (what the headline ran with: the line below describes THAT)
     # host cost of the per-frame scene update (animate + set_3d_instances + synchronize) without back-pressure
     host_sync_ms = None
+    host_render_ms = None
     if animated:
-        acc_t = 0.0
+        acc_t = acc_r = 0.0
         for i in range(20):
             torch.cuda.synchronize()
             t_s = time.perf_counter()
             scene.animate(frame_no[0] / 60.0)
             frame_no[0] += 1
             scene.sync(bes[0])
-            acc_t += time.perf_counter() - t_s
-            bes[0].render(views[0])
+            t_r = time.perf_counter()
+            acc_t += t_r - t_s
+            bes[0].render(views[0])   # (the frame slot's own instance update — staging copy, one upload, two launches — and the frame's four launches)
+            acc_r += time.perf_counter() - t_r
         bes[0].device_synchronize()
         host_sync_ms = acc_t / 20 * 1e3
+        host_render_ms = acc_r / 20 * 1e3
 
     ms_step = elapsed / args.steps * 1e3
     value = rays_total / elapsed / 1e6
@@ -754,6 +766,7 @@ def main():
                        "synchronize_s": round(sync_s, 2), "max_path_length": args.max_path_length,
                        "instances": sstats["instances"], "tlas_nodes": sstats["tlas_nodes"],
                        "per_frame_synchronize_ms": round(host_sync_ms, 3) if animated else None,
+                       "per_frame_render_call_ms": round(host_render_ms, 3) if animated else None,
                        "per_frame_synchronize_wall_ms_in_timed_region": round(sync_ms[0] / args.steps, 3) if animated else None},
             "roofline": roofline,
         }
@@ -772,12 +785,7 @@ def main():
                     res[name] = {"frame": int(vi) if name == "first" else args.steps - 1, "bit_identical": same, "rel_l2": rel}
                 res["all"] = all(v["bit_identical"] for v in res.values())
                 out["config"]["timed_frame_equals_oracle"] = res
-        if (single and not args.no_baseline_configs and not args.no_modes and args.workload == "atrium1m" and args.max_path_length == 1
-                and (w, h) == (1920, 1080) and not args.identical_frames and not args.readback):
-            for b in bes:   # (the children get the whole device)
-                b.close()
-            bes = []
-            out["config"]["modes"].update(baseline_configs(args))
+        out["config"]["modes"].update(baseline_rows)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -787,8 +795,8 @@ def main():
 
 
 def baseline_configs(args):
-    """BASELINE.json's other single-GPU configurations, each as a short run of this script in a child process (started after this process is
-    done with the device; nothing is exec'ed): C2 (Sponza-class, 262 k triangles, primary + shadow), C3 (C2 + 10 000 animated instances, the
+    """BASELINE.json's other single-GPU configurations, each as a short run of this script in a child process (one after the other, before this
+    process touches the device; nothing is exec'ed): C2 (Sponza-class, 262 k triangles, primary + shadow), C3 (C2 + 10 000 animated instances, the
     TLAS rebuilt every frame) and C4 as BASELINE.json words it (the 1 M-triangle scene path traced with NEE, max path length 3; 4 spp per call as
     one of its modes).  Every child checks its own first and last timed frame against the oracle and times the oracle on its own workload."""
     import subprocess
@@ -797,6 +805,8 @@ def baseline_configs(args):
             ("BASELINE config 3 (config 2 + 10 000 animated instances, TLAS rebuilt every frame)", ["--workload", "spheres10k"], False),
             ("BASELINE config 4 (~1 M triangles path traced with NEE, max path length 3)", ["--workload", "atrium1m", "--max-path-length", "3"], True))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if not QUEUES_SET_BY_CALLER:
+        env.pop("GPU_MAX_HW_QUEUES", None)  # (this process chose it for ITS configuration: a child chooses for its own — C3 runs 20 slots over 24 queues)
     for name, extra, with_modes in todo:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.baseline_steps), "--warmup", "20", "--no-baseline-configs",
                "--cpu-seconds", "3", "--mode-frames", "32"] + extra + ([] if with_modes else ["--no-modes"]) + (["--procedural"] if args.procedural else [])

@@ -695,7 +695,7 @@ int rfw_hip_set_option(void* inst, const char* key, double value)
         if ((int)value != 0 && (int)value != 256 && (int)value != 512) return fail(I, RFW_HIP_E_INVALID, "set_option: shade_group is 0, 256 or 512");
         I->shade_group = (int)value;
     }
-    else if (k == "tlas_fused") I->tlas_fused = value != 0.0; // 0: every instance update through the launch chain (lbvh_build) whatever the instance count
+    else if (k == "tlas_fused") I->tlas_fused = std::max(0, std::min(2, (int)value)); // 0: always the launch chain (lbvh_build); 1: always the one-workgroup build (up to 16 384 instances); 2: that where frames overlap (frame slots)
     else if (k == "sample_count") I->sample_count = (uint32_t)value;
     else if (k == "gather_format") { // 0 f32 accumulator RGB, 1 f16 finished frame, 2 presented BGRA8 (sharded frames only)
         if (value < 0 || value > 2) return fail(I, RFW_HIP_E_INVALID, "set_option: gather_format is 0, 1 or 2");

@@ -884,7 +884,8 @@ int build_instances(Instance* I, Instance* T)
     // Up to kTlasFusedMax live instances and no skinned copies (BASELINE config 3): the staging block goes up as ONE copy, the tree is built
     // by ONE workgroup (lbvh.hip, k_tlas_fused), nodes are quantised / copied per octant and the instance descriptors made by one more launch —
     // 3 API calls where the chain below takes 27, and the host thread that issues them was what bound that configuration
-    if (I->tlas_on_device && I->tlas_fused && I->derived.empty() && n_valid >= 2 && n_valid <= kTlasFusedMax) {
+    const bool fused = I->tlas_fused == 1 || (I->tlas_fused == 2 && !I->slots.empty()); // (api_internal.h: throughput with frames in flight, latency without)
+    if (I->tlas_on_device && fused && I->derived.empty() && n_valid >= 2 && n_valid <= kTlasFusedMax) {
         HIP_TRY(I, T->d_stage_dev.ensure(total));
         HIP_TRY(I, T->d_inst_boxes.ensure(n_valid));
         if ((rc = ensure_lbvh_ws(T, n_valid))) return rc;

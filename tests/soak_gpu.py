@@ -34,7 +34,7 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     mb = int(rng.choice([0, 5]))
     be = HipBackend.init(w, h, 1.0, max_path_length=3, builder=builder, frames_in_flight=fif, max_batch=mb)
     be.set_option("spatial_splits", float(rng.choice([0.0, 8e-5, 1e-6])))
-    be.set_option("tlas_fused", int(rng.choice([0, 1, 1])))   # round 6: the one-workgroup TLAS build (2 ... 16 384 instances) or the launch chain
+    be.set_option("tlas_fused", int(rng.choice([0, 1, 2])))   # round 6: the one-workgroup TLAS build (2 ... 16 384 instances) or the launch chain
     orc = Oracle(w, h, threads=8, max_path_length=3)
     # round 2: the blue-noise sampler with seeded tables, extension rays in sorted order, a material edit with a `changed` bit
     bn = int(rng.integers(0, 3))

@@ -719,6 +719,7 @@ def test_fused_tlas_build_equals_the_chain(n_inst):
     scene.set_aspect(w / h)
     view = scene.view(w, h)
     fused, chain = HipBackend.init(w, h, 1.0), HipBackend.init(w, h, 1.0)
+    fused.set_option("tlas_fused", 1)    # (the default, 2, takes the one-workgroup build only where the instance has frame slots)
     chain.set_option("tlas_fused", 0)
     orc = Oracle(w, h, threads=8)
     for frame in range(3):
@@ -750,3 +751,11 @@ def test_fused_tlas_build_equals_the_chain(n_inst):
     cc = chain.debug_read("build_counters", 20).view(np.uint32)
     assert cf[4] >= 3 and cc[4] == 0, (cf, cc)          # the fused path did run — and only where it was asked to
     fused.close(); chain.close()
+    # the default: fused where frames overlap (frame slots), the chain one frame at a time
+    for slots, want_fused in ((0, False), (3, True)):
+        be = HipBackend.init(w, h, 1.0, frames_in_flight=slots)
+        scene.mark_all_changed(); scene.sync(be)
+        be.render(view); be.device_synchronize()
+        used = int(be.debug_read("build_counters", 20).view(np.uint32)[4])
+        assert (used > 0) == want_fused, (slots, used)
+        be.close()

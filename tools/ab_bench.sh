@@ -13,7 +13,7 @@ for rep in $(seq 1 ${REPS:-2}); do for cfg in $CONFIGS; do
 import json, sys
 try:
     d = json.load(open(sys.argv[2]))
-    print(f"{sys.argv[1]:24s} {d['value']:9.1f} Mrays/s  {d['ms_per_step']:.4f} ms/frame  sync {d['config'].get('per_frame_synchronize_ms')}", flush=True)
+    print(f"{sys.argv[1]:24s} {d['value']:9.1f} Mrays/s  {d['ms_per_step']:.4f} ms/frame  sync {d['config'].get('per_frame_synchronize_ms')} render-call {d['config'].get('per_frame_render_call_ms')}", flush=True)
 except Exception as e:
     print(sys.argv[1], "FAILED", e, flush=True)
 PY
