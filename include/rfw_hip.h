@@ -211,7 +211,10 @@ RFW_HIP_API int rfw_hip_reset_accumulation(void* instance);
  *                  its idle lanes; setting it forces, the default 8 applies by "stream_auto" = 1 to single frames of an instance with >= 4 frame
  *                  slots and to batches), "stream_refill" (idle lanes that trigger a refill, 12), "stream_leaf_gate" (lanes at a leaf that
  *                  start the packet loop, 16) — images never depend on any of these
- *   builders       "sah_max_leaf", "sah_trav_cost", "build_threads" (host builder), "spill_rows" (test hook: rows of the HBM stack spill)
+ *   builders       "sah_max_leaf", "sah_trav_cost", "build_threads" (host builder), "spill_rows" (test hook: rows of the HBM stack spill),
+ *                  "spatial_splits" (threshold; 0 = off), "packet_trace" (bit 0 camera rays, bit 1 / 2 shadow rays as wavefront packets),
+ *                  "shade_group" 0 | 256 | 512, "tlas_fused" 0 | 1 | 2 (the TLAS of <= 16 384 instances by one workgroup + one finishing launch:
+ *                  never | always | where the instance has frame slots (default) — csrc/lbvh.hip, k_tlas_fused)
  *   multi-GPU      "gather_format" 0 | 1 | 2, "present_rank" r (see rfw_hip_shard_info), "p2p_timeout_ms" (see rfw_hip_p2p_*) */
 RFW_HIP_API int rfw_hip_set_option(void* instance, const char* key, double value);
 /* tonemapped frame, RGBA32F, sqrt(acc/samples) (backends/gpu-rt/shaders/blit.comp:15-23); n_floats = w*h*4 */
