@@ -120,3 +120,42 @@ def test_bench_launcher_fails_when_a_rank_fails():
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cornell"], {"HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_baseline_config_children_are_short_runs_of_the_same_script(monkeypatch):
+    """bench.py's headline run reports BASELINE.json's other single-GPU configurations (C2, C3, path-traced C4) as rows of config.modes, each
+    from a child run of the same script started BEFORE the parent touches the GPU.  No GPU here: the children are replaced by a fake that
+    records their command lines and environments and answers with a bench line."""
+    import importlib.util, json, subprocess, sys, types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec.loader.exec_module(bench)
+    seen = []
+
+    def fake_run(cmd, capture_output, text, timeout, env):
+        seen.append((cmd, env))
+        line = {"value": 1234.5, "ms_per_step": 0.5, "steps": 200, "cpu_baseline": {"value": 15.0, "cores": 16},
+                "config": {"workload": " ".join(cmd[2:]), "mode": "render() per frame, 12 frame slots", "rays_per_frame": 3000000,
+                           "timed_frame_equals_oracle": {"all": True}, "modes": {"x": {"Mrays_per_s": 1.0}, "value row": {"Mrays_per_s": 2.0, "is_value": True}}}}
+        return types.SimpleNamespace(returncode=0, stdout="noise\n" + json.dumps(line) + "\n", stderr="")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")   # as the parent sets it for ITS configuration ...
+    monkeypatch.setattr(bench, "QUEUES_SET_BY_CALLER", False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    args = types.SimpleNamespace(baseline_steps=200, procedural=False)
+    rows = bench.baseline_configs(args)
+    assert len(rows) == 3 and all(r["Mrays_per_s"] == 1234.5 and r["timed_frame_equals_oracle"]["all"] for r in rows.values())
+    kinds = [" ".join(c[0]) for c in seen]
+    assert any("--workload atrium262k" in k for k in kinds) and any("--workload spheres10k" in k for k in kinds)
+    assert any("--workload atrium1m --max-path-length 3" in k for k in kinds)
+    for cmd, env in seen:
+        assert "--no-baseline-configs" in cmd and "--gpus" in cmd and cmd[cmd.index("--steps") + 1] == "200"
+        assert "GPU_MAX_HW_QUEUES" not in env and "WORLD_SIZE" not in env   # ... a child chooses its own (C3: 20 slots over 24 queues)
+    path_traced = [r for k, r in rows.items() if "config 4" in k][0]
+    assert path_traced["modes"] == {"x": 1.0}                             # the child's own secondary modes ride along, its value row does not
+    # a child that fails costs its row, not the headline
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=3, stdout="", stderr="boom"))
+    rows = bench.baseline_configs(args)
+    assert all("error" in r for r in rows.values())
