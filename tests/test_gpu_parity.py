@@ -833,6 +833,34 @@ def test_frame_slots_with_instances_that_move_every_frame():
     be.close()
 
 
+@pytest.mark.parametrize("slots", [20, 24])
+def test_many_frame_slots_with_instances_that_move_every_frame(slots):
+    """BASELINE config 3 runs on 20 frame slots since round 6 (the library takes up to 24): 3 x slots frames queued without reading back,
+    every one with its own pose and its own TLAS on its slot (the one-workgroup build: the instance has frame slots) — the last frame and
+    three more, frame by frame, equal the oracle's.  (More slots than hardware queues only serialise: the runtime's default here is 4.)"""
+    w, h = 80, 48
+    from oracle.bindings import Oracle
+    from rfw_rs_amd import HipBackend, Scene
+    scene = Scene().build("cornell").build("spheres", 9, 7, 0.3)
+    view = scene.view(w, h)
+    be = HipBackend.init(w, h, 1.0, max_path_length=2, frames_in_flight=slots)
+    orc = Oracle(w, h, threads=4, max_path_length=2)
+    n = 3 * slots
+    for frame in range(n):
+        scene.animate(frame / 5.0)
+        scene.sync(be)
+        be.render(view)
+    scene.mark_all_changed(); scene.sync(orc); orc.reset(); orc.render(view)
+    assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32))
+    for frame in (1, slots - 1, slots + 3):
+        scene.animate(frame / 5.0)
+        scene.sync(be); scene.mark_all_changed(); scene.sync(orc)
+        orc.reset(); be.render(view); orc.render(view)
+        assert np.array_equal(be.accumulator().view(np.uint32), orc.accumulator().view(np.uint32)), frame
+    assert int(be.debug_read("build_counters", 20).view(np.uint32)[4]) >= n     # every frame's TLAS went through the fused path
+    be.close()
+
+
 def test_frame_slots_with_skinned_meshes_and_resize():
     """Skinned copies live in the owner's shared mesh buffers: with them the slots share one TLAS and synchronize() waits for the frames in
     flight before it re-skins.  Every pose must still match the oracle; resize keeps working with slots."""
