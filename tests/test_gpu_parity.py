@@ -136,6 +136,34 @@ def test_counts_and_queues_match_oracle_one_frame():
     assert (s["primary_rays"], s["extension_rays"], s["shadow_rays"]) == (o["primary"], o["extension"], o["shadow"])
 
 
+def test_queue_counters_are_those_of_the_latest_frame():
+    """Round 6: the queue counters live in a ring of two blocks per instance — a frame's k_primary clears the block of the NEXT frame instead
+    of a memset in front of every frame.  Whatever the number of frames rendered before, the counts read back are the latest frame's: two
+    views alternate (their ray counts differ), several samples accumulate, and a counting frame sits in between."""
+    from rfw_rs_amd import pod
+    w, h = 64, 64
+    scene, be, orc = make("soup", w, h, 1200, 4, seed=2, max_path_length=3)
+    va = scene.view(w, h)
+    vb = pod.CameraView3D.from_buffer_copy(va)
+    vb.pos.x += 0.4; vb.p1.x += 0.4
+    want = {}
+    for name, v in (("a", va), ("b", vb)):
+        orc.reset(); orc.render(v)
+        o = orc.stats()
+        want[name] = (o["primary"], o["extension"], o["shadow"])
+    assert want["a"] != want["b"]
+    got = lambda: tuple(be.frame_stats()[k] for k in ("primary_rays", "extension_rays", "shadow_rays"))
+    for k, name in enumerate("abbabaab"):
+        be.reset_accumulation()
+        be.render(va if name == "a" else vb)
+        assert got() == want[name], (k, name)
+        if k == 3:
+            be.set_option("count_traversal", 1); be.reset_accumulation(); be.render(vb)
+            assert got() == want["b"] and sum(be.frame_stats()["nodes_visited"]) > 0
+            be.set_option("count_traversal", 0)
+    be.close()
+
+
 def test_accumulation_reset_on_camera_change():
     w, h = 32, 32
     scene, be, orc = make("cornell", w, h)
