@@ -23,6 +23,8 @@ void read_env_switches()
     if (const char* v = getenv("RFW_SPATIAL_SPLITS")) { e.has_spatial_splits = true; e.spatial_splits = (float)std::max(0.0, atof(v)); }
     if (const char* v = getenv("RFW_PACKET_TRACE")) e.packet_trace = std::max(0, atoi(v));
     if (const char* v = getenv("RFW_NODE_ORDER")) e.node_order = std::max(0, atoi(v));
+    static std::mutex mu; // (instances may be created from several threads)
+    std::lock_guard<std::mutex> g(mu);
     g_env = e;
 }
 } // namespace rfwhip

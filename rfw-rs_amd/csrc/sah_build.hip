@@ -624,9 +624,6 @@ __global__ __launch_bounds__(kBlock) void k_partition_chunk(const DevBox* __rest
 //      its own bins, the larger child on a small stack.
 // (Round 2 finished ranges of 256 with one lane per axis sweeping the bins and one split at a time: 12.5 of the builder's 26 ms; the first
 // version of this round handed over at 64 primitives and paid for five more LEVELS of phase 1, ~0.5 ms each at 720 k primitives.)
-#ifndef RFW_SMALL_PAIR_CLOSED_FORM
-#define RFW_SMALL_PAIR_CLOSED_FORM 1
-#endif
 constexpr uint32_t kWaveRange = 64;
 constexpr int kListCap = 96;
 
@@ -661,7 +658,6 @@ template <uint32_t CAP> __device__ inline void finish_range_wave(SmallShared<CAP
 {
     int sp = 0;
     for (;;) {
-#if RFW_SMALL_PAIR_CLOSED_FORM
         if (count == 2u) {
             // Two primitives: the only possible split is one from the other (along the first axis on which their centroids differ, the
             // lower one left), its cost is the two boxes' half areas — no bins, no sweep, and both children are leaves as they stand.  Half
@@ -702,7 +698,6 @@ template <uint32_t CAP> __device__ inline void finish_range_wave(SmallShared<CAP
             wave_sync();
             continue;
         }
-#endif
         // (tried: ranges of 3 and 4 primitives by an exact search over all their bipartitions, every lane alike from the boxes in LDS — the
         // same trees, and no faster than the bins: 4.13 against 4.10 ms per build)
         const bool mine = lane < count;

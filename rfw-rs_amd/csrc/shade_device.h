@@ -75,6 +75,10 @@ struct ShadingData {
     f3 color, absorption, specular;
     float metallic, subsurface, specular_f, roughness, specular_tint, anisotropic, sheen, sheen_tint;
     float clearcoat, clearcoat_gloss, transmission, eta;
+    // Material-only terms of the two BSDF evaluations and pdfs of a hit, made once by extractParameters (round 6: inside BSDFEval / Fr they sit
+    // in lane-divergent branches, so the compiler evaluated them once per CALL — the logarithm of GTR1 and a division, twice per hit).  The
+    // same expressions in the same order: GTR1(NDotH, a) = (a^2 - 1) / ((PI * log(a^2)) * t) with a = mix(.1, .001, clearcoat_gloss); 1 / eta.
+    float cc_a, cc_a2m1, cc_pilog, inv_eta;
     uint32_t flags;
     int32_t diffuse_map, normal_map;
 };
@@ -105,6 +109,13 @@ RFW_DI ShadingData extractParameters(const rfw_device_material* m)
     d.clearcoat_gloss = CHAR2FLT(p.z, 8);
     d.transmission = CHAR2FLT(p.z, 16);
     d.eta = CHAR2FLT(p.z, 24);
+    d.cc_a = gl_mix(.1f, .001f, d.clearcoat_gloss);
+    {
+        const float a2 = d.cc_a * d.cc_a;
+        d.cc_a2m1 = a2 - 1.0f;
+        d.cc_pilog = RFW_PI * rfw_logf(a2);
+    }
+    d.inv_eta = 1.0f / d.eta;
     return d;
 }
 
@@ -128,14 +139,6 @@ RFW_DI float SchlickFresnel(float u)
     const float m = gl_clamp(1.0f - u, 0.0f, 1.0f);
     return (m * m) * (m * m) * m;
 }
-// disney.glsl:45-52
-RFW_DI float GTR1(float NDotH, float a)
-{
-    if (a >= 1.0f) return RFW_INVPI;
-    const float a2 = a * a;
-    const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-    return (a2 - 1.0f) / (RFW_PI * rfw_logf(a2) * t);
-}
 // disney.glsl:54-59
 RFW_DI float GTR2(float NDotH, float a)
 {
@@ -150,13 +153,20 @@ RFW_DI float SmithGGX(float NDotv, float alphaG)
     const float b = NDotv * NDotv;
     return 1.0f / (NDotv + __builtin_sqrtf(a + b - a * b));
 }
-// disney.glsl:68-78
-RFW_DI float Fr(float VDotN, float eio)
+// disney.glsl:45-52 (GTR1, for the clearcoat lobe's a = mix(.1, .001, clearcoat_gloss)) and disney.glsl:68-78 (Fr at the material's eta),
+// through the terms extractParameters made once (same expressions, same order)
+RFW_DI float GTR1_of(const ShadingData& sd, float NDotH)
 {
-    const float SinThetaT2 = sqr(eio) * (1.0f - VDotN * VDotN);
+    if (sd.cc_a >= 1.0f) return RFW_INVPI;
+    const float t = 1.0f + sd.cc_a2m1 * NDotH * NDotH;
+    return sd.cc_a2m1 / (sd.cc_pilog * t);
+}
+RFW_DI float Fr_of(const ShadingData& sd, float VDotN)
+{
+    const float SinThetaT2 = sqr(sd.eta) * (1.0f - VDotN * VDotN);
     if (SinThetaT2 > 1.0f) return 1.0f;
     const float LDotN = __builtin_sqrtf(1.0f - SinThetaT2);
-    const float eta = 1.0f / eio;
+    const float eta = sd.inv_eta;
     const float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
     const float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
     return 0.5f * (sqr(r1) + sqr(r2));
@@ -175,7 +185,7 @@ RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi)
     if (dot(wi, N) <= 0.0f) {
         brdfPdf = RFW_INV2PI * sd.subsurface * 0.5f;
     } else {
-        const float F = Fr(dot(N, wo), sd.eta);
+        const float F = Fr_of(sd, dot(N, wo));
         const f3 halfway = SafeNormalize(wi + wo);
         const float cosThetaHalf = gl_abs(dot(halfway, N));
         const float pdfHalf = GTR2(cosThetaHalf, sd.roughness) * cosThetaHalf;
@@ -202,12 +212,12 @@ RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool back
     f3 brdf = mk3(0.0f);
     if (sd.transmission > 0.0f) {
         if (NDotL <= 0.0f) {
-            const float F = Fr(NDotV, sd.eta);
+            const float F = Fr_of(sd, NDotV);
             bsdf = mk3((1.0f - F) / gl_abs(NDotL) * (1.0f - sd.metallic) * sd.transmission);
         } else {
             const float a = sd.roughness;
             const float Ds = GTR2(NDotH, a);
-            const float FH = Fr(LDotH, sd.eta);
+            const float FH = Fr_of(sd, LDotH);
             const f3 Fs = gl_mix(Cspec0, mk3(1.0f), FH);
             const float Gs = SmithGGX(NDotV, a) * SmithGGX(NDotL, a);
             bsdf = (Gs * Ds) * Fs;
@@ -230,7 +240,7 @@ RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool back
             const float FL = SchlickFresnel(NDotL), FV = SchlickFresnel(NDotV);
             const float Fd90 = 0.5f + 2.0f * LDotH * LDotH * a;
             const float Fd = gl_mix(1.0f, Fd90, FL) * gl_mix(1.0f, Fd90, FV);
-            const float Dr = GTR1(NDotH, gl_mix(.1f, .001f, sd.clearcoat_gloss));
+            const float Dr = GTR1_of(sd, NDotH);
             const float Fc = gl_mix(.04f, 1.0f, FH);
             const float Gr = SmithGGX(NDotL, .25f) * SmithGGX(NDotV, .25f);
             brdf = RFW_INVPI * Fd * Cdlin * (1.0f - sd.metallic) * (1.0f - sd.subsurface) + Gs * Fs * Ds + mk3(sd.clearcoat * Gr * Fc * Dr);
@@ -247,7 +257,7 @@ RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool back
 RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, float& pdf, int& type, float r3, float r4)
 {
     if (r3 < sd.transmission) {
-        const float F = Fr(dot(N, wo), sd.eta);
+        const float F = Fr_of(sd, dot(N, wo));
         if (r4 < F) {
             const float r1 = r3 / sd.transmission;
             const float r2 = r4 / F;
