@@ -830,6 +830,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                         N = normalize((T * m.x + B * m.y) + N * m.z); // mat3(T, B, N) * m
                     }
                 }
+                prepare_tint(sd);
                 const bool backFacing = dot(D, gN) >= 0.0f;
                 if (backFacing) {
                     N = N * -1.0f;
@@ -848,7 +849,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                     r1 = randf(seed);
                     r2 = randf(seed);
                 }
-                const f3 bsdf = SampleBSDF(sd, N, gN, T, B, D * -1.0f, T_VAL, backFacing, r1, r2, R, newBsdfPdf);
+                const float F_gN = Fr_of(sd, dot(gN, D * -1.0f)); // the Fresnel term both pdfs of this hit use (sampled direction, light direction: same normal, same wo)
+                const f3 bsdf = SampleBSDF(sd, N, gN, T, B, D * -1.0f, T_VAL, backFacing, r1, r2, R, newBsdfPdf, F_gN);
                 throughput = throughput * bsdf * gl_abs(dot(N, R));
                 throughput = gl_max(throughput, mk3(0.0f));
                 if (!(newBsdfPdf <= 1e-4f || gl_isnan(newBsdfPdf))) {
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const CameraParams cam, c
                         const float NdotL = dot(L, N);
                         if (NdotL > 0.0f && lightPdf > 0.0f) {
                             float shadowPdf = 0.0f;
-                            const f3 sampledBSDF = EvaluateBSDF(sd, gN, D * -1.0f, L, shadowPdf);
+                            const f3 sampledBSDF = EvaluateBSDF(sd, gN, D * -1.0f, L, shadowPdf, F_gN);
                             if (shadowPdf > 0.0f) {
                                 f3 contribution = throughput * sampledBSDF * lightColor * (NdotL / (lightPdf * pickProb));
                                 if (!(gl_isnan(contribution.x) || gl_isnan(contribution.y) || gl_isnan(contribution.z))) {
@@ -1523,7 +1525,8 @@ __global__ __launch_bounds__(64) void k_eval_shading(const SceneDev sc, const Ca
     const float* q = in + 48u * i;
     float* r = out + 12u * i;
     for (int k = 0; k < 12; k++) r[k] = 0.0f;
-    const ShadingData sd = extractParameters(reinterpret_cast<const rfw_device_material*>(q));
+    ShadingData sd = extractParameters(reinterpret_cast<const rfw_device_material*>(q));
+    prepare_tint(sd);
     const f3 N = mk3(q[24], q[25], q[26]), wo = mk3(q[27], q[28], q[29]), wi = mk3(q[30], q[31], q[32]);
     const f3 T = mk3(q[33], q[34], q[35]), B = mk3(q[36], q[37], q[38]);
     if (op == 0) {

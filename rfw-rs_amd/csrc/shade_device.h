@@ -79,6 +79,7 @@ struct ShadingData {
     // in lane-divergent branches, so the compiler evaluated them once per CALL — the logarithm of GTR1 and a division, twice per hit).  The
     // same expressions in the same order: GTR1(NDotH, a) = (a^2 - 1) / ((PI * log(a^2)) * t) with a = mix(.1, .001, clearcoat_gloss); 1 / eta.
     float cc_a, cc_a2m1, cc_pilog, inv_eta;
+    f3 cspec0; // prepare_tint(): Cspec0 of BSDFEval from the (textured) colour
     uint32_t flags;
     int32_t diffuse_map, normal_map;
 };
@@ -178,15 +179,26 @@ RFW_DI f3 SafeNormalize(f3 a)
     if (ls > 0.0f) return a * (1.0f / __builtin_sqrtf(ls));
     return mk3(0.0f);
 }
+// The half vector of a (wi, wo) pair, as far as BOTH the pdf (SafeNormalize, disney.glsl:80-87) and the evaluation (normalize) need it: the sum,
+// its squared length and 1 / its length — one square root and one division per pair instead of one per function (round 6)
+struct HalfVec { f3 v; float ls, inv; };
+RFW_DI HalfVec half_of(f3 wi, f3 wo)
+{
+    HalfVec h;
+    h.v = wi + wo;
+    h.ls = dot(h.v, h.v);
+    h.inv = 1.0f / __builtin_sqrtf(h.ls);
+    return h;
+}
 // disney.glsl:89-108
-RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi)
+// `F` = Fr_of(sd, dot(N, wo)): it does not depend on wi, and a hit evaluates this pdf for two directions over the same N and wo
+RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi, const HalfVec& hh, const float F)
 {
     float bsdfPdf = 0.0f, brdfPdf;
     if (dot(wi, N) <= 0.0f) {
         brdfPdf = RFW_INV2PI * sd.subsurface * 0.5f;
     } else {
-        const float F = Fr_of(sd, dot(N, wo));
-        const f3 halfway = SafeNormalize(wi + wo);
+        const f3 halfway = hh.ls > 0.0f ? hh.v * hh.inv : mk3(0.0f); // SafeNormalize(wi + wo)
         const float cosThetaHalf = gl_abs(dot(halfway, N));
         const float pdfHalf = GTR2(cosThetaHalf, sd.roughness) * cosThetaHalf;
         const float pdfSpec = 0.25f * pdfHalf / gl_max(1.e-6f, dot(wi, halfway));
@@ -196,18 +208,24 @@ RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi)
     }
     return gl_mix(brdfPdf, bsdfPdf, sd.transmission);
 }
-// disney.glsl:110-195
-RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool backfacing)
+RFW_DI float BSDFPdf(const ShadingData& sd, f3 N, f3 wo, f3 wi) { return BSDFPdf(sd, N, wo, wi, half_of(wi, wo), Fr_of(sd, dot(N, wo))); }
+RFW_DI void prepare_tint(ShadingData& sd)
 {
-    const float NDotL = dot(N, wi);
-    const float NDotV = dot(N, wo);
-    const f3 H = normalize(wi + wo);
-    const float NDotH = dot(N, H);
-    const float LDotH = dot(wi, H);
     const f3 Cdlin = sd.color;
     const float Cdlum = .3f * Cdlin.x + .6f * Cdlin.y + .1f * Cdlin.z;
     const f3 Ctint = Cdlum > 0.0f ? Cdlin / Cdlum : mk3(1.0f);
-    const f3 Cspec0 = gl_mix(sd.specular * .08f * gl_mix(mk3(1.0f), Ctint, sd.specular_tint), Cdlin, sd.metallic);
+    sd.cspec0 = gl_mix(sd.specular * .08f * gl_mix(mk3(1.0f), Ctint, sd.specular_tint), Cdlin, sd.metallic);
+}
+// disney.glsl:110-195
+RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool backfacing, const HalfVec& hh)
+{
+    const float NDotL = dot(N, wi);
+    const float NDotV = dot(N, wo);
+    const f3 H = hh.v * hh.inv; // normalize(wi + wo)
+    const float NDotH = dot(N, H);
+    const float LDotH = dot(wi, H);
+    const f3 Cdlin = sd.color;
+    const f3 Cspec0 = sd.cspec0;
     f3 bsdf = mk3(0.0f);
     f3 brdf = mk3(0.0f);
     if (sd.transmission > 0.0f) {
@@ -253,8 +271,10 @@ RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool back
     }
     return fin;
 }
-// disney.glsl:197-263
-RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, float& pdf, int& type, float r3, float r4)
+RFW_DI f3 BSDFEval(const ShadingData& sd, f3 N, f3 wo, f3 wi, float t, bool backfacing) { return BSDFEval(sd, N, wo, wi, t, backfacing, half_of(wi, wo)); }
+// disney.glsl:197-263.  Returns whether the pdf is still to be evaluated (BSDFPdf of the sampled direction): the callers do that with the half
+// vector they share with the evaluation
+RFW_DI bool BSDFSampleDirection(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, float& pdf, int& type, float r3, float r4)
 {
     if (r3 < sd.transmission) {
         const float F = Fr_of(sd, dot(N, wo));
@@ -275,7 +295,7 @@ RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, f
                 type = BSDF_TYPE_SPECULAR;
                 pdf = (1.0f - F) * sd.transmission;
             }
-            return;
+            return false;
         }
     } else {
         const float r1 = (r3 - sd.transmission) / (1.0f - sd.transmission);
@@ -310,21 +330,30 @@ RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, f
             type = BSDF_TYPE_REFLECTED;
         }
     }
-    pdf = BSDFPdf(sd, N, wo, wi);
+    return true;
+}
+RFW_DI void BSDFSample(const ShadingData& sd, f3 T, f3 B, f3 N, f3 wo, f3& wi, float& pdf, int& type, float r3, float r4)
+{
+    if (BSDFSampleDirection(sd, T, B, N, wo, wi, pdf, type, r3, r4)) pdf = BSDFPdf(sd, N, wo, wi);
 }
 // disney.glsl:265-270
-RFW_DI f3 EvaluateBSDF(const ShadingData& sd, f3 iN, f3 wo, f3 wi, float& pdf)
+// (`F_of_iN` = Fr_of(sd, dot(iN, wo)); k_shade has it from the sampling step, whose pdf is taken over the same normal)
+RFW_DI f3 EvaluateBSDF(const ShadingData& sd, f3 iN, f3 wo, f3 wi, float& pdf, const float F_of_iN)
 {
-    const f3 bsdf = BSDFEval(sd, iN, wo, wi, 0.0f, false);
-    pdf = BSDFPdf(sd, iN, wo, wi);
+    const HalfVec hh = half_of(wi, wo);
+    const f3 bsdf = BSDFEval(sd, iN, wo, wi, 0.0f, false, hh);
+    pdf = BSDFPdf(sd, iN, wo, wi, hh, F_of_iN);
     return bsdf;
 }
 // disney.glsl:272-283
-RFW_DI f3 SampleBSDF(const ShadingData& sd, f3 iN, f3 N, f3 T, f3 B, f3 wo, float t, bool backfacing, float r3, float r4, f3& wi, float& pdf)
+// (`F_of_N` = Fr_of(sd, dot(N, wo)), N the normal the direction is sampled and its pdf taken over)
+RFW_DI f3 SampleBSDF(const ShadingData& sd, f3 iN, f3 N, f3 T, f3 B, f3 wo, float t, bool backfacing, float r3, float r4, f3& wi, float& pdf, const float F_of_N)
 {
     int type = BSDF_TYPE_REFLECTED;
-    BSDFSample(sd, T, B, N, wo, wi, pdf, type, r3, r4);
-    return BSDFEval(sd, iN, wo, wi, t, backfacing);
+    const bool pdf_to_do = BSDFSampleDirection(sd, T, B, N, wo, wi, pdf, type, r3, r4);
+    const HalfVec hh = half_of(wi, wo);
+    if (pdf_to_do) pdf = BSDFPdf(sd, N, wo, wi, hh, F_of_N);
+    return BSDFEval(sd, iN, wo, wi, t, backfacing, hh);
 }
 
 // ---- texture sampling (shade.comp:268-281) with the sampler of gpu-rt/src/lib.rs:1026-1038: repeat addressing, linear at LOD 0,
