@@ -1,0 +1,56 @@
+"""The device builder's workgroup phase (k_small of csrc/sah_build.hip: a range of <= 512 primitives finished inside one workgroup, wave-
+synchronously) run on the CPU: tests/emu/wave_emu.h gives the kernel's SOURCE TEXT one OS thread per lane and makes every cross-lane operation
+(ballot, shuffles, DPP row operations, wave and workgroup barriers) a meeting of the wavefront's threads; tests/emu/k_small_emu.cpp compares
+the tree the kernel builds, node for node, with a serial restatement of the binned SAH it implements.  No GPU, no oracle: host logic of the
+device builder, checked here so that a change to the kernel is checked BEFORE it first runs on a device (a kernel that loops forever, or a
+tree with a cycle under the traversal kernels, takes the GPU box down with it)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+sys.path.insert(0, EMU)
+
+# capacity (= workgroup size), primitives, seed, kind of boxes (0 random, 1 lattice: equal costs and centroids, 2 two thirds share a centroid,
+# 3 flat and collinear, 4 very uneven), largest leaf, traversal cost
+CASES = [(256, 1, 1, 0, 8, 1.0), (256, 2, 2, 2, 1, 1.0), (256, 3, 3, 0, 8, 1.0), (256, 17, 4, 1, 8, 1.0), (256, 64, 5, 0, 8, 1.0), (256, 65, 6, 4, 1, 1.0),
+         (256, 100, 7, 2, 1, 1.0), (256, 200, 8, 3, 8, 0.5), (256, 256, 9, 0, 8, 1.0), (256, 256, 10, 1, 20, 2.0), (512, 300, 11, 0, 8, 1.0),
+         (512, 512, 12, 4, 4, 1.0)]
+
+
+def build_harness(tmp, source=None):
+    import extract
+    extract.extract(os.path.join(tmp, "k_small_extract.inc"), source)
+    exe = os.path.join(tmp, "k_small_emu")
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-pthread", "-I", EMU, "-I", tmp, "-o", exe, os.path.join(EMU, "k_small_emu.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def run_cases(exe):
+    for case in CASES:
+        r = subprocess.run([exe] + [str(x) for x in case], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), (case, r.stdout[-500:], r.stderr[-500:])
+        if case[1] >= 2 and case[4] == 1:   # largest leaf 1: a binary tree with a leaf per primitive
+            assert "leaves=%d " % case[1] in r.stdout, (case, r.stdout)
+
+
+def test_workgroup_phase_of_the_device_builder_equals_its_serial_restatement(tmp_path):
+    run_cases(build_harness(str(tmp_path)))
+
+
+def test_level_at_a_time_variant_of_the_workgroup_phase_builds_the_same_trees(tmp_path):
+    """experiments/segment_levels: the sub-ranges of <= 16 primitives finished one LEVEL per trip by all lanes of the wavefront instead of one
+    split after the other.  Not shipped (never run on a device: see its README); the same restatement holds for it."""
+    patch = os.path.join(ROOT, "experiments", "segment_levels", "segment_levels.patch")
+    src = os.path.join(str(tmp_path), "sah_build.hip")
+    with open(os.path.join(ROOT, "rfw-rs_amd", "csrc", "sah_build.hip")) as f, open(src, "w") as g:
+        g.write(f.read())
+    r = subprocess.run(["patch", "-p3", "-s", src, patch], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "finish_segments_wave" in open(src).read()
+    run_cases(build_harness(str(tmp_path), src))
