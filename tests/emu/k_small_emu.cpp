@@ -145,12 +145,18 @@ template <uint32_t CAP> int run(uint32_t n, uint32_t seed, int kind, int max_lea
         if (kind == 2 && i % 3) { c[0] = 1.0f; c[1] = 2.0f; c[2] = 3.0f; }                                                 // two thirds share one centroid
         if (kind == 3) { c[1] = 0.25f * c[0]; c[2] = 0.0f; e[2] = 0.0f; }                                                    // flat and nearly collinear
         if (kind == 4) for (int a = 0; a < 3; a++) c[a] = std::pow(U(rng), 6.0f) * 100.0f;                                // very uneven
+        if (kind == 5) { // pairs at exponentially growing distances: the SAH peels them off one pair at a time (more than kListCap sub-ranges)
+            const float d = std::pow(1.3f, (float)(i / 2));
+            c[0] = d; c[1] = 0.37f * d; c[2] = -0.11f * d;
+            for (int a = 0; a < 3; a++) { c[a] += 0.01f * d * (float)(i & 1u); e[a] = 0.004f * d; }
+        }
         for (int a = 0; a < 3; a++) { boxes[i].lo[a] = c[a] - e[a]; boxes[i].hi[a] = c[a] + e[a]; }
         boxes[i].lo[3] = boxes[i].hi[3] = 0.0f;
     }
     std::vector<uint32_t> order_in(n), order_out(n, 0xffffffffu), small(1, 0u);
     for (uint32_t i = 0; i < n; i++) order_in[i] = i;
     std::shuffle(order_in.begin(), order_in.end(), rng);
+    if (std::getenv("K_SMALL_EMU_VERBOSE")) std::fprintf(stderr, "kind %d\n", kind);
     const uint32_t n_nodes = 1 + 2 * n;
     std::vector<SNode> nodes(n_nodes);
     std::memset(nodes.data(), 0xff, nodes.size() * sizeof(SNode));
