@@ -21,5 +21,21 @@ def extract(out_path, source=None):
     open(out_path, "w").write("\n".join(parts))
 
 
+def extract_tlas(out_path, source=None):
+    """The fused TLAS build (k_tlas_fused of rfw-rs_amd/csrc/lbvh.hip) and the device functions it is made of."""
+    src = open(source or os.path.join(ROOT, "rfw-rs_amd", "csrc", "lbvh.hip")).read()
+    parts = [
+        cut(src, "__device__ inline uint32_t f_order(float f)", "__global__ void k_init_bounds"),
+        cut(src, "__device__ inline uint32_t expand10(uint32_t v)", "__global__ void k_morton"),
+        cut(src, "// longest common prefix of keys i and j", "__global__ void k_hierarchy"),
+        cut(src, "__device__ inline uint32_t node_slot(", "// bottom-up fit.  nbox[slot]"),
+        cut(src, "// The same fit for ONE workgroup whose threads own several leaves each", "__global__ void k_flag_even_depth"),
+        cut(src, "__device__ inline void emit4_node(", "__global__ void k_emit4"),
+        cut(src, "__device__ inline DevBox instance_box(", "__global__ void k_instance_boxes"),
+        cut(src, "constexpr uint32_t kFusedThreads = 1024;", "inline uint32_t blocks(uint32_t n)"),
+    ]
+    open(out_path, "w").write("\n".join(parts))
+
+
 if __name__ == "__main__":
     extract(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

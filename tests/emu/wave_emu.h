@@ -2,7 +2,7 @@
 // wave-synchronous kernel (the text of rfw-rs_amd/csrc/sah_build.hip's phase 2, cut out by tests/test_builder_emulated.py) under g++.
 //
 // One OS thread per lane.  Everything that crosses lanes on the GPU is a collective here — the lanes of a wavefront meet at a barrier, publish
-// their operand, meet again, read their source lane's: __ballot, __shfl, __shfl_xor, readlane / readfirstlane, the DPP row operations
+// their operand, read their source lane's: __ballot, __shfl, __shfl_xor, readlane / readfirstlane, the DPP row operations
 // (update_dpp with row_shr / row_shl / row_bcast:15 / row_bcast:31, the controls the builder uses), and the wave barrier of wave_sync().
 // Between collectives the lanes run free, so an LDS hand-over between lanes that the kernel forgot to fence with wave_sync() (on the GPU: left
 // to instruction order and the compiler's mercy) shows up here as a race.  LDS is a function-local static (one workgroup at a time), LDS and
@@ -13,6 +13,7 @@
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -28,7 +29,8 @@ namespace emu {
 struct Dim { unsigned x = 0, y = 0, z = 0; };
 struct WaveCtx {
     std::barrier<> bar{64};
-    uint32_t slot[64];
+    uint32_t slot[2][64]; // two sets, used in turn: ONE meeting per collective (a lane can only be writing set p again after every lane has
+                          // arrived at the collective in between, i.e. has finished reading set p)
 };
 struct GroupCtx {
     std::unique_ptr<std::barrier<>> bar;
@@ -36,6 +38,7 @@ struct GroupCtx {
 };
 inline thread_local Dim t_thread, t_block;
 inline thread_local WaveCtx* t_wave = nullptr;
+inline thread_local unsigned t_phase = 0; // the same in every lane of a wavefront: every lane takes part in every collective
 inline thread_local GroupCtx* t_group = nullptr;
 inline unsigned lane() { return t_thread.x & 63u; }
 
@@ -43,12 +46,11 @@ inline unsigned lane() { return t_thread.x & 63u; }
 template <class F> inline uint32_t exchange(uint32_t v, uint32_t old, F src)
 {
     WaveCtx& w = *t_wave;
-    w.slot[lane()] = v;
+    uint32_t* const slot = w.slot[t_phase++ & 1u];
+    slot[lane()] = v;
     w.bar.arrive_and_wait();
     const int s = src((int)lane());
-    const uint32_t r = s < 0 ? old : w.slot[s & 63];
-    w.bar.arrive_and_wait();
-    return r;
+    return s < 0 ? old : slot[s & 63];
 }
 
 // run kernel(args...) for one workgroup of `threads` threads with blockIdx.x = block
@@ -60,7 +62,7 @@ template <class K> inline void run_group(unsigned threads, unsigned block, K ker
     std::vector<std::thread> th;
     for (unsigned t = 0; t < threads; t++)
         th.emplace_back([&, t] {
-            t_thread.x = t; t_block.x = block; t_group = &g; t_wave = g.waves[t / 64].get();
+            t_thread.x = t; t_block.x = block; t_group = &g; t_wave = g.waves[t / 64].get(); t_phase = 0;
             kernel();
         });
     for (auto& x : th) x.join();
@@ -95,11 +97,11 @@ inline uint32_t atomicMax(uint32_t* p, uint32_t v)
 inline unsigned long long __ballot(bool p)
 {
     emu::WaveCtx& w = *emu::t_wave;
-    w.slot[emu::lane()] = p ? 1u : 0u;
+    uint32_t* const slot = w.slot[emu::t_phase++ & 1u];
+    slot[emu::lane()] = p ? 1u : 0u;
     w.bar.arrive_and_wait();
     unsigned long long m = 0;
-    for (int i = 0; i < 64; i++) m |= (unsigned long long)(w.slot[i] & 1u) << i;
-    w.bar.arrive_and_wait();
+    for (int i = 0; i < 64; i++) m |= (unsigned long long)(slot[i] & 1u) << i;
     return m;
 }
 inline int __shfl(int v, int src) { return (int)emu::exchange((uint32_t)v, 0u, [&](int) { return src & 63; }); }
@@ -132,5 +134,16 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
         std::abort();
     });
 }
+inline int __shfl_down(int v, int off) { return (int)emu::exchange((uint32_t)v, (uint32_t)v, [&](int l) { return l + off < 64 ? l + off : -1; }); }
+inline float __shfl_down(float v, int off) { return __int_as_float(__shfl_down(__float_as_int(v), off)); }
+inline uint32_t __shfl_up(uint32_t v, int off) { return emu::exchange(v, v, [&](int l) { return l - off >= 0 ? l - off : -1; }); }
+inline int __clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+struct alignas(16) float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+// scoped atomics: the scope is dropped (one process), the order kept
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline void __builtin_amdgcn_wave_barrier() { emu::t_wave->bar.arrive_and_wait(); }
