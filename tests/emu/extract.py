@@ -37,5 +37,14 @@ def extract_tlas(out_path, source=None):
     open(out_path, "w").write("\n".join(parts))
 
 
+def whole_file(out_path, name, source=None):
+    """A .hip file of the product as it stands, for a harness that compiles all of it against tests/emu/fake_hip; the one thing g++ cannot take
+    is gfx950 assembly: the `s_waitcnt` statements (drain this wave's stores) become full fences."""
+    src = open(source or os.path.join(ROOT, "rfw-rs_amd", "csrc", name)).read()
+    src = src.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', "__atomic_thread_fence(__ATOMIC_SEQ_CST);")
+    assert "asm volatile" not in src, "an assembly statement the emulation does not know"
+    open(out_path, "w").write(src)
+
+
 if __name__ == "__main__":
     extract(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -5,6 +5,7 @@
 // range fits a leaf, stable partition).  Node for node: same ranges, same boxes, same primitive order.
 //   usage: k_small_emu <cap: 256 | 512> <primitives> <seed> <kind> <max_leaf> <trav_cost>      prints "OK nodes=<n> leaves=<n> depth=<n>" or the first difference
 #include "wave_emu.h"
+#include "sah_reference.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -22,95 +23,8 @@ namespace {
 
 using namespace rfwhip;
 
+using namespace sahref;
 namespace {
-struct RefNode { uint32_t first, count; float lo[3], hi[3]; int left; };
-std::vector<RefNode> g_ref;
-std::vector<uint32_t> g_order; // position -> primitive
-const DevBox* g_boxes;
-int g_max_leaf;
-float g_trav;
-
-float ha(const float* lo, const float* hi)
-{
-    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-    if (!(ex >= 0.0f) || !(ey >= 0.0f) || !(ez >= 0.0f)) return 0.0f;
-    return ex * ey + ey * ez + ez * ex;
-}
-int ref_bin(float c, float lo, float hi)
-{
-    if (!(hi > lo)) return 0;
-    int b = (int)((c - lo) * (16.0f / (hi - lo)));
-    return b < 0 ? 0 : (b > 15 ? 15 : b);
-}
-struct RBin { uint32_t n = 0; float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}; };
-void grow(RBin& b, const RBin& o)
-{
-    b.n += o.n;
-    for (int c = 0; c < 3; c++) { b.lo[c] = std::min(b.lo[c], o.lo[c]); b.hi[c] = std::max(b.hi[c], o.hi[c]); }
-}
-
-void ref_build(int node)
-{
-    const uint32_t first = g_ref[node].first, count = g_ref[node].count;
-    if (count <= 1) return;
-    float nlo[3], nhi[3];
-    for (int a = 0; a < 3; a++) { nlo[a] = g_ref[node].lo[a]; nhi[a] = g_ref[node].hi[a]; }
-    std::vector<float> cen(3 * count);
-    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = 0; i < count; i++) {
-        const DevBox& b = g_boxes[g_order[first + i]];
-        for (int a = 0; a < 3; a++) { const float c = 0.5f * (b.lo[a] + b.hi[a]); cen[3 * i + a] = c; clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c); }
-    }
-    RBin bins[3][16];
-    std::vector<int> bin(3 * count);
-    for (uint32_t i = 0; i < count; i++) {
-        const DevBox& b = g_boxes[g_order[first + i]];
-        RBin one; one.n = 1;
-        for (int c = 0; c < 3; c++) { one.lo[c] = b.lo[c]; one.hi[c] = b.hi[c]; }
-        for (int a = 0; a < 3; a++) { bin[3 * i + a] = ref_bin(cen[3 * i + a], clo[a], chi[a]); grow(bins[a][bin[3 * i + a]], one); }
-    }
-    float best = INFINITY; int axis = -1, plane = -1; RBin bl, br;
-    for (int a = 0; a < 3; a++)
-        for (int p = 0; p < 15; p++) {
-            RBin l, r;
-            for (int k = 0; k <= p; k++) grow(l, bins[a][k]);
-            for (int k = p + 1; k < 16; k++) grow(r, bins[a][k]);
-            if (!l.n || !r.n) continue;
-            const float cost = (float)l.n * ha(l.lo, l.hi) + (float)r.n * ha(r.lo, r.hi);
-            if (axis < 0 || cost < best) { best = cost; axis = a; plane = p; bl = l; br = r; }
-        }
-    const float area = ha(nlo, nhi), leaf_cost = (float)count * area;
-    bool split = false, halves = false;
-    if (axis >= 0 && (best + g_trav * area < leaf_cost || (int)count > g_max_leaf)) split = true;
-    else if ((int)count > g_max_leaf) { split = true; halves = true; }
-    if (!split) return;
-    uint32_t lc;
-    RefNode l{}, r{};
-    if (halves) {
-        lc = count / 2;
-        for (int a = 0; a < 3; a++) { l.lo[a] = r.lo[a] = nlo[a]; l.hi[a] = r.hi[a] = nhi[a]; }
-        if (count == 2)
-            for (int a = 0; a < 3; a++) {
-                l.lo[a] = g_boxes[g_order[first]].lo[a]; l.hi[a] = g_boxes[g_order[first]].hi[a];
-                r.lo[a] = g_boxes[g_order[first + 1]].lo[a]; r.hi[a] = g_boxes[g_order[first + 1]].hi[a];
-            }
-    } else {
-        lc = bl.n;
-        for (int a = 0; a < 3; a++) { l.lo[a] = bl.lo[a]; l.hi[a] = bl.hi[a]; r.lo[a] = br.lo[a]; r.hi[a] = br.hi[a]; }
-        std::vector<uint32_t> left, right;
-        for (uint32_t i = 0; i < count; i++) (bin[3 * i + axis] <= plane ? left : right).push_back(g_order[first + i]);
-        std::copy(left.begin(), left.end(), g_order.begin() + first);
-        std::copy(right.begin(), right.end(), g_order.begin() + first + left.size());
-    }
-    l.first = first; l.count = lc; l.left = -1;
-    r.first = first + lc; r.count = count - lc; r.left = -1;
-    const int li = (int)g_ref.size();
-    g_ref.push_back(l); g_ref.push_back(r);
-    g_ref[node].left = li;
-    ref_build(li);
-    ref_build(li + 1);
-}
-
 int g_nodes = 0, g_leaves = 0, g_depth = 0;
 bool compare(const SNode* dev, uint32_t d, int r, const uint32_t* order_out, int depth, uint32_t n_dev_nodes)
 {
@@ -169,7 +83,8 @@ template <uint32_t CAP> int run(uint32_t n, uint32_t seed, int kind, int max_lea
     Counters ctr{};
     ctr.node_count = 1; ctr.n_small = 1;
     // reference first (it permutes its own copy of the order)
-    g_boxes = boxes.data(); g_max_leaf = max_leaf; g_trav = trav;
+    static_assert(sizeof(Box) == sizeof(DevBox), "");
+    g_boxes = reinterpret_cast<const Box*>(boxes.data()); g_max_leaf = max_leaf; g_trav = trav;
     g_order = order_in;
     g_ref.clear();
     RefNode rr{}; rr.first = 0; rr.count = n; rr.left = -1;

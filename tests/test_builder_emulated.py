@@ -17,14 +17,14 @@ sys.path.insert(0, EMU)
 # capacity (= workgroup size), primitives, seed, kind of boxes (0 random, 1 lattice: equal costs and centroids, 2 two thirds share a centroid,
 # 3 flat and collinear, 4 very uneven, 5 pairs at exponentially growing distances: a tree 38 levels deep), largest leaf, traversal cost
 CASES = [(256, 1, 1, 0, 8, 1.0), (256, 2, 2, 2, 1, 1.0), (256, 17, 4, 1, 8, 1.0), (256, 64, 5, 0, 8, 1.0), (256, 65, 6, 4, 1, 1.0), (256, 100, 7, 2, 1, 1.0),
-         (256, 130, 8, 3, 8, 0.5), (256, 256, 9, 0, 8, 1.0), (256, 128, 13, 5, 8, 1.0), (512, 300, 11, 4, 4, 1.0)]
-FEWER = [c for c in CASES if c[1] <= 128] + [(256, 256, 9, 0, 8, 1.0)]
+         (256, 130, 8, 3, 8, 0.5), (256, 128, 13, 5, 8, 1.0), (512, 300, 11, 4, 4, 1.0)]
+FEWER = [c for c in CASES if c[1] <= 128] + [(256, 256, 9, 0, 8, 1.0)]   # (the variant is several times quicker under the emulator, too)
 
 
 def compile_harness(tmp, name):
     exe = os.path.join(tmp, name)
-    r = subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-pthread", "-Wno-unknown-pragmas", "-I", EMU, "-I", tmp,
-                        "-I", os.path.join(ROOT, "rfw-rs_amd", "csrc"), "-o", exe, os.path.join(EMU, name + ".cpp")], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-pthread", "-Wno-unknown-pragmas", "-x", "c++", "-I", tmp, "-I", os.path.join(EMU, "fake_hip"),
+                        "-I", EMU, "-I", os.path.join(ROOT, "rfw-rs_amd", "csrc"), "-o", exe, os.path.join(EMU, name + ".cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe
 
@@ -70,4 +70,18 @@ def test_one_workgroup_tlas_build_equals_its_serial_restatement(tmp_path):
     exe = compile_harness(str(tmp_path), "tlas_fused_emu")
     for case in [(2, 1, 0), (3, 1, 0), (16, 8, 0), (17, 1, 0), (33, 9, 2), (777, 3, 2), (1000, 2, 1), (5000, 4, 3), (10000, 5, 0), (16383, 7, 0), (16384, 6, 1)]:
         r = subprocess.run([exe] + [str(x) for x in case], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), (case, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_device_sah_builder_as_a_whole_equals_the_serial_binned_sah(tmp_path):
+    """csrc/sah_build.hip — the file: host side, level kernels, workgroup phase, emission — compiled against tests/emu/fake_hip (a launch runs its
+    workgroups one after the other) builds trees on the CPU; the 4-wide tree it hands to the traversal is compared with the one that follows
+    from tests/emu/sah_reference.h.  Primitives, seed, kind (0 scattered, 1 a surface in mesh order, 4 very uneven), largest
+    leaf, traversal cost, meshes (> 1: the forest build; 0: one tree and then its REFIT — a16 / f3 — to unrelated triangles, every child box
+    checked against the union of what lies below it)."""
+    import extract
+    extract.whole_file(os.path.join(str(tmp_path), "sah_build.hip"), "sah_build.hip")
+    exe = compile_harness(str(tmp_path), "sah_build_emu")
+    for case in [(1, 1, 0, 8, 1.0), (2, 1, 0, 8, 1.0), (100, 1, 0, 8, 1.0), (280, 4, 4, 8, 1.0), (400, 2, 0, 8, 1.0), (520, 5, 1, 8, 1.0, 4), (300, 9, 1, 8, 1.0, 0)]:
+        r = subprocess.run([exe] + [str(x) for x in case], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.startswith("OK"), (case, r.stdout[-500:], r.stderr[-500:])
