@@ -81,6 +81,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline uint32_t atomicMin(uint32_t* p, uint32_t v)
 {
     uint32_t o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
@@ -144,6 +145,8 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), (order))
+#define __hip_atomic_load(p, order, scope) __uint_as_float(__atomic_load_n(reinterpret_cast<const uint32_t*>(p), (order)))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
 inline void __builtin_amdgcn_wave_barrier() { emu::t_wave->bar.arrive_and_wait(); }

@@ -85,3 +85,16 @@ def test_device_sah_builder_as_a_whole_equals_the_serial_binned_sah(tmp_path):
     for case in [(1, 1, 0, 8, 1.0), (2, 1, 0, 8, 1.0), (100, 1, 0, 8, 1.0), (280, 4, 4, 8, 1.0), (400, 2, 0, 8, 1.0), (520, 5, 1, 8, 1.0, 4), (300, 9, 1, 8, 1.0, 0)]:
         r = subprocess.run([exe] + [str(x) for x in case], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.startswith("OK"), (case, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_lbvh_file_on_the_cpu_passes_its_own_stress_test_and_builds_the_tlas_the_same_both_ways(tmp_path):
+    """csrc/lbvh.hip as a whole under the emulator.  `stress`: the library's own rfw_hip_debug_lbvh_stress path (jittered boxes -> lbvh_build with
+    the fence-free fit -> the device-side check of every child box and primitive) must report no mismatch; `tlas`: the chain of seventeen launches
+    (instance boxes, bounds, Morton keys, radix sort, hierarchy, fit, collapse, gather) and the one workgroup of tlas_build_fused give the same
+    instance boxes, leaf order and 4-wide nodes byte for byte — the GPU test of the same name's claim (tests/test_gpu_api.py), without a GPU."""
+    import extract
+    extract.whole_file(os.path.join(str(tmp_path), "lbvh.hip"), "lbvh.hip")
+    exe = compile_harness(str(tmp_path), "lbvh_emu")
+    for case in [("stress", 1000, 2, 1), ("stress", 3000, 1, 7), ("tlas", 2, 1), ("tlas", 3, 1), ("tlas", 17, 4), ("tlas", 1000, 2), ("tlas", 5000, 3)]:
+        r = subprocess.run([exe] + [str(x) for x in case], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), (case, r.stdout[-500:], r.stderr[-500:])
