@@ -1,23 +1,33 @@
 // wave_emu.h — TEST INFRASTRUCTURE: a lockstep-free emulator of one gfx950 workgroup on CPU threads, for running the DEVICE SOURCE of a
 // wave-synchronous kernel (the text of rfw-rs_amd/csrc/sah_build.hip's phase 2, cut out by tests/test_builder_emulated.py) under g++.
 //
-// One OS thread per lane.  Everything that crosses lanes on the GPU is a collective here — the lanes of a wavefront meet at a barrier, publish
-// their operand, read their source lane's: __ballot, __shfl, __shfl_xor, readlane / readfirstlane, the DPP row operations
-// (update_dpp with row_shr / row_shl / row_bcast:15 / row_bcast:31, the controls the builder uses), and the wave barrier of wave_sync().
-// Between collectives the lanes run free, so an LDS hand-over between lanes that the kernel forgot to fence with wave_sync() (on the GPU: left
-// to instruction order and the compiler's mercy) shows up here as a race.  LDS is a function-local static (one workgroup at a time), LDS and
+// A lane is a fiber of its wavefront's OS thread; with -DEMU_THREADS (for the sanitizers) an OS thread of its own.  Everything that crosses lanes
+// on the GPU is a collective here — the lanes of a wavefront publish their operand, meet, read their source lane's: __ballot, __shfl,
+// __shfl_xor / _up / _down, readlane / readfirstlane, the DPP row operations (update_dpp with row_shr / row_shl / row_bcast:15 / row_bcast:31,
+// the controls the builders use), and the wave barrier of wave_sync().  LDS is a function-local static (one workgroup at a time), LDS and
 // global atomics are __atomic builtins, __syncthreads is a barrier over the workgroup.
-// Limits: every lane of a wavefront must reach every collective (true for the builder: its wave-level branches are uniform); a kernel is
-// run for one blockIdx at a time.
+// Fibers: a lane runs until its next meeting, then the next lane does — a fixed schedule, fast (no kernel sleeps inside a wavefront), good
+// for what a kernel COMPUTES.  Threads: the lanes run free between collectives, so an LDS hand-over between lanes that the kernel forgot to
+// fence with wave_sync() (on the GPU: left to instruction order and the compiler's mercy) is a data race -fsanitize=thread reports.
+// Limits: a lane that waits at a collective for lanes that have returned is an error (the device would go on); a kernel is run for one
+// blockIdx at a time.
 #pragma once
+#include <algorithm>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <vector>
+
+#ifndef EMU_THREADS
+#include <sys/mman.h>
+#include <ucontext.h>
+#endif
 
 #define __device__
 #define __global__
@@ -27,6 +37,9 @@
 
 namespace emu {
 struct Dim { unsigned x = 0, y = 0, z = 0; };
+
+#ifdef EMU_THREADS
+// ---- one OS thread per lane (for the sanitizers: -fsanitize=thread sees every unfenced hand-over between lanes as a race)
 struct WaveCtx {
     std::barrier<> bar{64};
     uint32_t slot[2][64]; // two sets, used in turn: ONE meeting per collective (a lane can only be writing set p again after every lane has
@@ -40,20 +53,14 @@ inline thread_local Dim t_thread, t_block;
 inline thread_local WaveCtx* t_wave = nullptr;
 inline thread_local unsigned t_phase = 0; // the same in every lane of a wavefront: every lane takes part in every collective
 inline thread_local GroupCtx* t_group = nullptr;
+inline Dim& thread_idx() { return t_thread; }
+inline Dim& block_idx() { return t_block; }
 inline unsigned lane() { return t_thread.x & 63u; }
+inline uint32_t* next_slots() { return t_wave->slot[t_phase++ & 1u]; }
+inline void meet() { t_wave->bar.arrive_and_wait(); }          // the lanes of my wavefront
+inline void group_sync() { t_group->bar->arrive_and_wait(); }  // the threads of my workgroup
 
-// every lane publishes v and gets the value of lane src(lane) — or keeps `old` when src is negative
-template <class F> inline uint32_t exchange(uint32_t v, uint32_t old, F src)
-{
-    WaveCtx& w = *t_wave;
-    uint32_t* const slot = w.slot[t_phase++ & 1u];
-    slot[lane()] = v;
-    w.bar.arrive_and_wait();
-    const int s = src((int)lane());
-    return s < 0 ? old : slot[s & 63];
-}
-
-// run kernel(args...) for one workgroup of `threads` threads with blockIdx.x = block
+// run kernel() for one workgroup of `threads` threads with blockIdx.x = block
 template <class K> inline void run_group(unsigned threads, unsigned block, K kernel)
 {
     GroupCtx g;
@@ -67,12 +74,132 @@ template <class K> inline void run_group(unsigned threads, unsigned block, K ker
         });
     for (auto& x : th) x.join();
 }
+#else
+// ---- the default: one OS thread per WAVEFRONT, its lanes as fibers (ucontext) that hand the thread round at every meeting — no kernel
+// sleeps inside a wavefront, ~10 x the speed of a thread per lane.  A lane that returns from the kernel no longer counts at meetings and
+// barriers (as on the device); a wavefront whose lanes have all returned leaves the workgroup's barrier.
+struct WaveCtx;
+struct Fiber {
+    ucontext_t ctx;
+    Dim thread, block;
+    unsigned phase = 0;
+    bool done = false;
+    WaveCtx* wave = nullptr;
+};
+struct GroupCtx { std::unique_ptr<std::barrier<>> bar; };
+struct WaveCtx {
+    Fiber fib[64];
+    ucontext_t main_ctx;
+    int n = 0, cur = 0, alive = 0;
+    int arrived = 0; unsigned gen = 0;     // meetings of the wavefront
+    int s_arrived = 0; unsigned sgen = 0;  // __syncthreads
+    uint32_t slot[2][64];
+    GroupCtx* group = nullptr;
+    std::function<void()> kernel;
+    char* stacks = nullptr;
+};
+constexpr size_t kFiberStack = 256 * 1024;
+inline thread_local Fiber* t_cur = nullptr;
+inline Dim& thread_idx() { return t_cur->thread; }
+inline Dim& block_idx() { return t_cur->block; }
+inline unsigned lane() { return t_cur->thread.x & 63u; }
+inline uint32_t* next_slots() { return t_cur->wave->slot[t_cur->phase++ & 1u]; }
+inline int next_alive(WaveCtx& w, int from)
+{
+    for (int k = 1; k <= w.n; k++) { const int i = (from + k) % w.n; if (!w.fib[i].done) return i; }
+    return -1;
+}
+inline void yield()
+{
+    WaveCtx& w = *t_cur->wave;
+    const int from = w.cur, to = next_alive(w, from);
+    if (to < 0 || to == from) { std::fprintf(stderr, "wave_emu: a lane waits for lanes that have returned\n"); std::abort(); }
+    w.cur = to; t_cur = &w.fib[to];
+    swapcontext(&w.fib[from].ctx, &w.fib[to].ctx);
+}
+inline void meet()
+{
+    WaveCtx& w = *t_cur->wave;
+    const unsigned my = w.gen;
+    if (++w.arrived == w.alive) { w.arrived = 0; w.gen++; }
+    else while (w.gen == my) yield();
+}
+inline void group_sync()
+{
+    WaveCtx& w = *t_cur->wave;
+    const unsigned my = w.sgen;
+    if (++w.s_arrived == w.alive) { w.s_arrived = 0; w.group->bar->arrive_and_wait(); w.sgen++; }
+    else while (w.sgen == my) yield();
+}
+inline void fiber_entry(unsigned lo, unsigned hi)
+{
+    WaveCtx& w = *reinterpret_cast<WaveCtx*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    w.kernel();
+    // this lane has returned: the others may have been waiting for nobody else
+    Fiber& me = w.fib[w.cur];
+    me.done = true;
+    w.alive--;
+    if (w.alive > 0) {
+        if (w.arrived == w.alive) { w.arrived = 0; w.gen++; }
+        if (w.s_arrived == w.alive) { w.s_arrived = 0; w.group->bar->arrive_and_wait(); w.sgen++; }
+        const int to = next_alive(w, w.cur);
+        w.cur = to; t_cur = &w.fib[to];
+        setcontext(&w.fib[to].ctx);
+    }
+    setcontext(&w.main_ctx);
+}
+template <class K> inline void run_group(unsigned threads, unsigned block, K kernel)
+{
+    GroupCtx g;
+    const unsigned n_waves = (threads + 63) / 64;
+    g.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n_waves);
+    std::vector<std::unique_ptr<WaveCtx>> waves;
+    for (unsigned w = 0; w < n_waves; w++) waves.push_back(std::make_unique<WaveCtx>());
+    auto run_wave = [&](unsigned wi) {
+        WaveCtx& w = *waves[wi];
+        w.n = w.alive = (int)std::min(64u, threads - 64u * wi);
+        w.group = &g;
+        w.kernel = kernel;
+        w.stacks = static_cast<char*>(mmap(nullptr, kFiberStack * (size_t)w.n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+        if (w.stacks == MAP_FAILED) { std::perror("wave_emu: mmap"); std::abort(); }
+        for (int l = 0; l < w.n; l++) {
+            Fiber& f = w.fib[l];
+            f.thread.x = 64u * wi + (unsigned)l; f.block.x = block; f.wave = &w;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = w.stacks + kFiberStack * (size_t)l;
+            f.ctx.uc_stack.ss_size = kFiberStack;
+            f.ctx.uc_link = nullptr;
+            const uintptr_t p = reinterpret_cast<uintptr_t>(&w);
+            makecontext(&f.ctx, reinterpret_cast<void (*)()>(fiber_entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+        }
+        w.cur = 0; t_cur = &w.fib[0];
+        swapcontext(&w.main_ctx, &w.fib[0].ctx);
+        t_cur = nullptr;
+        g.bar->arrive_and_drop(); // (no lane of this wavefront will come to a barrier again)
+        munmap(w.stacks, kFiberStack * (size_t)w.n);
+    };
+    if (n_waves == 1) { run_wave(0); return; }
+    std::vector<std::thread> th;
+    for (unsigned wi = 0; wi < n_waves; wi++) th.emplace_back(run_wave, wi);
+    for (auto& x : th) x.join();
+}
+#endif
+
+// every lane publishes v and gets the value of lane src(lane) — or keeps `old` when src is negative
+template <class F> inline uint32_t exchange(uint32_t v, uint32_t old, F src)
+{
+    uint32_t* const slot = next_slots();
+    slot[lane()] = v;
+    meet();
+    const int s = src((int)lane());
+    return s < 0 ? old : slot[s & 63];
+}
 } // namespace emu
 
-#define threadIdx (emu::t_thread)
-#define blockIdx (emu::t_block)
+#define threadIdx (emu::thread_idx())
+#define blockIdx (emu::block_idx())
 
-inline void __syncthreads() { emu::t_group->bar->arrive_and_wait(); }
+inline void __syncthreads() { emu::group_sync(); }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
@@ -97,10 +224,9 @@ inline uint32_t atomicMax(uint32_t* p, uint32_t v)
 
 inline unsigned long long __ballot(bool p)
 {
-    emu::WaveCtx& w = *emu::t_wave;
-    uint32_t* const slot = w.slot[emu::t_phase++ & 1u];
+    uint32_t* const slot = emu::next_slots();
     slot[emu::lane()] = p ? 1u : 0u;
-    w.bar.arrive_and_wait();
+    emu::meet();
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) m |= (unsigned long long)(slot[i] & 1u) << i;
     return m;
@@ -149,4 +275,4 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 #define __hip_atomic_load(p, order, scope) __uint_as_float(__atomic_load_n(reinterpret_cast<const uint32_t*>(p), (order)))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
-inline void __builtin_amdgcn_wave_barrier() { emu::t_wave->bar.arrive_and_wait(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::meet(); }
