@@ -6,7 +6,7 @@
 //   usage: sah_build_emu <primitives> <seed> <kind> <max_leaf> <trav_cost> [trees]     trees > 1: the forest build over that many meshes;
 //          trees = 0: one tree, then its REFIT (a16 / f3: launch_refit_setup + launch_refit) to triangles that have nothing to do with the boxes
 //          it was built over — every child box must be the union of what lies below it, the leaves' from the padded triangle boxes
-//   prints "OK nodes4=<n> leaves=<n> groups=<workgroups run>" or the first difference
+//   prints "OK nodes4=<n> leaves=<n> groups=<workgroups run> wave_collectives=<meetings of a wavefront's lanes, all kernels>" or the first difference
 #include "sah_reference.h"
 
 #include "sah_build.hip" // (found through -I rfw-rs_amd/csrc; its <hip/hip_runtime.h> and <hipcub/hipcub.hpp> are tests/emu/fake_hip's)
@@ -209,6 +209,6 @@ int main(int argc, char** argv)
                 return 1;
             }
     }
-    std::printf("OK nodes4=%d leaves=%d groups=%llu\n", g_nodes4, g_leaves, emu::g_groups_run);
+    std::printf("OK nodes4=%d leaves=%d groups=%llu wave_collectives=%llu\n", g_nodes4, g_leaves, emu::g_groups_run, emu::g_meetings);
     return 0;
 }

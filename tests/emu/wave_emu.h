@@ -57,6 +57,7 @@ inline Dim& thread_idx() { return t_thread; }
 inline Dim& block_idx() { return t_block; }
 inline unsigned lane() { return t_thread.x & 63u; }
 inline uint32_t* next_slots() { return t_wave->slot[t_phase++ & 1u]; }
+inline unsigned long long g_meetings = 0;
 inline void meet() { t_wave->bar.arrive_and_wait(); }          // the lanes of my wavefront
 inline void group_sync() { t_group->bar->arrive_and_wait(); }  // the threads of my workgroup
 
@@ -117,11 +118,12 @@ inline void yield()
     w.cur = to; t_cur = &w.fib[to];
     swapcontext(&w.fib[from].ctx, &w.fib[to].ctx);
 }
+inline unsigned long long g_meetings = 0; // wave-level collectives executed, all wavefronts (a measure of a kernel's dependent cross-lane steps)
 inline void meet()
 {
     WaveCtx& w = *t_cur->wave;
     const unsigned my = w.gen;
-    if (++w.arrived == w.alive) { w.arrived = 0; w.gen++; }
+    if (++w.arrived == w.alive) { w.arrived = 0; w.gen++; __atomic_fetch_add(&g_meetings, 1ull, __ATOMIC_RELAXED); }
     else while (w.gen == my) yield();
 }
 inline void group_sync()

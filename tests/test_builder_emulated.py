@@ -75,6 +75,10 @@ def test_level_at_a_time_variant_of_the_workgroup_phase_builds_the_same_trees(tm
     assert r.returncode == 0, r.stdout + r.stderr
     assert "finish_segments_wave" in open(src).read()
     run_cases(build_harness(str(tmp_path), src), CASES, leaf_per_primitive=True)
+    # ... and the patched FILE as a whole, up to the size that takes workgroups of 512
+    import extract
+    extract.whole_file(os.path.join(str(tmp_path), "sah_build.hip"), "sah_build.hip", src)
+    run_cases(compile_harness(str(tmp_path), "sah_build_emu"), [(600, 2, 0, 8, 1.0), (700, 5, 1, 8, 1.0, 4), (6000, 7, 4, 8, 1.0), (40000, 3, 1, 8, 1.0)])
 
 
 def test_one_workgroup_tlas_build_equals_its_serial_restatement(tmp_path):
