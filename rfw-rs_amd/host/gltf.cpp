@@ -460,10 +460,15 @@ struct Doc {
         if (bi < 0 || (size_t)bi >= buffers.size()) return fail("gltf: buffer index out of range");
         const std::vector<uint8_t>& buf = buffers[(size_t)bi];
         const size_t elem = (size_t)nc * (size_t)cb;
-        size_t stride = (size_t)bv.integer("byteStride", 0);
+        // every field is checked by itself first: a negative or enormous offset must not wrap the sums below into range
+        const int64_t view_off = bv.integer("byteOffset", 0), acc_off = a.integer("byteOffset", 0), view_bytes = bv.integer("byteLength", 0), view_stride = bv.integer("byteStride", 0);
+        if (view_off < 0 || acc_off < 0 || view_bytes < 0 || view_stride < 0 || view_stride > 65536 || (uint64_t)view_off > buf.size() || (uint64_t)view_bytes > buf.size() - (size_t)view_off ||
+            acc_off > view_bytes)
+            return fail("gltf: buffer view or accessor offset out of range");
+        size_t stride = (size_t)view_stride;
         if (stride == 0) stride = elem;
-        const size_t base = (size_t)bv.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0);
-        const size_t view_len = (size_t)bv.integer("byteLength", 0), in_view = (size_t)a.integer("byteOffset", 0);
+        const size_t base = (size_t)view_off + (size_t)acc_off;
+        const size_t view_len = (size_t)view_bytes, in_view = (size_t)acc_off;
         if (count && (stride < elem || in_view + (count - 1) * stride + elem > view_len || base + (count - 1) * stride + elem > buf.size()))
             return fail("gltf: accessor reads past the end of its buffer view");
         out.assign(count * (size_t)nc, 0.0); // only now: the count is backed by bytes that exist
@@ -733,8 +738,9 @@ bool load_gltf(const std::string& path, Scene& scene, Camera3D* cam, std::string
             if (bvs && bi >= 0 && (size_t)bi < bvs->size()) {
                 const Json& bv = bvs->arr[(size_t)bi];
                 const int64_t b = bv.integer("buffer", -1);
-                const size_t o = (size_t)bv.integer("byteOffset", 0), n = (size_t)bv.integer("byteLength", 0);
-                if (b >= 0 && (size_t)b < doc.buffers.size() && o + n <= doc.buffers[(size_t)b].size()) {
+                const int64_t o64 = bv.integer("byteOffset", 0), n64 = bv.integer("byteLength", 0);
+                const size_t o = (size_t)o64, n = (size_t)n64;
+                if (b >= 0 && (size_t)b < doc.buffers.size() && o64 >= 0 && n64 >= 0 && o <= doc.buffers[(size_t)b].size() && n <= doc.buffers[(size_t)b].size() - o) {
                     file.assign(doc.buffers[(size_t)b].begin() + (long)o, doc.buffers[(size_t)b].begin() + (long)(o + n));
                     have = true;
                 }

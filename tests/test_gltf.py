@@ -68,6 +68,12 @@ def test_malformed_documents_are_errors_not_crashes(tmp_path):
     expect(lambda doc: doc["asset"].update(version="1.0"), "version", "c")
     expect(lambda doc: doc["buffers"][0].update(uri="../scene.bin"), "below the document", "d")
     expect(lambda doc: doc["accessors"][0].update(sparse={"count": 1}), "sparse", "e")
+    # offsets that would wrap the bounds arithmetic into range (round 6, found by a mutation run under the address sanitizer: a view at byte -1
+    # made `offset + length` small again and the accessor read in front of its buffer)
+    expect(lambda doc: doc["bufferViews"][0].update(byteOffset=-1), "out of range", "f")
+    expect(lambda doc: doc["accessors"][0].update(byteOffset=-4), "out of range", "g")
+    expect(lambda doc: doc["bufferViews"][1].update(byteOffset=2 ** 63 - 1), "out of range", "h")
+    expect(lambda doc: doc["bufferViews"][0].update(byteStride=2 ** 40), "out of range", "i")
     bad = tmp_path / "bad.gltf"
     bad.write_text('{"asset": {"version": "2.0"}, "meshes": [')
     with pytest.raises(ValueError, match="json"):
