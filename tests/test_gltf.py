@@ -169,7 +169,9 @@ def test_png_colour_types_and_broken_images(tmp_path):
 
 def test_mutated_documents_never_crash_the_importer(tmp_path):
     """A deterministic mutation run over the four containers (flip / delete / insert bytes, half of them inside the binary chunk): every
-    document either loads or is rejected with an error.  (6000 mutations under ASan + UBSan were clean in round 1.)"""
+    document either loads or is rejected with an error.  (6000 mutations under ASan + UBSan were clean in round 1; round 6, after the
+    JPEG / animation / OBJ importers had been added: tools/probes/fuzz_importers — 1.98 M byte-level and 72 000 JSON-level mutations, one finding, fixed:
+    test_malformed_documents_are_errors_not_crashes cases f - i.)"""
     import struct
     from gltf_util import write_skinned_gltf, write_textured_gltf
     rng = np.random.default_rng(7)
