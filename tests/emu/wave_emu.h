@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <barrier>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -55,22 +56,25 @@ inline thread_local unsigned t_phase = 0; // the same in every lane of a wavefro
 inline thread_local GroupCtx* t_group = nullptr;
 inline Dim& thread_idx() { return t_thread; }
 inline Dim& block_idx() { return t_block; }
-inline unsigned lane() { return t_thread.x & 63u; }
+inline thread_local unsigned t_linear = 0;
+inline unsigned lane() { return t_linear & 63u; }
 inline uint32_t* next_slots() { return t_wave->slot[t_phase++ & 1u]; }
 inline unsigned long long g_meetings = 0;
 inline void meet() { t_wave->bar.arrive_and_wait(); }          // the lanes of my wavefront
 inline void group_sync() { t_group->bar->arrive_and_wait(); }  // the threads of my workgroup
 
 // run kernel() for one workgroup of `threads` threads with blockIdx.x = block
-template <class K> inline void run_group(unsigned threads, unsigned block, K kernel)
+template <class K> inline void run_group(unsigned threads, unsigned block, K kernel, Dim block_dim = Dim{0, 1, 1}, Dim block_idx3 = Dim{0, 0, 0})
 {
     GroupCtx g;
+    if (block_dim.x == 0) { block_dim.x = threads; block_idx3.x = block; }
     g.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)threads);
     for (unsigned w = 0; w < (threads + 63) / 64; w++) g.waves.push_back(std::make_unique<WaveCtx>());
     std::vector<std::thread> th;
     for (unsigned t = 0; t < threads; t++)
         th.emplace_back([&, t] {
-            t_thread.x = t; t_block.x = block; t_group = &g; t_wave = g.waves[t / 64].get(); t_phase = 0;
+            t_linear = t; t_thread.x = t % block_dim.x; t_thread.y = t / block_dim.x % block_dim.y; t_thread.z = t / (block_dim.x * block_dim.y);
+            t_block = block_idx3; t_group = &g; t_wave = g.waves[t / 64].get(); t_phase = 0;
             kernel();
         });
     for (auto& x : th) x.join();
@@ -83,6 +87,7 @@ struct WaveCtx;
 struct Fiber {
     ucontext_t ctx;
     Dim thread, block;
+    unsigned linear = 0;   // x + y * blockDim.x + ...: the lane is its low six bits
     unsigned phase = 0;
     bool done = false;
     WaveCtx* wave = nullptr;
@@ -103,7 +108,7 @@ constexpr size_t kFiberStack = 256 * 1024;
 inline thread_local Fiber* t_cur = nullptr;
 inline Dim& thread_idx() { return t_cur->thread; }
 inline Dim& block_idx() { return t_cur->block; }
-inline unsigned lane() { return t_cur->thread.x & 63u; }
+inline unsigned lane() { return t_cur->linear & 63u; }
 inline uint32_t* next_slots() { return t_cur->wave->slot[t_cur->phase++ & 1u]; }
 inline int next_alive(WaveCtx& w, int from)
 {
@@ -150,10 +155,11 @@ inline void fiber_entry(unsigned lo, unsigned hi)
     }
     setcontext(&w.main_ctx);
 }
-template <class K> inline void run_group(unsigned threads, unsigned block, K kernel)
+template <class K> inline void run_group(unsigned threads, unsigned block, K kernel, Dim block_dim = Dim{0, 1, 1}, Dim block_idx3 = Dim{0, 0, 0})
 {
     GroupCtx g;
     const unsigned n_waves = (threads + 63) / 64;
+    if (block_dim.x == 0) { block_dim.x = threads; block_idx3.x = block; }
     g.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n_waves);
     std::vector<std::unique_ptr<WaveCtx>> waves;
     for (unsigned w = 0; w < n_waves; w++) waves.push_back(std::make_unique<WaveCtx>());
@@ -166,7 +172,8 @@ template <class K> inline void run_group(unsigned threads, unsigned block, K ker
         if (w.stacks == MAP_FAILED) { std::perror("wave_emu: mmap"); std::abort(); }
         for (int l = 0; l < w.n; l++) {
             Fiber& f = w.fib[l];
-            f.thread.x = 64u * wi + (unsigned)l; f.block.x = block; f.wave = &w;
+            f.linear = 64u * wi + (unsigned)l; f.wave = &w; f.block = block_idx3;
+            f.thread.x = f.linear % block_dim.x; f.thread.y = f.linear / block_dim.x % block_dim.y; f.thread.z = f.linear / (block_dim.x * block_dim.y);
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = w.stacks + kFiberStack * (size_t)l;
             f.ctx.uc_stack.ss_size = kFiberStack;
@@ -266,9 +273,37 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 inline int __shfl_down(int v, int off) { return (int)emu::exchange((uint32_t)v, (uint32_t)v, [&](int l) { return l + off < 64 ? l + off : -1; }); }
 inline float __shfl_down(float v, int off) { return __int_as_float(__shfl_down(__float_as_int(v), off)); }
 inline uint32_t __shfl_up(uint32_t v, int off) { return emu::exchange(v, v, [&](int l) { return l - off >= 0 ? l - off : -1; }); }
+inline uint32_t __shfl_down(uint32_t v, int off) { return (uint32_t)__shfl_down((int)v, off); }
+inline unsigned long long __shfl_down(unsigned long long v, int off)
+{
+    const uint32_t lo = __shfl_down((uint32_t)v, off), hi = __shfl_down((uint32_t)(v >> 32), off);
+    return ((unsigned long long)hi << 32) | lo;
+}
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
+{
+    unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return o;
+}
 inline int __clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; } // (the device's v_rcp_f32 is within 1 ulp of this; the traversal only uses it for conservative box tests)
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return __ballot(p); }
+inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> emu::lane()) & 1ull; }
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+inline unsigned long long wall_clock64() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10ull; } // 100 MHz
 struct alignas(16) float4 { float x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct alignas(8) float2 { float x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct float3 { float x, y, z; };
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+struct alignas(8) uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct alignas(16) int4 { int x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 // scoped atomics: the scope is dropped (one process), the order kept
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
