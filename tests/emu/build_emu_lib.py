@@ -28,11 +28,13 @@ def patched(text):
     return text
 
 
-def build(out_dir, jobs=4):
+def build(out_dir, jobs=4, replace=None):
+    """replace: {file name in csrc: path of another text for it} — an experiment's version of a source file (experiments/*/...patch applied)"""
     os.makedirs(out_dir, exist_ok=True)
     for name in os.listdir(CSRC):
         if name.endswith((".hip", ".cpp", ".h", ".inc")):
-            open(os.path.join(out_dir, name), "w").write(patched(open(os.path.join(CSRC, name)).read()))
+            src = (replace or {}).get(name, os.path.join(CSRC, name))
+            open(os.path.join(out_dir, name), "w").write(patched(open(src).read()))
     flags = ["-std=c++20", "-O1", "-g0", "-fPIC", "-ffp-contract=off", "-pthread", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-ignored-attributes",
              "-Wno-unused-value", "-D__forceinline__=inline", "-D__host__=", "-D__device__=", "-D__global__=", "-DRFW_EMULATED=1", "-x", "c++", "-I", out_dir, "-I", os.path.join(EMU, "fake_hip"), "-I", EMU,
              "-I", os.path.join(ROOT, "include")]
@@ -58,4 +60,4 @@ def build(out_dir, jobs=4):
 
 
 if __name__ == "__main__":
-    print(build(sys.argv[1]))
+    print(build(sys.argv[1], replace=dict(a.split("=", 1) for a in sys.argv[2:])))
