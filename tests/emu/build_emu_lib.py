@@ -28,7 +28,7 @@ def patched(text):
     return text
 
 
-def build(out_dir, jobs=4, replace=None):
+def build(out_dir, jobs=4, replace=None, extra_flags=()):
     """replace: {file name in csrc: path of another text for it} — an experiment's version of a source file (experiments/*/...patch applied)"""
     os.makedirs(out_dir, exist_ok=True)
     for name in os.listdir(CSRC):
@@ -37,7 +37,7 @@ def build(out_dir, jobs=4, replace=None):
             open(os.path.join(out_dir, name), "w").write(patched(open(src).read()))
     flags = ["-std=c++20", "-O1", "-g0", "-fPIC", "-ffp-contract=off", "-pthread", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-ignored-attributes",
              "-Wno-unused-value", "-D__forceinline__=inline", "-D__host__=", "-D__device__=", "-D__global__=", "-DRFW_EMULATED=1", "-x", "c++", "-I", out_dir, "-I", os.path.join(EMU, "fake_hip"), "-I", EMU,
-             "-I", os.path.join(ROOT, "include")]
+             "-I", os.path.join(ROOT, "include")] + list(extra_flags)
     procs, objs = [], []
     for u in UNITS:
         obj = os.path.join(out_dir, u.rsplit(".", 1)[0] + ".o")
@@ -53,11 +53,11 @@ def build(out_dir, jobs=4, replace=None):
         if p0.returncode != 0:
             raise RuntimeError(u0 + "\n" + err[-6000:])
     lib = os.path.join(out_dir, "librfw_hip_emu.so")
-    r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", lib] + objs, capture_output=True, text=True)
+    r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", lib] + objs + [f for f in extra_flags if f.startswith(("-fsanitize", "-shared-libsan"))], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-6000:])
     return lib
 
 
 if __name__ == "__main__":
-    print(build(sys.argv[1], replace=dict(a.split("=", 1) for a in sys.argv[2:])))
+    print(build(sys.argv[1], replace=dict(a.split("=", 1) for a in sys.argv[2:] if not a.startswith("-")), extra_flags=[a for a in sys.argv[2:] if a.startswith("-")]))
